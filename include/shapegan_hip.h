@@ -1,0 +1,139 @@
+/* include/shapegan_hip.h — C ABI of libshapegan_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (marian42/shapegan) has no FFI of its own: its hot path is the set of ATen kernels that
+ * torch.nn launches underneath model/gan.py, model/autoencoder.py, model/progressive_gan.py and
+ * model/sdf_net.py.  This header is the boundary a maintainer binds instead of those ATen calls; every entry
+ * point names the reference site it replaces.  The Python shells in shapegan_amd/model/ (gan.py, ...) (same class names,
+ * constructor arguments, state_dict keys and file names as the reference's model/ package) call these through
+ * ctypes on tensor.data_ptr() — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous, device pointers; NCDHW for voxel tensors, row-major [N,features] for MLPs;
+ *   - every call is asynchronous and ordered on `stream` (pass torch.cuda.current_stream().cuda_stream);
+ *   - the caller owns every buffer, including workspaces (sizes from the *_workspace_bytes helpers); nothing is
+ *     retained past the call; no global mutable state, so calls are re-entrant across threads/streams;
+ *   - return 0 on success, <0 on error (SG_ERR_*); sg_last_error() gives a thread-local message;
+ *   - `act` is one of SG_ACT_*, fused into the producing kernel's epilogue (slope = LeakyReLU negative slope).
+ */
+#ifndef SHAPEGAN_HIP_H
+#define SHAPEGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_ABI_VERSION 1
+
+typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
+
+#define SG_ACT_NONE_C 0
+#define SG_ACT_LEAKY_C 1
+#define SG_ACT_RELU_C 2
+#define SG_ACT_TANH_C 3
+#define SG_ACT_SIGMOID_C 4
+
+int sg_abi_version(void);
+const char* sg_last_error(void);
+
+/* ---- K1: nn.Conv3d(kernel 4, stride 2, padding 1) --------------------------------------------------------
+ * reference: model/gan.py:49-53 (Discriminator), model/autoencoder.py:16-24 (encoder),
+ *            model/progressive_gan.py:38 (optional_layers[i][0])  -> aten::convolution / convolution_backward.
+ * x [batch,Cx,ID,IH,IW] -> y [batch,Cout,ID/2,IH/2,IW/2]; w [Cout,Cin_total,4,4,4].
+ * Only input channels [0,Cin) are read (Cin < Cin_total reproduces from_SDF's zero padding,
+ * model/progressive_gan.py:9-16, without materialising the zero channels). */
+int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                         int Cx, int Cout, int ID, int IH, int IW, int act, float slope, hipStream_t stream);
+/* dx[batch,Cx(first Cin channels),ID,IH,IW] = conv^T(dy, w) (+bias[ci], act: used when this is a ConvTranspose fwd) */
+size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin);
+int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                           int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* dw[Cout, Cin_total(first Cin channels written), 4,4,4] = sum_{n,o} dy * x-patches; split-K workspace optional */
+size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin);
+int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                           int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream);
+
+/* ---- K2: nn.ConvTranspose3d(kernel 4, stride 2, padding 1) -------------------------------------------------
+ * reference: model/gan.py:13,17,21 (Generator), model/autoencoder.py:55,59,63 (decoder).
+ * x [batch,Cin_T,ID,IH,IW] -> y [batch,Cout_T,2ID,2IH,2IW]; w [Cin_T,Cout_T,4,4,4]. */
+int sg_convT3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
+                          int ID, int IH, int IW, int act, float slope, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream);
+int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
+                            int IW, hipStream_t stream);
+int sg_convT3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin_T, int Cout_T, int ID, int IH,
+                            int IW, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* ---- K3/K6: GEMM + bias (+activation) -------------------------------------------------------------------------
+ * reference: nn.Linear (model/autoencoder.py:34,41-42,45; model/progressive_gan.py:28,30) -> aten::addmm/mm, and the
+ * kernel-4 stride-1 convolutions on 1^3 / 4^3 grids (model/gan.py:9,55; model/autoencoder.py:28,51).
+ *   C(i,j) = act( sum_k A(i,k) B(k,j) + bias_i[i] + bias_j[j >> bias_j_shift] ), element strides for all operands;
+ *   each of A, B needs a unit stride on one axis. */
+size_t sg_gemm_workspace_bytes(int M, int N);
+int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, long sci, long scj,
+            const float* bias_i, const float* bias_j, int bias_j_shift, int M, int N, int K, int act, float slope,
+            void* workspace, size_t workspace_bytes, hipStream_t stream);
+int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
+int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
+
+/* ---- K4: nn.BatchNorm3d / nn.BatchNorm1d (+ fused following activation) -------------------------------------
+ * reference: model/gan.py:10,14,18; model/autoencoder.py:17,21,25,29,38,46,56,60,64 -> aten::batch_norm(_backward).
+ * x [N,C,S]; momentum/eps as torch (0.1 / 1e-5); running_var gets the unbiased estimate. */
+size_t sg_bn_workspace_bytes(int C);
+int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S,
+                    float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream);
+int sg_bn_eval_fwd(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,
+                   const float* running_var, float* save_mean, float* save_invstd, int N, int C, long S, float eps,
+                   int act, float slope, hipStream_t stream);
+int sg_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+              const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, long S, int train, int act,
+              float slope, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* ---- K5: activations (standalone; normally fused into K1-K4/K7 epilogues) ------------------------------------
+ * sg_act_bwd takes the activation OUTPUT y (LeakyReLU/ReLU masks, 1-y^2, y(1-y)); it is also LeakyReLU's
+ * double-backward (mask * gg) used by the WGAN-GP graph (train_hybrid_progressive_gan.py:102-111). */
+int sg_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);
+int sg_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, hipStream_t stream);
+
+/* ---- K7: SDFNet fused MLP -------------------------------------------------------------------------------------
+ * reference: SDFNet.forward, model/sdf_net.py:26-61 (+ autograd).  `params` = 16 device pointers in state_dict order
+ * (layers1.{0,2,4,6}.{weight,bias}, layers2.{0,2,4,6}.{weight,bias}).  sg_sdfnet_pack builds the MFMA-fragment
+ * image of the weights (call once per optimizer step); kin_used = 3+latent (per-point latents, reference
+ * semantics) or 3 (per-shape latents folded into zb1/zb5 biases; replaces the [B*R^3, L] tiling of
+ * train_hybrid_wgan.py:67-70 / train_hybrid_progressive_gan.py:90-93). */
+size_t sg_sdfnet_packed_floats(int kin_used);
+int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream);
+int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, const int64_t* latent_idx,
+                  int latent_size, const float* packed, int kin_used, const float* zb1, const float* zb5,
+                  long points_per_shape, float* out, float* acts, long ldn, long N, hipStream_t stream);
+int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* dx, long dx_ld,
+                  const float* packed, int kin_used, long ldn, long N, hipStream_t stream);
+
+/* ---- K8/K9/K10/K11: blends, reductions, latent-table rows, optimizers ------------------------------------------
+ * reference: fade-in / GP lerp (model/progressive_gan.py:50, train_hybrid_progressive_gan.py:105), batch means
+ * (train_wgan.py:68,82), latent_codes[model_indices] (train_sdf_autodecoder.py:78-82), optim.RMSprop / optim.Adam
+ * with torch defaults (train_wgan.py:45-46, train_autoencoder.py:35, ...), clip_weights (model/gan.py:67-69;
+ * fused into the RMSprop step when clip > 0). grad_scale multiplies the gradient on load (1/world for DP). */
+int sg_axpby(const float* x, const float* y, float* out, long n, float a, float b, hipStream_t stream);
+size_t sg_reduce_workspace_bytes(void);
+int sg_reduce_sum(const float* x, float* out, long n, float scale, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream);
+int sg_gather_rows(const float* table, const int64_t* idx, float* out, long n, int L, hipStream_t stream);
+int sg_scatter_add_rows(const float* rows, long rows_ld, const int64_t* idx, float* table_grad, long n, int L,
+                        hipStream_t stream);
+int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float lr, float alpha, float eps,
+                    float grad_scale, float clip, hipStream_t stream);
+int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                 float eps, long step, float grad_scale, hipStream_t stream);
+int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHAPEGAN_HIP_H */

@@ -1,0 +1,269 @@
+// shapegan_amd/csrc/batchnorm.hip — BatchNorm3d / BatchNorm1d (K4) with the following LeakyReLU folded in.
+//
+// Replaces ATen batch_norm / batch_norm_backward behind nn.BatchNorm3d (model/gan.py:10,14,18;
+// model/autoencoder.py:17,21,25,29,56,60,64) and nn.BatchNorm1d (model/autoencoder.py:38,46), with torch's
+// conventions: biased variance for normalisation, unbiased for running_var, momentum 0.1, eps inside the sqrt.
+//
+// x is [N, C, S] (S = D*H*W, 1 for BatchNorm1d).  Statistics are HBM-bound reductions: each (channel, split)
+// workgroup streams its slice with float4 loads, reduces per wave with shuffles (DPP), then across the 4 waves
+// through LDS; partials are combined in double by a finalize kernel that also updates the running statistics.
+// Sums are shifted by the channel's first element so E[x^2]-E[x]^2 does not cancel when |mean| >> std.
+#include "common.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+// iterate the elements of channel c: for n in [0,N): x[(n*C + c)*S + s], s in [0,S)
+// flat index e in [0, N*S): n = e / S, s = e % S
+__device__ __forceinline__ long chan_addr(long e, int c, int C, long S) {
+    const long n = e / S, s = e - n * S;
+    return (n * C + c) * S + s;
+}
+
+// partial[c][split] = {sum(x-K), sum((x-K)^2)}
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int N,
+                                                       int C, long S, int nsplit) {
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const long total = (long)N * S;
+    const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
+    const long beg = sp * chunk, end = min(total, beg + chunk);
+    const float K = x[(long)c * S];
+    float s1 = 0.f, s2 = 0.f;
+    if ((S & 3) == 0 && (beg & 3) == 0) {
+        for (long e = beg + (long)threadIdx.x * 4; e < end; e += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + chan_addr(e, c, C, S));
+            const float a = v.x - K, b = v.y - K, cc = v.z - K, d = v.w - K;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    } else {
+        for (long e = beg + threadIdx.x; e < end; e += 256) {
+            const float a = x[chan_addr(e, c, C, S)] - K;
+            s1 += a;
+            s2 += a * a;
+        }
+    }
+    __shared__ double red[2][4];
+    double d1 = sg_wave_sum_d((double)s1), d2 = sg_wave_sum_d((double)s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = d1;
+        red[1][threadIdx.x >> 6] = d2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((long)c * nsplit + sp) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[((long)c * nsplit + sp) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ partial,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* running_mean, float* running_var,
+                                                          long long* num_batches_tracked, int N, int C, long S,
+                                                          int nsplit, float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int i = 0; i < nsplit; ++i) {
+        s1 += partial[((long)c * nsplit + i) * 2];
+        s2 += partial[((long)c * nsplit + i) * 2 + 1];
+    }
+    const double n = (double)N * (double)S;
+    const double K = (double)x[(long)c * S];
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)(K + m);
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)(K + m);
+        const double unbiased = n > 1 ? var * n / (n - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_eval_stats_kernel(const float* __restrict__ running_mean,
+                                                            const float* __restrict__ running_var,
+                                                            float* __restrict__ mean, float* __restrict__ invstd, int C,
+                                                            float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = running_mean[c];
+    invstd[c] = 1.f / sqrtf(running_var[c] + eps);
+}
+
+// y = act(gamma * (x - mean) * invstd + beta)
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       int C, long S, long total, int act, float slope) {
+    if ((S & 3) == 0) {
+        for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += (long)gridDim.x * 1024) {
+            const int c = (int)((e / S) % C);
+            const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+            float4 v = *reinterpret_cast<const float4*>(x + e);
+            v.x = sg_apply_act(fmaf(v.x, sc, sh), act, slope);
+            v.y = sg_apply_act(fmaf(v.y, sc, sh), act, slope);
+            v.z = sg_apply_act(fmaf(v.z, sc, sh), act, slope);
+            v.w = sg_apply_act(fmaf(v.w, sc, sh), act, slope);
+            *reinterpret_cast<float4*>(y + e) = v;
+        }
+    } else {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int c = (int)((e / S) % C);
+            const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+            y[e] = sg_apply_act(fmaf(x[e], sc, sh), act, slope);
+        }
+    }
+}
+
+__device__ __forceinline__ float bn_act_grad(float xhat, float g, float b, float dy, int act, float slope) {
+    if (act == SG_ACT_LEAKY) return (fmaf(g, xhat, b) > 0.f) ? dy : dy * slope;
+    if (act == SG_ACT_RELU) return (fmaf(g, xhat, b) > 0.f) ? dy : 0.f;
+    return dy;
+}
+
+// partial[c][split] = {sum(g), sum(g * xhat)},  g = dy * act'(bn(x))
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, double* __restrict__ partial,
+                                                           int N, int C, long S, int nsplit, int act, float slope) {
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const long total = (long)N * S;
+    const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
+    const long beg = sp * chunk, end = min(total, beg + chunk);
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long e = beg + threadIdx.x; e < end; e += 256) {
+        const long ad = chan_addr(e, c, C, S);
+        const float xh = (x[ad] - mu) * is;
+        const float gg = bn_act_grad(xh, g, b, dy[ad], act, slope);
+        s1 += gg;
+        s2 += gg * xh;
+    }
+    __shared__ double red[2][4];
+    double d1 = sg_wave_sum_d((double)s1), d2 = sg_wave_sum_d((double)s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = d1;
+        red[1][threadIdx.x >> 6] = d2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((long)c * nsplit + sp) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[((long)c * nsplit + sp) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int C, int nsplit) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int i = 0; i < nsplit; ++i) {
+        s1 += partial[((long)c * nsplit + i) * 2];
+        s2 += partial[((long)c * nsplit + i) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+// train: dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n);  eval (stats constant): dx = gamma*invstd*g
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, int C, long S, long total,
+                                                           float inv_n, int train, int act, float slope) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)((e / S) % C);
+        const float is = invstd[c], g = gamma[c];
+        const float xh = (x[e] - mean[c]) * is;
+        const float gg = bn_act_grad(xh, g, beta[c], dy[e], act, slope);
+        float v = gg;
+        if (train) v = gg - dbeta[c] * inv_n - xh * dgamma[c] * inv_n;
+        dx[e] = g * is * v;
+    }
+}
+
+static int bn_nsplit(int N, int C, long S) {
+    const long per = (long)N * S;
+    long want = 1024 / (C > 0 ? C : 1);  // ~4 workgroups per CU overall
+    if (want < 1) want = 1;
+    long maxs = per / 4096;              // each split at least 4096 elements
+    if (maxs < 1) maxs = 1;
+    long s = want < maxs ? want : maxs;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+static int ew_blocks(long total, int per_thread) {
+    long b = (total + 256L * per_thread - 1) / (256L * per_thread);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+size_t sg_bn_workspace_bytes(int C) { return (size_t)C * 64 * 2 * sizeof(double); }
+
+int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S,
+                    float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+    SG_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && N > 0 && C > 0 && S > 0);
+    if (!workspace || workspace_bytes < sg_bn_workspace_bytes(C)) SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_fwd: workspace too small");
+    const int ns = bn_nsplit(N, C, S);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, stream, x, part, N, C, S, ns);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sg_cdiv(C, 256)), dim3(256), 0, stream, x, (const double*)part, save_mean,
+                       save_invstd, running_mean, running_var, num_batches_tracked, N, C, S, ns, eps, momentum);
+    const long total = (long)N * C * S;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total, 4)), dim3(256), 0, stream, x, y, gamma, beta,
+                       (const float*)save_mean, (const float*)save_invstd, C, S, total, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_bn_eval_fwd(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,
+                   const float* running_var, float* save_mean, float* save_invstd, int N, int C, long S, float eps,
+                   int act, float slope, hipStream_t stream) {
+    SG_CHECK_ARG(x && gamma && beta && y && running_mean && running_var && save_mean && save_invstd && N > 0 && C > 0);
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(sg_cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var,
+                       save_mean, save_invstd, C, eps);
+    const long total = (long)N * C * S;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total, 4)), dim3(256), 0, stream, x, y, gamma, beta,
+                       (const float*)save_mean, (const float*)save_invstd, C, S, total, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+              const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, long S, int train, int act,
+              float slope, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && N > 0 && C > 0 && S > 0);
+    if (!workspace || workspace_bytes < sg_bn_workspace_bytes(C)) SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_bwd: workspace too small");
+    const int ns = bn_nsplit(N, C, S);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, ns), dim3(256), 0, stream, dy, x, gamma, beta, save_mean, save_invstd,
+                       part, N, C, S, ns, act, slope);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sg_cdiv(C, 256)), dim3(256), 0, stream, (const double*)part, dgamma,
+                       dbeta, C, ns);
+    const long total = (long)N * C * S;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total, 1)), dim3(256), 0, stream, dy, x, dx, gamma, beta,
+                       save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, C, S, total,
+                       1.f / ((float)N * (float)S), train, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+}  // extern "C"

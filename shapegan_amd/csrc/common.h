@@ -1,0 +1,60 @@
+// shapegan_amd/csrc/common.h — shared host/device helpers for libshapegan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define SG_OK 0
+#define SG_ERR_ARG (-1)
+#define SG_ERR_HIP (-2)
+#define SG_ERR_WORKSPACE (-3)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// thread-local last-error string, read through sg_last_error()
+char* sg_err_buf();
+#define SG_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(sg_err_buf(), 512, __VA_ARGS__);            \
+        return (code);                                       \
+    } while (0)
+
+#define SG_CHECK_ARG(cond)                                                       \
+    do {                                                                         \
+        if (!(cond)) SG_FAIL(SG_ERR_ARG, "%s: bad argument: %s", __func__, #cond); \
+    } while (0)
+
+#define SG_CHECK_LAUNCH()                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess)                                                             \
+            SG_FAIL(SG_ERR_HIP, "%s: kernel launch failed: %s", __func__, hipGetErrorString(e__)); \
+    } while (0)
+
+// activation codes shared by every entry point that takes an `act` argument
+enum { SG_ACT_NONE = 0, SG_ACT_LEAKY = 1, SG_ACT_RELU = 2, SG_ACT_TANH = 3, SG_ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float sg_apply_act(float v, int act, float slope) {
+    switch (act) {
+        case SG_ACT_LEAKY: return v > 0.f ? v : v * slope;
+        case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SG_ACT_TANH: return tanhf(v);
+        case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float sg_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double sg_wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

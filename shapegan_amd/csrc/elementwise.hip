@@ -1,0 +1,229 @@
+// shapegan_amd/csrc/elementwise.hip — HBM-bound helpers: activations (K5), optimizers + clamp (K11),
+// latent-table gather / scatter-add (K10), reductions and losses (K9), lerp/fade blends (K8).
+//
+// Reference sites: nn.LeakyReLU/ReLU/Tanh/sigmoid throughout model/*.py; optim.RMSprop (train_wgan.py:45-46,
+// train_hybrid_progressive_gan.py:81-82, train_hybrid_wgan.py:56), optim.Adam (train_autoencoder.py:35,
+// train_sdf_autodecoder.py:44-45, train_hybrid_wgan.py:53) with torch defaults; Discriminator.clip_weights
+// (model/gan.py:67-69); latent_codes[model_indices] (train_sdf_autodecoder.py:78-82).
+// All kernels are grid-stride, float4 where alignment allows, one launch over a flat buffer.
+#include "common.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+static int ew_grid(long n, int per_thread) {
+    long b = (n + 256L * per_thread - 1) / (256L * per_thread);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ float act_grad_from_output(float y, float dy, int act, float slope) {
+    switch (act) {
+        case SG_ACT_LEAKY: return y > 0.f ? dy : dy * slope;
+        case SG_ACT_RELU: return y > 0.f ? dy : 0.f;
+        case SG_ACT_TANH: return dy * (1.f - y * y);
+        case SG_ACT_SIGMOID: return dy * y * (1.f - y);
+        default: return dy;
+    }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act,
+                                                      float slope) {
+    const long n4 = n >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(x)[e];
+        v.x = sg_apply_act(v.x, act, slope);
+        v.y = sg_apply_act(v.y, act, slope);
+        v.z = sg_apply_act(v.z, act, slope);
+        v.w = sg_apply_act(v.w, act, slope);
+        reinterpret_cast<float4*>(y)[e] = v;
+    }
+    for (long e = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        y[e] = sg_apply_act(x[e], act, slope);
+}
+
+// dx = dy * act'(.) with the derivative expressed through the OUTPUT y of the activation
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, long n, int act, float slope) {
+    const long n4 = n >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(y)[e];
+        const float4 g = reinterpret_cast<const float4*>(dy)[e];
+        float4 v;
+        v.x = act_grad_from_output(a.x, g.x, act, slope);
+        v.y = act_grad_from_output(a.y, g.y, act, slope);
+        v.z = act_grad_from_output(a.z, g.z, act, slope);
+        v.w = act_grad_from_output(a.w, g.w, act, slope);
+        reinterpret_cast<float4*>(dx)[e] = v;
+    }
+    for (long e = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        dx[e] = act_grad_from_output(y[e], dy[e], act, slope);
+}
+
+// torch.optim.RMSprop defaults (momentum 0, centered False, weight_decay 0):
+//   sq = alpha*sq + (1-alpha)*g*g ;  p -= lr * g / (sqrt(sq) + eps) ; optional clamp to [-clip, clip] (clip > 0)
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ sq, long n, float lr, float alpha, float eps,
+                                                      float gscale, float clip) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float gg = g[e] * gscale;
+        const float s = alpha * sq[e] + (1.f - alpha) * gg * gg;
+        sq[e] = s;
+        float v = p[e] - lr * (gg / (sqrtf(s) + eps));
+        if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+        p[e] = v;
+    }
+}
+
+// torch.optim.Adam defaults (amsgrad False, weight_decay 0):
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+    const float step = lr / bc1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float gg = g[e] * gscale;
+        const float mm = b1 * m[e] + (1.f - b1) * gg;
+        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, long n, float lo, float hi) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        p[e] = fminf(fmaxf(p[e], lo), hi);
+}
+
+// out = a*x + b*y   (y may be null)
+__global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    float* __restrict__ out, long n, float a, float b) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        out[e] = y ? fmaf(a, x[e], b * y[e]) : a * x[e];
+}
+
+// out[i][:] = table[idx[i]][:]
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, long n, int L) {
+    const long total = n * L;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / L;
+        const int k = (int)(e - i * L);
+        out[e] = table[idx[i] * L + k];
+    }
+}
+// table_grad[idx[i]][:] += rows[i][:]   (index_add; float atomics, device scope)
+__global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __restrict__ rows, long rows_ld,
+                                                               const int64_t* __restrict__ idx,
+                                                               float* __restrict__ table_grad, long n, int L) {
+    const long total = n * L;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / L;
+        const int k = (int)(e - i * L);
+        atomicAdd(&table_grad[idx[i] * L + k], rows[i * rows_ld + k]);
+    }
+}
+
+// two-stage deterministic sum: partial[block] then final
+__global__ void __launch_bounds__(256) sum_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, long n) {
+    double s = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += (double)x[e];
+    s = sg_wave_sum_d(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(64) sum_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int nb,
+                                                       float scale) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+    s = sg_wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)(s * (double)scale);
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+int sg_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream) {
+    SG_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, x, y, n, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, hipStream_t stream) {
+    SG_CHECK_ARG(y && dy && dx && n > 0);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, y, dy, dx, n, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float lr, float alpha, float eps,
+                    float grad_scale, float clip, hipStream_t stream) {
+    SG_CHECK_ARG(p && g && square_avg && n > 0);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, square_avg, n, lr, alpha, eps,
+                       grad_scale, clip);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                 float eps, long step, float grad_scale, hipStream_t stream) {
+    SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step > 0);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream) {
+    SG_CHECK_ARG(p && n > 0);
+    hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, n, lo, hi);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_axpby(const float* x, const float* y, float* out, long n, float a, float b, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && n > 0);
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, x, y, out, n, a, b);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_gather_rows(const float* table, const int64_t* idx, float* out, long n, int L, hipStream_t stream) {
+    SG_CHECK_ARG(table && idx && out && n > 0 && L > 0);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * L, 2)), dim3(256), 0, stream, table, idx, out, n, L);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_scatter_add_rows(const float* rows, long rows_ld, const int64_t* idx, float* table_grad, long n, int L,
+                        hipStream_t stream) {
+    SG_CHECK_ARG(rows && idx && table_grad && n > 0 && L > 0 && rows_ld >= L);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ew_grid(n * L, 2)), dim3(256), 0, stream, rows, rows_ld, idx,
+                       table_grad, n, L);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+size_t sg_reduce_workspace_bytes(void) { return 1024 * sizeof(double); }
+int sg_reduce_sum(const float* x, float* out, long n, float scale, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream) {
+    SG_CHECK_ARG(x && out && n > 0);
+    if (!workspace || workspace_bytes < sg_reduce_workspace_bytes()) SG_FAIL(SG_ERR_WORKSPACE, "sg_reduce_sum: workspace too small");
+    int nb = ew_grid(n, 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, stream, x, (double*)workspace, n);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, out, nb, scale);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+static thread_local char g_err[512];
+const char* sg_last_error(void) { return g_err; }
+int sg_abi_version(void) { return SG_ABI_VERSION; }
+
+}  // extern "C"
+
+char* sg_err_buf() { return g_err; }

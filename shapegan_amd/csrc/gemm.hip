@@ -1,0 +1,106 @@
+// shapegan_amd/csrc/gemm.hip — strided f32-MFMA GEMM (K3 "1^3<->4^3 convs as GEMMs", K6 nn.Linear).
+//
+// Replaces ATen addmm/mm behind nn.Linear (model/autoencoder.py:34,41-42,45; model/progressive_gan.py:28,30),
+// the k4/s1 convolutions on 1^3 / 4^3 grids that are plain GEMMs (model/gan.py:9,55; model/autoencoder.py:28,51)
+// and the SDFNet weight-gradient GEMMs (model/sdf_net.py:26-53 under autograd).
+//
+//   C(i,j) = act( sum_k A(i,k) * B(k,j) + bias_i[i] + bias_j[j >> bias_j_shift] )
+//
+// A, B, C are addressed through element strides; each operand must have one unit stride (either
+// along its row or along k) so that staging loads coalesce.  j is the lane axis of the MFMA C/D
+// fragment: pick j as the contiguous axis of C.
+#include "mfma_tile.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+struct GemmEpi {
+    float* c;
+    long sci, scj;
+    const float* bias_i;
+    const float* bias_j;
+    int bias_j_shift;
+    int act;
+    float slope;
+    struct Col {
+        long off;
+        float bj;
+    };
+    __device__ Col col(int j) const { return Col{(long)j * scj, bias_j ? bias_j[j >> bias_j_shift] : 0.f}; }
+    __device__ void store(const Col& cc, int i, int j, float v) const {
+        v += cc.bj;
+        if (bias_i) v += bias_i[i];
+        c[cc.off + (long)i * sci] = sg_apply_act(v, act, slope);
+    }
+};
+
+// sum over rows: out[j] = sum_i x[i*ld + j]   (bias gradients of Linear / 1^3 convs)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                     int cols, long ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < rows; ++i) s += x[(long)i * ld + j];
+    out[j] = s;
+}
+
+// out[r] = sum_{e<len} x[r*ld + e]; one wave per row
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                     long len, long ld) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + r * ld;
+    float s = 0.f;
+    for (long e = lane; e < len; e += 64) s += p[e];
+    s = sg_wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+size_t sg_gemm_workspace_bytes(int M, int N) { return (size_t)32 * M * N * sizeof(float); }
+
+int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, long sci, long scj,
+            const float* bias_i, const float* bias_j, int bias_j_shift, int M, int N, int K, int act, float slope,
+            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+    SG_CHECK_ARG(sai == 1 || sak == 1);
+    SG_CHECK_ARG(sbk == 1 || sbj == 1);
+    GemmEpi epi{C, sci, scj, bias_i, bias_j, bias_j_shift, act, slope};
+    float* ws = (float*)workspace;
+    // prefer the k-contiguous form when a dimension is degenerate (both strides legal)
+    const bool a_kfast = (sak == 1);
+    const bool b_kfast = (sbk == 1);
+    if (a_kfast && b_kfast) {
+        launch_tile_gemm(MatRowMajor{A, sai, 0}, MatRowMajor{B, sbj, 0}, epi, M, N, K, ws, workspace_bytes, stream);
+    } else if (a_kfast && !b_kfast) {
+        launch_tile_gemm(MatRowMajor{A, sai, 0}, MatColMajor{B, sbk, 0}, epi, M, N, K, ws, workspace_bytes, stream);
+    } else if (!a_kfast && b_kfast) {
+        launch_tile_gemm(MatColMajor{A, sak, 0}, MatRowMajor{B, sbj, 0}, epi, M, N, K, ws, workspace_bytes, stream);
+    } else {
+        launch_tile_gemm(MatColMajor{A, sak, 0}, MatColMajor{B, sbk, 0}, epi, M, N, K, ws, workspace_bytes, stream);
+    }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(sg_cdiv(cols, 256)), dim3(256), 0, stream, x, out, rows, cols, ld);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && rows > 0 && len > 0);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, out, rows, len, ld);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+}  // extern "C"

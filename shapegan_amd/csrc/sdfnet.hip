@@ -1,0 +1,543 @@
+// shapegan_amd/csrc/sdfnet.hip — the fused DeepSDF MLP (K7), the MFMA path of the north star.
+//
+// Replaces SDFNet.forward (model/sdf_net.py:56-61) and its autograd backward:
+//   input = cat(points[N,3], latent[N,L]);  x = layers1(input);  x = cat(x, input);  x = layers2(x)
+//   layers1 = Linear(3+L,256) ReLU, 3 x [Linear(256,256) ReLU]              (model/sdf_net.py:26-38)
+//   layers2 = Linear(259+L,256) ReLU, 2 x [Linear(256,256) ReLU], Linear(256,1) Tanh   (:40-52)
+//
+// One workgroup (512 threads = 8 waves, 2 per SIMD) walks a tile of P points through all eight layers
+// without touching HBM in between: the activation tile H[256][P] lives in LDS (feature-major, points
+// contiguous, so the MFMA B-fragment read of 32 consecutive points per half-wave is conflict-free), each
+// wave owns 32 output features x P points (P/32 accumulators of v_mfma_f32_32x32x2_f32, exact f32), and the
+// weights stream from L2 in an MFMA-A-fragment-packed image (one coalesced global_load_dwordx4 per lane per
+// 4 k-steps, 1 KiB per wave-instruction).  The 1.85 MB of weights are L2-resident; per point the kernel
+// moves 12 B in (xyz) + 4 B out, the 921 088 FLOP/point (L=128) are all on the matrix pipe.
+//
+// Two input modes:
+//   per-point latent (P=64):  X[3+L][P] is staged in LDS next to H; layers 1 and 5 run K over X as well
+//                             (reference semantics for arbitrary latent_codes[N,L], train_sdf_autodecoder.py:80-87)
+//   per-shape latent (P=128): every point of a shape shares z_s (hybrid GANs sample a fixed grid per shape,
+//                             train_hybrid_wgan.py:67-72, train_hybrid_progressive_gan.py:90-96) - the latent
+//                             columns of layers 1 and 5 fold into per-shape bias vectors zb1/zb5 (a [S,L]x[L,256]
+//                             GEMM), the [N,L] tiling (2.15 GB at 64^3, B=16) is never materialised.
+//
+// Training: `acts` receives H1..H7 (feature-major [7][256][ldn]); the fused backward-data kernel walks the
+// chain in reverse (dZ_l = dH_l * (H_l > 0), dH_{l-1} = W_l^T dZ_l on the matrix pipe with transposed packs),
+// writes dZ1..dZ7 for the weight-gradient GEMMs (gemm.hip, split-K over points) and the input gradient.
+#include "common.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+constexpr int kH = 256;  // SDF_NET_BREADTH, model/sdf_net.py:21
+
+struct PackDesc {
+    const float* src;
+    long rs, cs;  // element (r,c) at src[r*rs + c*cs]
+    int R, C;     // valid extent
+    int ntiles;   // padded rows / 32
+    int nsq;      // padded cols / 8
+    long dst_off;
+};
+struct PackDescs {
+    PackDesc d[16];
+    int n;
+};
+
+// dst[((t*nsq + sq)*64 + lane)*4 + j] = M(t*32 + (lane&31), (sq*4 + j)*2 + (lane>>5))
+__global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float* __restrict__ dst) {
+    const PackDesc d = descs.d[blockIdx.y];
+    const long total = (long)d.ntiles * d.nsq * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int j = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const long q = e >> 8;
+        const int sq = (int)(q % d.nsq);
+        const int t = (int)(q / d.nsq);
+        const int r = t * 32 + (lane & 31);
+        const int c = (sq * 4 + j) * 2 + (lane >> 5);
+        dst[d.dst_off + e] = (r < d.R && c < d.C) ? d.src[(long)r * d.rs + (long)c * d.cs] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_vectors_kernel(const float* b1, const float* b2, const float* b3,
+                                                           const float* b4, const float* b5, const float* b6,
+                                                           const float* b7, const float* b8, const float* w8,
+                                                           float* __restrict__ dst_b, float* __restrict__ dst_w8) {
+    const int t = threadIdx.x;
+    const float* bs[7] = {b1, b2, b3, b4, b5, b6, b7};
+#pragma unroll
+    for (int l = 0; l < 7; ++l) dst_b[l * kH + t] = bs[l][t];
+    dst_b[7 * kH + t] = (t == 0) ? b8[0] : 0.f;
+    dst_w8[t] = w8[t];
+}
+
+struct SdfPackLayout {
+    int KU, KUp, KUr;
+    long F1, F2, F3, F4, F5x, F5i, F6, F7;  // forward packs: A(i=out, k=in)
+    long T1, T2, T3, T4, T5x, T5i, T6, T7;  // transposed packs: A(i=in, k=out)
+    long W8, B;                              // w8[256], b[8][256]
+    long total;
+};
+static SdfPackLayout make_layout(int KU) {
+    SdfPackLayout L;
+    L.KU = KU;
+    L.KUp = (KU + 7) / 8 * 8;
+    L.KUr = (KU + 31) / 32 * 32;
+    long o = 0;
+    auto take = [&](long n) {
+        long r = o;
+        o += n;
+        return r;
+    };
+    L.F1 = take((long)kH * L.KUp);
+    L.F2 = take(kH * kH);
+    L.F3 = take(kH * kH);
+    L.F4 = take(kH * kH);
+    L.F5x = take(kH * kH);
+    L.F5i = take((long)kH * L.KUp);
+    L.F6 = take(kH * kH);
+    L.F7 = take(kH * kH);
+    L.T1 = take((long)L.KUr * kH);
+    L.T2 = take(kH * kH);
+    L.T3 = take(kH * kH);
+    L.T4 = take(kH * kH);
+    L.T5x = take(kH * kH);
+    L.T5i = take((long)L.KUr * kH);
+    L.T6 = take(kH * kH);
+    L.T7 = take(kH * kH);
+    L.W8 = take(kH);
+    L.B = take(8 * kH);
+    L.total = o;
+    return L;
+}
+
+// acc[t] += A_tile(32 x K) * B(K x [t*32, t*32+32)) ; wp = this wave's packed A rows, Bs = LDS [K][ld]
+template <int NT>
+__device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __restrict__ wp, int nsq,
+                                         const float* __restrict__ Bs, int ld, int lane) {
+    const int r = lane & 31, kh = lane >> 5;
+    const float* bp = Bs + kh * ld + r;
+    float4 a_next = wp[lane];
+    for (int sq = 0; sq < nsq; ++sq) {
+        const float4 a = a_next;
+        if (sq + 1 < nsq) a_next = wp[(sq + 1) * 64 + lane];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* bk = bp + (sq * 4 + j) * 2 * ld;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bk[t * 32], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ int frag_row(int q, int kh) { return (q & 3) + 8 * (q >> 2) + 4 * kh; }
+
+struct SdfFwdArgs {
+    const float* points;    // [*,3]
+    long points_period;     // >0: point index = p % period (shared voxel grid); 0: p
+    const float* latent;    // per-point mode: [N,L] rows, or table rows if latent_idx
+    const int64_t* latent_idx;  // optional [N] row index into latent
+    int L;
+    const float* packed;
+    SdfPackLayout lay;
+    const float* zb1;  // per-shape mode: [S][256] (bias of layer 1 incl. latent part)
+    const float* zb5;
+    long pps;          // points per shape (per-shape mode)
+    float* out;        // [N]
+    float* acts;       // optional [7][256][ldn]
+    long ldn;
+    long N;
+};
+
+template <int P, bool SHAPE_BIAS>
+__global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
+    constexpr int NT = P / 32;
+    constexpr int LDX = P + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                // [256][P]
+    float* Xs = Hs + kH * P;         // [KUp][LDX]
+    float* red = Xs + a.lay.KUp * LDX;  // [512]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    const long p0 = (long)blockIdx.x * P;
+    const int KU = a.lay.KU, KUp = a.lay.KUp;
+
+    // ---- stage X = [xyz | latent] feature-major ----
+    for (int e = tid; e < 3 * P; e += 512) {
+        const int p = e / 3, c = e - p * 3;
+        const long gp = p0 + p;
+        float v = 0.f;
+        if (gp < a.N) {
+            const long pi = a.points_period > 0 ? gp % a.points_period : gp;
+            v = a.points[pi * 3 + c];
+        }
+        Xs[c * LDX + p] = v;
+    }
+    if constexpr (!SHAPE_BIAS) {
+        const int L = a.L;
+        for (int e = tid; e < P * L; e += 512) {
+            const int p = e / L, k = e - p * L;
+            const long gp = p0 + p;
+            float v = 0.f;
+            if (gp < a.N) {
+                const long row = a.latent_idx ? (long)a.latent_idx[gp] : gp;
+                v = a.latent[row * L + k];
+            }
+            Xs[(3 + k) * LDX + p] = v;
+        }
+    }
+    for (int e = tid; e < (KUp - KU) * P; e += 512) {
+        const int k = KU + e / P, p = e % P;
+        Xs[k * LDX + p] = 0.f;
+    }
+    __syncthreads();
+
+    const float* bias = a.packed + a.lay.B;
+    const long shape = SHAPE_BIAS ? (p0 / a.pps) : 0;
+    const float4* pk = reinterpret_cast<const float4*>(a.packed);
+
+    f32x16 acc[NT];
+    auto init_acc = [&](const float* b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float bv = b[wave * 32 + frag_row(q, kh)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][q] = bv;
+        }
+    };
+    auto writeback = [&](int layer) {  // H <- relu(acc); optionally save
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = wave * 32 + frag_row(q, kh);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float v = fmaxf(acc[t][q], 0.f);
+                Hs[row * P + t * 32 + r] = v;
+                if (a.acts) {
+                    const long gp = p0 + t * 32 + r;
+                    if (gp < a.N) a.acts[((long)layer * kH + row) * a.ldn + gp] = v;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    auto wtile = [&](long off, int nsq) { return pk + (off >> 2) + (long)wave * nsq * 64; };
+
+    // layer 1: K over X
+    init_acc(SHAPE_BIAS ? a.zb1 + shape * kH : bias);
+    mlp_gemm<NT>(acc, wtile(a.lay.F1, KUp / 8), KUp / 8, Xs, LDX, lane);
+    writeback(0);
+    // layers 2..4
+    const long Fm[3] = {a.lay.F2, a.lay.F3, a.lay.F4};
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        init_acc(bias + (l + 1) * kH);
+        mlp_gemm<NT>(acc, wtile(Fm[l], kH / 8), kH / 8, Hs, P, lane);
+        writeback(l + 1);
+    }
+    // layer 5: K over H (256) then X (skip connection, model/sdf_net.py:59)
+    init_acc(SHAPE_BIAS ? a.zb5 + shape * kH : bias + 4 * kH);
+    mlp_gemm<NT>(acc, wtile(a.lay.F5x, kH / 8), kH / 8, Hs, P, lane);
+    mlp_gemm<NT>(acc, wtile(a.lay.F5i, KUp / 8), KUp / 8, Xs, LDX, lane);
+    writeback(4);
+    // layers 6, 7
+    const long Fn[2] = {a.lay.F6, a.lay.F7};
+#pragma unroll 1
+    for (int l = 0; l < 2; ++l) {
+        init_acc(bias + (5 + l) * kH);
+        mlp_gemm<NT>(acc, wtile(Fn[l], kH / 8), kH / 8, Hs, P, lane);
+        writeback(5 + l);
+    }
+    // layer 8: 256 -> 1, tanh.  512/P partial dot products per point, reduced through LDS.
+    {
+        constexpr int PARTS = 512 / P;
+        constexpr int ROWS = kH / PARTS;
+        const int p = tid % P, part = tid / P;
+        const float* w8 = a.packed + a.lay.W8;
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = part * ROWS; k < (part + 1) * ROWS; ++k) s = fmaf(w8[k], Hs[k * P + p], s);
+        red[tid] = s;
+        __syncthreads();
+        if (tid < P) {
+            float v = bias[7 * kH];
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) v += red[q * P + tid];
+            const long gp = p0 + tid;
+            if (gp < a.N) a.out[gp] = tanhf(v);
+        }
+    }
+}
+
+struct SdfBwdArgs {
+    const float* dout;   // [N]
+    const float* out;    // [N] forward output (tanh)
+    const float* acts;   // [7][256][ldn]
+    float* dz;           // [7][256][ldn]  dZ1..dZ7
+    float* dz8;          // [N]
+    float* dx;           // optional: input gradient, row-major [N][dx_ld] (first KU columns written)
+    long dx_ld;
+    const float* packed;
+    SdfPackLayout lay;
+    long ldn;
+    long N;
+};
+
+// Backward-data chain for one tile of P points.  G[256][P] holds dH_l; the X-gradient tile DX[KUr][P+1]
+// accumulates W5i^T dZ5 + W1^T dZ1 (only when a.dx != nullptr).
+template <int P>
+__global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
+    constexpr int NT = P / 32;
+    constexpr int LDX = P + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;            // [256][P]
+    float* DXs = Gs + kH * P;    // [KUr][LDX]
+    float* dz8s = DXs + (a.dx ? a.lay.KUr * LDX : 0);  // [P]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    const long p0 = (long)blockIdx.x * P;
+    const float4* pk = reinterpret_cast<const float4*>(a.packed);
+    const int KUr = a.lay.KUr;
+    const int nxt = KUr / 32;  // X row tiles
+
+    if (tid < P) {
+        const long gp = p0 + tid;
+        float v = 0.f;
+        if (gp < a.N) {
+            const float o = a.out[gp];
+            v = a.dout[gp] * (1.f - o * o);
+            a.dz8[gp] = v;
+        }
+        dz8s[tid] = v;
+    }
+    __syncthreads();
+    {  // dH7 = w8 (x) dz8
+        const float* w8 = a.packed + a.lay.W8;
+        for (int e = tid; e < kH * P; e += 512) {
+            const int row = e / P, p = e - row * P;
+            Gs[e] = w8[row] * dz8s[p];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    };
+    // G <- G * (H_l > 0), also stored as dZ_l
+    auto mask_and_save = [&](int layer) {
+        const float* h = a.acts + (long)layer * kH * a.ldn;
+        float* z = a.dz + (long)layer * kH * a.ldn;
+        for (int e = tid; e < kH * P; e += 512) {
+            const int row = e / P, p = e - row * P;
+            const long gp = p0 + p;
+            float g = 0.f;
+            if (gp < a.N) {
+                g = h[(long)row * a.ldn + gp] > 0.f ? Gs[e] : 0.f;
+                z[(long)row * a.ldn + gp] = g;
+            }
+            Gs[e] = g;
+        }
+        __syncthreads();
+    };
+    // DX (+)= T(KUr x 256) * G ; waves [0, nxt) each own one 32-row tile
+    auto x_grad = [&](long toff, bool first) {
+        if (a.dx) {
+            for (int xt = wave; xt < nxt; xt += 8) {
+                zero_acc();
+                mlp_gemm<NT>(acc, pk + (toff >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = xt * 32 + frag_row(q, kh);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        float* d = &DXs[row * LDX + t * 32 + r];
+                        *d = first ? acc[t][q] : (*d + acc[t][q]);
+                    }
+                }
+            }
+        }
+    };
+    auto back_step = [&](long toff) {  // G <- T_l * G
+        zero_acc();
+        mlp_gemm<NT>(acc, pk + (toff >> 2) + (long)wave * (kH / 8) * 64, kH / 8, Gs, P, lane);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = wave * 32 + frag_row(q, kh);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Gs[row * P + t * 32 + r] = acc[t][q];
+        }
+        __syncthreads();
+    };
+
+    mask_and_save(6);          // dZ7
+    back_step(a.lay.T7);       // dH6
+    mask_and_save(5);          // dZ6
+    back_step(a.lay.T6);       // dH5
+    mask_and_save(4);          // dZ5
+    x_grad(a.lay.T5i, true);   // dX  = W5[:,256:]^T dZ5
+    back_step(a.lay.T5x);      // dH4 (x_grad reads G before back_step's first barrier; DX is a separate region)
+    mask_and_save(3);          // dZ4
+    back_step(a.lay.T4);
+    mask_and_save(2);          // dZ3
+    back_step(a.lay.T3);
+    mask_and_save(1);          // dZ2
+    back_step(a.lay.T2);
+    mask_and_save(0);          // dZ1
+    x_grad(a.lay.T1, false);   // dX += W1^T dZ1
+    if (a.dx) {
+        __syncthreads();
+        const int KU = a.lay.KU;
+        for (int e = tid; e < P * KU; e += 512) {
+            const int p = e / KU, k = e - p * KU;
+            const long gp = p0 + p;
+            if (gp < a.N) a.dx[gp * a.dx_ld + k] = DXs[k * LDX + p];
+        }
+    }
+}
+
+static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
+static size_t bwd_lds_bytes(int P, int KUr, bool dx) {
+    return ((size_t)kH * P + (dx ? (size_t)KUr * (P + 1) : 0) + P) * sizeof(float);
+}
+
+template <class K>
+static int set_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess) return -1;
+    }
+    return 0;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+size_t sg_sdfnet_packed_floats(int kin_used) { return (size_t)make_layout(kin_used).total; }
+
+// params: host array of 16 device pointers in state_dict order
+//   layers1.{0,2,4,6}.{weight,bias}, layers2.{0,2,4,6}.{weight,bias}   (model/sdf_net.py:26-53)
+int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream) {
+    SG_CHECK_ARG(params && packed && latent >= 0 && (kin_used == 3 || kin_used == 3 + latent));
+    const SdfPackLayout L = make_layout(kin_used);
+    const int KIN = 3 + latent;
+    const float *W1 = params[0], *W2 = params[2], *W3 = params[4], *W4 = params[6];
+    const float *W5 = params[8], *W6 = params[10], *W7 = params[12], *W8 = params[14];
+    PackDescs D;
+    int n = 0;
+    auto add = [&](const float* src, long rs, long cs, int R, int C, int Rpad, int Cpad, long off) {
+        D.d[n++] = PackDesc{src, rs, cs, R, C, Rpad / 32, Cpad / 8, off};
+    };
+    const int ld5 = kH + KIN;
+    add(W1, KIN, 1, kH, L.KU, kH, L.KUp, L.F1);
+    add(W2, kH, 1, kH, kH, kH, kH, L.F2);
+    add(W3, kH, 1, kH, kH, kH, kH, L.F3);
+    add(W4, kH, 1, kH, kH, kH, kH, L.F4);
+    add(W5, ld5, 1, kH, kH, kH, kH, L.F5x);
+    add(W5 + kH, ld5, 1, kH, L.KU, kH, L.KUp, L.F5i);
+    add(W6, kH, 1, kH, kH, kH, kH, L.F6);
+    add(W7, kH, 1, kH, kH, kH, kH, L.F7);
+    add(W1, 1, KIN, L.KU, kH, L.KUr, kH, L.T1);
+    add(W2, 1, kH, kH, kH, kH, kH, L.T2);
+    add(W3, 1, kH, kH, kH, kH, kH, L.T3);
+    add(W4, 1, kH, kH, kH, kH, kH, L.T4);
+    add(W5, 1, ld5, kH, kH, kH, kH, L.T5x);
+    add(W5 + kH, 1, ld5, L.KU, kH, L.KUr, kH, L.T5i);
+    add(W6, 1, kH, kH, kH, kH, kH, L.T6);
+    add(W7, 1, kH, kH, kH, kH, kH, L.T7);
+    D.n = n;
+    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n), dim3(256), 0, stream, D, packed);
+    hipLaunchKernelGGL(copy_vectors_kernel, dim3(1), dim3(256), 0, stream, params[1], params[3], params[5], params[7],
+                       params[9], params[11], params[13], params[15], W8, packed + L.B, packed + L.W8);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Forward.  per-point latent mode: zb1 == zb5 == NULL, latent = [N,L] rows (or table + latent_idx), packed built
+// with kin_used = 3+L.  per-shape mode: zb1/zb5 = [S,256] folded biases, packed built with kin_used = 3,
+// points_per_shape a multiple of 128 (or >= N for a single shape).
+int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, const int64_t* latent_idx, int latent_size,
+                  const float* packed, int kin_used, const float* zb1, const float* zb5, long points_per_shape,
+                  float* out, float* acts, long ldn, long N, hipStream_t stream) {
+    SG_CHECK_ARG(points && packed && out && N > 0);
+    SdfFwdArgs a;
+    a.points = points;
+    a.points_period = points_period;
+    a.latent = latent;
+    a.latent_idx = latent_idx;
+    a.L = latent_size;
+    a.packed = packed;
+    a.lay = make_layout(kin_used);
+    a.zb1 = zb1;
+    a.zb5 = zb5;
+    a.pps = points_per_shape;
+    a.out = out;
+    a.acts = acts;
+    a.ldn = ldn;
+    a.N = N;
+    if (acts) SG_CHECK_ARG(ldn >= N);
+    const bool shape_bias = zb1 != nullptr;
+    if (shape_bias) {
+        SG_CHECK_ARG(zb5 && kin_used == 3 && points_per_shape > 0);
+        SG_CHECK_ARG(points_per_shape % 128 == 0 || points_per_shape >= N);
+        const size_t lds = fwd_lds_bytes(128, a.lay.KUp);
+        if (set_lds(sdfnet_fwd_kernel<128, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<128, true>), dim3((unsigned)((N + 127) / 128)), dim3(512), lds, stream, a);
+    } else {
+        SG_CHECK_ARG(latent && kin_used == 3 + latent_size);
+        const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
+        if (lds > 160 * 1024) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_fwd: latent size %d needs %zu B LDS (> 160 KiB)", latent_size, lds);
+        if (set_lds(sdfnet_fwd_kernel<64, false>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false>), dim3((unsigned)((N + 63) / 64)), dim3(512), lds, stream, a);
+    }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Backward-data.  Writes dz8[N], dz[7][256][ldn] and (if dx != NULL) the input gradient rows dx[N][dx_ld]
+// (kin_used columns: d/dpoints (3) then d/dlatent (L) in per-point mode, d/dpoints only in per-shape mode).
+int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* dx, long dx_ld,
+                  const float* packed, int kin_used, long ldn, long N, hipStream_t stream) {
+    SG_CHECK_ARG(dout && out && acts && dz && dz8 && packed && N > 0 && ldn >= N);
+    SdfBwdArgs a;
+    a.dout = dout;
+    a.out = out;
+    a.acts = acts;
+    a.dz = dz;
+    a.dz8 = dz8;
+    a.dx = dx;
+    a.dx_ld = dx_ld;
+    a.packed = packed;
+    a.lay = make_layout(kin_used);
+    a.ldn = ldn;
+    a.N = N;
+    if (dx) SG_CHECK_ARG(dx_ld >= kin_used);
+    if (kin_used == 3) {
+        const size_t lds = bwd_lds_bytes(128, a.lay.KUr, dx != nullptr);
+        if (set_lds(sdfnet_bwd_kernel<128>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_bwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_bwd_kernel<128>), dim3((unsigned)((N + 127) / 128)), dim3(512), lds, stream, a);
+    } else {
+        const size_t lds = bwd_lds_bytes(64, a.lay.KUr, dx != nullptr);
+        if (lds > 160 * 1024) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_bwd: kin %d needs %zu B LDS (> 160 KiB)", kin_used, lds);
+        if (set_lds(sdfnet_bwd_kernel<64>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_bwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_bwd_kernel<64>), dim3((unsigned)((N + 63) / 64)), dim3(512), lds, stream, a);
+    }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+}  // extern "C"

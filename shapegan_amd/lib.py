@@ -1,0 +1,126 @@
+"""ctypes binding of libshapegan_hip.so — the only door from Python into the HIP kernels.
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing (not built) or a call
+fails, this module raises.  Signatures mirror include/shapegan_hip.h one to one.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshapegan_hip.so")
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+_P, _I, _L, _F, _Z = c_void_p, c_int, c_long, c_float, c_size_t
+
+# name -> (restype, argtypes); every symbol include/shapegan_hip.h declares
+SIGNATURES = {
+    "sg_abi_version": (c_int, []),
+    "sg_last_error": (c_char_p, []),
+    "sg_conv3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
+    "sg_conv3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_conv3d_k4s2p1_wgrad_workspace_bytes": (_Z, [_I, _I]),
+    "sg_conv3d_k4s2p1_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "sg_convT3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_convT3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sg_convT3d_k4s2p1_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "sg_gemm_workspace_bytes": (_Z, [_I, _I]),
+    "sg_gemm": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_colsum": (c_int, [_P, _P, _I, _I, _L, _P]),
+    "sg_rowsum": (c_int, [_P, _P, _L, _L, _L, _P]),
+    "sg_bn_workspace_bytes": (_Z, [_I]),
+    "sg_bn_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
+    "sg_bn_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _F, _P]),
+    "sg_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _Z, _P]),
+    "sg_act_fwd": (c_int, [_P, _P, _L, _I, _F, _P]),
+    "sg_act_bwd": (c_int, [_P, _P, _P, _L, _I, _F, _P]),
+    "sg_sdfnet_packed_floats": (_Z, [_I]),
+    "sg_sdfnet_pack": (c_int, [_P, _I, _I, _P, _P]),
+    "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _L, _L, _P]),
+    "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _L, _L, _P]),
+    "sg_axpby": (c_int, [_P, _P, _P, _L, _F, _F, _P]),
+    "sg_reduce_workspace_bytes": (_Z, []),
+    "sg_reduce_sum": (c_int, [_P, _P, _L, _F, _P, _Z, _P]),
+    "sg_gather_rows": (c_int, [_P, _P, _P, _L, _I, _P]),
+    "sg_scatter_add_rows": (c_int, [_P, _L, _P, _P, _L, _I, _P]),
+    "sg_rmsprop_step": (c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
+    "sg_adam_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P]),
+    "sg_clamp": (c_int, [_P, _L, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libshapegan_hip.so is missing at %s — build it with `python -m shapegan_amd.build` "
+            "(there is no CPU / eager fallback for the shapegan_amd hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sg_abi_version() != 1:
+        raise RuntimeError("libshapegan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sg_last_error()
+        raise RuntimeError("shapegan_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("shapegan_amd kernels need tensors on the GPU (got %s); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("shapegan_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(name, nbytes, device):
+    """Caller-owned scratch, cached per (device, stream, name) and grown on demand."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream(), name)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def f32c(t):
+    """fp32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# Kernels that update parameters through raw pointers do not bump tensor._version; anything that caches a
+# derived image of parameters (the SDFNet MFMA weight pack) keys on this counter as well.
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1

@@ -1,0 +1,75 @@
+"""Voxel GAN: `Generator` (z[128] -> 32^3 SDF) and `Discriminator` (32^3 -> score), the reference's
+model/gan.py:4-69 surface on HIP kernels.
+
+state_dict keys match the reference (`layers.{0,3,6,9}.{weight,bias}` + BatchNorm3d at `layers.{1,4,7}` for the
+generator; `layers.{0,2,4,6}.{weight,bias}` for the discriminator), so checkpoints interchange.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import ACT_SIGMOID
+from ..util import device as default_device
+from ..util import standard_normal_distribution
+from . import LATENT_CODE_SIZE, Lambda, SavableModule
+from .stack import run_stack
+
+# (in, out, stride, padding) of the four transposed convolutions, model/gan.py:9-21
+_G_CONVS = ((LATENT_CODE_SIZE, 256, 1, 0), (256, 128, 2, 1), (128, 64, 2, 1), (64, 1, 2, 1))
+# model/gan.py:49-55
+_D_CONVS = ((1, 64, 2, 1), (64, 128, 2, 1), (128, 256, 2, 1), (256, 1, 1, 0))
+
+
+class Generator(SavableModule):
+    def __init__(self):
+        super().__init__(filename="generator.to")
+        layers = []
+        for idx, (cin, cout, stride, pad) in enumerate(_G_CONVS):
+            layers.append(nn.ConvTranspose3d(in_channels=cin, out_channels=cout, kernel_size=4, stride=stride,
+                                             padding=pad))
+            if idx + 1 < len(_G_CONVS):
+                layers += [nn.BatchNorm3d(cout), nn.LeakyReLU(negative_slope=0.2)]
+            else:
+                layers.append(nn.Tanh())
+        self.layers = nn.Sequential(*layers)
+        self.to(default_device)
+
+    def forward(self, x):
+        x = x.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1))
+        return run_stack(self.layers, x, self.training)
+
+    def generate(self, sample_size=1):
+        # latents are drawn on the CPU and moved (model/gan.py:31-34): reproducible across backends
+        z = standard_normal_distribution.sample(torch.Size((sample_size, LATENT_CODE_SIZE))).to(self.device)
+        return self(z)
+
+    def copy_autoencoder_weights(self, autoencoder):
+        raise Exception("Not implemented.")  # as in the reference (model/gan.py:36-40)
+
+
+class Discriminator(SavableModule):
+    def __init__(self):
+        super().__init__(filename="discriminator.to")
+        self.use_sigmoid = True
+        layers = []
+        for idx, (cin, cout, stride, pad) in enumerate(_D_CONVS):
+            layers.append(nn.Conv3d(in_channels=cin, out_channels=cout, kernel_size=4, stride=stride, padding=pad))
+            if idx + 1 < len(_D_CONVS):
+                layers.append(nn.LeakyReLU(negative_slope=0.2))
+        # `use_sigmoid` is read at call time, exactly like the reference's closure (model/gan.py:56)
+        layers.append(Lambda(lambda t: ops.Act.apply(t, ACT_SIGMOID, 0.0) if self.use_sigmoid else t))
+        self.layers = nn.Sequential(*layers)
+        self.to(default_device)
+
+    def forward(self, x):
+        if len(x.shape) < 5:
+            x = x.unsqueeze(dim=1)  # channel axis
+        return run_stack(self.layers, x, self.training).squeeze()
+
+    def clip_weights(self, value):
+        """WGAN weight clipping (model/gan.py:67-69) — one clamp launch per parameter tensor, in place on the
+        real storage.  shapegan_amd.optim.RMSprop(clip=value) fuses it into the optimizer step instead."""
+        lib = ops.L.load()
+        for p in self.parameters():
+            ops.check(lib.sg_clamp(ops.ptr(p.data), p.numel(), -value, value, ops.stream()), "clamp")
+        ops.L.bump_param_epoch()

@@ -1,0 +1,71 @@
+"""Progressively grown 3-D CNN discriminator (model/progressive_gan.py:4-61) on HIP kernels.
+
+Four optional Conv3d(k4,s2,p1)+LeakyReLU stages for 8^3/16^3/32^3/64^3 inputs and a Linear head; both registrations
+of every stage (`optional_layers.i.*` and `optional_layer_i.*`) are kept so state_dict keys match the reference.
+`from_SDF`'s C-1 zero channels are never materialised: the first stage's kernel reads channel 0 of its weight only,
+its weight gradient for the other input channels is exactly zero (as in the reference, whose inputs there are 0).
+"""
+import torch
+import torch.nn as nn
+
+from ..lib import ACT_LEAKY
+from .. import ops
+from . import LATENT_CODE_SIZE, Lambda, SavableModule  # noqa: F401  (LATENT_CODE_SIZE re-exported like the reference)
+from .stack import run_stack
+
+RESOLUTIONS = [8, 16, 32, 64]
+FEATURE_COUNTS = [128, 64, 32, 1]
+FINAL_LAYER_FEATURES = 256
+
+
+def from_SDF(x, iteration):
+    """Reference semantics (model/progressive_gan.py:9-16): [B,R,R,R] -> [B,C,R,R,R] with C-1 zero channels.
+    Kept for callers that want the materialised tensor; the discriminator itself does not use it."""
+    resolution = RESOLUTIONS[iteration]
+    features = FEATURE_COUNTS[iteration]
+    x = x.reshape((-1, 1, resolution, resolution, resolution))
+    pad = torch.zeros((x.shape[0], features - 1, resolution, resolution, resolution), device=x.device)
+    return torch.cat((x, pad), dim=1)
+
+
+class Discriminator(SavableModule):
+    def __init__(self):
+        super().__init__(filename="hybrid_progressive_gan_discriminator_0.to")
+        self.iteration = 0
+        self.filename_base = "hybrid_progressive_gan_discriminator_{:d}.to"
+        self.fade_in_progress = 1
+
+        self.head = nn.Sequential(
+            Lambda(lambda t: t.reshape(-1, 64 * FINAL_LAYER_FEATURES)),
+            nn.Linear(64 * FINAL_LAYER_FEATURES, 128),
+            nn.LeakyReLU(negative_slope=0.2),
+            nn.Linear(128, 1),
+        )
+        self.optional_layers = nn.ModuleList()
+        for i, cin in enumerate(FEATURE_COUNTS):
+            cout = FEATURE_COUNTS[i - 1] if i > 0 else FINAL_LAYER_FEATURES
+            stage = nn.Sequential(nn.Conv3d(in_channels=cin, out_channels=cout, kernel_size=4, stride=2, padding=1),
+                                  nn.LeakyReLU(negative_slope=0.2))
+            self.optional_layers.append(stage)
+            self.add_module('optional_layer_{:d}'.format(i), stage)
+
+    def forward(self, x):
+        it = self.iteration
+        res = RESOLUTIONS[it]
+        x_in = x
+        # stage `it` on the single real channel (the conv kernel skips the zero-padded channels of from_SDF)
+        x = x.reshape((-1, 1, res, res, res))
+        conv = self.optional_layers[it][0]
+        x = ops.conv3d_k4s2p1(x, conv.weight, conv.bias, ACT_LEAKY, 0.2)
+        if (self.fade_in_progress < 1.0) and it > 0:
+            # blend with the nearest-neighbour downsampled input injected on channel 0 (progressive_gan.py:48-50)
+            half = x_in.reshape((-1, res, res, res))[:, ::2, ::2, ::2]
+            x2 = from_SDF(half, it - 1)
+            x = self.fade_in_progress * x + (1.0 - self.fade_in_progress) * x2
+        for i in range(it - 1, -1, -1):
+            x = run_stack(self.optional_layers[i], x, self.training)
+        return run_stack(self.head, x, self.training).squeeze()
+
+    def set_iteration(self, value):
+        self.iteration = value
+        self.filename = self.filename_base.format(self.iteration)

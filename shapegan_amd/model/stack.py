@@ -1,0 +1,105 @@
+"""Executor that runs an nn.Sequential of *parameter containers* on the HIP kernels.
+
+The model classes keep torch.nn layer objects (nn.Conv3d, nn.BatchNorm3d, nn.Linear, ...) purely as owners of
+parameters and buffers: that gives the reference's state_dict keys, default initialisation (same RNG draws under
+the same seed) and .to()/.cuda() behaviour for free.  Their ATen forward is never called — `run_stack` walks the
+container, groups [conv|linear] -> [batchnorm] -> [activation] runs and dispatches each group to one fused
+shapegan_amd.ops call (bias and activation in the GEMM epilogue, LeakyReLU folded into the batch-norm apply pass).
+"""
+import torch.nn as nn
+
+from .. import ops
+from ..lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from . import Lambda
+
+
+def _act_of(m):
+    if isinstance(m, nn.LeakyReLU):
+        return ACT_LEAKY, float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return ACT_RELU, 0.0
+    if isinstance(m, nn.Tanh):
+        return ACT_TANH, 0.0
+    if isinstance(m, nn.Sigmoid):
+        return ACT_SIGMOID, 0.0
+    return None
+
+
+def _is_k4(m, stride, padding):
+    return tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (stride,) * 3 and tuple(m.padding) == (padding,) * 3
+
+
+def _producer(m, x, act, slope):
+    """One conv / linear layer with `act` fused into its epilogue."""
+    if isinstance(m, nn.Conv3d):
+        if _is_k4(m, 2, 1):
+            return ops.conv3d_k4s2p1(x, m.weight, m.bias, act, slope)
+        if _is_k4(m, 1, 0) and tuple(x.shape[2:]) == (4, 4, 4):
+            # 4^3 -> 1^3: a GEMM over (ci, tap)  (model/gan.py:55, model/autoencoder.py:28)
+            y = ops.LinearAct.apply(x.reshape(x.shape[0], -1), m.weight.reshape(m.out_channels, -1), m.bias, act, slope,
+                                    False, 0)
+            return y.reshape(x.shape[0], m.out_channels, 1, 1, 1)
+    elif isinstance(m, nn.ConvTranspose3d):
+        if _is_k4(m, 2, 1):
+            return ops.conv_transpose3d_k4s2p1(x, m.weight, m.bias, act, slope)
+        if _is_k4(m, 1, 0) and tuple(x.shape[2:]) == (1, 1, 1):
+            # 1^3 -> 4^3: y[b, co*64+tap] = x[b,:] @ W[:, co*64+tap] + bias[co]  (model/gan.py:9, autoencoder.py:51)
+            y = ops.LinearAct.apply(x.reshape(x.shape[0], -1), m.weight.reshape(m.in_channels, -1), m.bias, act, slope,
+                                    True, 6)
+            return y.reshape(x.shape[0], m.out_channels, 4, 4, 4)
+    elif isinstance(m, nn.Linear):
+        return ops.LinearAct.apply(x, m.weight, m.bias, act, slope, False, 0)
+    raise NotImplementedError("shapegan_amd has no HIP kernel for %r on input %s" % (m, tuple(x.shape)))
+
+
+def _batchnorm(m, x, act, slope, training):
+    use_batch_stats = training or not m.track_running_stats
+    momentum = 0.1 if m.momentum is None else m.momentum
+    return ops.BatchNormAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var,
+                                  m.num_batches_tracked if use_batch_stats else None, use_batch_stats, m.eps, momentum,
+                                  act, slope)
+
+
+def run_stack(modules, x, training):
+    mods = list(modules)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d, nn.Linear)):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, (nn.BatchNorm3d, nn.BatchNorm1d)):
+                x = _producer(m, x, ACT_NONE, 0.0)
+                a = _act_of(mods[i + 2]) if i + 2 < len(mods) else None
+                if a is not None:
+                    x = _batchnorm(nxt, x, a[0], a[1], training)
+                    i += 3
+                else:
+                    x = _batchnorm(nxt, x, ACT_NONE, 0.0, training)
+                    i += 2
+                continue
+            a = _act_of(nxt) if nxt is not None else None
+            if a is not None:
+                x = _producer(m, x, a[0], a[1])
+                i += 2
+            else:
+                x = _producer(m, x, ACT_NONE, 0.0)
+                i += 1
+            continue
+        if isinstance(m, (nn.BatchNorm3d, nn.BatchNorm1d)):
+            a = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+            if a is not None:
+                x = _batchnorm(m, x, a[0], a[1], training)
+                i += 2
+            else:
+                x = _batchnorm(m, x, ACT_NONE, 0.0, training)
+                i += 1
+            continue
+        a = _act_of(m)
+        if a is not None:
+            x = ops.Act.apply(x, a[0], a[1])
+        elif isinstance(m, Lambda):
+            x = m.function(x)
+        else:
+            raise NotImplementedError("shapegan_amd has no HIP kernel for %r" % (m,))
+        i += 1
+    return x

@@ -1,0 +1,616 @@
+"""torch.autograd.Function shells over the C ABI (include/shapegan_hip.h).
+
+Every Function's backward is written in terms of the other Functions here, so the set is closed under
+differentiation: `autograd.grad(..., create_graph=True)` (WGAN-GP, train_hybrid_progressive_gan.py:102-111) works
+without any extra kernel — convolution and matmul are bilinear, LeakyReLU's derivative is a mask.
+
+PyTorch is used for storage (device tensors), the autograd tape and stream handles only; all arithmetic on the
+hot path runs in libshapegan_hip.so.  There is no CPU fallback: tensors must live on the GPU.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib as L
+from .lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, check, f32c, ptr, stream, workspace  # noqa: F401
+
+
+def _lib():
+    return L.load()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# raw launches (no autograd)
+# --------------------------------------------------------------------------------------------------------------
+def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0):
+    """x [N,Cx,D,H,W], w [Co,Ct,4,4,4] -> act(conv_k4s2p1(x, w[:, :Cx]) + bias) [N,Co,D/2,H/2,W/2]."""
+    N, Cx, D, H, W = x.shape
+    Co, Ct = w.shape[0], w.shape[1]
+    if Cx > Ct:
+        raise RuntimeError("conv: input has %d channels, weight expects %d" % (Cx, Ct))
+    y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    check(_lib().sg_conv3d_k4s2p1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope,
+                                      stream()), "conv3d_fwd")
+    return y
+
+
+def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
+    """dy [N,Co,O,O,O], w [Co,Ct,4,4,4] -> act(conv^T(dy, w[:, :cin]) + bias) [N,cin,2O,2O,2O]."""
+    N, Co, OD, OH, OW = dy.shape
+    Ct = w.shape[1]
+    if w.shape[0] != Co or cin > Ct:
+        raise RuntimeError("conv dgrad: shape mismatch")
+    dx = torch.empty((N, cin, 2 * OD, 2 * OH, 2 * OW), dtype=torch.float32, device=dy.device)
+    lib = _lib()
+    nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes(Co, cin)
+    ws = workspace("dgrad", nb, dy.device)
+    check(lib.sg_conv3d_k4s2p1_dgrad(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
+                                     act, slope, ptr(ws), ws.numel(), stream()), "conv3d_dgrad")
+    return dx
+
+
+_WGRAD_WS_CAP = 256 << 20
+
+
+def conv_wgrad_raw(dy, x, ct):
+    """dy [N,Co,O,O,O], x [N,Cx,2O,2O,2O] -> dw [Co,ct,4,4,4] (channels >= Cx are zero)."""
+    N, Co, OD, OH, OW = dy.shape
+    Cx = x.shape[1]
+    if x.shape[0] != N or x.shape[2] != 2 * OD:
+        raise RuntimeError("conv wgrad: shape mismatch")
+    if Cx < ct:
+        dw = torch.zeros((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
+    else:
+        dw = torch.empty((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
+    lib = _lib()
+    nb = min(lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(Co, Cx), _WGRAD_WS_CAP)
+    ws = workspace("splitk", nb, dy.device)
+    check(lib.sg_conv3d_k4s2p1_wgrad(ptr(dy), ptr(x), ptr(dw), N, Cx, ct, Cx, Co, 2 * OD, 2 * OH, 2 * OW, ptr(ws),
+                                     ws.numel(), stream()), "conv3d_wgrad")
+    return dw
+
+
+def gemm_raw(a, ta, b, tb, bias_j=None, bias_shift=0, act=ACT_NONE, slope=0.0, out=None, a_off=0, b_off=0, M=None,
+             N=None, K=None, lda=None, ldb=None, ldc=None, c_off=0):
+    """out = act(op(a) @ op(b) + bias_j[j >> shift]);  a, b are 2-D row-major (leading dims lda/ldb),
+    op = transpose when ta/tb.  Offsets (elements) and explicit M/N/K allow column slices of bigger matrices."""
+    lda = a.shape[-1] if lda is None else lda
+    ldb = b.shape[-1] if ldb is None else ldb
+    if M is None:
+        M = a.shape[1] if ta else a.shape[0]
+    if K is None:
+        K = a.shape[0] if ta else a.shape[1]
+    if N is None:
+        N = b.shape[0] if tb else b.shape[1]
+    sai, sak = (1, lda) if ta else (lda, 1)
+    sbk, sbj = (1, ldb) if tb else (ldb, 1)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ldc = out.shape[-1] if ldc is None else ldc
+    lib = _lib()
+    nb = min(lib.sg_gemm_workspace_bytes(M, N), _WGRAD_WS_CAP)
+    ws = workspace("splitk", nb, a.device)
+    check(lib.sg_gemm(ptr(a) + 4 * a_off, sai, sak, ptr(b) + 4 * b_off, sbk, sbj, ptr(out) + 4 * c_off, ldc, 1, None,
+                      ptr(bias_j), bias_shift, M, N, K, act, slope, ptr(ws), ws.numel(), stream()), "gemm")
+    return out
+
+
+def act_bwd_raw(y, dy, act, slope):
+    dx = torch.empty_like(y)
+    check(_lib().sg_act_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), act, slope, stream()), "act_bwd")
+    return dx
+
+
+def act_fwd_raw(x, act, slope):
+    y = torch.empty_like(x)
+    check(_lib().sg_act_fwd(ptr(x), ptr(y), x.numel(), act, slope, stream()), "act_fwd")
+    return y
+
+
+def channel_sum_raw(g):
+    """g [N,C,*S] -> [C]  (bias gradient of a convolution)."""
+    N, C = g.shape[0], g.shape[1]
+    S = g.numel() // (N * C)
+    lib = _lib()
+    if S == 1:
+        out = torch.empty(C, dtype=torch.float32, device=g.device)
+        check(lib.sg_colsum(ptr(g), ptr(out), N, C, C, stream()), "colsum")
+        return out
+    tmp = torch.empty(N * C, dtype=torch.float32, device=g.device)
+    check(lib.sg_rowsum(ptr(g), ptr(tmp), N * C, S, S, stream()), "rowsum")
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    check(lib.sg_colsum(ptr(tmp), ptr(out), N, C, C, stream()), "colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# activations
+# --------------------------------------------------------------------------------------------------------------
+class ActBwd(Function):
+    """dx = dy * act'(.) with the derivative read off the activation OUTPUT y.  Linear in dy, so its own
+    backward w.r.t. dy is itself (this is LeakyReluBackwardBackward of the reference's GP graph)."""
+
+    @staticmethod
+    def forward(ctx, y, dy, act, slope):
+        y, dy = f32c(y), f32c(dy)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return act_bwd_raw(y, dy, act, slope)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        (y,) = ctx.saved_tensors
+        g_dy = ActBwd.apply(y, ggx, ctx.act, ctx.slope) if ctx.needs_input_grad[1] else None
+        # d/dy is zero almost everywhere for LeakyReLU/ReLU (the only activations on double-backward paths)
+        return None, g_dy, None, None
+
+
+class Act(Function):
+    """Stand-alone activation (used where no producer kernel exists to fuse into)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = f32c(x)
+        y = act_fwd_raw(x, act, slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ActBwd.apply(y, gy, ctx.act, ctx.slope), None, None
+
+
+class ChannelSum(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = f32c(g)
+        ctx.shape = g.shape
+        return channel_sum_raw(g)
+
+    @staticmethod
+    def backward(ctx, gg):
+        shape = ctx.shape
+        view = [1, shape[1]] + [1] * (len(shape) - 2)
+        return gg.reshape(view).expand(shape)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# convolution k4 s2 p1: three primitives closed under differentiation
+# --------------------------------------------------------------------------------------------------------------
+class ConvFwd(Function):
+    """y = act(conv3d_k4s2p1(x, w[:, :Cx]) + b) — nn.Conv3d forward and nn.ConvTranspose3d input-gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        x, w = f32c(x), f32c(w)
+        y = conv_fwd_raw(x, w, b, act, slope)
+        ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gz = ActBwd.apply(y, gy, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gy
+        gx = ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        gw = ConvWgrad.apply(gz, x, w.shape[1]) if ctx.needs_input_grad[1] else None
+        gb = ChannelSum.apply(gz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None
+
+
+class ConvDgrad(Function):
+    """dx = act(conv^T(dy, w[:, :cin]) + b) — nn.Conv3d input-gradient and nn.ConvTranspose3d forward."""
+
+    @staticmethod
+    def forward(ctx, dy, w, b, cin, act, slope):
+        dy, w = f32c(dy), f32c(w)
+        dx = conv_dgrad_raw(dy, w, b, cin, act, slope)
+        ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
+        ctx.save_for_backward(dy, w, dx if act != ACT_NONE else None)
+        return dx
+
+    @staticmethod
+    def backward(ctx, gdx):
+        dy, w, dx = ctx.saved_tensors
+        gz = ActBwd.apply(dx, gdx, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gdx
+        g_dy = ConvFwd.apply(gz, w, None, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        g_w = ConvWgrad.apply(dy, gz, w.shape[1]) if ctx.needs_input_grad[1] else None
+        g_b = ChannelSum.apply(gz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return g_dy, g_w, g_b, None, None, None
+
+
+class ConvWgrad(Function):
+    """dw[Co,ct,4,4,4] = sum_{n,o} dy[n,co,o] * x[n,ci,2o+tap-1] (channels >= Cx stay zero)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, ct):
+        dy, x = f32c(dy), f32c(x)
+        ctx.save_for_backward(dy, x)
+        return conv_wgrad_raw(dy, x, ct)
+
+    @staticmethod
+    def backward(ctx, gdw):
+        dy, x = ctx.saved_tensors
+        g_dy = ConvFwd.apply(x, gdw, None, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        g_x = ConvDgrad.apply(dy, gdw, None, x.shape[1], ACT_NONE, 0.0) if ctx.needs_input_grad[1] else None
+        return g_dy, g_x, None
+
+
+def conv3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0):
+    return ConvFwd.apply(x, w, b, act, slope)
+
+
+def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0):
+    """nn.ConvTranspose3d(k4,s2,p1): weight [Cin_T, Cout_T, 4,4,4] is the adjoint conv's [Cout, Cin] layout."""
+    return ConvDgrad.apply(x, w, b, w.shape[1], act, slope)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# GEMM / Linear
+# --------------------------------------------------------------------------------------------------------------
+class Gemm(Function):
+    """C = op(a) @ op(b) for 2-D a, b."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb):
+        a, b = f32c(a), f32c(b)
+        ctx.ta, ctx.tb = ta, tb
+        ctx.save_for_backward(a, b)
+        return gemm_raw(a, ta, b, tb)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                ga = Gemm.apply(gc, b, False, not tb)       # gC op(b)^T
+            else:
+                ga = Gemm.apply(b, gc, tb, True)            # op(b) gC^T
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                gb = Gemm.apply(a, gc, not ta, False)       # op(a)^T gC
+            else:
+                gb = Gemm.apply(gc, a, True, ta)            # gC^T op(a)
+        return ga, gb, None, None
+
+
+class ColSum(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = f32c(g)
+        ctx.rows = g.shape[0]
+        out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
+        check(_lib().sg_colsum(ptr(g), ptr(out), g.shape[0], g.shape[1], g.shape[1], stream()), "colsum")
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        return gg.unsqueeze(0).expand(ctx.rows, gg.shape[0])
+
+
+class LinearAct(Function):
+    """y = act(x @ W' + bias) with W' = w^T (nn.Linear layout [out,in]) or w (layout [in,out], w_kn=True);
+    bias[j >> bias_shift] lets one bias entry cover 64 taps of a 1^3 -> 4^3 ConvTranspose (model/gan.py:9)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope, w_kn, bias_shift):
+        x, w = f32c(x), f32c(w)
+        y = gemm_raw(x, False, w, not w_kn, bias_j=b, bias_shift=bias_shift, act=act, slope=slope)
+        ctx.cfg = (act, slope, w_kn, bias_shift, b is not None)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        act, slope, w_kn, bias_shift, has_b = ctx.cfg
+        gz = ActBwd.apply(y, gy, act, slope) if act != ACT_NONE else gy
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Gemm.apply(gz, w, False, w_kn)             # gz @ w  (or gz @ w^T when w is [in,out])
+        if ctx.needs_input_grad[1]:
+            gw = Gemm.apply(x, gz, True, False) if w_kn else Gemm.apply(gz, x, True, False)
+        if has_b and ctx.needs_input_grad[2]:
+            gb = ColSum.apply(gz)
+            if bias_shift:
+                gb = ColSum.apply(gb.reshape(-1, 1 << bias_shift).t())
+        return gx, gw, gb, None, None, None, None
+
+
+def linear(x, w, b, act=ACT_NONE, slope=0.0):
+    return LinearAct.apply(x, w, b, act, slope, False, 0)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BatchNorm (+ fused activation)
+# --------------------------------------------------------------------------------------------------------------
+class BatchNormAct(Function):
+    """act(batch_norm(x)) for x [N,C,*S]; training updates running stats in place exactly like torch
+    (momentum 0.1, unbiased running_var, num_batches_tracked += 1)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, eps, momentum, act,
+                slope):
+        x = f32c(x)
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        lib = _lib()
+        if training:
+            nb = lib.sg_bn_workspace_bytes(C)
+            ws = workspace("bn", nb, x.device)
+            check(lib.sg_bn_train_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
+                                      ptr(running_var), ptr(num_batches_tracked), N, C, S, eps, momentum, act, slope,
+                                      ptr(ws), ws.numel(), stream()), "bn_train_fwd")
+        else:
+            check(lib.sg_bn_eval_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(running_mean), ptr(running_var),
+                                     ptr(mean), ptr(invstd), N, C, S, eps, act, slope, stream()), "bn_eval_fwd")
+        ctx.cfg = (N, C, S, bool(training), act, slope)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, S, training, act, slope = ctx.cfg
+        gy = f32c(gy)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        lib = _lib()
+        ws = workspace("bn", lib.sg_bn_workspace_bytes(C), x.device)
+        check(lib.sg_bn_bwd(ptr(gy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dgamma),
+                            ptr(dbeta), N, C, S, 1 if training else 0, act, slope, ptr(ws), ws.numel(), stream()),
+              "bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# SDFNet fused MLP
+# --------------------------------------------------------------------------------------------------------------
+_H = 256
+
+
+class _PackCache(object):
+    """MFMA-fragment image of the 16 SDFNet tensors, rebuilt only when a parameter changed (in-place optimizer
+    steps bump tensor._version)."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+
+    def get(self, params, latent, kin_used):
+        key = (kin_used, latent, L.PARAM_EPOCH) + tuple((p.data_ptr(), p._version) for p in params)
+        if key != self.key or self.packed is None:
+            lib = _lib()
+            n = lib.sg_sdfnet_packed_floats(kin_used)
+            packed = torch.empty(n, dtype=torch.float32, device=params[0].device)
+            arr = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params])
+            check(lib.sg_sdfnet_pack(arr, latent, kin_used, ptr(packed), stream()), "sdfnet_pack")
+            self.key, self.packed = key, packed
+        return self.packed
+
+
+def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total):
+    """Weight/bias gradients from the saved dZ_l / H_l images.  x_parts: list of (tensor [N,w], col_offset, w)
+    blocks of the per-point input X that are materialised row-major (points, and latents in per-point mode)."""
+    lib = _lib()
+    dev = dz.device
+    grads = [None] * 16
+
+    def wgrad_from_acts(layer_dz, act_idx, out, c_off=0, ldc=_H):
+        # out[o, c_off + k] = sum_p dZ[o,p] * H[k,p]
+        gemm_raw(dz, False, acts, True, out=out, a_off=layer_dz * _H * ldn, b_off=act_idx * _H * ldn, M=_H, N=_H, K=N,
+                 lda=ldn, ldb=ldn, ldc=ldc, c_off=c_off)
+
+    def wgrad_from_rows(layer_dz, rows, width, out, c_off, ldc):
+        # out[o, c_off + k] = sum_p dZ[o,p] * rows[p,k]
+        gemm_raw(dz, False, rows, False, out=out, a_off=layer_dz * _H * ldn, M=_H, N=width, K=N, lda=ldn,
+                 ldb=rows.shape[1], ldc=ldc, c_off=c_off)
+
+    def bgrad(layer_dz):
+        out = torch.empty(_H, dtype=torch.float32, device=dev)
+        check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
+        return out
+
+    # layers1.0 / layers2.0 take X; pieces not materialised per point are filled by the caller afterwards
+    w1 = torch.zeros((_H, kin_total), dtype=torch.float32, device=dev)
+    w5 = torch.zeros((_H, _H + kin_total), dtype=torch.float32, device=dev)
+    for rows, off, width in x_parts:
+        wgrad_from_rows(0, rows, width, w1, off, kin_total)
+        wgrad_from_rows(4, rows, width, w5, _H + off, _H + kin_total)
+    wgrad_from_acts(4, 3, w5, 0, _H + kin_total)
+    grads[0], grads[8] = w1, w5
+    grads[1], grads[9] = bgrad(0), bgrad(4)
+    for pi, (ldz, ai) in zip((2, 4, 6, 10, 12), ((1, 0), (2, 1), (3, 2), (5, 4), (6, 5))):
+        g = torch.empty((_H, _H), dtype=torch.float32, device=dev)
+        wgrad_from_acts(ldz, ai, g)
+        grads[pi] = g
+        grads[pi + 1] = bgrad(ldz)
+    # layers2.6: W8 [1,256], b8 [1]
+    w8 = torch.empty((1, _H), dtype=torch.float32, device=dev)
+    gemm_raw(dz8, False, acts, True, out=w8, b_off=6 * _H * ldn, M=1, N=_H, K=N, lda=N, ldb=ldn, ldc=_H)
+    b8 = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib.sg_rowsum(ptr(dz8), ptr(b8), 1, N, N, stream()), "rowsum")
+    grads[14], grads[15] = w8, b8
+    return grads
+
+
+class SDFNetPoints(Function):
+    """SDFNet.forward(points[N,3], latent_codes[N,L]) with reference semantics (model/sdf_net.py:56-61)."""
+
+    @staticmethod
+    def forward(ctx, cache, points, latent, *params):
+        points, latent = f32c(points), f32c(latent)
+        N, Lz = latent.shape
+        kin = 3 + Lz
+        lib = _lib()
+        packed = cache.get(params, Lz, kin)
+        need_grad = any(ctx.needs_input_grad[1:])
+        out = torch.empty(N, dtype=torch.float32, device=points.device)
+        acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
+        check(lib.sg_sdfnet_fwd(ptr(points), 0, ptr(latent), None, Lz, ptr(packed), kin, None, None, 0, ptr(out),
+                                ptr(acts), N, N, stream()), "sdfnet_fwd")
+        ctx.cache, ctx.Lz = cache, Lz
+        ctx.save_for_backward(points, latent, out, acts, packed, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        points, latent, out, acts, packed = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        N, Lz = latent.shape
+        kin = 3 + Lz
+        gout = f32c(gout)
+        lib = _lib()
+        dev = out.device
+        dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
+        dz8 = torch.empty(N, dtype=torch.float32, device=dev)
+        need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(dx), kin, ptr(packed), kin, N, N,
+                                stream()), "sdfnet_bwd")
+        grads = [None] * 16
+        if any(ctx.needs_input_grad[3:]):
+            grads = _sdf_param_grads(params, ctx.needs_input_grad[3:], dz, dz8, acts, N, N,
+                                     [(points, 0, 3), (latent, 3, Lz)], kin)
+        gp = dx[:, :3] if ctx.needs_input_grad[1] else None
+        gl = dx[:, 3:] if ctx.needs_input_grad[2] else None
+        return (None, gp, gl) + tuple(grads)
+
+
+class SDFNetShapes(Function):
+    """Per-shape latents: out[s*pps + q] = SDFNet(points[s*pps + q], z[s]) without tiling z per point.
+    The latent columns of layers1.0 / layers2.0 become per-shape biases (same products, summed in a different
+    order than cat+Linear).  Replaces sample_latent_codes + generator(...) in train_hybrid_wgan.py:67-72,84-86 and
+    train_hybrid_progressive_gan.py:90-96,138-139."""
+
+    @staticmethod
+    def forward(ctx, cache, points, z, pps, *params):
+        points, z = f32c(points), f32c(z)
+        S, Lz = z.shape
+        N = S * pps
+        if points.shape[0] != N:
+            raise RuntimeError("SDFNetShapes: need points for all %d x %d samples" % (S, pps))
+        kin_total = 3 + Lz
+        lib = _lib()
+        packed = cache.get(params, Lz, 3)
+        w1, b1, w5, b5 = f32c(params[0]), params[1], f32c(params[8]), params[9]
+        # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]
+        zb1 = gemm_raw(z, False, w1, True, bias_j=b1, b_off=3, M=S, N=_H, K=Lz, lda=Lz, ldb=kin_total)
+        zb5 = gemm_raw(z, False, w5, True, bias_j=b5, b_off=_H + 3, M=S, N=_H, K=Lz, lda=Lz, ldb=_H + kin_total)
+        need_grad = any(ctx.needs_input_grad[1:])
+        out = torch.empty(N, dtype=torch.float32, device=points.device)
+        acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
+        check(lib.sg_sdfnet_fwd(ptr(points), 0, None, None, Lz, ptr(packed), 3, ptr(zb1), ptr(zb5), pps, ptr(out),
+                                ptr(acts), N, N, stream()), "sdfnet_fwd")
+        ctx.pps = pps
+        ctx.save_for_backward(points, z, out, acts, packed, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        points, z, out, acts, packed = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        S, Lz = z.shape
+        pps = ctx.pps
+        N = S * pps
+        kin_total = 3 + Lz
+        gout = f32c(gout)
+        lib = _lib()
+        dev = out.device
+        dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
+        dz8 = torch.empty(N, dtype=torch.float32, device=dev)
+        dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(dx), 3, ptr(packed), 3, N, N,
+                                stream()), "sdfnet_bwd")
+        need_p = any(ctx.needs_input_grad[4:])
+        need_z = ctx.needs_input_grad[2]
+        grads = [None] * 16
+        gz = None
+        if need_p or need_z:
+            # per-shape sums of dZ1 / dZ5: T[o, s] = sum_{p in shape s} dZ[o, p]   (rows of length pps are contiguous)
+            t1 = torch.empty((_H, S), dtype=torch.float32, device=dev)
+            t5 = torch.empty((_H, S), dtype=torch.float32, device=dev)
+            check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
+            check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
+        if need_p:
+            grads = _sdf_param_grads(params, ctx.needs_input_grad[4:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total)
+            # latent columns: dW1[:, 3:] = T1 @ z ; dW5[:, 259:] = T5 @ z
+            gemm_raw(t1, False, z, False, out=grads[0], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=kin_total, c_off=3)
+            gemm_raw(t5, False, z, False, out=grads[8], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=_H + kin_total,
+                     c_off=_H + 3)
+        if need_z:
+            w1, w5 = f32c(params[0]), f32c(params[8])
+            g1 = gemm_raw(t1, True, w1, False, b_off=3, M=S, N=Lz, K=_H, lda=S, ldb=kin_total)
+            g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
+            gz = torch.empty_like(g1)
+            check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
+        return (None, dx, gz, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# reductions and latent-table rows (K9 / K10)
+# --------------------------------------------------------------------------------------------------------------
+class Mean(Function):
+    """torch.mean over all elements as a two-stage deterministic HIP reduction (train_wgan.py:68,82)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = f32c(x)
+        ctx.shape, ctx.n = x.shape, x.numel()
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        lib = _lib()
+        ws = workspace("reduce", lib.sg_reduce_workspace_bytes(), x.device)
+        check(lib.sg_reduce_sum(ptr(x), ptr(out), x.numel(), 1.0 / x.numel(), ptr(ws), ws.numel(), stream()), "reduce_sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.n).expand(ctx.shape)
+
+
+def mean(x):
+    return Mean.apply(x)
+
+
+class GatherRows(Function):
+    """table[idx] for a 2-D table (latent_codes[model_indices], train_sdf_autodecoder.py:80); backward is the
+    index_add scatter into a zero table-shaped gradient."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        table = f32c(table)
+        n, width = idx.numel(), table.shape[1]
+        out = torch.empty((n, width), dtype=torch.float32, device=table.device)
+        check(_lib().sg_gather_rows(ptr(table), ptr(idx), ptr(out), n, width, stream()), "gather_rows")
+        ctx.rows = table.shape[0]
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        width = g.shape[1]
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        tg = torch.zeros((ctx.rows, width), dtype=torch.float32, device=g.device)
+        check(_lib().sg_scatter_add_rows(g.data_ptr(), g.stride(0), ptr(idx), ptr(tg), idx.numel(), width, stream()),
+              "scatter_add_rows")
+        return tg, None
+
+
+def gather_rows(table, idx):
+    return GatherRows.apply(table, idx)

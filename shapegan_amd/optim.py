@@ -1,0 +1,132 @@
+"""Fused flat-buffer optimizers (K11): torch.optim.RMSprop / torch.optim.Adam semantics with torch defaults, one
+HIP launch per step over a flat fp32 parameter buffer (instead of ~5 ATen launches per tensor), WGAN weight
+clipping folded into the RMSprop step, and the same flat gradient buffer serving as the RCCL all-reduce bucket.
+
+Reference call sites: optim.RMSprop(lr) in train_wgan.py:45-46, train_hybrid_progressive_gan.py:81-82,
+train_hybrid_wgan.py:56; optim.Adam(lr) in train_autoencoder.py:35, train_sdf_autodecoder.py:44-45,
+train_hybrid_wgan.py:53; critic.clip_weights(0.01) in train_wgan.py:71 / train_hybrid_wgan.py:94.
+
+The constructor re-points every parameter's `.data` (and `.grad`) at slices of two flat buffers; Parameter objects,
+state_dict keys and shapes are unchanged.  Parameters whose `.grad` is None at step time are skipped exactly like
+torch.optim does (unused progressive-GAN stages).
+"""
+import torch
+
+from . import lib as L
+from .lib import check, ptr, stream
+
+
+class _Flat(object):
+    def __init__(self, params):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        # 4-float alignment of every slice keeps float4 access legal for any consumer
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            if p.grad is not None:
+                self.grad[o:o + n].copy_(p.grad.reshape(-1))
+            p.grad = self.grad[o:o + n].view(p.shape)
+        L.bump_param_epoch()
+
+    def grad_view_ok(self, i):
+        p = self.params[i]
+        return p.grad is not None and p.grad.data_ptr() == self.grad.data_ptr() + 4 * self.offsets[i] \
+            and p.grad.is_contiguous()
+
+    def coherent(self):
+        return all(self.grad_view_ok(i) for i in range(len(self.params)))
+
+    def zero_grad(self):
+        """Zeroes the flat gradient buffer and re-attaches views that were dropped (e.g. by module.zero_grad())."""
+        self.grad.zero_()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if not self.grad_view_ok(i):
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class _Base(object):
+    def __init__(self, params):
+        self.f = _Flat(params)
+        self.grad_scale = 1.0  # set to 1/world_size by shapegan_amd.parallel for data-parallel averaging
+        self.param_groups = [{"params": self.f.params}]
+
+    def zero_grad(self, set_to_none=False):
+        self.f.zero_grad()
+
+    @property
+    def flat_grad(self):
+        return self.f.grad
+
+    def _segments(self):
+        """[(offset, length, grad_ptr)] of what to update: the whole buffer when every grad is the flat view,
+        else one segment per parameter that has a gradient."""
+        f = self.f
+        if f.coherent():
+            return [(0, f.total, f.grad.data_ptr())]
+        segs = []
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            if p.grad is None:
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if g.dtype != torch.float32:
+                g = g.float()
+            segs.append((o, p.numel(), g.data_ptr(), g))
+        return segs
+
+
+class RMSprop(_Base):
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, clip=0.0):
+        super().__init__(params)
+        self.lr, self.alpha, self.eps, self.clip = lr, alpha, eps, clip
+        self.square_avg = torch.zeros_like(self.f.flat)
+
+    def step(self):
+        lib = L.load()
+        base_p, base_s = self.f.flat.data_ptr(), self.square_avg.data_ptr()
+        for seg in self._segments():
+            o, n, g = seg[0], seg[1], seg[2]
+            check(lib.sg_rmsprop_step(base_p + 4 * o, g, base_s + 4 * o, n, self.lr, self.alpha, self.eps,
+                                      self.grad_scale, self.clip, stream()), "rmsprop_step")
+        L.bump_param_epoch()
+
+
+class Adam(_Base):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.exp_avg = torch.zeros_like(self.f.flat)
+        self.exp_avg_sq = torch.zeros_like(self.f.flat)
+        # torch keeps one step counter per parameter; a parameter that never had a grad never advances
+        self.steps = [0] * len(self.f.params)
+
+    def step(self):
+        lib = L.load()
+        f = self.f
+        base_p, base_m, base_v = f.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        uniform = f.coherent() and len(set(self.steps)) == 1
+        if uniform:
+            self.steps = [s + 1 for s in self.steps]
+            check(lib.sg_adam_step(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
+                                   self.betas[1], self.eps, self.steps[0], self.grad_scale, stream()), "adam_step")
+        else:
+            for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+                if p.grad is None:
+                    continue
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                self.steps[i] += 1
+                check(lib.sg_adam_step(base_p + 4 * o, g.data_ptr(), base_m + 4 * o, base_v + 4 * o, p.numel(), self.lr,
+                                       self.betas[0], self.betas[1], self.eps, self.steps[i], self.grad_scale,
+                                       stream()), "adam_step")
+        L.bump_param_epoch()

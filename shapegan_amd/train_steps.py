@@ -1,0 +1,260 @@
+"""The inner-loop bodies of the five in-scope training scripts, restated as step methods on the native modules.
+
+Python owns the loops (north star); every heavy op inside a step is a HIP kernel behind shapegan_amd.ops /
+shapegan_amd.optim.  Each method cites the reference lines it restates; random draws (latents, GP alpha) are
+arguments so that parity tests can inject the reference's values.  Data-parallel runs insert exactly one flat
+gradient all-reduce per optimizer step (shapegan_amd.parallel.GradBucket); single-process runs skip it.
+"""
+import contextlib
+
+import torch
+
+from . import ops, optim
+from .parallel import GradBucket, allreduce_tensor_, world_size
+
+
+@contextlib.contextmanager
+def frozen(module):
+    """Skip weight-gradient kernels for a network whose gradients the step discards anyway."""
+    flags = [p.requires_grad for p in module.parameters()]
+    for p in module.parameters():
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in zip(module.parameters(), flags):
+            p.requires_grad_(f)
+
+
+class WGANTrainer(object):
+    """train_wgan.py: RMSprop(lr 5e-5) for both nets, n_critic 5, weight clipping 0.01, batch 64."""
+
+    def __init__(self, generator, critic, lr=0.00005, clip=0.01):
+        self.generator, self.critic = generator, critic
+        critic.use_sigmoid = False                                   # train_wgan.py:31
+        self.g_opt = optim.RMSprop(generator.parameters(), lr=lr)    # :45
+        self.c_opt = optim.RMSprop(critic.parameters(), lr=lr, clip=clip)  # :46 + clip_weights :71 fused
+        self.g_bucket, self.c_bucket = GradBucket(self.g_opt), GradBucket(self.c_opt)
+
+    def critic_step(self, real, z):
+        """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw."""
+        self.c_opt.zero_grad()
+        with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
+            fake = self.generator(z)
+        out_fake = self.critic(fake)
+        out_real = self.critic(real)
+        loss = ops.mean(out_fake) - ops.mean(out_real)
+        loss.backward()
+        self.c_bucket.allreduce()
+        self.c_opt.step()
+        return loss.detach(), out_fake.detach(), out_real.detach()
+
+    def generator_step(self, z):
+        """train_wgan.py:74-84 (always BATCH_SIZE fresh latents).  The reference also accumulates critic weight
+        gradients here and throws them away at the next critic.zero_grad(); they are not computed."""
+        self.g_opt.zero_grad()
+        fake = self.generator(z)
+        with frozen(self.critic):
+            out = self.critic(fake)
+        loss = -ops.mean(out)
+        loss.backward()
+        self.g_bucket.allreduce()
+        self.g_opt.step()
+        return loss.detach(), out.detach()
+
+    def step(self, reals, zs_critic, z_gen):
+        """One 5+1 unit: batch_index % 5 == 0 trains the critic and the generator, the next four batches the critic."""
+        last = None
+        for i, (real, z) in enumerate(zip(reals, zs_critic)):
+            last = self.critic_step(real, z)
+            if i == 0:
+                self.generator_step(z_gen)
+        return last
+
+
+def reconstruction_loss(output, target):
+    """train_autoencoder.py:57-62: mean |d|, d = output - target, d *= 32 where target < 0."""
+    difference = output - target
+    difference = torch.where(target < 0, difference * 32, difference)
+    return torch.mean(torch.abs(difference))
+
+
+def kld_loss(mean, log_variance):
+    """train_autoencoder.py:54-55."""
+    return -0.5 * torch.sum(1 + log_variance - mean.pow(2) - log_variance.exp()) / mean.nelement()
+
+
+def voxel_difference(output, target):
+    """train_autoencoder.py:50-52: fraction of sign mismatches (integer count, bit-exact)."""
+    wrong = (output * target) < 0
+    return torch.sum(wrong).item() / wrong.nelement()
+
+
+class AutoencoderTrainer(object):
+    """train_autoencoder.py: Adam(lr 5e-5); classic (AE) or variational."""
+
+    def __init__(self, autoencoder, lr=0.00005):
+        self.autoencoder = autoencoder
+        self.opt = optim.Adam(autoencoder.parameters(), lr=lr)       # :35
+        self.bucket = GradBucket(self.opt)
+
+    def step(self, batch):
+        """train_autoencoder.py:98-117."""
+        ae = self.autoencoder
+        self.opt.zero_grad()
+        ae.train()
+        if ae.is_variational:
+            output, mean, log_variance = ae(batch)
+            kld = kld_loss(mean, log_variance)
+        else:
+            output = ae(batch)
+            kld = 0
+        rec = reconstruction_loss(output, batch)
+        loss = rec + kld
+        loss.backward()
+        self.bucket.allreduce()
+        self.opt.step()
+        return rec.detach(), output.detach()
+
+
+class SDFAutoDecoderTrainer(object):
+    """train_sdf_autodecoder.py: DeepSDF auto-decoder, Adam(lr 1e-5) for the net and for the latent table."""
+
+    def __init__(self, sdf_net, latent_codes, points, sdf, pointcloud_size=200000, lr=1e-5, sigma=0.01, cutoff=0.1):
+        self.net, self.latent_codes = sdf_net, latent_codes
+        self.points = points
+        self.sdf = sdf.clamp(-cutoff, cutoff)                         # :27
+        self.pointcloud_size, self.sigma = pointcloud_size, sigma
+        latent_codes.requires_grad = True                             # :42
+        self.net_opt = optim.Adam(sdf_net.parameters(), lr=lr)        # :44
+        self.lat_opt = optim.Adam([latent_codes], lr=lr)              # :45
+        self.net_bucket, self.lat_bucket = GradBucket(self.net_opt), GradBucket(self.lat_opt)
+
+    def step(self, indices):
+        """train_sdf_autodecoder.py:77-91 (with the integer floor division `:78` intends)."""
+        model_indices = torch.div(indices, self.pointcloud_size, rounding_mode='floor')
+        self.net_opt.zero_grad()
+        self.lat_opt.zero_grad()
+        batch_latent = ops.gather_rows(self.latent_codes, model_indices)
+        batch_points = ops.gather_rows(self.points, indices)
+        batch_sdf = self.sdf[indices]
+        output = self.net(batch_points, batch_latent)
+        loss = torch.mean(torch.abs(output - batch_sdf)) + self.sigma * torch.mean(torch.pow(batch_latent, 2))
+        loss.backward()
+        self.net_bucket.allreduce()
+        self.lat_bucket.allreduce()
+        self.net_opt.step()
+        self.lat_opt.step()
+        return loss.detach()
+
+
+class HybridWGANTrainer(object):
+    """train_hybrid_wgan.py: SDFNet generator sampled on a fixed 32^3 grid (Adam 1e-5) + gan.Discriminator critic
+    (RMSprop 1e-5, clip 0.01), batch 8, n_critic 5."""
+
+    def __init__(self, generator, critic, grid_points, resolution=32, lr=0.00001, clip=0.01):
+        self.generator, self.critic = generator, critic
+        critic.use_sigmoid = False                                    # :40
+        self.res = resolution
+        self.grid = grid_points                                       # [R^3, 3], get_voxel_coordinates(R)  (:72)
+        self.g_opt = optim.Adam(generator.parameters(), lr=lr)        # :53
+        self.c_opt = optim.RMSprop(critic.parameters(), lr=lr, clip=clip)  # :56 + :94
+        self.g_bucket, self.c_bucket = GradBucket(self.g_opt), GradBucket(self.c_opt)
+        self._tiled = {}
+
+    def _points(self, count):
+        if count not in self._tiled:
+            self._tiled[count] = self.grid.repeat((count, 1))
+        return self._tiled[count]
+
+    def generate(self, z):
+        """generator(grid_points, tiled latents).reshape(-1,R,R,R) (:84-86) without tiling the latents."""
+        r3 = self.res ** 3
+        sdf = self.generator.forward_shapes(self._points(z.shape[0]), z, r3)
+        return sdf.reshape(-1, self.res, self.res, self.res)
+
+    def critic_step(self, real, z):
+        """train_hybrid_wgan.py:83-94: the generator graph is kept in the reference (its grads are discarded by the
+        next generator_optimizer.zero_grad()); they are not computed here."""
+        self.c_opt.zero_grad()
+        with torch.no_grad():
+            fake = self.generate(z)
+        out_fake = self.critic(fake)
+        out_real = self.critic(real)
+        loss = ops.mean(out_fake) - ops.mean(out_real)
+        loss.backward()
+        self.c_bucket.allreduce()
+        self.c_opt.step()
+        return loss.detach(), out_fake.detach(), out_real.detach()
+
+    def generator_step(self, z):
+        """train_hybrid_wgan.py:97-115."""
+        self.g_opt.zero_grad()
+        fake = self.generate(z)
+        with frozen(self.critic):
+            out = self.critic(fake)
+        loss = ops.mean(-out)
+        loss.backward()
+        self.g_bucket.allreduce()
+        self.g_opt.step()
+        return loss.detach(), out.detach()
+
+
+class HybridProgressiveGANTrainer(object):
+    """train_hybrid_progressive_gan.py: SDFNet generator + progressive discriminator, WGAN-GP (lambda 10),
+    RMSprop(lr 1e-4) for both, batch 16; the DataParallel wrap (:62-68) becomes process-per-GPU + GradBucket."""
+
+    def __init__(self, generator, discriminator, grid_points, resolution, lr=0.0001, gp_weight=10.0):
+        self.generator, self.discriminator = generator, discriminator
+        self.res, self.gp_weight = resolution, gp_weight
+        self.grid = grid_points
+        self.g_opt = optim.RMSprop(generator.parameters(), lr=lr)           # :81
+        self.d_opt = optim.RMSprop(discriminator.parameters(), lr=lr)       # :82
+        self.g_bucket, self.d_bucket = GradBucket(self.g_opt), GradBucket(self.d_opt)
+        self._tiled = {}
+
+    def _points(self, count):
+        if count not in self._tiled:
+            self._tiled[count] = self.grid.repeat((count, 1))
+        return self._tiled[count]
+
+    def generate(self, z):
+        r3 = self.res ** 3
+        sdf = self.generator.forward_shapes(self._points(z.shape[0]), z, r3)
+        return sdf.reshape(-1, self.res, self.res, self.res)
+
+    def gradient_penalty(self, real, fake, alpha):
+        """train_hybrid_progressive_gan.py:102-111; `alpha` [B,1,1,1] replaces the on-device torch.rand."""
+        alpha = alpha.expand(real.shape)
+        interpolated = alpha * real + ((1 - alpha) * fake)
+        interpolated.requires_grad = True
+        out = self.discriminator(interpolated)
+        gradients = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones_like(out),
+                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
+        return ((gradients.norm(2, dim=(1, 2, 3)) - 1) ** 2).mean() * self.gp_weight
+
+    def generator_step(self, z):
+        """:135-149."""
+        self.g_opt.zero_grad()
+        fake = self.generate(z)
+        with frozen(self.discriminator):
+            out = self.discriminator(fake)
+        loss = -ops.mean(out)
+        loss.backward()
+        self.g_bucket.allreduce()
+        self.g_opt.step()
+        return loss.detach()
+
+    def discriminator_step(self, real, z, alpha):
+        """:153-166.  The reference back-propagates into the generator here too and discards the result."""
+        self.d_opt.zero_grad()
+        with torch.no_grad():
+            fake = self.generate(z)
+        out_fake = self.discriminator(fake)
+        out_real = self.discriminator(real)
+        gp = self.gradient_penalty(real.detach(), fake.detach(), alpha)
+        loss = ops.mean(out_fake) - ops.mean(out_real) + gp
+        loss.backward()
+        self.d_bucket.allreduce()
+        self.d_opt.step()
+        return loss.detach(), gp.detach()

@@ -1,0 +1,350 @@
+"""GPU tier: every HIP kernel family against the CPU oracle on the same seeded inputs.
+Tolerance: 1e-4 relative fp32 (BASELINE.json north star); integer/index work bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_oracle
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def close(a, b, rtol=RTOL, atol=None, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if atol is None:
+        atol = rtol * max(float(b.abs().mean()), 1e-30)   # relative to the tensor's typical magnitude
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: what + ": " + m)
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ---- convolution ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, Cin, Cout, R
+    (2, 3, 5, 8), (1, 1, 4, 6), (3, 8, 1, 4), (1, 2, 2, 2),       # tiny + ragged (R=6 -> 3^3, R=2 -> 1^3)
+    (2, 64, 128, 16), (2, 128, 256, 8), (4, 1, 64, 32),            # gan.Discriminator layers
+    (2, 24, 48, 16), (2, 48, 96, 8),                               # autoencoder encoder
+    (1, 32, 64, 32), (1, 1, 32, 64),                               # progressive D at 64^3
+    (2, 70, 130, 8),                                               # non-multiple-of-tile channels
+]
+
+
+@pytest.mark.parametrize("N,Ci,Co,R", CONV_CASES)
+def test_conv3d_fwd_dgrad_wgrad(N, Ci, Co, R):
+    from shapegan_amd import ops
+    torch.manual_seed(N * 1000 + Ci * 10 + Co + R)
+    x = torch.randn(N, Ci, R, R, R)
+    w = torch.randn(Co, Ci, 4, 4, 4) / (Ci * 64) ** 0.5
+    b = torch.randn(Co)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, br, stride=2, padding=1)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.conv3d_k4s2p1(xg, wg, bg)
+    close(y, y_ref, what="fwd")
+    y.backward(dev(dy))
+    close(xg.grad, xr.grad, what="dgrad")
+    close(wg.grad, wr.grad, what="wgrad")
+    close(bg.grad, br.grad, what="bias grad")
+    if N * Ci * Co * R ** 3 <= 2 * 3 * 5 * 512:
+        close(y, torch.from_numpy(c_oracle.conv_fwd(x.numpy(), w.numpy(), b.numpy())), what="fwd vs C oracle")
+
+
+@pytest.mark.parametrize("N,Ci,Co,R", [(2, 256, 128, 4), (2, 128, 64, 8), (3, 64, 1, 16), (2, 96, 48, 4), (2, 24, 1, 16),
+                                       (1, 5, 3, 3)])
+def test_conv_transpose3d(N, Ci, Co, R):
+    """nn.ConvTranspose3d(k4,s2,p1) with fused LeakyReLU / Tanh epilogues (model/gan.py:13-22)."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY, ACT_NONE, ACT_TANH
+    torch.manual_seed(N + Ci + Co + R)
+    x = torch.randn(N, Ci, R, R, R)
+    w = torch.randn(Ci, Co, 4, 4, 4) / (Ci * 8) ** 0.5
+    b = torch.randn(Co)
+    for act, fn in ((ACT_NONE, lambda t: t), (ACT_LEAKY, lambda t: F.leaky_relu(t, 0.2)), (ACT_TANH, torch.tanh)):
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y_ref = fn(F.conv_transpose3d(xr, wr, br, stride=2, padding=1))
+        dy = torch.randn_like(y_ref)
+        y_ref.backward(dy)
+        xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        y = ops.conv_transpose3d_k4s2p1(xg, wg, bg, act, 0.2)
+        close(y, y_ref, what="convT fwd act%d" % act)
+        y.backward(dev(dy))
+        close(xg.grad, xr.grad, what="convT dgrad act%d" % act)
+        close(wg.grad, wr.grad, what="convT wgrad act%d" % act)
+        close(bg.grad, br.grad, what="convT bias grad act%d" % act)
+
+
+def test_conv_from_sdf_zero_channels():
+    """First progressive stage: conv over [x, 0, ..., 0] == conv over channel 0 only; dW of the zero channels is 0."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 16, 16)
+    w = torch.randn(64, 32, 4, 4, 4) * 0.05
+    b = torch.randn(64)
+    wr = w.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    padded = torch.cat((xr.reshape(2, 1, 16, 16, 16), torch.zeros(2, 31, 16, 16, 16)), 1)   # from_SDF, iteration 2
+    y_ref = F.leaky_relu(F.conv3d(padded, wr, b, stride=2, padding=1), 0.2)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    y = ops.conv3d_k4s2p1(xg.reshape(2, 1, 16, 16, 16), wg, dev(b), ACT_LEAKY, 0.2)
+    close(y, y_ref)
+    y.backward(dev(dy))
+    close(xg.grad, xr.grad)
+    close(wg.grad, wr.grad)
+    assert float(wg.grad[:, 1:].abs().sum()) == 0.0
+
+
+def test_conv_linearity_and_adjoint_full_size():
+    """Size-independent properties at the BASELINE config-2 size (B=64): linearity of the forward and
+    <conv(x), y> == <x, conv^T(y)> between the fwd and dgrad kernels."""
+    from shapegan_amd import ops
+    torch.manual_seed(1)
+    w = (torch.randn(128, 64, 4, 4, 4) / 64).cuda()
+    x1, x2 = torch.randn(64, 64, 16, 16, 16, device="cuda"), torch.randn(64, 64, 16, 16, 16, device="cuda")
+    y1, y2 = ops.conv_fwd_raw(x1, w, None), ops.conv_fwd_raw(x2, w, None)
+    y12 = ops.conv_fwd_raw(0.5 * x1 - 2.0 * x2, w, None)
+    close(y12, 0.5 * y1 - 2.0 * y2, rtol=2e-4)
+    g = torch.randn_like(y1)
+    dx = ops.conv_dgrad_raw(g, w, None, 64)
+    lhs, rhs = (y1.double() * g.double()).sum().item(), (x1.double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), (y1.double() * g.double()).abs().sum().item() * 1e-3)
+    dw = ops.conv_wgrad_raw(g, x1, 64)
+    lhs_w = (dw.double() * w.double()).sum().item()
+    assert abs(lhs - lhs_w) <= 1e-4 * max(abs(lhs), (y1.double() * g.double()).abs().sum().item() * 1e-3)
+
+
+# ---- GEMM / Linear / 1^3<->4^3 convs --------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(64, 128, 256), (4, 128, 256), (16, 128, 16384), (64, 1, 16384), (5, 7, 3),
+                                   (200, 300, 130), (64, 16384, 128)])
+def test_linear_fwd_bwd(M, N, K):
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    torch.manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.leaky_relu(F.linear(xr, wr, br), 0.2)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.linear(xg, wg, bg, ACT_LEAKY, 0.2)
+    close(y, y_ref, what="linear fwd")
+    y.backward(dev(dy))
+    close(xg.grad, xr.grad, what="linear dx")
+    close(wg.grad, wr.grad, what="linear dw")
+    close(bg.grad, br.grad, what="linear db")
+
+
+def test_gemm_double_backward():
+    from shapegan_amd import ops
+    torch.manual_seed(2)
+    a, b = torch.randn(6, 10, dtype=torch.float32), torch.randn(7, 10, dtype=torch.float32)
+    for ta, tb in ((False, True), (False, False), (True, False), (True, True)):
+        aa = (a.t() if ta else a).contiguous()
+        bb = (b if tb else b.t()).contiguous()
+        ar, br = aa.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+        ag, bg = dev(aa).requires_grad_(True), dev(bb).requires_grad_(True)
+
+        def f(p, q, mm):
+            c = mm(p, q)
+            (g,) = torch.autograd.grad(c.pow(2).sum(), p, create_graph=True)
+            return (g.pow(2).sum() + c.sum())
+
+        ref = f(ar, br, lambda p, q: (p.t() if ta else p) @ (q.t() if tb else q))
+        ref.backward()
+        got = f(ag, bg, lambda p, q: ops.Gemm.apply(p, q, ta, tb))
+        got.backward()
+        close(got, ref, what="gemm dbl value %s%s" % (ta, tb))
+        close(ag.grad, ar.grad, what="gemm dbl ga")
+        close(bg.grad, br.grad, what="gemm dbl gb")
+
+
+# ---- BatchNorm --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C,S", [(64, 256, 64), (8, 128, 512), (4, 64, 4096), (4, 24, 4096), (4, 256, 1), (3, 7, 27)])
+def test_batchnorm_train_fwd_bwd(N, C, S):
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    torch.manual_seed(N + C + S)
+    shape = (N, C, S) if S > 1 else (N, C)
+    x = torch.randn(shape) * 1.7 + 3.0
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y_ref = F.leaky_relu(F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5), 0.2)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    xg, gg, bg = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    rm_g, rv_g, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.long, device="cuda")
+    y = ops.BatchNormAct.apply(xg, gg, bg, rm_g, rv_g, nbt, True, 1e-5, 0.1, ACT_LEAKY, 0.2)
+    close(y, y_ref, what="bn fwd")
+    close(rm_g, rm_r, what="running_mean")
+    close(rv_g, rv_r, what="running_var")
+    assert int(nbt.item()) == 1
+    y.backward(dev(dy))
+    tol = 1e-3 if N * S <= 8 else RTOL     # 4 values per channel: torch's own CPU/GPU BN differ at this level
+    close(xg.grad, xr.grad, rtol=tol, what="bn dx")
+    close(gg.grad, gr.grad, rtol=tol, what="bn dgamma")
+    close(bg.grad, br.grad, rtol=tol, what="bn dbeta")
+    # eval mode uses the running statistics
+    y_eval_ref = F.batch_norm(x, rm_r, rv_r, gamma, beta, False, 0.1, 1e-5)
+    y_eval = ops.BatchNormAct.apply(dev(x), dev(gamma), dev(beta), rm_g, rv_g, None, False, 1e-5, 0.1, 0, 0.0)
+    close(y_eval, y_eval_ref, what="bn eval")
+
+
+# ---- activations, optimizers, rows --------------------------------------------------------------------------------------
+def test_activations():
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY, ACT_RELU, ACT_SIGMOID, ACT_TANH
+    torch.manual_seed(3)
+    x = torch.randn(1001) * 2
+    for act, fn in ((ACT_LEAKY, lambda t: F.leaky_relu(t, 0.2)), (ACT_RELU, F.relu), (ACT_TANH, torch.tanh),
+                    (ACT_SIGMOID, torch.sigmoid)):
+        xr, xg = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+        yr, yg = fn(xr), ops.Act.apply(xg, act, 0.2)
+        close(yg, yr, atol=1e-6)
+        dy = torch.randn(1001)
+        yr.backward(dy)
+        yg.backward(dev(dy))
+        close(xg.grad, xr.grad, atol=1e-6)
+
+
+def test_rmsprop_adam_clamp_match_torch():
+    from shapegan_amd import optim
+    torch.manual_seed(4)
+    shapes = [(64, 1, 4, 4, 4), (64,), (33, 7), (5,)]
+    for kind in ("rmsprop", "adam", "rmsprop_clip"):
+        ref_p = [torch.randn(s).requires_grad_(True) for s in shapes]
+        gpu_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+        if kind == "adam":
+            ro, go = torch.optim.Adam(ref_p, lr=1e-3), optim.Adam(gpu_p, lr=1e-3)
+        else:
+            ro = torch.optim.RMSprop(ref_p, lr=1e-3)
+            go = optim.RMSprop(gpu_p, lr=1e-3, clip=0.5 if kind == "rmsprop_clip" else 0.0)
+        for step in range(4):
+            go.zero_grad()
+            for i, (rp, gp) in enumerate(zip(ref_p, gpu_p)):
+                g = torch.randn(rp.shape)
+                rp.grad = g.clone()
+                if step == 2 and i == 3:
+                    rp.grad = None          # a parameter without gradient is skipped (unused progressive stage)
+                    gp.grad = None
+                else:
+                    gp.grad.copy_(g.cuda()) if gp.grad is not None else setattr(gp, "grad", g.cuda())
+            ro.step()
+            go.step()
+            if kind == "rmsprop_clip":
+                with torch.no_grad():
+                    for rp in ref_p:
+                        rp.clamp_(-0.5, 0.5)
+        for rp, gp in zip(ref_p, gpu_p):
+            close(gp.data, rp.data, rtol=1e-5, atol=1e-6, what=kind)
+
+
+def test_gather_scatter_rows_bit_exact():
+    from shapegan_amd import ops
+    torch.manual_seed(5)
+    table = torch.randn(37, 128)
+    idx = torch.randint(0, 37, (1000,))
+    tg = dev(table).requires_grad_(True)
+    rows = ops.gather_rows(tg, dev(idx))
+    assert torch.equal(rows.cpu(), table[idx])                       # index work: bit-exact
+    g = torch.randn(1000, 128)
+    rows.backward(dev(g))
+    ref = torch.zeros_like(table).index_add_(0, idx, g)
+    close(tg.grad, ref, rtol=1e-5, atol=1e-5)                        # float atomics: order differs
+
+
+def test_mean_reduction():
+    from shapegan_amd import ops
+    torch.manual_seed(6)
+    x = torch.randn(64) + 3
+    xg = dev(x).requires_grad_(True)
+    m = ops.mean(xg)
+    close(m, x.mean(), rtol=1e-6)
+    m.backward()
+    close(xg.grad, torch.full((64,), 1 / 64.0), rtol=1e-6)
+    big = torch.randn(3_000_001)
+    close(ops.mean(dev(big)), big.double().mean().float(), rtol=1e-5, atol=1e-7)
+
+
+# ---- SDFNet fused MLP ------------------------------------------------------------------------------------------------------
+def _sdf_state(seed, latent=128):
+    from shapegan_amd.model.sdf_net import SDFNet
+    torch.manual_seed(seed)
+    return SDFNet(latent_code_size=latent)
+
+
+@pytest.mark.parametrize("N,latent", [(1, 128), (63, 128), (64, 128), (1000, 128), (20000, 128), (777, 256), (130, 16)])
+def test_sdfnet_points_mode(N, latent):
+    net = _sdf_state(8, latent)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.manual_seed(N)
+    pts, lat = torch.rand(N, 3) * 2 - 1, torch.randn(N, latent) * 0.5
+    P = O.clone_state(sd)
+    pr, lr_ = pts.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+    out_ref = O.sdfnet_forward(P, pr, lr_)
+    out_ref = out_ref.reshape(-1)
+    pg, lg = dev(pts).requires_grad_(True), dev(lat).requires_grad_(True)
+    out = net(pg, lg).reshape(-1)
+    close(out, out_ref, atol=2e-6, what="sdfnet fwd")
+    dy = torch.randn(N)
+    out_ref.backward(dy)
+    out.backward(dev(dy))
+    close(pg.grad, pr.grad, what="d points")
+    close(lg.grad, lr_.grad, what="d latent")
+    for k, p in net.named_parameters():
+        close(p.grad, P[k].grad, what="grad " + k)
+
+
+@pytest.mark.parametrize("S,pps", [(1, 128), (3, 512), (2, 4096), (1, 1000), (1, 37)])
+def test_sdfnet_shapes_mode(S, pps):
+    """Per-shape latents (folded biases) == the reference's tiled-latent forward."""
+    net = _sdf_state(9)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.manual_seed(S * pps)
+    pts, z = torch.rand(S * pps, 3) * 2 - 1, torch.randn(S, 128)
+    P = O.clone_state(sd)
+    pr, zr = pts.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    out_ref = O.sdfnet_forward(P, pr, O.tile_latents(zr, pps)).reshape(-1)
+    pg, zg = dev(pts).requires_grad_(True), dev(z).requires_grad_(True)
+    out = net.forward_shapes(pg, zg, pps)
+    close(out, out_ref, atol=2e-6, what="shapes fwd")
+    dy = torch.randn(S * pps)
+    out_ref.backward(dy)
+    out.backward(dev(dy))
+    close(pg.grad, pr.grad, what="d points")
+    close(zg.grad, zr.grad, what="d z")
+    for k, p in net.named_parameters():
+        close(p.grad, P[k].grad, what="grad " + k)
+
+
+def test_sdfnet_chairs_known_answers(golden_sdf, chairs_state):
+    """HIP path on the reference's shipped checkpoint reproduces its known answers."""
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.util import get_voxel_coordinates
+    net = SDFNet()
+    net.load_state_dict(chairs_state)
+    pts = torch.tensor(get_voxel_coordinates(32)).cuda()
+    z = torch.from_numpy(golden_sdf["z"]).cuda()
+    with torch.no_grad():
+        a = net(pts, z.repeat(32768, 1)).cpu()
+        b = net.forward_shapes(pts, z.reshape(1, -1), 32768).cpu()
+        c = net.evaluate_in_batches(pts, z, batch_size=10000)
+    for out in (a, b, c):
+        assert abs(out.mean().item() - 0.072827) < 5e-6 and int((out < 0).sum()) == 4187
+        assert abs(out[0].item() - 0.098810) < 5e-6 and abs(out[16912].item() - 0.086498) < 5e-6
+        np.testing.assert_allclose(out[:4096].numpy(), golden_sdf["chairs/out_head"], rtol=1e-4, atol=2e-6)
+    voxels = net.get_voxels(z, 32)                                   # sphere mask scatter: index work is bit-exact
+    mask = np.linalg.norm(get_voxel_coordinates(32), axis=1) < 1.1
+    assert voxels.shape == (32, 32, 32) and np.all(voxels.reshape(-1)[~mask] == 1.0)
+    np.testing.assert_allclose(voxels.reshape(-1)[mask], a.numpy()[mask], rtol=1e-4, atol=2e-6)

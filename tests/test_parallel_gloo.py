@@ -1,0 +1,60 @@
+"""CPU tier: the N>1 data-parallel path with world_size 2 over gloo (the same code runs over RCCL on GPUs).
+The batch-axis sharding must give, after one flat all-reduce and the 1/world scale, the full-batch gradient."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import torch_oracle as O
+    from shapegan_amd import optim, parallel
+    from shapegan_amd.model.gan import Discriminator
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world_size() == world
+    torch.manual_seed(7)                      # identical replicas by seed, no parameter broadcast needed
+    critic = Discriminator()                  # CPU construct-only shell; gradients come from the oracle below
+    opt = optim.RMSprop(critic.parameters(), lr=1e-4)
+    bucket = parallel.GradBucket(opt)
+    assert abs(opt.grad_scale - 1.0 / world) < 1e-12
+    g = torch.Generator().manual_seed(123)
+    full = torch.rand(4, 32, 32, 32, generator=g) * 2 - 1
+    shard = full[rank * 2:(rank + 1) * 2]
+    P = {k: v for k, v in critic.named_parameters()}
+    opt.zero_grad()
+    loss = O.discriminator_forward(P, shard, False).mean()   # local-batch mean, as each rank's step computes it
+    loss.backward()
+    assert opt.f.coherent()
+    bucket.allreduce()
+    np.save(os.path.join(out_dir, "grad%d.npy" % rank), (opt.flat_grad * opt.grad_scale).numpy())
+    if rank == 0:
+        opt.zero_grad()
+        O.discriminator_forward(P, full, False).mean().backward()
+        np.save(os.path.join(out_dir, "full.npy"), opt.flat_grad.numpy())
+    parallel.allreduce_tensor_(torch.ones(3))
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_gradient_equals_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
+    full = np.load(tmp_path / "full.npy")
+    np.testing.assert_array_equal(g0, g1)                       # replicas see the same reduced gradient
+    np.testing.assert_allclose(g0, full, rtol=1e-4, atol=1e-7)  # and it is the full-batch gradient
