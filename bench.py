@@ -88,7 +88,9 @@ def sdfnet_numbers():
 def cpu_baseline(reals, zs, zg, g_state, c_state):
     """The CPU oracle (torch fp32 ops = the reference's own arithmetic engine, all host cores) on the same step."""
     from oracle import torch_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # oneDNN's conv3d backward stops scaling past ~32 threads on the GPU box's 256-core host (measured: 0.49 s per
+    # critic update at 16-32 threads, 1.6 s at 128, 15 s at 256): use the fastest setting and report it as `cores`
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     orc = O.WGANOracle(g_state, c_state)
     reals = [r.cpu() for r in reals]
     zs = [z.cpu() for z in zs]

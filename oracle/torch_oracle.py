@@ -133,7 +133,7 @@ def from_sdf(x, iteration):
     """from_SDF, model/progressive_gan.py:9-16 (zero-channel padding)."""
     r, c = RESOLUTIONS[iteration], FEATURE_COUNTS[iteration]
     x = x.reshape((-1, 1, r, r, r))
-    return torch.cat((x, torch.zeros((x.shape[0], c - 1, r, r, r), device=x.device)), dim=1)
+    return torch.cat((x, torch.zeros((x.shape[0], c - 1, r, r, r), device=x.device, dtype=x.dtype)), dim=1)
 
 
 def progressive_forward(P, x, iteration, fade_in_progress=1.0):
@@ -166,6 +166,26 @@ def sdfnet_forward(P, points, latent_codes):
         x = F.relu(F.linear(x, P["layers2.%d.weight" % i], P["layers2.%d.bias" % i]))
     x = torch.tanh(F.linear(x, P["layers2.6.weight"], P["layers2.6.bias"]))
     return x.squeeze()
+
+
+def sdfnet_min_preactivation(P, points, latent_codes):
+    """min over the 7 hidden layers and 256 units of |pre-activation| per point.  A point whose smallest
+    |pre-activation| is within fp32 rounding of 0 sits on a ReLU kink: two correct implementations may take different
+    sides, so parity tests give such points zero upstream gradient (they are reported, not hidden)."""
+    with torch.no_grad():
+        inp = torch.cat((points, latent_codes), dim=1)
+        x = inp
+        m = torch.full((points.shape[0],), float("inf"), dtype=points.dtype)
+        for i in (0, 2, 4, 6):
+            z = F.linear(x, P["layers1.%d.weight" % i], P["layers1.%d.bias" % i])
+            m = torch.minimum(m, z.abs().min(dim=1).values)
+            x = F.relu(z)
+        x = torch.cat((x, inp), dim=1)
+        for i in (0, 2, 4):
+            z = F.linear(x, P["layers2.%d.weight" % i], P["layers2.%d.bias" % i])
+            m = torch.minimum(m, z.abs().min(dim=1).values)
+            x = F.relu(z)
+    return m
 
 
 def tile_latents(z, points_per_shape):
@@ -336,7 +356,7 @@ class HybridProgressiveGANOracle(object):
         interpolated = alpha * real + ((1 - alpha) * fake)
         interpolated.requires_grad = True
         out = self.disc(interpolated)
-        gradients = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones(out.shape),
+        gradients = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones_like(out),
                                         create_graph=True, retain_graph=True, only_inputs=True)[0]
         return ((gradients.norm(2, dim=(1, 2, 3)) - 1) ** 2).mean() * self.gp_weight
 

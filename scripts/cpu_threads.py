@@ -1,0 +1,15 @@
+import sys, time, os, torch
+sys.path.insert(0, os.getcwd())
+from oracle import torch_oracle as O
+from shapegan_amd.model.gan import Generator, Discriminator
+torch.manual_seed(0)
+g, c = Generator(), Discriminator()
+gs = {k: v.cpu() for k, v in g.state_dict().items()}; cs = {k: v.cpu() for k, v in c.state_dict().items()}
+real = torch.rand(64,32,32,32)*2-1; z = torch.randn(64,128)
+for n in (8, 16, 32, 64, 128):
+    torch.set_num_threads(n)
+    orc = O.WGANOracle(gs, cs)
+    orc.critic_step(real, z)
+    t0 = time.perf_counter(); orc.critic_step(real, z); dt = time.perf_counter() - t0
+    print("threads", n, "critic step s", round(dt, 3), flush=True)
+    if dt > 20: break
