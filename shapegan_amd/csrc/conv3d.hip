@@ -60,15 +60,17 @@ __device__ __forceinline__ void decode_pos(const ConvGeom& g, uint32_t j, int& n
     n = (int)t3;
 }
 
-// patch of x around output position pos=(n,od,oh,ow): element (ci,kd,kh,kw) = x[n,ci,2od-1+kd,2oh-1+kh,2ow-1+kw]
+// patch of x around output position pos=(n,od,oh,ow): element (ci,kd,kh,kw) = x[n,ci,2od-1+kd,2oh-1+kh,2ow-1+kw].
+// `base` is the (possibly negative) element offset of tap (0,0,0) of channel 0; mask bits 0-3 / 4-7 / 8-11 say which
+// kd / kh / kw taps fall inside the tensor.  Offsets are 32-bit: the entry points reject tensors >= 2^31 elements.
 struct PatchCtx {
-    long base;
+    int base;
     int mask;
     __device__ __forceinline__ void set(const ConvGeom& g, uint32_t pos) {
         int n, od, oh, ow;
         decode_pos(g, pos, n, od, oh, ow);
         const int id0 = 2 * od - 1, ih0 = 2 * oh - 1, iw0 = 2 * ow - 1;
-        base = (long)n * g.Cx * g.ID * g.IH * g.IW + ((long)id0 * g.IH + ih0) * g.IW + iw0;
+        base = n * g.Cx * g.ID * g.IH * g.IW + (id0 * g.IH + ih0) * g.IW + iw0;
         int m = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -78,22 +80,47 @@ struct PatchCtx {
         }
         mask = m;
     }
-    // c = ci*64 + kd*16 + kh*4 + kw
-    __device__ __forceinline__ float get(const ConvGeom& g, const float* x, int c) const {
-        const int ci = c >> 6, kd = (c >> 4) & 3, kh = (c >> 2) & 3, kw = c & 3;
-        const bool ok = ((mask >> kd) & (mask >> (4 + kh)) & (mask >> (8 + kw)) & 1) != 0;
-        return ok ? x[base + ((long)ci * g.ID + kd) * g.IH * g.IW + kh * g.IW + kw] : 0.f;
-    }
 };
 
 // ---- fwd -------------------------------------------------------------------------------------
-struct FwdPatchLoader {  // B(k=(ci,tap), j=pos), lanes along positions
-    static constexpr bool K_FAST = false;
+// B(k=(ci,kd,kh,kw), j=pos), lanes along positions.  A 16-aligned k-tile has ONE (ci,kd) and all 16 (kh,kw):
+// per thread the (kh,kw) of its E elements never change, so their offsets/validity are precomputed once and the
+// per-tile part (ci*I^3 + kd*IH*IW, the kd validity bit) is wave-uniform.
+struct FwdPatchLoader {
     const float* x;
     ConvGeom g;
-    PatchCtx c;
-    __device__ void fix(int j) { c.set(g, (uint32_t)j); }
-    __device__ float get(int k) const { return c.get(g, x, k); }
+    int base, mask, tid_;
+    int off[8];
+    unsigned okbits;
+    template <int BR>
+    __device__ void init(int tid, int j0, int N) {
+        constexpr int E = BR * kBK / 256, STEP = 256 / BR;
+        tid_ = tid;
+        const int j = j0 + tid % BR, kq = tid / BR;
+        PatchCtx c;
+        c.set(g, (uint32_t)(j < N ? j : 0));
+        base = c.base;
+        mask = j < N ? c.mask : 0;
+        okbits = 0;
+#pragma unroll
+        for (int it = 0; it < E; ++it) {
+            const int kk = kq + it * STEP, kh = kk >> 2, kw = kk & 3;
+            off[it] = kh * g.IW + kw;
+            if (((mask >> (4 + kh)) & (mask >> (8 + kw)) & 1) != 0) okbits |= 1u << it;
+        }
+    }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        const int ci = k0 >> 6, kd = (k0 >> 4) & 3;
+        const int toff = base + (ci * g.ID + kd) * g.IH * g.IW;
+        const unsigned ok = ((mask >> kd) & 1) ? okbits : 0u;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it) r[it] = ((ok >> it) & 1u) ? x[toff + off[it]] : 0.f;
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageRowFast<BR>::store(S, r, tid_);
+    }
 };
 struct FwdEpi {  // y[n][co][o] = act(v + bias[co])
     float* y;
@@ -118,40 +145,68 @@ struct FwdEpi {  // y[n][co][o] = act(v + bias[co])
 };
 
 // ---- dgrad -----------------------------------------------------------------------------------
-struct DgradWeightLoader {  // A(i=ci, k=co*8+t) = Wt[parity][k][ci]
-    static constexpr bool K_FAST = false;
+struct DgradWeightLoader {  // A(i=ci, k=co*8+t) = Wt[parity][k][ci]  (ci contiguous)
     const float* wt;
     int Cin;
     long pstride;
-    int rr;
-    __device__ void fix(int row) { rr = row; }
-    __device__ float get(int k) const { return wt[(long)blockIdx.z * pstride + (long)k * Cin + rr]; }
+    MatColMajor m;
+    template <int BR>
+    __device__ void init(int tid, int row0, int nrows) {
+        m.p = wt + (long)blockIdx.z * pstride;
+        m.ld = Cin;
+        m.template init<BR>(tid, row0, nrows);
+    }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        m.template load<BR>(k0, kend, r);
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        m.template store<BR>(S, r);
+    }
 };
-struct DgradPatchLoader {  // B(k=co*8+t, j=(n,qd,qh,qw)) = dy[n,co,qd+pd-td,qh+ph-th,qw+pw-tw]
-    static constexpr bool K_FAST = false;
+// B(k=co*8+t, j=(n,qd,qh,qw)) = dy[n,co,qd+pd-td,qh+ph-th,qw+pw-tw], lanes along positions.  A 16-aligned k-tile
+// covers two output channels x 8 taps: per-thread tap offsets/validity are precomputed, the tile part is co0*O^3.
+struct DgradPatchLoader {
     const float* dy;
     ConvGeom g;
-    long base;
-    int mask;
-    __device__ void fix(int j) {
+    int base, tid_, kq;
+    int off[8];
+    unsigned okbits;
+    template <int BR>
+    __device__ void init(int tid, int j0, int N) {
+        constexpr int E = BR * kBK / 256, STEP = 256 / BR;
+        tid_ = tid;
+        const int j = j0 + tid % BR;
+        kq = tid / BR;
         int n, qd, qh, qw;
-        decode_pos(g, (uint32_t)j, n, qd, qh, qw);
+        decode_pos(g, (uint32_t)(j < N ? j : 0), n, qd, qh, qw);
         const int p = blockIdx.z;
         const int d1 = qd + ((p >> 2) & 1), h1 = qh + ((p >> 1) & 1), w1 = qw + (p & 1);
-        base = (long)n * g.Cy * g.OD * g.OH * g.OW + ((long)d1 * g.OH + h1) * g.OW + w1;
-        int m = 0;
+        const int O3 = g.OD * g.OH * g.OW;
+        base = n * g.Cy * O3 + (d1 * g.OH + h1) * g.OW + w1;
+        okbits = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if ((unsigned)(d1 - t) < (unsigned)g.OD) m |= 1 << t;
-            if ((unsigned)(h1 - t) < (unsigned)g.OH) m |= 1 << (2 + t);
-            if ((unsigned)(w1 - t) < (unsigned)g.OW) m |= 1 << (4 + t);
+        for (int it = 0; it < E; ++it) {
+            const int kk = kq + it * STEP, t = kk & 7, dco = kk >> 3;
+            const int td = (t >> 2) & 1, th = (t >> 1) & 1, tw = t & 1;
+            off[it] = dco * O3 - (td * g.OH + th) * g.OW - tw;
+            const bool ok = j < N && (unsigned)(d1 - td) < (unsigned)g.OD && (unsigned)(h1 - th) < (unsigned)g.OH &&
+                            (unsigned)(w1 - tw) < (unsigned)g.OW;
+            if (ok) okbits |= 1u << it;
         }
-        mask = m;
     }
-    __device__ float get(int k) const {
-        const int co = k >> 3, td = (k >> 2) & 1, th = (k >> 1) & 1, tw = k & 1;
-        const bool ok = ((mask >> td) & (mask >> (2 + th)) & (mask >> (4 + tw)) & 1) != 0;
-        return ok ? dy[base + ((long)co * g.OD - td) * g.OH * g.OW - th * g.OW - tw] : 0.f;
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        constexpr int STEP = 256 / BR;
+        const int toff = base + (k0 >> 3) * g.OD * g.OH * g.OW;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it)
+            r[it] = (((okbits >> it) & 1u) && (k0 + kq + it * STEP) < kend) ? dy[toff + off[it]] : 0.f;
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageRowFast<BR>::store(S, r, tid_);
     }
 };
 struct DgradEpi {  // dx[n][ci][2qd+pd][2qh+ph][2qw+pw] = act(v + bias[ci])
@@ -194,83 +249,144 @@ __global__ void __launch_bounds__(256) pack_dgrad_weights_kernel(const float* __
     }
 }
 
-// dgrad-form with ONE output channel (G's last ConvTranspose 64->1, D's first conv dgrad): a 1-row
-// GEMM would waste 63/64 of every MFMA, so this is a plain VALU gather: one thread per output voxel,
-// weights [Cout][64] staged in LDS, dy re-reads served by L1/L2 (each dy element feeds 8 outputs).
+// dgrad-form with ONE output channel (G's last ConvTranspose 64->1, D's first conv dgrad, the progressive D's
+// from_SDF stage): a 1-row GEMM would waste 63/64 of every MFMA, so this is a VALU kernel.  One thread owns the 2x2x2
+// output block of position q: all 8 outputs read the same 3x3x3 neighbourhood of dy per channel (27 coalesced
+// loads, lanes along qw) and the channel's 64 weights from LDS as 16 broadcast ds_read_b128.
+//   output i = 2q + p:   p = 0 -> taps (o = q, k = 1), (o = q-1, k = 3);   p = 1 -> (o = q+1, k = 0), (o = q, k = 2)
 __global__ void __launch_bounds__(256) dgrad_out1_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ dx,
-                                                        ConvGeom g, int Cout, int Cin_total, long total, int act,
+                                                        ConvGeom g, int Cout, int Cin_total, int total, int act,
                                                         float slope) {
-    extern __shared__ float wl[];  // [Cout][64] (ci = 0 slice)
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cout][64] (ci = 0 slice)
     for (int e = threadIdx.x; e < Cout * 64; e += 256) wl[e] = w[((long)(e >> 6) * Cin_total) * 64 + (e & 63)];
     __syncthreads();
-    const long O3 = (long)g.OD * g.OH * g.OW;
-    const int IHW = g.IH * g.IW;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int iw = (int)(e % g.IW);
-        long r = e / g.IW;
-        const int ih = (int)(r % g.IH);
-        r /= g.IH;
-        const int id = (int)(r % g.ID);
-        const int n = (int)(r / g.ID);
-        // x index i = 2*o + k - 1  ->  o = (i + 1 - k) / 2 for the two k of matching parity
-        int od[2], kd[2], oh[2], kh[2], ow[2], kw[2];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    int n, qd, qh, qw;
+    decode_pos(g, (uint32_t)j, n, qd, qh, qw);
+    const int OHW = g.OH * g.OW, O3 = g.OD * OHW;
+    // neighbour offsets / validity, a in {-1, 0, +1} -> index a + 1
+    int offd[3], offh[3], offw[3];
+    bool vd[3], vh[3], vw[3];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            kd[t] = ((id + 1) & 1) + 2 * t;
-            od[t] = (id + 1 - kd[t]) >> 1;
-            kh[t] = ((ih + 1) & 1) + 2 * t;
-            oh[t] = (ih + 1 - kh[t]) >> 1;
-            kw[t] = ((iw + 1) & 1) + 2 * t;
-            ow[t] = (iw + 1 - kw[t]) >> 1;
-        }
-        float acc = 0.f;
-        const float* dyn = dy + (long)n * g.Cy * O3;
-        for (int co = 0; co < Cout; ++co) {
-            const float* dyc = dyn + (long)co * O3;
-            const float* wc = wl + co * 64;
+    for (int a = 0; a < 3; ++a) {
+        vd[a] = (unsigned)(qd + a - 1) < (unsigned)g.OD;
+        vh[a] = (unsigned)(qh + a - 1) < (unsigned)g.OH;
+        vw[a] = (unsigned)(qw + a - 1) < (unsigned)g.OW;
+        offd[a] = (qd + a - 1) * OHW;
+        offh[a] = (qh + a - 1) * g.OW;
+        offw[a] = qw + a - 1;
+    }
+    float acc[2][2][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                if ((unsigned)od[a] >= (unsigned)g.OD) continue;
+    for (int a = 0; a < 8; ++a) (&acc[0][0][0])[a] = 0.f;
+    const float* dyn = dy + (long)n * g.Cy * O3;
+    for (int co = 0; co < Cout; ++co) {
+        const float* dyc = dyn + (long)co * O3;
+        float v[3][3][3];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if ((unsigned)oh[b] >= (unsigned)g.OH) continue;
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        if ((unsigned)ow[c] >= (unsigned)g.OW) continue;
-                        acc = fmaf(dyc[((long)od[a] * g.OH + oh[b]) * g.OW + ow[c]], wc[kd[a] * 16 + kh[b] * 4 + kw[c]],
-                                   acc);
-                    }
-                }
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[a][b][c] = (vd[a] && vh[b] && vw[c]) ? dyc[offd[a] + offh[b] + offw[c]] : 0.f;
+        const float4* wc = reinterpret_cast<const float4*>(wl + co * 64);
+        // neighbour index for (parity p, slot s): p=0: s0 -> a=1 (k=1), s1 -> a=0 (k=3); p=1: s0 -> a=2 (k=0), s1 -> a=1 (k=2)
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd) {
+            const int pd = (kd & 1) ? 0 : 1, ad = (kd == 0) ? 2 : (kd == 3 ? 0 : 1);
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int ph = (kh & 1) ? 0 : 1, ah = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
+                const float4 w4 = wc[kd * 4 + kh];
+                // kw = 0 -> pw 1, a 2 ; kw = 1 -> pw 0, a 1 ; kw = 2 -> pw 1, a 1 ; kw = 3 -> pw 0, a 0
+                acc[pd][ph][1] = fmaf(v[ad][ah][2], w4.x, acc[pd][ph][1]);
+                acc[pd][ph][0] = fmaf(v[ad][ah][1], w4.y, acc[pd][ph][0]);
+                acc[pd][ph][1] = fmaf(v[ad][ah][1], w4.z, acc[pd][ph][1]);
+                acc[pd][ph][0] = fmaf(v[ad][ah][0], w4.w, acc[pd][ph][0]);
             }
         }
-        if (bias) acc += bias[0];
-        dx[(long)n * g.Cx * g.ID * IHW + ((long)id * g.IH + ih) * g.IW + iw] = sg_apply_act(acc, act, slope);
     }
+    const float b0 = bias ? bias[0] : 0.f;
+    float* out = dx + (long)n * g.Cx * g.ID * g.IH * g.IW;
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float2 o;
+            o.x = sg_apply_act(acc[pd][ph][0] + b0, act, slope);
+            o.y = sg_apply_act(acc[pd][ph][1] + b0, act, slope);
+            *reinterpret_cast<float2*>(out + ((long)(2 * qd + pd) * g.IH + (2 * qh + ph)) * g.IW + 2 * qw) = o;
+        }
 }
 
 // ---- wgrad -----------------------------------------------------------------------------------
-struct WgradDyLoader {  // A(i=co, k=(n,o)) = dy[n][co][o], lanes along k
-    static constexpr bool K_FAST = true;
+// A(i=co, k=(n,o)) = dy[n][co][o], lanes along k (positions).  Per k-tile each thread decodes its one position.
+struct WgradDyLoader {
     const float* dy;
-    long O3;
-    int Cy;
+    int O3, Cy;
     FastDiv dO3;
-    long base;
-    __device__ void fix(int k) {
-        uint32_t n, o;
-        dO3.divmod((uint32_t)k, n, o);
-        base = (long)n * Cy * O3 + o;
+    int tid_, kk, rowoff0, rbase, nrows_;
+    template <int BR>
+    __device__ void init(int tid, int row0, int nrows) {
+        tid_ = tid;
+        kk = tid & 15;
+        rbase = row0 + (tid >> 4);
+        nrows_ = nrows;
+        rowoff0 = rbase * O3;
     }
-    __device__ float get(int row) const { return dy[base + (long)row * O3]; }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        const int k = k0 + kk;
+        const bool kok = k < kend;
+        uint32_t n, o;
+        dO3.divmod((uint32_t)(kok ? k : 0), n, o);
+        const int base = (int)n * Cy * O3 + (int)o + rowoff0;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it)
+            r[it] = (kok && (rbase + it * 16) < nrows_) ? dy[base + it * 16 * O3] : 0.f;
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageKFast<BR>::store(S, r, tid_);
+    }
 };
-struct WgradPatchLoader {  // B(k=pos, j=(ci,tap)), lanes along positions
-    static constexpr bool K_FAST = true;
+// B(k=pos, j=(ci,tap)), lanes along k (positions).  Rows of one thread: j = j0 + tid/16 + 16*it with j0 % 64 == 0, so
+// (kh,kw) = tid/16 is a thread constant, kd = it & 3 and ci = j0/64 + it/4 are compile-time/uniform.
+struct WgradPatchLoader {
     const float* x;
     ConvGeom g;
-    PatchCtx c;
-    __device__ void fix(int k) { c.set(g, (uint32_t)k); }
-    __device__ float get(int j) const { return c.get(g, x, j); }
+    int tid_, kk, ci0, ncin, hw, off0;
+    template <int BR>
+    __device__ void init(int tid, int j0, int N) {
+        tid_ = tid;
+        kk = tid & 15;
+        hw = tid >> 4;  // kh*4 + kw
+        ci0 = j0 >> 6;
+        ncin = N >> 6;
+        off0 = (hw >> 2) * g.IW + (hw & 3);
+    }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        const int k = k0 + kk;
+        const bool kok = k < kend;
+        PatchCtx c;
+        c.set(g, (uint32_t)(kok ? k : 0));
+        const bool hwok = kok && (((c.mask >> (4 + (hw >> 2))) & (c.mask >> (8 + (hw & 3))) & 1) != 0);
+        const int I3 = g.ID * g.IH * g.IW, IHW = g.IH * g.IW;
+        const int b = c.base + off0 + ci0 * I3;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it) {
+            const bool ok = hwok && ((c.mask >> (it & 3)) & 1) && (ci0 + (it >> 2)) < ncin;
+            r[it] = ok ? x[b + (it >> 2) * I3 + (it & 3) * IHW] : 0.f;
+        }
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageKFast<BR>::store(S, r, tid_);
+    }
 };
 struct WgradEpi {  // dW[co][j], row stride ldw (= Cin_total*64)
     float* dw;
@@ -307,21 +423,40 @@ extern "C" {
 size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) { return (size_t)8 * Cout * 8 * Cin * sizeof(float); }
 
 size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin) {
-    // up to 64 split-K partials of the [Cout, Cin*64] weight gradient
-    return (size_t)64 * Cout * Cin * 64 * sizeof(float);
+    // up to 16 split-K partials of the [Cout, Cin*64] weight gradient
+    return (size_t)16 * Cout * Cin * 64 * sizeof(float);
+}
+
+size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cout, int OD, int OH, int OW) {
+    // split-K partials are only used when batch*O^3 x Cout gives fewer than 512 tiles of 64x64: <= 8 partials
+    const size_t per = (size_t)batch * Cout * OD * OH * OW;
+    const size_t tiles = ((size_t)batch * OD * OH * OW + 63) / 64 * ((Cout + 63) / 64);
+    return tiles >= 512 ? 0 : per * 8 * sizeof(float);
+}
+
+static int check_sizes(const ConvGeom& g, int batch, const char* who) {
+    const long npos = (long)batch * g.O3();
+    if (npos >= (1L << 31) || (long)batch * g.Cx * g.I3() >= (1L << 31) || (long)batch * g.Cy * g.O3() >= (1L << 31))
+        SG_FAIL(SG_ERR_ARG, "%s: tensors of 2^31 elements or more are not supported (32-bit gather offsets)", who);
+    return 0;
 }
 
 int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
-                         int Cx, int Cout, int ID, int IH, int IW, int act, float slope, hipStream_t stream) {
+                         int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
     SG_CHECK_ARG(x && w && y && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd: spatial dims must be even and >= 2");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_fwd")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    SG_CHECK_ARG(npos < (1L << 31) && (long)batch * Cx * g.I3() < (1L << 40));
-    MatRowMajor la{w, (long)Cin_total * 64, 0};
-    FwdPatchLoader lb{x, g, {}};
+    MatRowMajor la;
+    la.p = w;
+    la.ld = (long)Cin_total * 64;
+    FwdPatchLoader lb;
+    lb.x = x;
+    lb.g = g;
     FwdEpi epi{y, bias, g.O3(), Cout, FastDiv((uint32_t)g.O3()), act, slope};
-    launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, nullptr, 0, stream);
+    launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, (float*)workspace, workspace ? workspace_bytes : 0, stream);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -332,14 +467,12 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad: spatial dims must be even and >= 2");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    SG_CHECK_ARG(npos < (1L << 31));
-    if (Cin == 1 && Cout <= 256) {
-        const long total = (long)batch * g.I3();
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(dgrad_out1_kernel, dim3(blocks), dim3(256), (size_t)Cout * 64 * sizeof(float), stream, dy, w,
-                           bias, dx, g, Cout, Cin_total, total, act, slope);
+    if (Cin == 1 && Cout <= 512) {
+        hipLaunchKernelGGL(dgrad_out1_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256),
+                           (size_t)Cout * 64 * sizeof(float), stream, dy, w, bias, dx, g, Cout, Cin_total, (int)npos, act,
+                           slope);
         SG_CHECK_LAUNCH();
         return SG_OK;
     }
@@ -353,18 +486,29 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wt, Cout, Cin_total, Cin);
     }
-    DgradWeightLoader la{wt, Cin, (long)Cout * 8 * Cin, 0};
-    DgradPatchLoader lb{dy, g, 0, 0};
+    DgradWeightLoader la;
+    la.wt = wt;
+    la.Cin = Cin;
+    la.pstride = (long)Cout * 8 * Cin;
+    DgradPatchLoader lb;
+    lb.dy = dy;
+    lb.g = g;
     DgradEpi epi{dx, bias, g, act, slope};
     const int M = Cin, N = (int)npos, K = Cout * 8;
-    const int tm = M > 64 ? 2 : 1;
-    dim3 grid(sg_cdiv(N, 128), sg_cdiv(M, 64 * tm), 8);
-    if (tm == 2)
-        hipLaunchKernelGGL((tile_gemm_kernel<2, 2, DgradWeightLoader, DgradPatchLoader, DgradEpi>), grid, dim3(256), 0,
-                           stream, la, lb, epi, M, N, K, 0);
+    const TilePlan p = plan_tiles(M, N, K, 0, 8);
+    dim3 grid(sg_cdiv(N, 64 * p.tn), sg_cdiv(M, 64 * p.tm), 8);
+#define SG_DGRAD_LAUNCH(TM_, TN_)                                                                                     \
+    hipLaunchKernelGGL((tile_gemm_kernel<TM_, TN_, DgradWeightLoader, DgradPatchLoader, DgradEpi>), grid, dim3(256), 0, \
+                       stream, la, lb, epi, M, N, K, 0)
+    if (p.tm == 2 && p.tn == 2)
+        SG_DGRAD_LAUNCH(2, 2);
+    else if (p.tm == 2)
+        SG_DGRAD_LAUNCH(2, 1);
+    else if (p.tn == 2)
+        SG_DGRAD_LAUNCH(1, 2);
     else
-        hipLaunchKernelGGL((tile_gemm_kernel<1, 2, DgradWeightLoader, DgradPatchLoader, DgradEpi>), grid, dim3(256), 0,
-                           stream, la, lb, epi, M, N, K, 0);
+        SG_DGRAD_LAUNCH(1, 1);
+#undef SG_DGRAD_LAUNCH
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -375,12 +519,18 @@ int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch
     SG_CHECK_ARG(dy && x && dw && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad: spatial dims must be even and >= 2");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    SG_CHECK_ARG(npos < (1L << 31));
-    WgradDyLoader la{dy, g.O3(), Cout, FastDiv((uint32_t)g.O3()), 0};
-    WgradPatchLoader lb{x, g, {}};
+    WgradDyLoader la;
+    la.dy = dy;
+    la.O3 = (int)g.O3();
+    la.Cy = Cout;
+    la.dO3 = FastDiv((uint32_t)g.O3());
+    WgradPatchLoader lb;
+    lb.x = x;
+    lb.g = g;
     WgradEpi epi{dw, (long)Cin_total * 64};
-    launch_tile_gemm(la, lb, epi, Cout, Cin * 64, (int)npos, (float*)workspace, workspace_bytes, stream);
+    launch_tile_gemm(la, lb, epi, Cout, Cin * 64, (int)npos, (float*)workspace, workspace ? workspace_bytes : 0, stream);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -395,9 +545,9 @@ int sg_convT3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, flo
                                   slope, workspace, workspace_bytes, stream);
 }
 int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
-                            int IW, hipStream_t stream) {
+                            int IW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return sg_conv3d_k4s2p1_fwd(dy, w, nullptr, dx, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW,
-                                SG_ACT_NONE, 0.f, stream);
+                                SG_ACT_NONE, 0.f, workspace, workspace_bytes, stream);
 }
 int sg_convT3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin_T, int Cout_T, int ID, int IH,
                             int IW, void* workspace, size_t workspace_bytes, hipStream_t stream) {

@@ -14,10 +14,14 @@
 //     D frag: j = l&31, i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //   * LDS tiles are stored [k][row] with an odd leading dimension (BM+1): the fragment reads
 //     (32 consecutive rows per half-wave) and both staging write patterns (lanes along rows,
-//     or lanes along k) are bank-conflict free for ds_read_b32/ds_write_b32.
+//     or lanes along k) are (nearly) bank-conflict free for ds_read_b32/ds_write_b32.
 //   * 256 threads = 4 waves as 2x2; each wave owns TM x TN 32x32 tiles, so the block tile is
 //     (64*TM) x (64*TN) x 16.  Global loads for tile t+1 are issued before the MFMAs of tile t
-//     (register staging), two barriers per k-tile; >=2 blocks per CU hide the barrier.
+//     (register staging), two barriers per k-tile; the launcher sizes tiles / split-K so that
+//     every CU holds >= 2 workgroups and one wave's staging VALU overlaps another's MFMAs.
+//   * A loader owns its staging lane map and precomputes everything that does not change from
+//     k-tile to k-tile (per-thread offsets, validity bits), so the per-element cost in the hot
+//     loop is an add, a predicate and the load.  k-tiles are 16-aligned (kbeg is a multiple of 16).
 #pragma once
 #include "common.h"
 
@@ -25,32 +29,90 @@ namespace sg {
 
 constexpr int kBK = 16;
 
-// ---- loader concept -------------------------------------------------------------------------
-//   static constexpr bool K_FAST;     staging lane order: lanes along k (true) or along rows
-//   void  fix(int a);                 pins the slow index (row if !K_FAST, k if K_FAST)
-//   float get(int b) const;           element at (pinned, b); only called in-bounds
+// ---- loader concept (BR = rows of this operand's block tile, E = BR*16/256 elements per thread) ----------
+//   template <int BR> void init(int tid, int row0, int nrows);          once per workgroup
+//   template <int BR> void load(int k0, int kend, float (&r)[E]);       global -> registers, tile [k0, k0+16)
+//   template <int BR> void store(float (*S)[BR + 1], const float (&r)[E]) const;   registers -> LDS S[k][row]
+// Two staging lane maps are used:
+//   lanes-along-k   : kk = tid & 15,          local row = (tid >> 4) + 16*it
+//   lanes-along-rows: local row = tid % BR,   kk = tid / BR + it * (256 / BR)
 //
 // ---- epilogue concept -----------------------------------------------------------------------
 //   struct Col;  Col col(int j) const;                    decode a column once
 //   void store(const Col&, int i, int j, float v) const;  only called in-bounds
 
-// Plain matrix, element (row,k) at p[row*ld + k]  (k contiguous)
-struct MatRowMajor {
-    static constexpr bool K_FAST = true;
-    const float* p;
-    long ld;
-    int kk;
-    __device__ void fix(int k) { kk = k; }
-    __device__ float get(int row) const { return p[(long)row * ld + kk]; }
+template <int BR>
+struct StageKFast {  // lanes along k
+    static constexpr int E = BR * kBK / 256;
+    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid) {
+        const int kk = tid & 15, lrow = tid >> 4;
+#pragma unroll
+        for (int it = 0; it < E; ++it) S[kk][lrow + it * 16] = r[it];
+    }
 };
-// Plain matrix, element (row,k) at p[k*ld + row]  (row contiguous)
-struct MatColMajor {
-    static constexpr bool K_FAST = false;
+template <int BR>
+struct StageRowFast {  // lanes along rows
+    static constexpr int E = BR * kBK / 256;
+    static constexpr int STEP = 256 / BR;
+    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid) {
+        const int lrow = tid % BR, kq = tid / BR;
+#pragma unroll
+        for (int it = 0; it < E; ++it) S[kq + it * STEP][lrow] = r[it];
+    }
+};
+
+// Plain matrix, element (row,k) at p[row*ld + k]  (k contiguous): lanes along k
+struct MatRowMajor {
     const float* p;
     long ld;
-    int rr;
-    __device__ void fix(int row) { rr = row; }
-    __device__ float get(int k) const { return p[(long)k * ld + rr]; }
+    const float* q;  // p + (row0 + tid/16)*ld + tid%16
+    int rbase, nrows_, kk, tid_;
+    template <int BR>
+    __device__ void init(int tid, int row0, int nrows) {
+        tid_ = tid;
+        kk = tid & 15;
+        rbase = row0 + (tid >> 4);
+        nrows_ = nrows;
+        q = p + (long)rbase * ld + kk;
+    }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        const bool kok = (k0 + kk) < kend;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it)
+            r[it] = (kok && (rbase + it * 16) < nrows_) ? q[(long)it * 16 * ld + k0] : 0.f;
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageKFast<BR>::store(S, r, tid_);
+    }
+};
+// Plain matrix, element (row,k) at p[k*ld + row]  (row contiguous): lanes along rows
+struct MatColMajor {
+    const float* p;
+    long ld;
+    const float* q;  // p + (tid/BR)*ld + row
+    int kq, tid_;
+    bool rok;
+    template <int BR>
+    __device__ void init(int tid, int row0, int nrows) {
+        tid_ = tid;
+        const int row = row0 + tid % BR;
+        kq = tid / BR;
+        rok = row < nrows;
+        q = p + (long)kq * ld + row;
+    }
+    template <int BR>
+    __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
+        constexpr int STEP = 256 / BR;
+#pragma unroll
+        for (int it = 0; it < BR * kBK / 256; ++it)
+            r[it] = (rok && (k0 + kq + it * STEP) < kend) ? q[(long)(k0 + it * STEP) * ld] : 0.f;
+    }
+    template <int BR>
+    __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
+        StageRowFast<BR>::store(S, r, tid_);
+    }
 };
 
 // Split-K partial sums: ws[split][i][j]
@@ -78,69 +140,10 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
     const int kbeg = kchunk > 0 ? blockIdx.z * kchunk : 0;
     const int kend = kchunk > 0 ? min(K, kbeg + kchunk) : K;
 
-    // staging coordinates
-    const int a_row = LA::K_FAST ? (tid >> 4) : (tid % BM);  // + it*16 if K_FAST
-    const int a_k = LA::K_FAST ? (tid & 15) : (tid / BM);    // + it*(256/BM) if !K_FAST
-    const int b_row = LB::K_FAST ? (tid >> 4) : (tid % BN);
-    const int b_k = LB::K_FAST ? (tid & 15) : (tid / BN);
-
-    if constexpr (!LA::K_FAST) la.fix(i0 + a_row);
-    if constexpr (!LB::K_FAST) lb.fix(j0 + b_row);
-    const bool a_row_ok = (i0 + a_row) < M;
-    const bool b_row_ok = (j0 + b_row) < N;
+    la.template init<BM>(tid, i0, M);
+    lb.template init<BN>(tid, j0, N);
 
     float ra[EA], rb[EB];
-
-    auto gload = [&](int k0) {
-        if constexpr (LA::K_FAST) {
-            const int k = k0 + a_k;
-            la.fix(k);
-            const bool kok = k < kend;
-#pragma unroll
-            for (int it = 0; it < EA; ++it) {
-                const int row = i0 + a_row + it * 16;
-                ra[it] = (kok && row < M) ? la.get(row) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < EA; ++it) {
-                const int k = k0 + a_k + it * (256 / BM);
-                ra[it] = (a_row_ok && k < kend) ? la.get(k) : 0.f;
-            }
-        }
-        if constexpr (LB::K_FAST) {
-            const int k = k0 + b_k;
-            lb.fix(k);
-            const bool kok = k < kend;
-#pragma unroll
-            for (int it = 0; it < EB; ++it) {
-                const int row = j0 + b_row + it * 16;
-                rb[it] = (kok && row < N) ? lb.get(row) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < EB; ++it) {
-                const int k = k0 + b_k + it * (256 / BN);
-                rb[it] = (b_row_ok && k < kend) ? lb.get(k) : 0.f;
-            }
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int it = 0; it < EA; ++it) {
-            if constexpr (LA::K_FAST)
-                As[a_k][a_row + it * 16] = ra[it];
-            else
-                As[a_k + it * (256 / BM)][a_row] = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < EB; ++it) {
-            if constexpr (LB::K_FAST)
-                Bs[b_k][b_row + it * 16] = rb[it];
-            else
-                Bs[b_k + it * (256 / BN)][b_row] = rb[it];
-        }
-    };
 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -154,11 +157,18 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-    if (kbeg < kend) gload(kbeg);
+    if (kbeg < kend) {
+        la.template load<BM>(kbeg, kend, ra);
+        lb.template load<BN>(kbeg, kend, rb);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        lstore();
+        la.template store<BM>(As, ra);
+        lb.template store<BN>(Bs, rb);
         __syncthreads();
-        if (k0 + BK < kend) gload(k0 + BK);
+        if (k0 + BK < kend) {
+            la.template load<BM>(k0 + BK, kend, ra);
+            lb.template load<BN>(k0 + BK, kend, rb);
+        }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[TM], b[TN];
@@ -203,17 +213,53 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* ws, E
     }
 }
 
-// Picks the split-K factor: enough blocks to cover 256 CUs about twice, each split >= 8 k-tiles.
-static inline int choose_splitk(int M, int N, int K, int tm, int tn, long ws_floats_avail) {
-    const long tiles = (long)sg_cdiv(M, 64 * tm) * sg_cdiv(N, 64 * tn);
-    if (tiles >= 256 || K < 2 * 8 * kBK) return 1;
-    long s = (512 + tiles - 1) / tiles;
-    const long smax_k = K / (8 * kBK);
-    if (s > smax_k) s = smax_k;
-    const long per = (long)M * N;
-    if (per * s > ws_floats_avail) s = ws_floats_avail / per;
-    if (s < 1) s = 1;
-    return (int)s;
+constexpr long kTargetBlocks = 512;  // >= 2 workgroups on each of the 256 CUs
+
+struct TilePlan {
+    int tm, tn, splitk;
+};
+// Largest tile that still gives kTargetBlocks workgroups; if even 64x64 does not, split K (when a workspace is there).
+static inline TilePlan plan_tiles(int M, int N, int K, long ws_floats_avail, int nbatch = 1) {
+    const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    TilePlan best{1, 1, 1};
+    bool found = false;
+    for (int c = 0; c < 4 && !found; ++c) {
+        int tm = cand[c][0], tn = cand[c][1];
+        if (tm == 2 && M <= 64) continue;
+        if (tn == 2 && N <= 64) continue;
+        const long tiles = (long)sg_cdiv(M, 64 * tm) * sg_cdiv(N, 64 * tn) * nbatch;
+        if (tiles >= kTargetBlocks) {
+            best = TilePlan{tm, tn, 1};
+            found = true;
+        }
+    }
+    if (found) return best;
+    // smallest legal tile; add split-K if allowed
+    int tm = 1, tn = 1;
+    const long tiles = (long)sg_cdiv(M, 64) * sg_cdiv(N, 64) * nbatch;
+    long s = 1;
+    if (ws_floats_avail > 0 && K >= 2 * 8 * kBK) {
+        s = (kTargetBlocks + tiles - 1) / tiles;
+        const long smax_k = K / (8 * kBK);
+        if (s > smax_k) s = smax_k;
+        const long per = (long)M * N;
+        if (per * s > ws_floats_avail) s = ws_floats_avail / per;
+        if (s < 1) s = 1;
+    }
+    // with split-K active a larger tile may already reach the target
+    if (s > 1) {
+        for (int c = 0; c < 4; ++c) {
+            int a = cand[c][0], b = cand[c][1];
+            if ((a == 2 && M <= 64) || (b == 2 && N <= 64)) continue;
+            const long t2 = (long)sg_cdiv(M, 64 * a) * sg_cdiv(N, 64 * b) * nbatch;
+            if (t2 * s >= kTargetBlocks) {
+                tm = a;
+                tn = b;
+                break;
+            }
+        }
+    }
+    return TilePlan{tm, tn, (int)s};
 }
 
 template <int TM, int TN, class LA, class LB, class EPI>
@@ -238,12 +284,11 @@ static int launch_tile_gemm_t(LA la, LB lb, EPI epi, int M, int N, int K, int sp
 // ws may be null (then no split-K). ws_bytes is the size of the caller-owned workspace.
 template <class LA, class LB, class EPI>
 static int launch_tile_gemm(LA la, LB lb, EPI epi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st) {
-    const int tm = M > 64 ? 2 : 1, tn = N > 64 ? 2 : 1;
-    const int splitk = ws ? choose_splitk(M, N, K, tm, tn, (long)(ws_bytes / sizeof(float))) : 1;
-    if (tm == 2 && tn == 2) return launch_tile_gemm_t<2, 2>(la, lb, epi, M, N, K, splitk, ws, st);
-    if (tm == 2 && tn == 1) return launch_tile_gemm_t<2, 1>(la, lb, epi, M, N, K, splitk, ws, st);
-    if (tm == 1 && tn == 2) return launch_tile_gemm_t<1, 2>(la, lb, epi, M, N, K, splitk, ws, st);
-    return launch_tile_gemm_t<1, 1>(la, lb, epi, M, N, K, splitk, ws, st);
+    const TilePlan p = plan_tiles(M, N, K, ws ? (long)(ws_bytes / sizeof(float)) : 0);
+    if (p.tm == 2 && p.tn == 2) return launch_tile_gemm_t<2, 2>(la, lb, epi, M, N, K, p.splitk, ws, st);
+    if (p.tm == 2 && p.tn == 1) return launch_tile_gemm_t<2, 1>(la, lb, epi, M, N, K, p.splitk, ws, st);
+    if (p.tm == 1 && p.tn == 2) return launch_tile_gemm_t<1, 2>(la, lb, epi, M, N, K, p.splitk, ws, st);
+    return launch_tile_gemm_t<1, 1>(la, lb, epi, M, N, K, p.splitk, ws, st);
 }
 
 }  // namespace sg

@@ -30,9 +30,13 @@ def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0):
     Co, Ct = w.shape[0], w.shape[1]
     if Cx > Ct:
         raise RuntimeError("conv: input has %d channels, weight expects %d" % (Cx, Ct))
+    ptr(x)  # fail loudly on CPU tensors before anything else
     y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    check(_lib().sg_conv3d_k4s2p1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope,
-                                      stream()), "conv3d_fwd")
+    lib = _lib()
+    nb = lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Co, D // 2, H // 2, W // 2)
+    ws = workspace("splitk", nb, x.device) if nb else None
+    check(lib.sg_conv3d_k4s2p1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope, ptr(ws),
+                                   ws.numel() if ws is not None else 0, stream()), "conv3d_fwd")
     return y
 
 

@@ -29,7 +29,7 @@ def check_against_oracles(got, ref32, ref64, what, rtol=RTOL, gscale=0.0, noise_
     values per channel at batch 4, or gradients that are mathematically zero, carry noise far above 1e-4 in the
     reference itself).  LeakyReLU/ReLU kinks: an activation within rounding of 0 may take the other branch in two
     correct fp32 implementations, which changes a few isolated gradient entries by a finite amount; at most 0.1 % of
-    the elements may exceed the bound, and then by no more than 5 % of the tensor's largest entry."""
+    the elements (or 4 elements) may exceed the bound, and then by no more than 5 % of the tensor's largest entry."""
     g, r32, r64 = got.detach().double().cpu(), ref32.detach().double(), ref64.detach().double()
     noise = float((r32 - r64).abs().max())
     scale = max(float(r64.abs().mean()), gscale * 1e-3)
@@ -37,7 +37,8 @@ def check_against_oracles(got, ref32, ref64, what, rtol=RTOL, gscale=0.0, noise_
     err = (g - r64).abs()
     bad = err > tol
     frac = float(bad.double().mean())
-    assert frac <= 1e-3, "%s: %.3f%% of elements beyond tol %.3e (max err %.3e, fp32-oracle noise %.3e, scale %.3e)" % (
+    allowed = max(1e-3, 4.0 / bad.numel())       # a handful of kink outliers even in small tensors
+    assert frac <= allowed, "%s: %.3f%% of elements beyond tol %.3e (max err %.3e, fp32-oracle noise %.3e, scale %.3e)" % (
         what, 100 * frac, tol, float(err.max()), noise, scale)
     if frac > 0:
         assert float(err.max()) <= 0.05 * max(float(r64.abs().max()), gscale), what + ": kink outlier too large"
