@@ -1,5 +1,5 @@
 import sys, time, os, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_oracle as O
 from shapegan_amd.model.gan import Generator, Discriminator
 torch.manual_seed(0)

@@ -1,7 +1,7 @@
 """Diagnostic: full-tensor comparison HIP vs CPU oracle (fp32 and fp64) for the Generator at B=3 (golden case)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_oracle as O
 from shapegan_amd.model.gan import Generator
 z = np.load("tests/golden/modules.npz")

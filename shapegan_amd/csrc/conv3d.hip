@@ -91,7 +91,7 @@ struct FwdPatchLoader {
     ConvGeom g;
     int base, mask, tid_;
     int off[8];
-    unsigned okbits;
+    unsigned okbits, pend;
     template <int BR>
     __device__ void init(int tid, int j0, int N) {
         constexpr int E = BR * kBK / 256, STEP = 256 / BR;
@@ -115,11 +115,12 @@ struct FwdPatchLoader {
         const int toff = base + (ci * g.ID + kd) * g.IH * g.IW;
         const unsigned ok = ((mask >> kd) & 1) ? okbits : 0u;
 #pragma unroll
-        for (int it = 0; it < BR * kBK / 256; ++it) r[it] = ((ok >> it) & 1u) ? x[toff + off[it]] : 0.f;
+        for (int it = 0; it < BR * kBK / 256; ++it) r[it] = x[((ok >> it) & 1u) ? toff + off[it] : 0];
+        pend = ok;
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_);
+        StageRowFast<BR>::store(S, r, tid_, pend);
     }
 };
 struct FwdEpi {  // y[n][co][o] = act(v + bias[co])
@@ -172,7 +173,7 @@ struct DgradPatchLoader {
     ConvGeom g;
     int base, tid_, kq;
     int off[8];
-    unsigned okbits;
+    unsigned okbits, pend;
     template <int BR>
     __device__ void init(int tid, int j0, int N) {
         constexpr int E = BR * kBK / 256, STEP = 256 / BR;
@@ -200,13 +201,17 @@ struct DgradPatchLoader {
     __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
         constexpr int STEP = 256 / BR;
         const int toff = base + (k0 >> 3) * g.OD * g.OH * g.OW;
+        pend = 0;
 #pragma unroll
-        for (int it = 0; it < BR * kBK / 256; ++it)
-            r[it] = (((okbits >> it) & 1u) && (k0 + kq + it * STEP) < kend) ? dy[toff + off[it]] : 0.f;
+        for (int it = 0; it < BR * kBK / 256; ++it) {
+            const bool e = ((okbits >> it) & 1u) && (k0 + kq + it * STEP) < kend;
+            r[it] = dy[e ? toff + off[it] : 0];
+            pend |= (e ? 1u : 0u) << it;
+        }
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_);
+        StageRowFast<BR>::store(S, r, tid_, pend);
     }
 };
 struct DgradEpi {  // dx[n][ci][2qd+pd][2qh+ph][2qw+pw] = act(v + bias[ci])
@@ -329,6 +334,7 @@ struct WgradDyLoader {
     int O3, Cy;
     FastDiv dO3;
     int tid_, kk, rowoff0, rbase, nrows_;
+    unsigned pend;
     template <int BR>
     __device__ void init(int tid, int row0, int nrows) {
         tid_ = tid;
@@ -344,13 +350,17 @@ struct WgradDyLoader {
         uint32_t n, o;
         dO3.divmod((uint32_t)(kok ? k : 0), n, o);
         const int base = (int)n * Cy * O3 + (int)o + rowoff0;
+        pend = 0;
 #pragma unroll
-        for (int it = 0; it < BR * kBK / 256; ++it)
-            r[it] = (kok && (rbase + it * 16) < nrows_) ? dy[base + it * 16 * O3] : 0.f;
+        for (int it = 0; it < BR * kBK / 256; ++it) {
+            const bool e = kok && (rbase + it * 16) < nrows_;
+            r[it] = dy[e ? base + it * 16 * O3 : 0];
+            pend |= (e ? 1u : 0u) << it;
+        }
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_);
+        StageKFast<BR>::store(S, r, tid_, pend);
     }
 };
 // B(k=pos, j=(ci,tap)), lanes along k (positions).  Rows of one thread: j = j0 + tid/16 + 16*it with j0 % 64 == 0, so
@@ -359,6 +369,7 @@ struct WgradPatchLoader {
     const float* x;
     ConvGeom g;
     int tid_, kk, ci0, ncin, hw, off0;
+    unsigned pend;
     template <int BR>
     __device__ void init(int tid, int j0, int N) {
         tid_ = tid;
@@ -377,15 +388,17 @@ struct WgradPatchLoader {
         const bool hwok = kok && (((c.mask >> (4 + (hw >> 2))) & (c.mask >> (8 + (hw & 3))) & 1) != 0);
         const int I3 = g.ID * g.IH * g.IW, IHW = g.IH * g.IW;
         const int b = c.base + off0 + ci0 * I3;
+        pend = 0;
 #pragma unroll
         for (int it = 0; it < BR * kBK / 256; ++it) {
             const bool ok = hwok && ((c.mask >> (it & 3)) & 1) && (ci0 + (it >> 2)) < ncin;
-            r[it] = ok ? x[b + (it >> 2) * I3 + (it & 3) * IHW] : 0.f;
+            r[it] = x[ok ? b + (it >> 2) * I3 + (it & 3) * IHW : 0];
+            pend |= (ok ? 1u : 0u) << it;
         }
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_);
+        StageKFast<BR>::store(S, r, tid_, pend);
     }
 };
 struct WgradEpi {  // dW[co][j], row stride ldw (= Cin_total*64)

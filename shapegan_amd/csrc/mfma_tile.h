@@ -31,8 +31,10 @@ constexpr int kBK = 16;
 
 // ---- loader concept (BR = rows of this operand's block tile, E = BR*16/256 elements per thread) ----------
 //   template <int BR> void init(int tid, int row0, int nrows);          once per workgroup
-//   template <int BR> void load(int k0, int kend, float (&r)[E]);       global -> registers, tile [k0, k0+16)
-//   template <int BR> void store(float (*S)[BR + 1], const float (&r)[E]) const;   registers -> LDS S[k][row]
+//   template <int BR> void load(int k0, int kend, float (&r)[E]);       global -> registers, tile [k0, k0+16):
+//        UNCONDITIONAL loads from clamped addresses (no branches), validity kept as a bit mask in the loader
+//   template <int BR> void store(float (*S)[BR + 1], const float (&r)[E]) const;   registers -> LDS S[k][row]:
+//        applies the validity mask here, so nothing consumes a load result before the MFMAs of the current tile
 // Two staging lane maps are used:
 //   lanes-along-k   : kk = tid & 15,          local row = (tid >> 4) + 16*it
 //   lanes-along-rows: local row = tid % BR,   kk = tid / BR + it * (256 / BR)
@@ -44,20 +46,20 @@ constexpr int kBK = 16;
 template <int BR>
 struct StageKFast {  // lanes along k
     static constexpr int E = BR * kBK / 256;
-    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid) {
+    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid, unsigned ok) {
         const int kk = tid & 15, lrow = tid >> 4;
 #pragma unroll
-        for (int it = 0; it < E; ++it) S[kk][lrow + it * 16] = r[it];
+        for (int it = 0; it < E; ++it) S[kk][lrow + it * 16] = ((ok >> it) & 1u) ? r[it] : 0.f;
     }
 };
 template <int BR>
 struct StageRowFast {  // lanes along rows
     static constexpr int E = BR * kBK / 256;
     static constexpr int STEP = 256 / BR;
-    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid) {
+    static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid, unsigned ok) {
         const int lrow = tid % BR, kq = tid / BR;
 #pragma unroll
-        for (int it = 0; it < E; ++it) S[kq + it * STEP][lrow] = r[it];
+        for (int it = 0; it < E; ++it) S[kq + it * STEP][lrow] = ((ok >> it) & 1u) ? r[it] : 0.f;
     }
 };
 
@@ -67,6 +69,7 @@ struct MatRowMajor {
     long ld;
     const float* q;  // p + (row0 + tid/16)*ld + tid%16
     int rbase, nrows_, kk, tid_;
+    unsigned pend;
     template <int BR>
     __device__ void init(int tid, int row0, int nrows) {
         tid_ = tid;
@@ -78,13 +81,17 @@ struct MatRowMajor {
     template <int BR>
     __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
         const bool kok = (k0 + kk) < kend;
+        pend = 0;
 #pragma unroll
-        for (int it = 0; it < BR * kBK / 256; ++it)
-            r[it] = (kok && (rbase + it * 16) < nrows_) ? q[(long)it * 16 * ld + k0] : 0.f;
+        for (int it = 0; it < BR * kBK / 256; ++it) {
+            const bool ok = kok && (rbase + it * 16) < nrows_;
+            r[it] = *(ok ? q + ((long)it * 16 * ld + k0) : p);
+            pend |= (ok ? 1u : 0u) << it;
+        }
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_);
+        StageKFast<BR>::store(S, r, tid_, pend);
     }
 };
 // Plain matrix, element (row,k) at p[k*ld + row]  (row contiguous): lanes along rows
@@ -94,6 +101,7 @@ struct MatColMajor {
     const float* q;  // p + (tid/BR)*ld + row
     int kq, tid_;
     bool rok;
+    unsigned pend;
     template <int BR>
     __device__ void init(int tid, int row0, int nrows) {
         tid_ = tid;
@@ -105,13 +113,17 @@ struct MatColMajor {
     template <int BR>
     __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
         constexpr int STEP = 256 / BR;
+        pend = 0;
 #pragma unroll
-        for (int it = 0; it < BR * kBK / 256; ++it)
-            r[it] = (rok && (k0 + kq + it * STEP) < kend) ? q[(long)(k0 + it * STEP) * ld] : 0.f;
+        for (int it = 0; it < BR * kBK / 256; ++it) {
+            const bool ok = rok && (k0 + kq + it * STEP) < kend;
+            r[it] = *(ok ? q + (long)(k0 + it * STEP) * ld : p);
+            pend |= (ok ? 1u : 0u) << it;
+        }
     }
     template <int BR>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_);
+        StageRowFast<BR>::store(S, r, tid_, pend);
     }
 };
 
@@ -162,27 +174,35 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
         lb.template load<BN>(kbeg, kend, rb);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        la.template store<BM>(As, ra);
+        la.template store<BM>(As, ra);  // consumes the loads issued one tile ago (their latency hid behind the MFMAs)
         lb.template store<BN>(Bs, rb);
-        __syncthreads();
+        __syncthreads();                // A: tile visible
         if (k0 + BK < kend) {
             la.template load<BM>(k0 + BK, kend, ra);
             lb.template load<BN>(k0 + BK, kend, rb);
         }
+        // all fragment reads of the k-tile up front, then ONE early barrier (B: LDS free for the next tile) that is
+        // followed by the uninterrupted MFMA burst; global loads stay in flight across it (raw s_barrier, no vmcnt)
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = As[2 * s + kh][wm * 32 * TM + t * 32 + r];
+            for (int t = 0; t < TM; ++t) af[s][t] = As[2 * s + kh][wm * 32 * TM + t * 32 + r];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = Bs[2 * s + kh][wn * 32 * TN + t * 32 + r];
+            for (int t = 0; t < TN; ++t) bf[s][t] = Bs[2 * s + kh][wn * 32 * TN + t * 32 + r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only (vmcnt/expcnt fields left at max)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < TN; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][ta], bf[s][tb], acc[ta][tb], 0, 0, 0);
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);  // pin the next tile's selects / ds_writes below the MFMAs
     }
 
 #pragma unroll
