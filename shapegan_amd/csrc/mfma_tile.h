@@ -238,48 +238,29 @@ constexpr long kTargetBlocks = 512;  // >= 2 workgroups on each of the 256 CUs
 struct TilePlan {
     int tm, tn, splitk;
 };
-// Largest tile that still gives kTargetBlocks workgroups; if even 64x64 does not, split K (when a workspace is there).
+// Largest tile that reaches kTargetBlocks workgroups, using split-K (when a workspace is there) to multiply the
+// workgroup count of big tiles: big tiles stage fewer bytes per MFMA, split-K costs one extra pass over M*N*s floats.
 static inline TilePlan plan_tiles(int M, int N, int K, long ws_floats_avail, int nbatch = 1) {
     const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    const long smax_k = K / (8 * kBK) > 0 ? K / (8 * kBK) : 1;  // every split keeps >= 8 k-tiles
+    const long smax_ws = ws_floats_avail > 0 ? ws_floats_avail / ((long)M * N) : 1;
     TilePlan best{1, 1, 1};
-    bool found = false;
-    for (int c = 0; c < 4 && !found; ++c) {
-        int tm = cand[c][0], tn = cand[c][1];
-        if (tm == 2 && M <= 64) continue;
-        if (tn == 2 && N <= 64) continue;
+    long best_blocks = -1;
+    for (int c = 0; c < 4; ++c) {
+        const int tm = cand[c][0], tn = cand[c][1];
+        if ((tm == 2 && M <= 64) || (tn == 2 && N <= 64)) continue;
         const long tiles = (long)sg_cdiv(M, 64 * tm) * sg_cdiv(N, 64 * tn) * nbatch;
-        if (tiles >= kTargetBlocks) {
-            best = TilePlan{tm, tn, 1};
-            found = true;
-        }
-    }
-    if (found) return best;
-    // smallest legal tile; add split-K if allowed
-    int tm = 1, tn = 1;
-    const long tiles = (long)sg_cdiv(M, 64) * sg_cdiv(N, 64) * nbatch;
-    long s = 1;
-    if (ws_floats_avail > 0 && K >= 2 * 8 * kBK) {
-        s = (kTargetBlocks + tiles - 1) / tiles;
-        const long smax_k = K / (8 * kBK);
+        long s = (kTargetBlocks + tiles - 1) / tiles;
         if (s > smax_k) s = smax_k;
-        const long per = (long)M * N;
-        if (per * s > ws_floats_avail) s = ws_floats_avail / per;
+        if (s > smax_ws) s = smax_ws;
         if (s < 1) s = 1;
-    }
-    // with split-K active a larger tile may already reach the target
-    if (s > 1) {
-        for (int c = 0; c < 4; ++c) {
-            int a = cand[c][0], b = cand[c][1];
-            if ((a == 2 && M <= 64) || (b == 2 && N <= 64)) continue;
-            const long t2 = (long)sg_cdiv(M, 64 * a) * sg_cdiv(N, 64 * b) * nbatch;
-            if (t2 * s >= kTargetBlocks) {
-                tm = a;
-                tn = b;
-                break;
-            }
+        if (tiles * s >= kTargetBlocks) return TilePlan{tm, tn, (int)s};
+        if (tiles * s > best_blocks) {
+            best_blocks = tiles * s;
+            best = TilePlan{tm, tn, (int)s};
         }
     }
-    return TilePlan{tm, tn, (int)s};
+    return best;
 }
 
 template <int TM, int TN, class LA, class LB, class EPI>
