@@ -52,7 +52,7 @@ def roofline_conv():
     ms = event_time_ms(lambda: ops.conv_fwd_raw(x, w, b, 1, 0.2), 20)
     flop = CONV2_FLOP_PER_SAMPLE * BATCH
     achieved = flop / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "tile_gemm_kernel<2,2,MatRowMajor,FwdPatchLoader,FwdEpi> (Conv3d 64->128 fwd, B=64)",
+    return {"bound": "mfma", "kernel": "conv_fwd_halo_kernel (Conv3d 64->128 k4 s2 p1 forward, 16^3 -> 8^3, B=64; the largest GEMM of the step)",
             "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
             "flop_per_launch": flop}

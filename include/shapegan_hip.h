@@ -44,10 +44,14 @@ const char* sg_last_error(void);
  * x [batch,Cx,ID,IH,IW] -> y [batch,Cout,ID/2,IH/2,IW/2]; w [Cout,Cin_total,4,4,4].
  * Only input channels [0,Cin) are read (Cin < Cin_total reproduces from_SDF's zero padding,
  * model/progressive_gan.py:9-16, without materialising the zero channels). */
-size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cout, int OD, int OH, int OW); /* split-K, small grids */
+size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
 int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                          int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
                          size_t workspace_bytes, hipStream_t stream);
+/* testing / tuning: force one forward implementation (0 = gather implicit GEMM, 1 = LDS-halo implicit GEMM) */
+int sg_conv3d_k4s2p1_fwd_impl(const float* x, const float* w, const float* bias, float* y, int batch, int Cin,
+                              int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                              void* workspace, size_t workspace_bytes, int impl, int debug, hipStream_t stream);
 /* dx[batch,Cx(first Cin channels),ID,IH,IW] = conv^T(dy, w) (+bias[ci], act: used when this is a ConvTranspose fwd) */
 size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin);
 int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,

@@ -19,46 +19,10 @@
 // Double backward (WGAN-GP, train_hybrid_progressive_gan.py:102-111) needs nothing else because the
 // convolution is bilinear in (x, W).
 #include "mfma_tile.h"
+#include "conv_common.h"
 #include "../../include/shapegan_hip.h"
 
 namespace sg {
-
-// n / d for n < 2^31 with precomputed magic (round-up method)
-struct FastDiv {
-    uint32_t m, s, d;
-    FastDiv() : m(0), s(0), d(1) {}
-    explicit FastDiv(uint32_t dd) : d(dd) {
-        s = 0;
-        while ((1u << s) < dd) ++s;
-        m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - dd)) / dd + 1);
-    }
-    __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, m) + n) >> s; }
-    __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
-        q = div(n);
-        r = n - q * d;
-    }
-};
-
-struct ConvGeom {
-    int ID, IH, IW;   // spatial size of the stride-1 side (x of the conv)
-    int OD, OH, OW;   // spatial size of the stride-2 side (y of the conv) = I/2
-    int Cx, Cy;       // channels physically present in x / y tensors (batch strides)
-    FastDiv dOW, dOH, dOD;
-    long I3() const { return (long)ID * IH * IW; }
-    long O3() const { return (long)OD * OH * OW; }
-};
-
-// decode a flat (n,od,oh,ow) position of the O grid
-__device__ __forceinline__ void decode_pos(const ConvGeom& g, uint32_t j, int& n, int& od, int& oh, int& ow) {
-    uint32_t t1, t2, t3, a, b, c;
-    g.dOW.divmod(j, t1, a);
-    g.dOH.divmod(t1, t2, b);
-    g.dOD.divmod(t2, t3, c);
-    ow = (int)a;
-    oh = (int)b;
-    od = (int)c;
-    n = (int)t3;
-}
 
 // patch of x around output position pos=(n,od,oh,ow): element (ci,kd,kh,kw) = x[n,ci,2od-1+kd,2oh-1+kh,2ow-1+kw].
 // `base` is the (possibly negative) element offset of tap (0,0,0) of channel 0; mask bits 0-3 / 4-7 / 8-11 say which
@@ -411,22 +375,6 @@ struct WgradEpi {  // dW[co][j], row stride ldw (= Cin_total*64)
     __device__ void store(const Col& c, int i, int j, float v) const { dw[(long)i * ldw + c.j] = v; }
 };
 
-static int make_geom(ConvGeom& g, int ID, int IH, int IW, int Cx, int Cy) {
-    if (ID < 2 || IH < 2 || IW < 2 || (ID & 1) || (IH & 1) || (IW & 1)) return -1;
-    g.ID = ID;
-    g.IH = IH;
-    g.IW = IW;
-    g.OD = ID / 2;
-    g.OH = IH / 2;
-    g.OW = IW / 2;
-    g.Cx = Cx;
-    g.Cy = Cy;
-    g.dOW = FastDiv(g.OW);
-    g.dOH = FastDiv(g.OH);
-    g.dOD = FastDiv(g.OD);
-    return 0;
-}
-
 }  // namespace sg
 
 using namespace sg;
@@ -440,11 +388,14 @@ size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin) {
     return (size_t)16 * Cout * Cin * 64 * sizeof(float);
 }
 
-size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cout, int OD, int OH, int OW) {
-    // split-K partials are only used when batch*O^3 x Cout gives fewer than 512 tiles of 64x64: <= 8 partials
+size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
+    // (a) the LDS-halo kernel's packed weight image, (b) split-K partials of the gather kernel, used only when
+    // batch*O^3 x Cout gives fewer than 512 tiles of 64x64 (<= 8 partials)
     const size_t per = (size_t)batch * Cout * OD * OH * OW;
     const size_t tiles = ((size_t)batch * OD * OH * OW + 63) / 64 * ((Cout + 63) / 64);
-    return tiles >= 512 ? 0 : per * 8 * sizeof(float);
+    const size_t splitk = tiles >= 512 ? 0 : per * 8 * sizeof(float);
+    const size_t pack = halo_fwd_workspace_bytes(Cin, Cout);
+    return splitk > pack ? splitk : pack;
 }
 
 static int check_sizes(const ConvGeom& g, int batch, const char* who) {
@@ -461,6 +412,44 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_fwd")) return SG_ERR_ARG;
+    const long npos = (long)batch * g.O3();
+    {
+        const int rc = halo_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
+                                    stream);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            SG_CHECK_LAUNCH();
+            return SG_OK;
+        }
+    }
+    MatRowMajor la;
+    la.p = w;
+    la.ld = (long)Cin_total * 64;
+    FwdPatchLoader lb;
+    lb.x = x;
+    lb.g = g;
+    FwdEpi epi{y, bias, g.O3(), Cout, FastDiv((uint32_t)g.O3()), act, slope};
+    launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Forces one implementation of the forward (testing / tuning): impl 0 = gather kernel, 1 = LDS-halo kernel
+// (SG_ERR_ARG if the shape is not eligible).  `debug` is for timing experiments only.
+int sg_conv3d_k4s2p1_fwd_impl(const float* x, const float* w, const float* bias, float* y, int batch, int Cin,
+                              int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                              void* workspace, size_t workspace_bytes, int impl, int debug, hipStream_t stream) {
+    SG_CHECK_ARG(x && w && y && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
+    ConvGeom g;
+    if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd_impl: bad spatial dims");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_fwd_impl")) return SG_ERR_ARG;
+    if (impl == 1) {
+        const int rc = halo_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
+                                    stream, 1, debug);
+        if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd_impl: shape not eligible for the LDS-halo kernel");
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     const long npos = (long)batch * g.O3();
     MatRowMajor la;
     la.p = w;

@@ -1,0 +1,281 @@
+// shapegan_amd/csrc/conv3d_halo.hip — LDS-halo implicit GEMM for the channel-heavy Conv3d(k4,s2,p1) forward.
+//
+// Same math as conv3d.hip's `fwd` form (nn.Conv3d forward: model/gan.py:49-53, model/autoencoder.py:16-24,
+// model/progressive_gan.py:38; nn.ConvTranspose3d input-gradient), different data movement:
+//
+//   * a workgroup owns 64 output positions of ONE sample (a TD x TH x TW box) x 64*TM output channels;
+//   * per stage it copies the input HALO box (2TD+2)(2TH+2)(2TW+2) of CC channels into LDS with row-coalesced
+//     global loads — every input voxel is fetched once per workgroup instead of once per tap (8x less TA/L1
+//     traffic than the gather kernel) — W columns de-interleaved by parity so that the stride-2 window walk of
+//     the 32 positions of a half-wave is conflict-free;
+//   * MFMA B fragments (v_mfma_f32_32x32x2_f32: lane = position, k-pair) are read straight from that box: the tap
+//     offset is uniform per k-step, so a read is one ds_read_b32 with an immediate offset — no staging copy of B;
+//   * MFMA A fragments come from a pre-packed weight image in global memory (L2-resident), one coalesced
+//     global_load_dwordx4 per lane per 4 k-steps, prefetched one group ahead — no LDS and no staging for A either
+//     (the same scheme as the fused SDFNet kernel).
+//   Per stage of CC=8 channels a wave issues 256*TM MFMAs (16K-32K matrix-pipe cycles) against ~70 loads and
+//   ~70 LDS writes per thread of staging.
+#include "conv_common.h"
+
+namespace sg {
+
+// Fixed tile: 1 x 8 x 8 output positions (one D slice, 8 rows, 8 columns) -> halo box 4 x 18 x 18 input voxels.
+constexpr int kHD = 4, kHH = 18, kHWF = 18;  // halo extent in D, H, W
+constexpr int kHWH = 10;                      // W halves per parity (9 used, padded so that 4*kHWH = 8 mod 32)
+constexpr int kROWH = 2 * kHWH;               // one H row = [even columns | odd columns]
+constexpr int kROWD = kHH * kROWH;            // 360
+constexpr int kHS = kHD * kROWD;              // 1440 floats per channel
+constexpr int kCC = 4;                        // channels per stage; LDS = 2 buffers x 4 x 1440 x 4 B = 46 KB
+
+struct HaloFwdArgs {
+    const float* x;
+    const float4* wp;
+    const float* bias;
+    float* y;
+    ConvGeom g;
+    int Cin, Cout;
+    int nth, ntw;  // tiles per H / W (one tile per D slice)
+    FastDiv dntw, dnth, dOD;
+    int act;
+    float slope;
+    int debug;  // tuning experiments only: 1 = fill the halo once, 2 = skip the MFMAs
+};
+
+// Wp[(mt*G + g)*64 + lane] = float4{ W[mt*32 + (lane&31)][8g + 2j + (lane>>5)] , j = 0..3 }   (G = Cin*8 groups)
+__global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __restrict__ w, float4* __restrict__ wp,
+                                                               int Cout, int Cin_total, int Cin, int ntile) {
+    const long G = (long)Cin * 8;
+    const long total = (long)ntile * G * 64;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const long q = e >> 6;
+        const long g = q % G;
+        const int mt = (int)(q / G);
+        const int co = mt * 32 + (lane & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < Cout) {
+            const float* src = w + (long)co * Cin_total * 64 + g * 8 + (lane >> 5);
+            v = make_float4(src[0], src[2], src[4], src[6]);
+        }
+        wp[e] = v;
+    }
+}
+
+// Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 8*TM MFMAs each):
+//   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1:
+//     each k-group issues one global load of the next box (9 per channel per thread), the values are written to LDS
+//     one channel (64*TM MFMAs) later, so neither the load latency nor the copy sits on the matrix pipe's critical path;
+//   * B fragments of group g+1 are read from LDS before the MFMAs of group g are issued; A fragments (packed weights,
+//     L2) are prefetched one group ahead; one barrier per stage.
+template <int TM, int NW>
+__global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
+    constexpr int kFR = NW * 2;                          // halo rows copied per pass (one per half-wave)
+    constexpr int kNF = (kHD * kHH + kFR - 1) / kFR;     // fill elements per thread per channel (72 rows)
+    constexpr int ROWS = (NW / 2) * TM * 32;             // output channels per workgroup
+    extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][kCC][kHD][kHH][2][kHWH]
+
+    uint32_t twi, thi, od, n, q1, q2;
+    a.dntw.divmod(blockIdx.x, q1, twi);
+    a.dnth.divmod(q1, q2, thi);
+    a.dOD.divmod(q2, n, od);
+    const int oh0 = thi * 8, ow0 = twi * 8;
+    const int co0 = blockIdx.y * ROWS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int p = wn * 32 + r, pw = p & 7, ph = p >> 3;  // position inside the 8x8 tile
+    const int lanebase = 2 * ph * kROWH + kpar * kHWH + pw;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const long G = (long)a.Cin * 8;
+    const float4* wrow[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) wrow[t] = a.wp + ((long)(co0 / 32 + wm * TM + t) * G) * 64 + lane;
+
+    // ---- fill bookkeeping: element fl (0..8) of a channel is halo row 8*fl + tid/32, column tid%32 ----
+    const int I3 = a.g.ID * a.g.IH * a.g.IW;
+    const float* xn = a.x + (long)n * a.g.Cx * I3;
+    const int fl_w = tid & 31, frow = tid >> 5;
+    const int iw = 2 * ow0 - 1 + fl_w;
+    const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
+    const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
+    int goff[kNF], loff[kNF];  // global offset inside a channel (-1: zero), LDS offset inside a channel (-1: none)
+#pragma unroll
+    for (int f = 0; f < kNF; ++f) {
+        const int row = kFR * f + frow, hd = row / kHH, hh = row - hd * kHH;
+        const int id = 2 * (int)od - 1 + hd, ih = 2 * oh0 - 1 + hh;
+        const bool inbox = fl_w < kHWF && row < kHD * kHH;
+        const bool ok = inbox && wok && (unsigned)id < (unsigned)a.g.ID && (unsigned)ih < (unsigned)a.g.IH;
+        goff[f] = ok ? (id * a.g.IH + ih) * a.g.IW + iw : -1;
+        loff[f] = inbox ? hd * kROWD + hh * kROWH + lds_w : -1;
+    }
+    float fv[kNF];
+    auto fill_load = [&](int f, int cglob) {  // issue the load of element f of global channel cglob
+        fv[f] = xn[goff[f] >= 0 ? cglob * I3 + goff[f] : 0];
+    };
+    auto fill_store = [&](int f, float* buf, int ci) {
+        if (loff[f] >= 0) buf[ci * kHS + loff[f]] = goff[f] >= 0 ? fv[f] : 0.f;
+    };
+
+    // ---- prologue: box of stage 0 into buffer 0 ----
+    for (int ci = 0; ci < kCC; ++ci) {
+#pragma unroll
+        for (int f = 0; f < kNF; ++f) fill_load(f, ci);
+#pragma unroll
+        for (int f = 0; f < kNF; ++f) fill_store(f, halo, ci);
+    }
+    // packed weights: a ring of 4 k-groups in flight.  Vector loads return in order, so a weight load issued after a
+    // copy load of x (HBM latency) cannot complete before it: 4 groups (~2000 matrix-pipe cycles) cover that latency.
+    float4 aring[4][TM];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) aring[u][t] = wrow[t][u * 64];
+    long g = 0;
+    __syncthreads();
+
+    const int nstage = a.Cin / kCC;
+    for (int s = 0; s < nstage; ++s) {
+        const float* cur = halo + (s & 1) * (kCC * kHS);
+        float* nxt = halo + ((s + 1) & 1) * (kCC * kHS);
+        const bool more = (s + 1 < nstage) && !(a.debug & 1);
+        const int cnext = (s + 1) * kCC;
+        if (!(a.debug & 2)) {
+            const float* hb0 = cur + lanebase;
+            float bq[4] = {hb0[0], hb0[1], hb0[kROWH], hb0[kROWH + 1]};  // B fragments of the first group
+#pragma unroll
+            for (int ci = 0; ci < kCC; ++ci) {
+                // values loaded during the previous channel's MFMAs go to LDS now
+                if (ci > 0 && more) {
+#pragma unroll
+                    for (int f = 0; f < kNF; ++f) fill_store(f, nxt, ci - 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
+                    float4 a_cur[TM];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) a_cur[t] = aring[j & 3][t];
+                    if (g + 4 < G) {
+#pragma unroll
+                        for (int t = 0; t < TM; ++t) aring[j & 3][t] = wrow[t][(g + 4) * 64];
+                    }
+                    ++g;
+                    const float b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
+                    if (!(ci == kCC - 1 && j == 7)) {  // B fragments of the next group of this stage
+                        const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
+                        const float* hb = cur + lanebase + cin * kHS + (jn >> 1) * kROWD + (2 * (jn & 1)) * kROWH;
+                        bq[0] = hb[0];
+                        bq[1] = hb[1];
+                        bq[2] = hb[kROWH];
+                        bq[3] = hb[kROWH + 1];
+                    }
+                    if (more) {  // spread this channel's kNF copy loads over its 8 k-groups
+#pragma unroll
+                        for (int f = 0; f < kNF; ++f)
+                            if (f * 8 / kNF == j) fill_load(f, cnext + ci);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, b0, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, b1, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, b2, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, b3, acc[t], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int f = 0; f < kNF; ++f) fill_store(f, nxt, kCC - 1);
+            }
+        } else if (more) {  // ablation: copy only
+            for (int ci = 0; ci < kCC; ++ci) {
+#pragma unroll
+                for (int f = 0; f < kNF; ++f) fill_load(f, cnext + ci);
+#pragma unroll
+                for (int f = 0; f < kNF; ++f) fill_store(f, nxt, ci);
+            }
+        }
+        __syncthreads();  // next box complete and visible; everyone is done reading the current one
+    }
+
+    // epilogue: y[n][co][od][oh0+ph][ow0+pw] = act(acc + bias[co])
+    const long O3 = (long)a.g.OD * a.g.OH * a.g.OW;
+    float* yo = a.y + (long)n * a.Cout * O3 + ((long)od * a.g.OH + (oh0 + ph)) * a.g.OW + (ow0 + pw);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+            if (co < a.Cout) {
+                float v = acc[t][q];
+                if (a.bias) v += a.bias[co];
+                yo[(long)co * O3] = sg_apply_act(v, a.act, a.slope);
+            }
+        }
+    }
+}
+
+size_t halo_fwd_workspace_bytes(int Cin, int Cout) { return (size_t)((Cout + 127) / 128) * 128 * Cin * 64 * sizeof(float); }
+
+int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                 const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream, int force, int debug) {
+    // eligible: 8x8 position tiles exist, whole stages of 4 channels, enough output channels to fill 64-row MFMA tiles
+    if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin % kCC != 0 || Cin < 8 || Cout < 32) return 0;
+    if (!workspace || workspace_bytes < halo_fwd_workspace_bytes(Cin, Cout)) return 0;
+    if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
+    // configuration: 128 output channels per workgroup as 8 waves x 1 tile (variant 0, more waves per SIMD to hide the
+    // copy / weight-load latency) or 4 waves x 2 tiles (variant 1); 64 channels as 4 waves x 1 tile
+    // measured (scripts/halo_bench.py): 4 waves x 2 tiles wins below ~1024 workgroups, 8 waves x 1 tile above
+    int variant = (debug >> 4) & 3;
+    const int rows = Cout > 64 ? 128 : 64;
+    const int ntw = g.OW / 8, nth = g.OH / 8;
+    const long tiles = (long)batch * g.OD * nth * ntw;
+    const int mtiles = sg_cdiv(Cout, rows);
+    // auto-dispatch only where it wins (A/B on MI355X, scripts/halo_bench.py): >= 128 output channels, >= 384 workgroups
+    if (!force && (rows != 128 || tiles * mtiles < 384)) return 0;
+    if (tiles >= (1L << 31)) return 0;
+    if (variant == 0) variant = (tiles * mtiles < 1024) ? 1 : 2;   // 0 = auto, 1 = 4 waves, 2 = 8 waves
+    const size_t lds = (size_t)2 * kCC * kHS * sizeof(float);
+
+    float4* wp = (float4*)workspace;
+    {
+        const int ntile = mtiles * rows / 32;  // every row tile a workgroup may touch exists (zero rows beyond Cout)
+        const long total = (long)ntile * Cin * 8 * 64;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, Cout, Cin_total, Cin, ntile);
+    }
+    HaloFwdArgs a;
+    a.x = x;
+    a.wp = wp;
+    a.bias = bias;
+    a.y = y;
+    a.g = g;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.nth = nth;
+    a.ntw = ntw;
+    a.dntw = FastDiv(ntw);
+    a.dnth = FastDiv(nth);
+    a.dOD = FastDiv(g.OD);
+    a.act = act;
+    a.slope = slope;
+    a.debug = debug & 15;
+    dim3 grid((unsigned)tiles, mtiles);
+    if (rows == 128 && variant == 2)
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8>), grid, dim3(512), lds, stream, a);
+    else if (rows == 128)
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4>), grid, dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4>), grid, dim3(256), lds, stream, a);
+    return 1;
+}
+
+}  // namespace sg

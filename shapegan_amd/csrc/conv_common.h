@@ -1,0 +1,68 @@
+// shapegan_amd/csrc/conv_common.h — geometry helpers shared by the k4/s2/p1 convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace sg {
+
+// n / d for n < 2^31 with precomputed magic (round-up method)
+struct FastDiv {
+    uint32_t m, s, d;
+    FastDiv() : m(0), s(0), d(1) {}
+    explicit FastDiv(uint32_t dd) : d(dd) {
+        s = 0;
+        while ((1u << s) < dd) ++s;
+        m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - dd)) / dd + 1);
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, m) + n) >> s; }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
+struct ConvGeom {
+    int ID, IH, IW;   // spatial size of the stride-1 side (x of the conv)
+    int OD, OH, OW;   // spatial size of the stride-2 side (y of the conv) = I/2
+    int Cx, Cy;       // channels physically present in x / y tensors (batch strides)
+    FastDiv dOW, dOH, dOD;
+    long I3() const { return (long)ID * IH * IW; }
+    long O3() const { return (long)OD * OH * OW; }
+};
+
+// decode a flat (n,od,oh,ow) position of the O grid
+__device__ __forceinline__ void decode_pos(const ConvGeom& g, uint32_t j, int& n, int& od, int& oh, int& ow) {
+    uint32_t t1, t2, t3, a, b, c;
+    g.dOW.divmod(j, t1, a);
+    g.dOH.divmod(t1, t2, b);
+    g.dOD.divmod(t2, t3, c);
+    ow = (int)a;
+    oh = (int)b;
+    od = (int)c;
+    n = (int)t3;
+}
+
+static inline int make_geom(ConvGeom& g, int ID, int IH, int IW, int Cx, int Cy) {
+    if (ID < 2 || IH < 2 || IW < 2 || (ID & 1) || (IH & 1) || (IW & 1)) return -1;
+    g.ID = ID;
+    g.IH = IH;
+    g.IW = IW;
+    g.OD = ID / 2;
+    g.OH = IH / 2;
+    g.OW = IW / 2;
+    g.Cx = Cx;
+    g.Cy = Cy;
+    g.dOW = FastDiv(g.OW);
+    g.dOH = FastDiv(g.OH);
+    g.dOD = FastDiv(g.OD);
+    return 0;
+}
+
+
+// conv3d_halo.hip: LDS-halo forward kernel.  Returns 1 if it handled the call, 0 if the shape is not eligible
+// (the caller then uses the generic gather kernel), <0 on error.
+size_t halo_fwd_workspace_bytes(int Cin, int Cout);
+int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                 const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream, int force = 0, int debug = 0);
+
+}  // namespace sg

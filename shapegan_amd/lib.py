@@ -20,8 +20,9 @@ _P, _I, _L, _F, _Z = c_void_p, c_int, c_long, c_float, c_size_t
 SIGNATURES = {
     "sg_abi_version": (c_int, []),
     "sg_last_error": (c_char_p, []),
-    "sg_conv3d_k4s2p1_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "sg_conv3d_k4s2p1_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_conv3d_k4s2p1_fwd_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _I, _P]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
     "sg_conv3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_conv3d_k4s2p1_wgrad_workspace_bytes": (_Z, [_I, _I]),

@@ -33,10 +33,23 @@ def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0):
     ptr(x)  # fail loudly on CPU tensors before anything else
     y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
     lib = _lib()
-    nb = lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Co, D // 2, H // 2, W // 2)
+    nb = lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Cx, Co, D // 2, H // 2, W // 2)
     ws = workspace("splitk", nb, x.device) if nb else None
     check(lib.sg_conv3d_k4s2p1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope, ptr(ws),
                                    ws.numel() if ws is not None else 0, stream()), "conv3d_fwd")
+    return y
+
+
+def conv_fwd_impl_raw(x, w, bias, act, slope, impl, debug=0):
+    """Forward through a forced implementation (0 gather, 1 LDS-halo) — tests and tuning only."""
+    N, Cx, D, H, W = x.shape
+    Co, Ct = w.shape[0], w.shape[1]
+    y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    lib = _lib()
+    nb = max(lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Cx, Co, D // 2, H // 2, W // 2), 1 << 20)
+    ws = workspace("splitk", nb, x.device)
+    check(lib.sg_conv3d_k4s2p1_fwd_impl(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope,
+                                        ptr(ws), ws.numel(), impl, debug, stream()), "conv3d_fwd_impl")
     return y
 
 

@@ -367,3 +367,19 @@ def test_sdfnet_chairs_known_answers(golden_sdf, chairs_state):
     mask = np.linalg.norm(get_voxel_coordinates(32), axis=1) < 1.1
     assert voxels.shape == (32, 32, 32) and np.all(voxels.reshape(-1)[~mask] == 1.0)
     np.testing.assert_allclose(voxels.reshape(-1)[mask], a.numpy()[mask], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,Ci,Co,R", [(2, 64, 128, 16), (1, 8, 32, 16), (2, 24, 48, 16), (1, 32, 64, 32), (3, 16, 96, 16),
+                                       (1, 128, 256, 16), (1, 12, 40, 16), (2, 4 * 17, 130, 16)])
+def test_conv_fwd_halo_kernel(N, Ci, Co, R):
+    """The LDS-halo forward (forced, whatever the grid size) == the gather kernel == the oracle."""
+    from shapegan_amd import ops
+    torch.manual_seed(N + Ci + Co + R)
+    x = torch.randn(N, Ci, R, R, R)
+    w = torch.randn(Co, Ci, 4, 4, 4) / (Ci * 64) ** 0.5
+    b = torch.randn(Co)
+    ref = F.leaky_relu(F.conv3d(x, w, b, stride=2, padding=1), 0.2)
+    y_halo = ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=1)
+    y_gather = ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=0)
+    close(y_halo, ref, what="halo vs oracle")
+    close(y_gather, ref, what="gather vs oracle")
