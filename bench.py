@@ -59,8 +59,11 @@ def roofline_conv():
 
 
 def sdfnet_numbers():
-    """SDFNet forward on a 32^3 x 8 grid (config 5's generator pass) and one auto-decoder training step of 20 000
-    points (config 3); FLOP/point from SURVEY.md 8d (921 088 fwd at L=128, ~3x for a training step)."""
+    """SDFNet half of the metric.  Forward: a 32^3 x 8 grid pass (config 5's generator forward).  Training: one
+    auto-decoder step (train_sdf_autodecoder.py:77-91: gather, fused forward, L1+reg loss, fused backward, weight-grad
+    GEMMs, two Adam updates) at the reference's 20 000 points/step with latent 128, and at BASELINE configs[2]'s
+    200 000 points/step with latent 256.  FLOP/point from SURVEY.md 8d (921 088 fwd at L=128, 1 052 160 at L=256,
+    ~3x for a training step)."""
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     from shapegan_amd.util import get_voxel_coordinates
@@ -72,17 +75,19 @@ def sdfnet_numbers():
         ms_fwd = event_time_ms(lambda: net.forward_shapes(grid, z, 32768), 10)
     n_fwd = 8 * 32768
     fwd_tflops = n_fwd * 921088 / (ms_fwd * 1e-3) / 1e12
+    out = {"fwd_mpoints_per_s": round(n_fwd / ms_fwd / 1e3, 2), "fwd_tflops": round(fwd_tflops, 2),
+           "fwd_frac_of_f32_mfma_peak": round(fwd_tflops / F32_MFMA_PEAK_TFLOPS, 4)}
     pc, shapes = 200000, 64
     pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
     sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
-    lat = torch.randn(shapes, 128, device="cuda") * 1e-2
-    tr = SDFAutoDecoderTrainer(SDFNet(), lat, pts, sdf, pointcloud_size=pc)
-    idx = torch.randint(0, shapes * pc, (20000,), device="cuda")
-    ms_train = event_time_ms(lambda: tr.step(idx), 10)
-    return {"fwd_mpoints_per_s": round(n_fwd / ms_fwd / 1e3, 2), "fwd_tflops": round(fwd_tflops, 2),
-            "fwd_frac_of_f32_mfma_peak": round(fwd_tflops / F32_MFMA_PEAK_TFLOPS, 4),
-            "train_mpoints_per_s": round(20000 / ms_train / 1e3, 3), "train_points_per_step": 20000,
-            "train_ms_per_step": round(ms_train, 3)}
+    for tag, npts, lat, flop_pt in (("train_ref_20k_L128", 20000, 128, 3 * 921088), ("train_cfg_200k_L256", 200000, 256, 3 * 1052160)):
+        table = torch.randn(shapes, lat, device="cuda") * 1e-2
+        tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
+        idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
+        ms = event_time_ms(lambda: tr.step(idx), 10)
+        out[tag] = {"mpoints_per_s": round(npts / ms / 1e3, 3), "ms_per_step": round(ms, 3),
+                    "tflops": round(npts * flop_pt / (ms * 1e-3) / 1e12, 2)}
+    return out
 
 
 def cpu_baseline(reals, zs, zg, g_state, c_state):

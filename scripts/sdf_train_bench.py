@@ -1,0 +1,25 @@
+"""Auto-decoder (train_sdf_autodecoder.py) step timing at several batch sizes / latent sizes."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shapegan_amd.model.sdf_net import SDFNet
+from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+cases = [(20000, 128), (200000, 128), (200000, 256)] if len(sys.argv) < 2 else [(int(sys.argv[1]), int(sys.argv[2]))]
+for npts, L in cases:
+    torch.manual_seed(0)
+    pc, shapes = 200000, 64
+    pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
+    sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
+    lat = torch.randn(shapes, L, device="cuda") * 1e-2
+    tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=L), lat, pts, sdf, pointcloud_size=pc)
+    idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
+    ms = timeit(lambda: tr.step(idx))
+    t0 = time.perf_counter(); tr.step(idx); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+    flop = npts * (2.76e6 if L == 128 else 3.16e6)
+    print("points %d L %d: %.3f ms/step (wall %.3f)  %.2f Mpoints/s  ~%.1f TFLOP/s" % (npts, L, ms, wall, npts / ms / 1e3, flop / ms / 1e9), flush=True)

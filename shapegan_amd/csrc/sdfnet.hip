@@ -333,21 +333,36 @@ __global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     };
-    // G <- G * (H_l > 0), also stored as dZ_l
-    auto mask_and_save = [&](int layer) {
+    // G <- G * (H_l > 0), also stored as dZ_l.  The H_l tile is fetched into registers one layer ahead (load_h is
+    // issued right after the previous mask, so its HBM latency hides behind that layer's W^T dZ GEMM).
+    constexpr int HE = kH * P / 512;
+    float hreg[HE];
+    auto load_h = [&](int layer) {
         const float* h = a.acts + (long)layer * kH * a.ldn;
+#pragma unroll
+        for (int i = 0; i < HE; ++i) {
+            const int e = tid + i * 512;
+            const int row = e / P, p = e - row * P;
+            const long gp = p0 + p;
+            hreg[i] = h[gp < a.N ? (long)row * a.ldn + gp : 0];
+        }
+    };
+    auto mask_and_save = [&](int layer) {
         float* z = a.dz + (long)layer * kH * a.ldn;
-        for (int e = tid; e < kH * P; e += 512) {
+#pragma unroll
+        for (int i = 0; i < HE; ++i) {
+            const int e = tid + i * 512;
             const int row = e / P, p = e - row * P;
             const long gp = p0 + p;
             float g = 0.f;
             if (gp < a.N) {
-                g = h[(long)row * a.ldn + gp] > 0.f ? Gs[e] : 0.f;
+                g = hreg[i] > 0.f ? Gs[e] : 0.f;
                 z[(long)row * a.ldn + gp] = g;
             }
             Gs[e] = g;
         }
         __syncthreads();
+        if (layer > 0) load_h(layer - 1);
     };
     // DX (+)= T(KUr x 256) * G ; waves [0, nxt) each own one 32-row tile
     auto x_grad = [&](long toff, bool first) {
@@ -380,6 +395,7 @@ __global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
         __syncthreads();
     };
 
+    load_h(6);
     mask_and_save(6);          // dZ7
     back_step(a.lay.T7);       // dH6
     mask_and_save(5);          // dZ6
