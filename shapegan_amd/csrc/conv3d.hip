@@ -381,7 +381,10 @@ using namespace sg;
 
 extern "C" {
 
-size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) { return (size_t)8 * Cout * 8 * Cin * sizeof(float); }
+size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) {
+    const size_t a = (size_t)8 * Cout * 8 * Cin * sizeof(float), b = halo_dgrad_workspace_bytes(Cin, Cout);
+    return a > b ? a : b;
+}
 
 size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin) {
     // up to 16 split-K partials of the [Cout, Cin*64] weight gradient
@@ -478,7 +481,16 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
         SG_CHECK_LAUNCH();
         return SG_OK;
     }
-    const size_t need = sg_conv3d_k4s2p1_dgrad_workspace_bytes(Cout, Cin);
+    {
+        const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace,
+                                      workspace_bytes, stream, 0);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            SG_CHECK_LAUNCH();
+            return SG_OK;
+        }
+    }
+    const size_t need = (size_t)8 * Cout * 8 * Cin * sizeof(float);
     if (!workspace || workspace_bytes < need)
         SG_FAIL(SG_ERR_WORKSPACE, "sg_conv3d_k4s2p1_dgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     float* wt = (float*)workspace;
@@ -511,6 +523,21 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     else
         SG_DGRAD_LAUNCH(1, 1);
 #undef SG_DGRAD_LAUNCH
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// testing / tuning: impl 1 forces the LDS-halo dgrad kernel (SG_ERR_ARG if the shape is not eligible)
+int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                                void* workspace, size_t workspace_bytes, int impl, hipStream_t stream) {
+    SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && impl == 1);
+    ConvGeom g;
+    if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: bad spatial dims");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad_impl")) return SG_ERR_ARG;
+    const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
+                                  stream, 1);
+    if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: shape not eligible for the LDS-halo kernel");
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

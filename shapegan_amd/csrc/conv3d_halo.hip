@@ -278,4 +278,222 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     return 1;
 }
 
+
+// ================================================================================================================
+// dgrad form (nn.Conv3d input-gradient, nn.ConvTranspose3d forward) with the same data movement.
+//   dx[n,ci,2q+p] = sum_{co,t in {0,1}^3} W[co,ci,tap(p,t)] * dy[n,co,q+p-t],   tap = 1 - p + 2t per dimension
+// One workgroup = one output parity p (grid z) x 64 input channels x a 2x8x8 box of q (128 positions).  Per stage it
+// copies the (2+1)x9x9 box of dy it needs for 16 output channels into LDS (dense, index = copy index), B fragments are
+// read from the box with immediate offsets (the tap shift (1-td)*81 + (1-th)*9 is a compile-time constant per k-step),
+// A fragments come from a per-parity packed weight image.  K per channel is 8 = one k-group.
+constexpr int kDB = 3 * 9 * 9;   // box floats per channel
+constexpr int kDCC = 16;         // channels per stage: 16 k-groups, 128 MFMAs per wave
+constexpr int kDNF = (kDCC * kDB + 255) / 256;  // 16 copy elements per thread per stage
+
+struct HaloDgradArgs {
+    const float* dy;
+    const float4* wp;   // [8 parities][Cin_pad/32][Cout][64 lanes] float4
+    const float* bias;
+    float* dx;
+    ConvGeom g;
+    int Cin, Cout, mtiles;  // mtiles = row tiles (of 64) per parity
+    FastDiv dntw, dnth, dntd;
+    int act;
+    float slope;
+};
+
+// wp[((p*MT + mt)*Cout + co)*64 + lane] = float4{ W[co][mt*32 + (lane&31)][tap(p, t = 2j + (lane>>5))], j = 0..3 }
+__global__ void __launch_bounds__(256) pack_dgrad_frag_kernel(const float* __restrict__ w, float4* __restrict__ wp,
+                                                              int Cout, int Cin_total, int Cin, int MT) {
+    const long total = 8L * MT * Cout * 64;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        long q = e >> 6;
+        const int co = (int)(q % Cout);
+        q /= Cout;
+        const int mt = (int)(q % MT);
+        const int p = (int)(q / MT);
+        const int ci = mt * 32 + (lane & 31);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ci < Cin) {
+            const float* src = w + ((long)co * Cin_total + ci) * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 2 * j + (lane >> 5);
+                const int kd = 1 - ((p >> 2) & 1) + 2 * ((t >> 2) & 1);
+                const int kh = 1 - ((p >> 1) & 1) + 2 * ((t >> 1) & 1);
+                const int kw = 1 - (p & 1) + 2 * (t & 1);
+                v[j] = src[kd * 16 + kh * 4 + kw];
+            }
+        }
+        wp[e] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDCC][3][9][9]
+    const int par = blockIdx.z, pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
+    uint32_t twi, thi, tdi, n, q1, q2;
+    a.dntw.divmod(blockIdx.x, q1, twi);
+    a.dnth.divmod(q1, q2, thi);
+    a.dntd.divmod(q2, n, tdi);
+    const int qd0 = tdi * 2, qh0 = thi * 8, qw0 = twi * 8;
+    const int ci0 = blockIdx.y * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int lw = r & 7, lh4 = r >> 3;  // + 4*tn
+    // address of (td,th) for column tile tn: lanebase + tn*36 + (1-td)*81 + (1-th)*9
+    const int lanebase = wn * 81 + lh4 * 9 + lw + 1 - kpar;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const long G = a.Cout;  // one k-group per output channel
+    const float4* wrow = a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64 + lane;
+
+    // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f = (ci, hd, hh, hw) dense ----
+    const int O3 = a.g.OD * a.g.OH * a.g.OW;
+    const float* dyn = a.dy + (long)n * a.g.Cy * O3;
+    int goff[kDNF];  // offset inside the stage's first channel block (-1: zero, -2: beyond the box)
+#pragma unroll
+    for (int f = 0; f < kDNF; ++f) {
+        const int e = tid + 256 * f;
+        const int ci = e / kDB, rem = e - ci * kDB, hd = rem / 81, hh = (rem - hd * 81) / 9, hw = rem % 9;
+        const int od = qd0 + pd - 1 + hd, oh = qh0 + ph - 1 + hh, ow = qw0 + pw - 1 + hw;
+        const bool ok = (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH && (unsigned)ow < (unsigned)a.g.OW;
+        goff[f] = e >= kDCC * kDB ? -2 : (ok ? ci * O3 + (od * a.g.OH + oh) * a.g.OW + ow : -1);
+    }
+    float fv[kDNF];
+    auto copy_load = [&](int f, int c0) { fv[f] = dyn[goff[f] >= 0 ? c0 * O3 + goff[f] : 0]; };
+    auto copy_store = [&](int f, float* buf) {
+        if (goff[f] != -2) buf[tid + 256 * f] = goff[f] >= 0 ? fv[f] : 0.f;
+    };
+
+#pragma unroll
+    for (int f = 0; f < kDNF; ++f) copy_load(f, 0);
+#pragma unroll
+    for (int f = 0; f < kDNF; ++f) copy_store(f, box);
+    float4 aring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) aring[u] = wrow[(u < G ? u : 0) * 64];
+    long g = 0;
+    __syncthreads();
+
+    const int nstage = a.Cout / kDCC;
+    for (int s = 0; s < nstage; ++s) {
+        const float* cur = box + (s & 1) * (kDCC * kDB);
+        float* nxt = box + ((s + 1) & 1) * (kDCC * kDB);
+        const bool more = s + 1 < nstage;
+        const int cnext = (s + 1) * kDCC;
+        const float* hb0 = cur + lanebase;
+        float bq[2][4];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            bq[tn][0] = hb0[tn * 36 + 81 + 9];   // j=0: td=0, th=0
+            bq[tn][1] = hb0[tn * 36 + 81];       // j=1: td=0, th=1
+            bq[tn][2] = hb0[tn * 36 + 9];        // j=2: td=1, th=0
+            bq[tn][3] = hb0[tn * 36];            // j=3: td=1, th=1
+        }
+#pragma unroll
+        for (int c = 0; c < kDCC; ++c) {  // one k-group per channel
+            const float4 a_cur = aring[c & 3];
+            if (g + 4 < G) aring[c & 3] = wrow[(g + 4) * 64];
+            ++g;
+            float b[2][4];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[tn][j] = bq[tn][j];
+            if (c + 1 < kDCC) {
+                const float* hb = hb0 + (c + 1) * kDB;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    bq[tn][0] = hb[tn * 36 + 81 + 9];
+                    bq[tn][1] = hb[tn * 36 + 81];
+                    bq[tn][2] = hb[tn * 36 + 9];
+                    bq[tn][3] = hb[tn * 36];
+                }
+            }
+            if (more) {
+                // copy schedule: loads of the next box in groups 0..11, each value stored 4 groups after its load
+#pragma unroll
+                for (int f = 0; f < kDNF; ++f) {
+                    if (f * 3 / 4 + 4 == c) copy_store(f, nxt);
+                    if (f * 3 / 4 == c) copy_load(f, cnext);
+                }
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[0][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[1][0], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[0][1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[1][1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[0][2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[1][2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[0][3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[1][3], acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: dx[n][ci][2(qd0+wn)+pd][2(qh0+lh)+ph][2(qw0+lw)+pw] = act(acc + bias[ci])
+    const long I3 = (long)a.g.ID * a.g.IH * a.g.IW;
+    float* out = a.dx + (long)n * a.g.Cx * I3;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int lh = tn * 4 + lh4;
+        const long pos = ((long)(2 * (qd0 + wn) + pd) * a.g.IH + (2 * (qh0 + lh) + ph)) * a.g.IW + (2 * (qw0 + lw) + pw);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+            if (ci < a.Cin) {
+                float v = acc[tn][q];
+                if (a.bias) v += a.bias[ci];
+                out[(long)ci * I3 + pos] = sg_apply_act(v, a.act, a.slope);
+            }
+        }
+    }
+}
+
+size_t halo_dgrad_workspace_bytes(int Cin, int Cout) { return (size_t)8 * ((Cin + 63) / 64) * 64 * Cout * 8 * sizeof(float); }
+
+int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                   const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream, int force) {
+    if (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0 || Cout % kDCC != 0 || Cin < 32) return 0;
+    if (!workspace || workspace_bytes < halo_dgrad_workspace_bytes(Cin, Cout)) return 0;
+    if ((long)batch * g.Cy * g.OD * g.OH * g.OW >= (1L << 31)) return 0;
+    const int ntw = g.OW / 8, nth = g.OH / 8, ntd = g.OD / 2;
+    const long tiles = (long)batch * ntd * nth * ntw;
+    const int mtiles = (Cin + 63) / 64;
+    if (!force && tiles * mtiles * 8 < 512) return 0;
+    if (tiles >= (1L << 31) || mtiles > 65535) return 0;
+    float4* wp = (float4*)workspace;
+    {
+        const long total = 8L * mtiles * 2 * Cout * 64;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_dgrad_frag_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, Cout, Cin_total, Cin, mtiles * 2);
+    }
+    HaloDgradArgs a;
+    a.dy = dy;
+    a.wp = wp;
+    a.bias = bias;
+    a.dx = dx;
+    a.g = g;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.mtiles = mtiles;
+    a.dntw = FastDiv(ntw);
+    a.dnth = FastDiv(nth);
+    a.dntd = FastDiv(ntd);
+    a.act = act;
+    a.slope = slope;
+    const size_t lds = (size_t)2 * kDCC * kDB * sizeof(float);
+    hipLaunchKernelGGL(conv_dgrad_halo_kernel, dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    return 1;
+}
+
 }  // namespace sg

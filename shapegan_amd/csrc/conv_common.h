@@ -65,4 +65,9 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
                  const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                  hipStream_t stream, int force = 0, int debug = 0);
 
+size_t halo_dgrad_workspace_bytes(int Cin, int Cout);
+int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                   const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream, int force = 0);
+
 }  // namespace sg

@@ -383,3 +383,17 @@ def test_conv_fwd_halo_kernel(N, Ci, Co, R):
     y_gather = ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=0)
     close(y_halo, ref, what="halo vs oracle")
     close(y_gather, ref, what="gather vs oracle")
+
+
+@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 32, 16, 8), (1, 64, 32, 16), (2, 128, 64, 8), (1, 40, 48, 8)])
+def test_conv_dgrad_halo_kernel(N, Ci, Co, O):
+    """The LDS-halo dgrad / ConvTranspose3d forward (forced) == ATen conv_transpose3d."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    torch.manual_seed(N + Ci + Co + O)
+    dy = torch.randn(N, Co, O, O, O)
+    w = torch.randn(Co, Ci, 4, 4, 4) / (Co * 8) ** 0.5
+    b = torch.randn(Ci)
+    ref = F.leaky_relu(F.conv_transpose3d(dy, w, b, stride=2, padding=1), 0.2)
+    got = ops.conv_dgrad_halo_raw(dev(dy), dev(w), dev(b), Ci, ACT_LEAKY, 0.2)
+    close(got, ref, what="dgrad halo vs oracle")
