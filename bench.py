@@ -52,9 +52,17 @@ def roofline_conv():
     ms = event_time_ms(lambda: ops.conv_fwd_raw(x, w, b, 1, 0.2), 20)
     flop = CONV2_FLOP_PER_SAMPLE * BATCH
     achieved = flop / (ms * 1e-3) / 1e12
+    # HBM bytes per launch of this kernel: PMC counters cannot be read in-process, so the figure measured with
+    # rocprofv3 (--pmc FETCH_SIZE / WRITE_SIZE, separate passes, guide corrections) is read from profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_conv_fwd_halo_hbm.json")) as fh:
+            traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "mfma", "kernel": "conv_fwd_halo_kernel (Conv3d 64->128 k4 s2 p1 forward, 16^3 -> 8^3, B=64; the largest GEMM of the step)",
             "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
             "flop_per_launch": flop}
 
 
@@ -125,7 +133,7 @@ def main():
     from shapegan_amd import parallel
     rank, world, local = parallel.init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
 
