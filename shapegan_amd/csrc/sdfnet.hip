@@ -290,14 +290,14 @@ struct SdfBwdArgs {
 
 // Backward-data chain for one tile of P points.  G[256][P] holds dH_l; the X-gradient tile DX[KUr][P+1]
 // accumulates W5i^T dZ5 + W1^T dZ1 (only when a.dx != nullptr).
+// P = 64: 64.3 KB of LDS and <= 128 VGPRs, so two workgroups (16 waves) share a CU and one's mask / write-back phases
+// overlap the other's MFMA phases; P = 128 fills the LDS with one workgroup.
 template <int P>
-__global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
+__global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfBwdArgs a) {
     constexpr int NT = P / 32;
-    constexpr int LDX = P + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;            // [256][P]
-    float* DXs = Gs + kH * P;    // [KUr][LDX]
-    float* dz8s = DXs + (a.dx ? a.lay.KUr * LDX : 0);  // [P]
+    float* dz8s = Gs + kH * P;   // [P]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -335,52 +335,26 @@ __global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
     };
     // G <- G * (H_l > 0), also stored as dZ_l.  The H_l tile is fetched into registers one layer ahead (load_h is
     // issued right after the previous mask, so its HBM latency hides behind that layer's W^T dZ GEMM).
-    constexpr int HE = kH * P / 512;
-    float hreg[HE];
-    auto load_h = [&](int layer) {
-        const float* h = a.acts + (long)layer * kH * a.ldn;
-#pragma unroll
-        for (int i = 0; i < HE; ++i) {
-            const int e = tid + i * 512;
-            const int row = e / P, p = e - row * P;
-            const long gp = p0 + p;
-            hreg[i] = h[gp < a.N ? (long)row * a.ldn + gp : 0];
-        }
-    };
+    constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
+    constexpr int RSTEP = 512 / P;
+    const int mrow = tid / P, mp = tid % P;
+    const long mgp = p0 + mp;
+    const bool mok = mgp < a.N;
+    const long moff = mok ? (long)mrow * a.ldn + mgp : 0;   // element 0 of this thread inside a layer's [256][ldn] image
+    const long mstride = (long)RSTEP * a.ldn;
+    // G <- G * (H_l > 0), also stored as dZ_l.  (No register prefetch of H: with two workgroups per CU the other
+    // workgroup's MFMA phase covers this load; a prefetch array pushes the kernel past 128 VGPRs.)
     auto mask_and_save = [&](int layer) {
-        float* z = a.dz + (long)layer * kH * a.ldn;
-#pragma unroll
+        const float* h = a.acts + (long)layer * kH * a.ldn + moff;
+        float* z = a.dz + (long)layer * kH * a.ldn + moff;
+#pragma unroll 8
         for (int i = 0; i < HE; ++i) {
-            const int e = tid + i * 512;
-            const int row = e / P, p = e - row * P;
-            const long gp = p0 + p;
-            float g = 0.f;
-            if (gp < a.N) {
-                g = hreg[i] > 0.f ? Gs[e] : 0.f;
-                z[(long)row * a.ldn + gp] = g;
-            }
-            Gs[e] = g;
+            const float hv = h[mok ? i * mstride : 0];
+            const float g = (mok && hv > 0.f) ? Gs[tid + i * 512] : 0.f;
+            if (mok) z[i * mstride] = g;
+            Gs[tid + i * 512] = g;
         }
         __syncthreads();
-        if (layer > 0) load_h(layer - 1);
-    };
-    // DX (+)= T(KUr x 256) * G ; waves [0, nxt) each own one 32-row tile
-    auto x_grad = [&](long toff, bool first) {
-        if (a.dx) {
-            for (int xt = wave; xt < nxt; xt += 8) {
-                zero_acc();
-                mlp_gemm<NT>(acc, pk + (toff >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int row = xt * 32 + frag_row(q, kh);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        float* d = &DXs[row * LDX + t * 32 + r];
-                        *d = first ? acc[t][q] : (*d + acc[t][q]);
-                    }
-                }
-            }
-        }
     };
     auto back_step = [&](long toff) {  // G <- T_l * G
         zero_acc();
@@ -395,14 +369,12 @@ __global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
         __syncthreads();
     };
 
-    load_h(6);
     mask_and_save(6);          // dZ7
     back_step(a.lay.T7);       // dH6
     mask_and_save(5);          // dZ6
     back_step(a.lay.T6);       // dH5
     mask_and_save(4);          // dZ5
-    x_grad(a.lay.T5i, true);   // dX  = W5[:,256:]^T dZ5
-    back_step(a.lay.T5x);      // dH4 (x_grad reads G before back_step's first barrier; DX is a separate region)
+    back_step(a.lay.T5x);      // dH4
     mask_and_save(3);          // dZ4
     back_step(a.lay.T4);
     mask_and_save(2);          // dZ3
@@ -410,22 +382,48 @@ __global__ void __launch_bounds__(512) sdfnet_bwd_kernel(SdfBwdArgs a) {
     mask_and_save(1);          // dZ2
     back_step(a.lay.T2);
     mask_and_save(0);          // dZ1
-    x_grad(a.lay.T1, false);   // dX += W1^T dZ1
+    // ---- input gradient dX = W1^T dZ1 + W5[:,256:]^T dZ5 (rows = input features, 32-row tiles round-robin over waves) ----
+    // G holds dZ1 now; the dZ5 tile is read back from the dz image this workgroup wrote (L2-hot).  Accumulating both
+    // products in registers and writing dx once needs neither LDS nor a read-modify-write.
     if (a.dx) {
-        __syncthreads();
-        const int KU = a.lay.KU;
-        for (int e = tid; e < P * KU; e += 512) {
-            const int p = e / KU, k = e - p * KU;
-            const long gp = p0 + p;
-            if (gp < a.N) a.dx[gp * a.dx_ld + k] = DXs[k * LDX + p];
+        auto reload = [&](int layer) {  // G <- dZ_{layer+1} tile
+            const float* z = a.dz + (long)layer * kH * a.ldn + moff;
+            __syncthreads();
+#pragma unroll 8
+            for (int i = 0; i < HE; ++i) {
+                const float v = z[mok ? i * mstride : 0];
+                Gs[tid + i * 512] = mok ? v : 0.f;
+            }
+            __syncthreads();
+        };
+        for (int pass = 0; pass * 8 < nxt; ++pass) {
+            const int xt = pass * 8 + wave;
+            const bool mine = xt < nxt;
+            if (pass > 0) reload(0);
+            zero_acc();
+            if (mine) mlp_gemm<NT>(acc, pk + (a.lay.T1 >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
+            reload(4);
+            if (mine) {
+                mlp_gemm<NT>(acc, pk + (a.lay.T5i >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const long gp = p0 + t * 32 + r;
+                    if (gp < a.N) {
+                        float* d = a.dx + gp * a.dx_ld;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int row = xt * 32 + frag_row(q, kh);
+                            if (row < a.lay.KU) d[row] = acc[t][q];
+                        }
+                    }
+                }
+            }
         }
     }
 }
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
-static size_t bwd_lds_bytes(int P, int KUr, bool dx) {
-    return ((size_t)kH * P + (dx ? (size_t)KUr * (P + 1) : 0) + P) * sizeof(float);
-}
+static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + P) * sizeof(float); }
 
 template <class K>
 static int set_lds(K kern, size_t bytes) {

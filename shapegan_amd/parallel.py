@@ -34,26 +34,81 @@ def world_size():
 
 
 class GradBucket(object):
-    """Flat gradient bucket of one optimizer: launch() starts the asynchronous sum, wait() blocks the compute
-    stream on it.  With a single process both are no-ops."""
+    """Gradient exchange of one optimizer: its flat fp32 gradient buffer is summed across ranks in (at most) two
+    contiguous slices.  The TAIL slice holds the parameters whose gradients autograd finishes FIRST (the deepest
+    layers, which come last in parameter order): its all-reduce is launched from a post-accumulate-grad hook as soon
+    as those gradients are complete and runs on RCCL's stream while the remaining backward kernels execute; the HEAD
+    slice goes out when backward returns.  `wait()` blocks the compute stream on both.  With one process everything
+    is a no-op.
 
-    def __init__(self, optimizer):
+    Call pattern per optimizer step:   bucket.arm(); loss.backward(); bucket.finish(); optimizer.step()
+    (`allreduce()` = arm-less variant: one exchange of the whole buffer after backward.)"""
+
+    def __init__(self, optimizer, overlap=True, tail_fraction=0.5):
         self.opt = optimizer
-        self.work = None
+        self.works = []
+        self.armed = False
+        self.pending = 0
+        self.tail = None            # (start, end) element range of the early slice
+        self.tail_params = []
+        self.hooks = []
         optimizer.grad_scale = 1.0 / world_size()
+        if overlap and world_size() > 1:
+            self._plan(tail_fraction)
 
-    def launch(self):
+    def _plan(self, tail_fraction):
+        f = self.opt.f
+        total = f.total
+        # the largest suffix of the parameter list that is at least `tail_fraction` of the bytes (but not everything)
+        start_idx = len(f.params)
+        for i in range(len(f.params) - 1, 0, -1):
+            start_idx = i
+            if total - f.offsets[i] >= tail_fraction * total:
+                break
+        if start_idx >= len(f.params) or start_idx == 0:
+            return
+        self.tail = (f.offsets[start_idx], total)
+        self.tail_params = f.params[start_idx:]
+        for p in self.tail_params:
+            self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, param):
+        if not self.armed:
+            return
+        self.pending -= 1
+        if self.pending == 0:
+            self.armed = False
+            if self.opt.f.coherent():
+                a, b = self.tail
+                self.works.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                self.tail_done = True
+
+    def arm(self):
+        """Call right before loss.backward(): the tail slice will be exchanged from inside backward."""
+        self.tail_done = False
+        if self.tail is not None:
+            self.pending = sum(1 for p in self.tail_params if p.requires_grad)
+            self.armed = self.pending > 0
+
+    def finish(self):
+        """Call right after loss.backward(): exchanges whatever has not gone out yet and waits."""
+        self.armed = False
         if world_size() > 1:
-            self.work = dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+            if getattr(self, "tail_done", False):
+                a, _ = self.tail
+                self.works.append(dist.all_reduce(self.opt.flat_grad[:a], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                self.works.append(dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM, async_op=True))
+        self.tail_done = False
+        self.wait()
 
     def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        for w in self.works:
+            w.wait()
+        self.works = []
 
     def allreduce(self):
-        self.launch()
-        self.wait()
+        self.finish()
 
 
 def allreduce_tensor_(t):

@@ -44,8 +44,9 @@ class WGANTrainer(object):
         out_fake = self.critic(fake)
         out_real = self.critic(real)
         loss = ops.mean(out_fake) - ops.mean(out_real)
+        self.c_bucket.arm()
         loss.backward()
-        self.c_bucket.allreduce()
+        self.c_bucket.finish()
         self.c_opt.step()
         return loss.detach(), out_fake.detach(), out_real.detach()
 
@@ -57,8 +58,9 @@ class WGANTrainer(object):
         with frozen(self.critic):
             out = self.critic(fake)
         loss = -ops.mean(out)
+        self.g_bucket.arm()
         loss.backward()
-        self.g_bucket.allreduce()
+        self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach(), out.detach()
 
@@ -111,8 +113,9 @@ class AutoencoderTrainer(object):
             kld = 0
         rec = reconstruction_loss(output, batch)
         loss = rec + kld
+        self.bucket.arm()
         loss.backward()
-        self.bucket.allreduce()
+        self.bucket.finish()
         self.opt.step()
         return rec.detach(), output.detach()
 
@@ -182,8 +185,9 @@ class HybridWGANTrainer(object):
         out_fake = self.critic(fake)
         out_real = self.critic(real)
         loss = ops.mean(out_fake) - ops.mean(out_real)
+        self.c_bucket.arm()
         loss.backward()
-        self.c_bucket.allreduce()
+        self.c_bucket.finish()
         self.c_opt.step()
         return loss.detach(), out_fake.detach(), out_real.detach()
 
@@ -194,8 +198,9 @@ class HybridWGANTrainer(object):
         with frozen(self.critic):
             out = self.critic(fake)
         loss = ops.mean(-out)
+        self.g_bucket.arm()
         loss.backward()
-        self.g_bucket.allreduce()
+        self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach(), out.detach()
 
@@ -240,8 +245,9 @@ class HybridProgressiveGANTrainer(object):
         with frozen(self.discriminator):
             out = self.discriminator(fake)
         loss = -ops.mean(out)
+        self.g_bucket.arm()
         loss.backward()
-        self.g_bucket.allreduce()
+        self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach()
 
@@ -254,7 +260,8 @@ class HybridProgressiveGANTrainer(object):
         out_real = self.discriminator(real)
         gp = self.gradient_penalty(real.detach(), fake.detach(), alpha)
         loss = ops.mean(out_fake) - ops.mean(out_real) + gp
+        self.d_bucket.arm()
         loss.backward()
-        self.d_bucket.allreduce()
+        self.d_bucket.finish()
         self.d_opt.step()
         return loss.detach(), gp.detach()

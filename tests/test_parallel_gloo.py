@@ -37,11 +37,13 @@ def _worker(rank, world, port, out_dir):
     full = torch.rand(4, 32, 32, 32, generator=g) * 2 - 1
     shard = full[rank * 2:(rank + 1) * 2]
     P = {k: v for k, v in critic.named_parameters()}
+    assert bucket.tail is not None and bucket.tail[0] > 0       # layers.4/6 (80 % of the bytes) form the early slice
     opt.zero_grad()
     loss = O.discriminator_forward(P, shard, False).mean()   # local-batch mean, as each rank's step computes it
-    loss.backward()
-    assert opt.f.coherent()
-    bucket.allreduce()
+    bucket.arm()
+    loss.backward()                                          # the tail slice is exchanged from inside backward
+    assert opt.f.coherent() and bucket.tail_done and len(bucket.works) == 1
+    bucket.finish()
     np.save(os.path.join(out_dir, "grad%d.npy" % rank), (opt.flat_grad * opt.grad_scale).numpy())
     if rank == 0:
         opt.zero_grad()
