@@ -380,7 +380,7 @@ def test_full_size_hybrid_progressive_config():
         real = torch.rand(B, R, R, R, device="cuda") * 2 - 1
         whole = d(real)
         halves = torch.cat((d(real[:8]), d(real[8:])))
-        assert torch.equal(whole, halves)
+        close(whole, halves, rtol=1e-5, what="batch-split invariance")   # tile / split-K plans differ with the batch size
     gl = tr.generator_step(z)
     dl, gp = tr.discriminator_step(real, torch.randn(B, 128).cuda(), torch.rand(B, 1, 1, 1).cuda())
     assert all(torch.isfinite(t).all() for t in (gl, dl, gp)) and float(gp) > 0
