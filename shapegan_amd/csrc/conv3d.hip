@@ -82,9 +82,9 @@ struct FwdPatchLoader {
         for (int it = 0; it < BR * kBK / 256; ++it) r[it] = x[((ok >> it) & 1u) ? toff + off[it] : 0];
         pend = ok;
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_, pend);
+        StageRowFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 struct FwdEpi {  // y[n][co][o] = act(v + bias[co])
@@ -125,9 +125,9 @@ struct DgradWeightLoader {  // A(i=ci, k=co*8+t) = Wt[parity][k][ci]  (ci contig
     __device__ void load(int k0, int kend, float (&r)[BR * kBK / 256]) {
         m.template load<BR>(k0, kend, r);
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        m.template store<BR>(S, r);
+        m.template store<BR, LO, HI>(S, r);
     }
 };
 // B(k=co*8+t, j=(n,qd,qh,qw)) = dy[n,co,qd+pd-td,qh+ph-th,qw+pw-tw], lanes along positions.  A 16-aligned k-tile
@@ -173,9 +173,9 @@ struct DgradPatchLoader {
             pend |= (e ? 1u : 0u) << it;
         }
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_, pend);
+        StageRowFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 struct DgradEpi {  // dx[n][ci][2qd+pd][2qh+ph][2qw+pw] = act(v + bias[ci])
@@ -322,9 +322,9 @@ struct WgradDyLoader {
             pend |= (e ? 1u : 0u) << it;
         }
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_, pend);
+        StageKFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 // B(k=pos, j=(ci,tap)), lanes along k (positions).  Rows of one thread: j = j0 + tid/16 + 16*it with j0 % 64 == 0, so
@@ -360,9 +360,9 @@ struct WgradPatchLoader {
             pend |= (ok ? 1u : 0u) << it;
         }
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_, pend);
+        StageKFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 struct WgradEpi {  // dW[co][j], row stride ldw (= Cin_total*64)

@@ -234,12 +234,13 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     // copy / weight-load latency) or 4 waves x 2 tiles (variant 1); 64 channels as 4 waves x 1 tile
     // measured (scripts/halo_bench.py): 4 waves x 2 tiles wins below ~1024 workgroups, 8 waves x 1 tile above
     int variant = (debug >> 4) & 3;
-    const int rows = Cout > 64 ? 128 : 64;
+    const int rows = (Cout > 64 && ((debug >> 4) & 3) != 3) ? 128 : 64;   // variant 3: 64-row tiles, twice the workgroups
     const int ntw = g.OW / 8, nth = g.OH / 8;
     const long tiles = (long)batch * g.OD * nth * ntw;
     const int mtiles = sg_cdiv(Cout, rows);
-    // auto-dispatch only where it wins (A/B on MI355X, scripts/halo_bench.py): >= 128 output channels, >= 384 workgroups
-    if (!force && (rows != 128 || tiles * mtiles < 384)) return 0;
+    // auto-dispatch only where it wins (A/B on MI355X, scripts/halo_bench.py): enough workgroups to fill the chip;
+    // below that the split-K gather kernel is faster
+    if (!force && tiles * mtiles < 384) return 0;
     if (tiles >= (1L << 31)) return 0;
     if (variant == 0) variant = (tiles * mtiles < 1024) ? 1 : 2;   // 0 = auto, 1 = 4 waves, 2 = 8 waves
     const size_t lds = (size_t)2 * kCC * kHS * sizeof(float);

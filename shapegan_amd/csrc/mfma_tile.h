@@ -33,7 +33,8 @@ constexpr int kBK = 16;
 //   template <int BR> void init(int tid, int row0, int nrows);          once per workgroup
 //   template <int BR> void load(int k0, int kend, float (&r)[E]);       global -> registers, tile [k0, k0+16):
 //        UNCONDITIONAL loads from clamped addresses (no branches), validity kept as a bit mask in the loader
-//   template <int BR> void store(float (*S)[BR + 1], const float (&r)[E]) const;   registers -> LDS S[k][row]:
+//   template <int BR, int LO, int HI> void store(float (*S)[BR + 1], const float (&r)[E]) const;   elements [LO,HI)
+//        registers -> LDS S[k][row]:
 //        applies the validity mask here, so nothing consumes a load result before the MFMAs of the current tile
 // Two staging lane maps are used:
 //   lanes-along-k   : kk = tid & 15,          local row = (tid >> 4) + 16*it
@@ -46,20 +47,22 @@ constexpr int kBK = 16;
 template <int BR>
 struct StageKFast {  // lanes along k
     static constexpr int E = BR * kBK / 256;
+    template <int LO, int HI>
     static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid, unsigned ok) {
         const int kk = tid & 15, lrow = tid >> 4;
 #pragma unroll
-        for (int it = 0; it < E; ++it) S[kk][lrow + it * 16] = ((ok >> it) & 1u) ? r[it] : 0.f;
+        for (int it = LO; it < HI; ++it) S[kk][lrow + it * 16] = ((ok >> it) & 1u) ? r[it] : 0.f;
     }
 };
 template <int BR>
 struct StageRowFast {  // lanes along rows
     static constexpr int E = BR * kBK / 256;
     static constexpr int STEP = 256 / BR;
+    template <int LO, int HI>
     static __device__ __forceinline__ void store(float (*S)[BR + 1], const float (&r)[E], int tid, unsigned ok) {
         const int lrow = tid % BR, kq = tid / BR;
 #pragma unroll
-        for (int it = 0; it < E; ++it) S[kq + it * STEP][lrow] = ((ok >> it) & 1u) ? r[it] : 0.f;
+        for (int it = LO; it < HI; ++it) S[kq + it * STEP][lrow] = ((ok >> it) & 1u) ? r[it] : 0.f;
     }
 };
 
@@ -89,9 +92,9 @@ struct MatRowMajor {
             pend |= (ok ? 1u : 0u) << it;
         }
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageKFast<BR>::store(S, r, tid_, pend);
+        StageKFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 // Plain matrix, element (row,k) at p[k*ld + row]  (row contiguous): lanes along rows
@@ -121,9 +124,9 @@ struct MatColMajor {
             pend |= (ok ? 1u : 0u) << it;
         }
     }
-    template <int BR>
+    template <int BR, int LO, int HI>
     __device__ void store(float (*S)[BR + 1], const float (&r)[BR * kBK / 256]) const {
-        StageRowFast<BR>::store(S, r, tid_, pend);
+        StageRowFast<BR>::template store<LO, HI>(S, r, tid_, pend);
     }
 };
 
@@ -169,21 +172,13 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-    if (kbeg < kend) {
-        la.template load<BM>(kbeg, kend, ra);
-        lb.template load<BN>(kbeg, kend, rb);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        la.template store<BM>(As, ra);  // consumes the loads issued one tile ago (their latency hid behind the MFMAs)
-        lb.template store<BN>(Bs, rb);
-        __syncthreads();                // A: tile visible
-        if (k0 + BK < kend) {
-            la.template load<BM>(k0 + BK, kend, ra);
-            lb.template load<BN>(k0 + BK, kend, rb);
-        }
-        // all fragment reads of the k-tile up front, then ONE early barrier (B: LDS free for the next tile) that is
-        // followed by the uninterrupted MFMA burst; global loads stay in flight across it (raw s_barrier, no vmcnt)
-        float af[BK / 2][TM], bf[BK / 2][TN];
+    // Pipeline (per k-tile t):  [MFMA burst(t) with the LDS stores of tile t+1 woven into its second half]
+    //   -> barrier A (tile t+1 visible) -> issue global loads of tile t+2 -> read all fragments of tile t+1
+    //   -> lgkmcnt(0) + raw barrier B (LDS free again) -> burst(t+1) ...
+    // The loads of tile t+1 were issued a whole burst earlier, so nothing waits on HBM/L2 in front of an MFMA, and
+    // the matrix pipe only idles for the two barriers and the fragment reads between bursts.
+    float af[BK / 2][TM], bf[BK / 2][TN];
+    auto read_frags = [&]() {
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
@@ -193,6 +188,21 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only (vmcnt/expcnt fields left at max)
         __builtin_amdgcn_s_barrier();
+    };
+    if (kbeg < kend) {
+        la.template load<BM>(kbeg, kend, ra);
+        lb.template load<BN>(kbeg, kend, rb);
+        la.template store<BM, 0, EA>(As, ra);
+        lb.template store<BN, 0, EB>(Bs, rb);
+        __syncthreads();
+        if (kbeg + BK < kend) {
+            la.template load<BM>(kbeg + BK, kend, ra);
+            lb.template load<BN>(kbeg + BK, kend, rb);
+        }
+        read_frags();
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -201,8 +211,31 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
 #pragma unroll
                 for (int tb = 0; tb < TN; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][ta], bf[s][tb], acc[ta][tb], 0, 0, 0);
+            if (more) {  // second half of the burst: a quarter of tile t+1's LDS stores behind each k-step
+                if (s == 4) {
+                    la.template store<BM, 0, EA / 4>(As, ra);
+                    lb.template store<BN, 0, EB / 4>(Bs, rb);
+                } else if (s == 5) {
+                    la.template store<BM, EA / 4, EA / 2>(As, ra);
+                    lb.template store<BN, EB / 4, EB / 2>(Bs, rb);
+                } else if (s == 6) {
+                    la.template store<BM, EA / 2, 3 * EA / 4>(As, ra);
+                    lb.template store<BN, EB / 2, 3 * EB / 4>(Bs, rb);
+                } else if (s == 7) {
+                    la.template store<BM, 3 * EA / 4, EA>(As, ra);
+                    lb.template store<BN, 3 * EB / 4, EB>(Bs, rb);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);  // pin the next tile's selects / ds_writes below the MFMAs
+        if (more) {
+            __syncthreads();  // A: tile t+1 visible
+            if (k0 + 2 * BK < kend) {
+                la.template load<BM>(k0 + 2 * BK, kend, ra);
+                lb.template load<BN>(k0 + 2 * BK, kend, rb);
+            }
+            read_frags();     // fragments of tile t+1, then barrier B
+        }
     }
 
 #pragma unroll
