@@ -88,6 +88,8 @@ int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long s
             void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
+/* out[r*nseg + s] = sum of x[r*ld + e] over e in [seg_off[s], seg_off[s+1])  (per-shape sums of SDFNet dZ columns) */
+int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, hipStream_t stream);
 
 /* ---- K4: nn.BatchNorm3d / nn.BatchNorm1d (+ fused following activation) -------------------------------------
  * reference: model/gan.py:10,14,18; model/autoencoder.py:17,21,25,29,38,46,56,60,64 -> aten::batch_norm(_backward).
@@ -120,9 +122,11 @@ size_t sg_sdfnet_packed_floats(int kin_used);
 int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream);
 int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, const int64_t* latent_idx,
                   int latent_size, const float* packed, int kin_used, const float* zb1, const float* zb5,
-                  long points_per_shape, float* out, float* acts, long ldn, long N, hipStream_t stream);
-int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* dx, long dx_ld,
-                  const float* packed, int kin_used, long ldn, long N, hipStream_t stream);
+                  long points_per_shape, const int* shape_index, float* out, float* acts, long ldn, long N,
+                  hipStream_t stream);
+long sg_sdfnet_bwd_blocks(long N); /* workgroups of the backward kernel = columns of bias_partials */
+int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
+                  float* dx, long dx_ld, const float* packed, int kin_used, long ldn, long N, hipStream_t stream);
 
 /* ---- K8/K9/K10/K11: blends, reductions, latent-table rows, optimizers ------------------------------------------
  * reference: fade-in / GP lerp (model/progressive_gan.py:50, train_hybrid_progressive_gan.py:105), batch means

@@ -20,6 +20,8 @@ for npts, L in cases:
     tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=L), lat, pts, sdf, pointcloud_size=pc)
     idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
     ms = timeit(lambda: tr.step(idx))
+    ms_s = timeit(lambda: tr.step_sorted(idx))
+    ms_g = timeit(lambda: tr.step_gathered(idx))
     t0 = time.perf_counter(); tr.step(idx); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
     flop = npts * (2.76e6 if L == 128 else 3.16e6)
-    print("points %d L %d: %.3f ms/step (wall %.3f)  %.2f Mpoints/s  ~%.1f TFLOP/s" % (npts, L, ms, wall, npts / ms / 1e3, flop / ms / 1e9), flush=True)
+    print("points %d L %d: %.3f ms/step (wall %.3f)  %.2f Mpoints/s  ~%.1f TFLOP/s   [sorted %.3f ms, gathered %.3f ms]" % (npts, L, ms, wall, npts / ms / 1e3, flop / ms / 1e9, ms_s, ms_g), flush=True)

@@ -74,6 +74,21 @@ __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) out[r] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out[r*S + s] = sum_{e in [off[s], off[s+1])} x[r*ld + e]: one wave per (row, segment) pair
+__global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                     long ld, const int64_t* __restrict__ off, long S) {
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= rows * S) return;
+    const long r = pair / S, sg = pair - r * S;
+    const long beg = off[sg], end = off[sg + 1];
+    const int lane = threadIdx.x & 63;
+    const float* p = x + r * ld;
+    float acc = 0.f;
+    for (long e = beg + lane; e < end; e += 64) acc += p[e];
+    acc = sg_wave_sum(acc);
+    if (lane == 0) out[pair] = acc;
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -117,6 +132,14 @@ int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream) {
     SG_CHECK_ARG(x && out && rows > 0 && len > 0);
     hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, out, rows, len, ld);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && seg_off && rows > 0 && nseg > 0);
+    hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((rows * nseg + 3) / 4)), dim3(256), 0, stream, x, out, rows, ld,
+                       seg_off, nseg);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -429,7 +429,7 @@ class _PackCache(object):
         return self.packed
 
 
-def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total):
+def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None):
     """Weight/bias gradients from the saved dZ_l / H_l images.  x_parts: list of (tensor [N,w], col_offset, w)
     blocks of the per-point input X that are materialised row-major (points, and latents in per-point mode)."""
     lib = _lib()
@@ -446,7 +446,15 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
         gemm_raw(dz, False, rows, False, out=out, a_off=layer_dz * _H * ldn, M=_H, N=width, K=N, lda=ldn,
                  ldb=rows.shape[1], ldc=ldc, c_off=c_off)
 
+    ball = None
+    if bsum is not None:  # [7*256][nblk] partial row sums from the fused backward: one short reduction for all layers
+        nblk = bsum.shape[1]
+        ball = torch.empty(7 * _H, dtype=torch.float32, device=dev)
+        check(lib.sg_rowsum(ptr(bsum), ptr(ball), 7 * _H, nblk, nblk, stream()), "rowsum")
+
     def bgrad(layer_dz):
+        if ball is not None:
+            return ball[layer_dz * _H:(layer_dz + 1) * _H]
         out = torch.empty(_H, dtype=torch.float32, device=dev)
         check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
         return out
@@ -487,7 +495,7 @@ class SDFNetPoints(Function):
         need_grad = any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
-        check(lib.sg_sdfnet_fwd(ptr(points), 0, ptr(latent), None, Lz, ptr(packed), kin, None, None, 0, ptr(out),
+        check(lib.sg_sdfnet_fwd(ptr(points), 0, ptr(latent), None, Lz, ptr(packed), kin, None, None, 0, None, ptr(out),
                                 ptr(acts), N, N, stream()), "sdfnet_fwd")
         ctx.cache, ctx.Lz = cache, Lz
         ctx.save_for_backward(points, latent, out, acts, packed, *params)
@@ -507,12 +515,14 @@ class SDFNetPoints(Function):
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
-        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(dx), kin, ptr(packed), kin, N, N,
-                                stream()), "sdfnet_bwd")
+        need_p = any(ctx.needs_input_grad[3:])
+        bsum = torch.empty((7 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(dx), kin, ptr(packed),
+                                kin, N, N, stream()), "sdfnet_bwd")
         grads = [None] * 16
-        if any(ctx.needs_input_grad[3:]):
+        if need_p:
             grads = _sdf_param_grads(params, ctx.needs_input_grad[3:], dz, dz8, acts, N, N,
-                                     [(points, 0, 3), (latent, 3, Lz)], kin)
+                                     [(points, 0, 3), (latent, 3, Lz)], kin, bsum)
         gp = dx[:, :3] if ctx.needs_input_grad[1] else None
         gl = dx[:, 3:] if ctx.needs_input_grad[2] else None
         return (None, gp, gl) + tuple(grads)
@@ -525,10 +535,12 @@ class SDFNetShapes(Function):
     train_hybrid_progressive_gan.py:90-96,138-139."""
 
     @staticmethod
-    def forward(ctx, cache, points, z, pps, *params):
+    def forward(ctx, cache, points, z, pps, sid, seg_off, *params):
+        """Uniform segments: sid is None, row s*pps+q uses z[s].  Ragged segments: sid[N] (int32) names each point's
+        latent row and seg_off[S+1] (int64) bounds the contiguous run of every shape (points sorted by shape)."""
         points, z = f32c(points), f32c(z)
         S, Lz = z.shape
-        N = S * pps
+        N = points.shape[0] if sid is not None else S * pps
         if points.shape[0] != N:
             raise RuntimeError("SDFNetShapes: need points for all %d x %d samples" % (S, pps))
         kin_total = 3 + Lz
@@ -541,9 +553,10 @@ class SDFNetShapes(Function):
         need_grad = any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
-        check(lib.sg_sdfnet_fwd(ptr(points), 0, None, None, Lz, ptr(packed), 3, ptr(zb1), ptr(zb5), pps, ptr(out),
-                                ptr(acts), N, N, stream()), "sdfnet_fwd")
+        check(lib.sg_sdfnet_fwd(ptr(points), 0, None, None, Lz, ptr(packed), 3, ptr(zb1), ptr(zb5), pps, ptr(sid),
+                                ptr(out), ptr(acts), N, N, stream()), "sdfnet_fwd")
         ctx.pps = pps
+        ctx.seg_off = seg_off
         ctx.save_for_backward(points, z, out, acts, packed, *params)
         return out
 
@@ -554,7 +567,7 @@ class SDFNetShapes(Function):
         params = ctx.saved_tensors[5:]
         S, Lz = z.shape
         pps = ctx.pps
-        N = S * pps
+        N = out.shape[0]
         kin_total = 3 + Lz
         gout = f32c(gout)
         lib = _lib()
@@ -562,20 +575,26 @@ class SDFNetShapes(Function):
         dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(dx), 3, ptr(packed), 3, N, N,
-                                stream()), "sdfnet_bwd")
-        need_p = any(ctx.needs_input_grad[4:])
+        need_p = any(ctx.needs_input_grad[6:])
+        bsum = torch.empty((7 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(dx), 3, ptr(packed), 3,
+                                N, N, stream()), "sdfnet_bwd")
         need_z = ctx.needs_input_grad[2]
         grads = [None] * 16
         gz = None
         if need_p or need_z:
-            # per-shape sums of dZ1 / dZ5: T[o, s] = sum_{p in shape s} dZ[o, p]   (rows of length pps are contiguous)
+            # per-shape sums of dZ1 / dZ5: T[o, s] = sum_{p in shape s} dZ[o, p]   (each shape's points are contiguous)
             t1 = torch.empty((_H, S), dtype=torch.float32, device=dev)
             t5 = torch.empty((_H, S), dtype=torch.float32, device=dev)
-            check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
-            check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
+            if ctx.seg_off is None:
+                check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
+                check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
+            else:
+                check(lib.sg_segsum(ptr(dz), ptr(t1), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
+                check(lib.sg_segsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
         if need_p:
-            grads = _sdf_param_grads(params, ctx.needs_input_grad[4:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total)
+            grads = _sdf_param_grads(params, ctx.needs_input_grad[6:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
+                                     bsum)
             # latent columns: dW1[:, 3:] = T1 @ z ; dW5[:, 259:] = T5 @ z
             gemm_raw(t1, False, z, False, out=grads[0], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=kin_total, c_off=3)
             gemm_raw(t5, False, z, False, out=grads[8], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=_H + kin_total,
@@ -586,7 +605,7 @@ class SDFNetShapes(Function):
             g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
             gz = torch.empty_like(g1)
             check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
-        return (None, dx, gz, None) + tuple(grads)
+        return (None, dx, gz, None, None, None) + tuple(grads)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -134,7 +134,44 @@ class SDFAutoDecoderTrainer(object):
         self.net_bucket, self.lat_bucket = GradBucket(self.net_opt), GradBucket(self.lat_opt)
 
     def step(self, indices):
-        """train_sdf_autodecoder.py:77-91 (with the integer floor division `:78` intends)."""
+        """train_sdf_autodecoder.py:77-91 (with the integer floor division `:78` intends).
+
+        The batch is re-ordered by shape (a permutation of the batch changes neither the loss nor any gradient, only
+        fp32 summation order): the fused kernel then reads each point's latent contribution as a per-shape bias row
+        and the latent-table gradient is assembled from per-shape sums, so `latent_codes[model_indices]` ([N,L]) and
+        its scatter-add backward never exist.  The regulariser mean(z_batch^2) is evaluated through shape counts:
+        sum_s count_s |z_s|^2 / (N L)."""
+        if indices.numel() < 65536:   # small batches: the sort / count bookkeeping costs more than it saves
+            return self.step_gathered(indices)
+        return self.step_sorted(indices)
+
+    def step_sorted(self, indices):
+        """The shape-sorted data flow described in `step`."""
+        model_indices = torch.div(indices, self.pointcloud_size, rounding_mode='floor')
+        order = torch.argsort(model_indices)
+        indices, model_indices = indices[order], model_indices[order]
+        shapes = self.latent_codes.shape[0]
+        counts = torch.bincount(model_indices, minlength=shapes)
+        seg_off = torch.zeros(shapes + 1, dtype=torch.int64, device=indices.device)
+        seg_off[1:] = torch.cumsum(counts, 0)
+        self.net_opt.zero_grad()
+        self.lat_opt.zero_grad()
+        batch_points = ops.gather_rows(self.points, indices)
+        batch_sdf = self.sdf[indices]
+        output = self.net.forward_segments(batch_points, self.latent_codes, model_indices.int(), seg_off)
+        n, width = indices.shape[0], self.latent_codes.shape[1]
+        reg = (counts.to(torch.float32).unsqueeze(1) * torch.pow(self.latent_codes, 2)).sum() / (n * width)
+        loss = torch.mean(torch.abs(output - batch_sdf)) + self.sigma * reg
+        loss.backward()
+        self.net_bucket.allreduce()
+        self.lat_bucket.allreduce()
+        self.net_opt.step()
+        self.lat_opt.step()
+        return loss.detach()
+
+    def step_gathered(self, indices):
+        """The same step through the reference's data flow (materialised latent_codes[model_indices], per-point
+        latent kernel mode) — kept for A/B and parity."""
         model_indices = torch.div(indices, self.pointcloud_size, rounding_mode='floor')
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()

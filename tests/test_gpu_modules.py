@@ -273,7 +273,8 @@ def test_sdf_autodecoder_trajectory(golden_steps):
     losses = []
     for i in range(3):
         idx = golden_steps.t("sdf/idx%d" % i)
-        losses.append(tr.step(idx.cuda()).item())
+        # step 0/2: batch sorted by shape + folded per-shape biases; step 1: the reference's gathered-latent data flow
+        losses.append((tr.step_gathered if i == 1 else tr.step_sorted)(idx.cuda()).item())
         o32.step(idx)
         o64.step(idx)
     np.testing.assert_allclose(losses, golden_steps["sdf/losses"], rtol=1e-4)
