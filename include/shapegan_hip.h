@@ -61,7 +61,10 @@ int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bi
                                 int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                                 void* workspace, size_t workspace_bytes, int impl, hipStream_t stream); /* tests */
 /* dw[Cout, Cin_total(first Cin channels written), 4,4,4] = sum_{n,o} dy * x-patches; split-K workspace optional */
-size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin);
+size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
+int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                                int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes, int impl,
+                                hipStream_t stream); /* tests */
 int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
                            int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);

@@ -386,9 +386,11 @@ size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) {
     return a > b ? a : b;
 }
 
-size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int Cout, int Cin) {
-    // up to 16 split-K partials of the [Cout, Cin*64] weight gradient
-    return (size_t)16 * Cout * Cin * 64 * sizeof(float);
+size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
+    // gather kernel: up to 16 split-K partials of the [Cout, Cin*64] weight gradient; LDS-halo kernel: packed dy + partials
+    const size_t a = (size_t)16 * Cout * Cin * 64 * sizeof(float);
+    const size_t b = halo_wgrad_workspace_bytes(batch, Cin, Cout, OD, OH, OW);
+    return a > b ? a : b;
 }
 
 size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
@@ -542,6 +544,20 @@ int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bi
     return SG_OK;
 }
 
+// testing / tuning: impl 1 forces the LDS-halo wgrad kernel (SG_ERR_ARG if the shape is not eligible)
+int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                                int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes, int impl,
+                                hipStream_t stream) {
+    SG_CHECK_ARG(dy && x && dw && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && impl == 1);
+    ConvGeom g;
+    if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_impl: bad spatial dims");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad_impl")) return SG_ERR_ARG;
+    const int rc = halo_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace_bytes, stream, 1);
+    if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_impl: shape not eligible for the LDS-halo kernel");
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
 int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
                            int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes,
                            hipStream_t stream) {
@@ -550,6 +566,15 @@ int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
+    {
+        const int rc = halo_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace ? workspace_bytes : 0,
+                                      stream, 0);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            SG_CHECK_LAUNCH();
+            return SG_OK;
+        }
+    }
     WgradDyLoader la;
     la.dy = dy;
     la.O3 = (int)g.O3();

@@ -497,4 +497,288 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     return 1;
 }
 
+
+// ================================================================================================================
+// wgrad form (nn.Conv3d / nn.ConvTranspose3d weight gradient):
+//   dW[co, ci, tap] = sum_{n, o} dy[n, co, o] * x[n, ci, 2o + tap - 1]      GEMM  M = Cout, N = Cin*64, K = positions
+// Both operands are activations, so A cannot be packed once per call like a weight — but it can be packed once per
+// launch by a streaming pre-pass: dy is rewritten into MFMA A-fragment order (one coalesced float4 per lane per 8
+// positions), after which the main kernel has the fwd-halo structure with the roles turned: A fragments stream from
+// global, B fragments are read from the x halo box of the TWO input channels this workgroup owns (lane = tap,
+// position offset immediate), accumulators live for the whole launch, K (positions) is split over workgroups
+// (deterministic workspace + finalize).  One stage = one 1x8x8 position tile = 8 k-groups = 32*TM*TN MFMAs per wave
+// against 10 copy loads per thread.
+constexpr int kWROWD = 368;                 // 18 rows x 20 floats, padded so that a kd step shifts banks by 16
+constexpr int kWHS = kHD * kWROWD;          // floats per channel box
+constexpr int kWNF = (2 * kHD * kHH + 7) / 8;  // 18 copy elements per thread per stage (2 channels x 72 rows / 8 half-waves)
+
+struct HaloWgradArgs {
+    const float4* ap;   // packed dy: [mt][slice][8 groups][64 lanes]
+    const float* x;
+    float* ws;          // [nsplit][Cout][Cin*64] partials (or dw itself when nsplit == 1)
+    ConvGeom g;
+    int Cin, Cout, nslice, per_split, mt_total;
+    long ldw;           // row stride of the output (Cin_total*64 when writing dw directly, Cin*64 for partials)
+    FastDiv dntw, dnth, dOD;
+};
+
+// ap[((mt*nslice + sl)*8 + gq)*64 + lane] = float4{ dy[n][mt*32 + (lane&31)][od][oh0 + gq][ow0 + 2j + (lane>>5)], j=0..3 }
+__global__ void __launch_bounds__(256) pack_wgrad_dy_kernel(const float* __restrict__ dy, float4* __restrict__ ap,
+                                                            ConvGeom g, int Cout, int MT, int nslice, FastDiv dntw,
+                                                            FastDiv dnth, FastDiv dOD) {
+    const long total = (long)MT * nslice * 8 * 64;
+    const long O3 = (long)g.OD * g.OH * g.OW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const int gq = (int)((e >> 6) & 7);
+        const long q = e >> 9;
+        const uint32_t sl = (uint32_t)(q % nslice);
+        const int mt = (int)(q / nslice);
+        uint32_t twi, thi, od, n, q1, q2;
+        dntw.divmod(sl, q1, twi);
+        dnth.divmod(q1, q2, thi);
+        dOD.divmod(q2, n, od);
+        const int co = mt * 32 + (lane & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < Cout) {
+            const float* src = dy + ((long)n * Cout + co) * O3 + ((long)od * g.OH + (thi * 8 + gq)) * g.OW + twi * 8 + (lane >> 5);
+            v = make_float4(src[0], src[2], src[4], src[6]);
+        }
+        ap[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wbox[];  // [2 buffers][2 channels][kHD][kWROWD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int ci0 = blockIdx.x * 2;          // the two input channels (128 output columns) of this workgroup
+    const int mt0 = blockIdx.y * 4;          // 128 output rows = 4 row tiles of 32
+    const int split = blockIdx.z;
+    const int s_beg = split * a.per_split, s_end = min(a.nslice, s_beg + a.per_split);
+
+    // lane -> tap of its column inside each of the wave's two 32-column tiles: col = wn*64 + tn*32 + r
+    int lanebase[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = wn * 64 + tn * 32 + r;  // == (ci_l = wn, tap = tn*32 + r)
+        const int tap = col & 63, kd = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
+        lanebase[tn] = (col >> 6) * kWHS + kd * kWROWD + kh * kROWH + (kw & 1) * kHWH + (kw >> 1) + kpar;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // ---- copy bookkeeping: element f is (channel c = f / 9, row 8*(f%9) + tid/32, column tid%32) of the 2-channel box ----
+    const int I3 = a.g.ID * a.g.IH * a.g.IW;
+    const int fl_w = tid & 31, frow = tid >> 5;
+    const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
+    int rowoff[kWNF / 2];   // LDS offset of the row inside a channel (-1: none); identical for both channels
+    int hdv[kWNF / 2], hhv[kWNF / 2];
+#pragma unroll
+    for (int f = 0; f < kWNF / 2; ++f) {
+        const int row = 8 * f + frow;
+        hdv[f] = row / kHH;
+        hhv[f] = row - hdv[f] * kHH;
+        rowoff[f] = (fl_w < kHWF && row < kHD * kHH) ? hdv[f] * kWROWD + hhv[f] * kROWH + lds_w : -1;
+    }
+    float fv[kWNF];
+    int goff[kWNF];  // per stage: global offset or -1 (zero)
+    auto copy_prepare = [&](int sl) {  // geometry of slice sl -> goff[]
+        uint32_t twi, thi, od, n, q1, q2;
+        a.dntw.divmod((uint32_t)sl, q1, twi);
+        a.dnth.divmod(q1, q2, thi);
+        a.dOD.divmod(q2, n, od);
+        const int iw = 2 * (int)twi * 8 - 1 + fl_w;
+        const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
+        const int nbase = (int)n * a.g.Cx * I3;
+#pragma unroll
+        for (int f = 0; f < kWNF; ++f) {
+            const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
+            const int id = 2 * (int)od - 1 + hdv[fr], ih = 2 * (int)thi * 8 - 1 + hhv[fr];
+            const bool ok = wok && rowoff[fr] >= 0 && (ci0 + c) < a.Cin && (unsigned)id < (unsigned)a.g.ID &&
+                            (unsigned)ih < (unsigned)a.g.IH;
+            goff[f] = ok ? nbase + (ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw : -1;
+        }
+    };
+    auto copy_load = [&](int f) { fv[f] = a.x[goff[f] >= 0 ? goff[f] : 0]; };
+    auto copy_store = [&](int f, float* buf) {
+        const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
+        if (rowoff[fr] >= 0) buf[c * kWHS + rowoff[fr]] = goff[f] >= 0 ? fv[f] : 0.f;
+    };
+
+    const int nst = s_end - s_beg;
+    if (nst > 0) {
+        copy_prepare(s_beg);
+#pragma unroll
+        for (int f = 0; f < kWNF; ++f) copy_load(f);
+#pragma unroll
+        for (int f = 0; f < kWNF; ++f) copy_store(f, wbox);
+    }
+    // A fragments: ring of 4 k-groups; group index runs over (slice, gq)
+    const float4* arow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) arow[t] = a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64 + lane;
+    const long G = (long)nst * 8;
+    float4 aring[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) aring[u][t] = arow[t][(u < G ? u : 0) * 64];
+    long g = 0;
+    __syncthreads();
+
+    for (int st = 0; st < nst; ++st) {
+        const float* cur = wbox + (st & 1) * (2 * kWHS);
+        float* nxt = wbox + ((st + 1) & 1) * (2 * kWHS);
+        const bool more = st + 1 < nst;
+        if (more) copy_prepare(s_beg + st + 1);
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {   // k-group gq = output row ph of the 8x8 tile; j = column pair
+            float4 a_cur[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a_cur[t] = aring[gq & 3][t];
+            if (g + 4 < G) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) aring[gq & 3][t] = arow[t][(g + 4) * 64];
+            }
+            ++g;
+            float b[2][4];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float* hb = cur + lanebase[tn] + 2 * gq * kROWH;
+                b[tn][0] = hb[0];
+                b[tn][1] = hb[2];
+                b[tn][2] = hb[4];
+                b[tn][3] = hb[6];
+            }
+            if (more) {  // copy schedule: 18 loads in groups 0..5 (3 each), stores two groups later
+#pragma unroll
+                for (int f = 0; f < kWNF; ++f) {
+                    if (f / 3 + 2 == gq) copy_store(f, nxt);
+                    if (f / 3 == gq) copy_load(f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = j == 0 ? a_cur[0].x : (j == 1 ? a_cur[0].y : (j == 2 ? a_cur[0].z : a_cur[0].w));
+                const float a1 = j == 0 ? a_cur[1].x : (j == 1 ? a_cur[1].y : (j == 2 ? a_cur[1].z : a_cur[1].w));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[0][j], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[0][j], acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[1][j], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[1][j], acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: out[split][co][ci*64 + tap]
+    float* out = a.ws + (long)split * a.Cout * a.ldw;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = wn * 64 + tn * 32 + r;
+        const int ci = ci0 + (col >> 6);
+        if (ci >= a.Cin) continue;
+        const long cbase = (long)ci * 64 + (col & 63);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = (mt0 + wm * 2 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+                if (co < a.Cout) out[(long)co * a.ldw + cbase] = acc[t][tn][q];
+            }
+        }
+    }
+}
+
+// sums the split partials [nsplit][Cout][Cin*64] into dw[Cout][Cin_total*64]
+__global__ void __launch_bounds__(256) wgrad_halo_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                  int Cout, int ncol, long ldw, int nsplit) {
+    const long total = (long)Cout * ncol;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += ws[(long)s * total + e];
+        const long co = e / ncol, c = e - co * ncol;
+        dw[co * ldw + c] = v;
+    }
+}
+
+static void wgrad_halo_plan(int batch, const ConvGeom& g, int Cin, int Cout, int& nslice, int& nsplit, int& mtiles) {
+    nslice = batch * g.OD * (g.OH / 8) * (g.OW / 8);
+    mtiles = (Cout + 127) / 128;
+    const int ntiles = ((Cin + 1) / 2) * mtiles;
+    nsplit = (512 + ntiles - 1) / ntiles;
+    if (nsplit > nslice / 4) nsplit = nslice / 4 > 0 ? nslice / 4 : 1;   // >= 4 stages per workgroup
+    if (nsplit < 1) nsplit = 1;
+}
+
+size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
+    if (OH % 8 != 0 || OW % 8 != 0) return 0;
+    ConvGeom g;
+    g.OD = OD;
+    g.OH = OH;
+    g.OW = OW;
+    int nslice, nsplit, mtiles;
+    wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
+    const size_t pack = (size_t)mtiles * 4 * nslice * 8 * 64 * sizeof(float4);
+    const size_t part = (size_t)nsplit * Cout * Cin * 64 * sizeof(float);
+    return pack + part + 256;
+}
+
+int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force) {
+    if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin < 2 || Cout < 32) return 0;
+    if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
+    int nslice, nsplit, mtiles;
+    wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
+    const int ntiles = ((Cin + 1) / 2) * mtiles;
+    // auto-dispatch where it wins (scripts/conv_bench.py): full 128-row tiles and enough workgroups
+    if (!force && (Cout <= 64 || (long)ntiles * nsplit < 384)) return 0;
+    const size_t need = halo_wgrad_workspace_bytes(batch, Cin, Cout, g.OD, g.OH, g.OW);
+    if (!workspace || workspace_bytes < need) return 0;
+    const int per_split = (nslice + nsplit - 1) / nsplit;
+    nsplit = (nslice + per_split - 1) / per_split;
+
+    const FastDiv dntw(g.OW / 8), dnth(g.OH / 8), dOD(g.OD);
+    float4* ap = (float4*)workspace;
+    const size_t pack_floats4 = (size_t)mtiles * 4 * nslice * 8 * 64;
+    float* part = (float*)(ap + pack_floats4);
+    {
+        int blocks = (int)((pack_floats4 + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(pack_wgrad_dy_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, g, Cout, mtiles * 4, nslice, dntw,
+                           dnth, dOD);
+    }
+    HaloWgradArgs a;
+    a.ap = ap;
+    a.x = x;
+    a.g = g;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.nslice = nslice;
+    a.per_split = per_split;
+    a.mt_total = mtiles * 4;
+    a.dntw = dntw;
+    a.dnth = dnth;
+    a.dOD = dOD;
+    const bool direct = nsplit == 1;
+    a.ws = direct ? dw : part;
+    a.ldw = direct ? (long)Cin_total * 64 : (long)Cin * 64;
+    const size_t lds = (size_t)2 * 2 * kWHS * sizeof(float);
+    hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256), lds, stream, a);
+    if (!direct) {
+        const long total = (long)Cout * Cin * 64;
+        int fb = (int)((total + 255) / 256);
+        if (fb > 2048) fb = 2048;
+        hipLaunchKernelGGL(wgrad_halo_finalize_kernel, dim3(fb), dim3(256), 0, stream, (const float*)part, dw, Cout, Cin * 64,
+                           (long)Cin_total * 64, nsplit);
+    }
+    return 1;
+}
+
 }  // namespace sg

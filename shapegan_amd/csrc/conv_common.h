@@ -70,4 +70,8 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force = 0);
 
+size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
+int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0);
+
 }  // namespace sg

@@ -94,10 +94,22 @@ def conv_wgrad_raw(dy, x, ct):
     else:
         dw = torch.empty((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
     lib = _lib()
-    nb = min(lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(Co, Cx), _WGRAD_WS_CAP)
+    nb = min(lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(N, Cx, Co, OD, OH, OW), _WGRAD_WS_CAP)
     ws = workspace("splitk", nb, dy.device)
     check(lib.sg_conv3d_k4s2p1_wgrad(ptr(dy), ptr(x), ptr(dw), N, Cx, ct, Cx, Co, 2 * OD, 2 * OH, 2 * OW, ptr(ws),
                                      ws.numel(), stream()), "conv3d_wgrad")
+    return dw
+
+
+def conv_wgrad_halo_raw(dy, x, ct):
+    """wgrad through the forced LDS-halo kernel — tests and tuning only."""
+    N, Co, OD, OH, OW = dy.shape
+    Cx = x.shape[1]
+    dw = torch.zeros((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
+    lib = _lib()
+    ws = workspace("splitk", lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(N, Cx, Co, OD, OH, OW), dy.device)
+    check(lib.sg_conv3d_k4s2p1_wgrad_impl(ptr(dy), ptr(x), ptr(dw), N, Cx, ct, Cx, Co, 2 * OD, 2 * OH, 2 * OW, ptr(ws),
+                                          ws.numel(), 1, stream()), "conv3d_wgrad_impl")
     return dw
 
 

@@ -428,3 +428,16 @@ def test_sdfnet_segments_mode(S, N):
     close(tg.grad, tr.grad, rtol=2e-4, what="d latent table")
     for k, p in net.named_parameters():
         close(p.grad, P[k].grad, rtol=2e-4, what="grad " + k)
+
+
+@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 3, 32, 8), (3, 16, 40, 8), (1, 8, 160, 16), (5, 2, 64, 8)])
+def test_conv_wgrad_halo_kernel(N, Ci, Co, O):
+    """The LDS-halo weight gradient (forced) == autograd of ATen conv3d."""
+    from shapegan_amd import ops
+    torch.manual_seed(N + Ci + Co + O)
+    x = torch.randn(N, Ci, 2 * O, 2 * O, 2 * O)
+    dy = torch.randn(N, Co, O, O, O)
+    w = torch.zeros(Co, Ci, 4, 4, 4, requires_grad=True)
+    F.conv3d(x, w, None, stride=2, padding=1).backward(dy)
+    got = ops.conv_wgrad_halo_raw(dev(dy), dev(x), Ci)
+    close(got, w.grad, what="wgrad halo vs oracle")
