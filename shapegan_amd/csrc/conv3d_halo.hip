@@ -287,9 +287,20 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
 // copies the (2+1)x9x9 box of dy it needs for 16 output channels into LDS (dense, index = copy index), B fragments are
 // read from the box with immediate offsets (the tap shift (1-td)*81 + (1-th)*9 is a compile-time constant per k-step),
 // A fragments come from a per-parity packed weight image.  K per channel is 8 = one k-group.
-constexpr int kDB = 3 * 9 * 9;   // box floats per channel
+// MODE 0: one sample, q box 2x8x8 -> dy box 3x9x9 per channel (O >= 8).  MODE 1: O = 4: the whole 4x4x4 grid of TWO
+// samples -> dy box 2 x 5x5x5 per channel.  Both give 128 positions and ~245 box floats per channel.
+template <int MODE>
+struct DBox;
+template <>
+struct DBox<0> {
+    static constexpr int BH = 9, BW = 9, PL = 81, CH = 243, TNOFF = 36, WNOFF = 81;
+};
+template <>
+struct DBox<1> {
+    static constexpr int BH = 5, BW = 5, PL = 25, CH = 250, TNOFF = 50, WNOFF = 125;
+};
 constexpr int kDCC = 16;         // channels per stage: 16 k-groups, 128 MFMAs per wave
-constexpr int kDNF = (kDCC * kDB + 255) / 256;  // 16 copy elements per thread per stage
+constexpr int kDNF = 16;         // copy elements per thread per stage (3888 resp. 4000 box floats / 256 threads)
 
 struct HaloDgradArgs {
     const float* dy;
@@ -297,7 +308,7 @@ struct HaloDgradArgs {
     const float* bias;
     float* dx;
     ConvGeom g;
-    int Cin, Cout, mtiles;  // mtiles = row tiles (of 64) per parity
+    int Cin, Cout, mtiles, batch;  // mtiles = row tiles (of 64) per parity
     FastDiv dntw, dnth, dntd;
     int act;
     float slope;
@@ -331,21 +342,28 @@ __global__ void __launch_bounds__(256) pack_dgrad_frag_kernel(const float* __res
     }
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDCC][3][9][9]
+    using BX = DBox<MODE>;
+    constexpr int kDB = BX::CH;
+    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDCC][kDB]
     const int par = blockIdx.z, pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
-    uint32_t twi, thi, tdi, n, q1, q2;
-    a.dntw.divmod(blockIdx.x, q1, twi);
-    a.dnth.divmod(q1, q2, thi);
-    a.dntd.divmod(q2, n, tdi);
+    uint32_t twi = 0, thi = 0, tdi = 0, n, q1, q2;
+    if (MODE == 0) {
+        a.dntw.divmod(blockIdx.x, q1, twi);
+        a.dnth.divmod(q1, q2, thi);
+        a.dntd.divmod(q2, n, tdi);
+    } else {
+        n = blockIdx.x * 2;  // first sample of the pair
+    }
     const int qd0 = tdi * 2, qh0 = thi * 8, qw0 = twi * 8;
     const int ci0 = blockIdx.y * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
-    const int lw = r & 7, lh4 = r >> 3;  // + 4*tn
-    // address of (td,th) for column tile tn: lanebase + tn*36 + (1-td)*81 + (1-th)*9
-    const int lanebase = wn * 81 + lh4 * 9 + lw + 1 - kpar;
+    // lane -> position inside a 32-position column tile; address of tap (td,th): lanebase + tn*TNOFF + (1-td)*PL + (1-th)*BW
+    const int lpart = MODE == 0 ? (r >> 3) * BX::BW + (r & 7) : (r >> 4) * BX::PL + ((r >> 2) & 3) * BX::BW + (r & 3);
+    const int lanebase = wn * BX::WNOFF + lpart + 1 - kpar;
 
     f32x16 acc[2];
 #pragma unroll
@@ -356,17 +374,24 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const long G = a.Cout;  // one k-group per output channel
     const float4* wrow = a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64 + lane;
 
-    // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f = (ci, hd, hh, hw) dense ----
+    // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw) ----
     const int O3 = a.g.OD * a.g.OH * a.g.OW;
     const float* dyn = a.dy + (long)n * a.g.Cy * O3;
-    int goff[kDNF];  // offset inside the stage's first channel block (-1: zero, -2: beyond the box)
+    int goff[kDNF];  // offset from dyn of channel 0 of the stage (-1: zero, -2: beyond the box)
 #pragma unroll
     for (int f = 0; f < kDNF; ++f) {
         const int e = tid + 256 * f;
-        const int ci = e / kDB, rem = e - ci * kDB, hd = rem / 81, hh = (rem - hd * 81) / 9, hw = rem % 9;
+        const int ci = e / kDB;
+        int rem = e - ci * kDB, smp = 0;
+        if (MODE == 1) {
+            smp = rem / 125;
+            rem -= smp * 125;
+        }
+        const int hd = rem / BX::PL, hh = (rem - hd * BX::PL) / BX::BW, hw = rem % BX::BW;
         const int od = qd0 + pd - 1 + hd, oh = qh0 + ph - 1 + hh, ow = qw0 + pw - 1 + hw;
-        const bool ok = (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH && (unsigned)ow < (unsigned)a.g.OW;
-        goff[f] = e >= kDCC * kDB ? -2 : (ok ? ci * O3 + (od * a.g.OH + oh) * a.g.OW + ow : -1);
+        const bool ok = (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH && (unsigned)ow < (unsigned)a.g.OW &&
+                        (int)n + smp < a.batch;
+        goff[f] = e >= kDCC * kDB ? -2 : (ok ? (smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow : -1);
     }
     float fv[kDNF];
     auto copy_load = [&](int f, int c0) { fv[f] = dyn[goff[f] >= 0 ? c0 * O3 + goff[f] : 0]; };
@@ -384,6 +409,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     long g = 0;
     __syncthreads();
 
+    constexpr int O00 = BX::PL + BX::BW, O01 = BX::PL, O10 = BX::BW, O11 = 0;  // (td,th) -> box offset
     const int nstage = a.Cout / kDCC;
     for (int s = 0; s < nstage; ++s) {
         const float* cur = box + (s & 1) * (kDCC * kDB);
@@ -394,10 +420,10 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         float bq[2][4];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            bq[tn][0] = hb0[tn * 36 + 81 + 9];   // j=0: td=0, th=0
-            bq[tn][1] = hb0[tn * 36 + 81];       // j=1: td=0, th=1
-            bq[tn][2] = hb0[tn * 36 + 9];        // j=2: td=1, th=0
-            bq[tn][3] = hb0[tn * 36];            // j=3: td=1, th=1
+            bq[tn][0] = hb0[tn * BX::TNOFF + O00];   // j=0: td=0, th=0
+            bq[tn][1] = hb0[tn * BX::TNOFF + O01];   // j=1: td=0, th=1
+            bq[tn][2] = hb0[tn * BX::TNOFF + O10];   // j=2: td=1, th=0
+            bq[tn][3] = hb0[tn * BX::TNOFF + O11];   // j=3: td=1, th=1
         }
 #pragma unroll
         for (int c = 0; c < kDCC; ++c) {  // one k-group per channel
@@ -413,10 +439,10 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                 const float* hb = hb0 + (c + 1) * kDB;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    bq[tn][0] = hb[tn * 36 + 81 + 9];
-                    bq[tn][1] = hb[tn * 36 + 81];
-                    bq[tn][2] = hb[tn * 36 + 9];
-                    bq[tn][3] = hb[tn * 36];
+                    bq[tn][0] = hb[tn * BX::TNOFF + O00];
+                    bq[tn][1] = hb[tn * BX::TNOFF + O01];
+                    bq[tn][2] = hb[tn * BX::TNOFF + O10];
+                    bq[tn][3] = hb[tn * BX::TNOFF + O11];
                 }
             }
             if (more) {
@@ -439,13 +465,24 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         __syncthreads();
     }
 
-    // epilogue: dx[n][ci][2(qd0+wn)+pd][2(qh0+lh)+ph][2(qw0+lw)+pw] = act(acc + bias[ci])
+    // epilogue: dx[n'][ci][2 qd + pd][2 qh + ph][2 qw + pw] = act(acc + bias[ci])
     const long I3 = (long)a.g.ID * a.g.IH * a.g.IW;
-    float* out = a.dx + (long)n * a.g.Cx * I3;
+    const int nn = MODE == 0 ? (int)n : (int)n + wn;
+    if (nn >= a.batch) return;
+    float* out = a.dx + (long)nn * a.g.Cx * I3;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        const int lh = tn * 4 + lh4;
-        const long pos = ((long)(2 * (qd0 + wn) + pd) * a.g.IH + (2 * (qh0 + lh) + ph)) * a.g.IW + (2 * (qw0 + lw) + pw);
+        int qd, qh, qw;
+        if (MODE == 0) {
+            qd = qd0 + wn;
+            qh = qh0 + tn * 4 + (r >> 3);
+            qw = qw0 + (r & 7);
+        } else {
+            qd = 2 * tn + (r >> 4);
+            qh = (r >> 2) & 3;
+            qw = r & 3;
+        }
+        const long pos = ((long)(2 * qd + pd) * a.g.IH + (2 * qh + ph)) * a.g.IW + (2 * qw + pw);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
@@ -463,11 +500,13 @@ size_t halo_dgrad_workspace_bytes(int Cin, int Cout) { return (size_t)8 * ((Cin 
 int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force) {
-    if (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0 || Cout % kDCC != 0 || Cin < 32) return 0;
+    const bool mode1 = g.OD == 4 && g.OH == 4 && g.OW == 4;
+    if (!mode1 && (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0)) return 0;
+    if (Cout % kDCC != 0 || Cin < 32) return 0;
     if (!workspace || workspace_bytes < halo_dgrad_workspace_bytes(Cin, Cout)) return 0;
     if ((long)batch * g.Cy * g.OD * g.OH * g.OW >= (1L << 31)) return 0;
-    const int ntw = g.OW / 8, nth = g.OH / 8, ntd = g.OD / 2;
-    const long tiles = (long)batch * ntd * nth * ntw;
+    const int ntw = mode1 ? 1 : g.OW / 8, nth = mode1 ? 1 : g.OH / 8, ntd = mode1 ? 1 : g.OD / 2;
+    const long tiles = mode1 ? (batch + 1) / 2 : (long)batch * ntd * nth * ntw;
     const int mtiles = (Cin + 63) / 64;
     if (!force && tiles * mtiles * 8 < 512) return 0;
     if (tiles >= (1L << 31) || mtiles > 65535) return 0;
@@ -487,16 +526,21 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     a.Cin = Cin;
     a.Cout = Cout;
     a.mtiles = mtiles;
+    a.batch = batch;
     a.dntw = FastDiv(ntw);
     a.dnth = FastDiv(nth);
     a.dntd = FastDiv(ntd);
     a.act = act;
     a.slope = slope;
-    const size_t lds = (size_t)2 * kDCC * kDB * sizeof(float);
-    hipLaunchKernelGGL(conv_dgrad_halo_kernel, dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    if (mode1) {
+        const size_t lds = (size_t)2 * kDCC * DBox<1>::CH * sizeof(float);
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)2 * kDCC * DBox<0>::CH * sizeof(float);
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    }
     return 1;
 }
-
 
 // ================================================================================================================
 // wgrad form (nn.Conv3d / nn.ConvTranspose3d weight gradient):

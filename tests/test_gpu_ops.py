@@ -385,7 +385,8 @@ def test_conv_fwd_halo_kernel(N, Ci, Co, R):
     close(y_gather, ref, what="gather vs oracle")
 
 
-@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 32, 16, 8), (1, 64, 32, 16), (2, 128, 64, 8), (1, 40, 48, 8)])
+@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 32, 16, 8), (1, 64, 32, 16), (2, 128, 64, 8), (1, 40, 48, 8),
+                                       (4, 128, 256, 4), (3, 96, 32, 4), (1, 64, 16, 4)])
 def test_conv_dgrad_halo_kernel(N, Ci, Co, O):
     """The LDS-halo dgrad / ConvTranspose3d forward (forced) == ATen conv_transpose3d."""
     from shapegan_amd import ops
