@@ -129,11 +129,12 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
 #pragma unroll
         for (int f = 0; f < kNF; ++f) fill_store(f, halo, ci);
     }
-    // packed weights: a ring of 4 k-groups in flight.  Vector loads return in order, so a weight load issued after a
+    constexpr int kRing = 8;
+    // packed weights: a ring of kRing k-groups in flight.  Vector loads return in order, so a weight load issued after a
     // copy load of x (HBM latency) cannot complete before it: 4 groups (~2000 matrix-pipe cycles) cover that latency.
-    float4 aring[4][TM];
+    float4 aring[kRing][TM];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kRing; ++u)
 #pragma unroll
         for (int t = 0; t < TM; ++t) aring[u][t] = wrow[t][u * 64];
     long g = 0;
@@ -159,10 +160,10 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
                 for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
                     float4 a_cur[TM];
 #pragma unroll
-                    for (int t = 0; t < TM; ++t) a_cur[t] = aring[j & 3][t];
-                    if (g + 4 < G) {
+                    for (int t = 0; t < TM; ++t) a_cur[t] = aring[j % kRing][t];
+                    if (g + kRing < G) {
 #pragma unroll
-                        for (int t = 0; t < TM; ++t) aring[j & 3][t] = wrow[t][(g + 4) * 64];
+                        for (int t = 0; t < TM; ++t) aring[j % kRing][t] = wrow[t][(g + kRing) * 64];
                     }
                     ++g;
                     const float b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
