@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __re
 //     one channel (64*TM MFMAs) later, so neither the load latency nor the copy sits on the matrix pipe's critical path;
 //   * B fragments of group g+1 are read from LDS before the MFMAs of group g are issued; A fragments (packed weights,
 //     L2) are prefetched one group ahead; one barrier per stage.
-template <int TM, int NW>
+template <int TM, int NW, bool BURST>
 __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     constexpr int kFR = NW * 2;                          // halo rows copied per pass (one per half-wave)
     constexpr int kNF = (kHD * kHH + kFR - 1) / kFR;     // fill elements per thread per channel (72 rows)
@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     auto fill_store = [&](int f, float* buf, int ci) {
         if (loff[f] >= 0) buf[ci * kHS + loff[f]] = goff[f] >= 0 ? fv[f] : 0.f;
     };
+    // BURST: all copy loads of the next stage are issued at the top of the stage, so that only the first few weight
+    // loads queue behind HBM-latency loads (vector loads return in order); values are stored one channel per channel.
+    float fvb[BURST ? kCC : 1][kNF];
 
     // ---- prologue: box of stage 0 into buffer 0 ----
     for (int ci = 0; ci < kCC; ++ci) {
@@ -149,12 +152,21 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
         if (!(a.debug & 2)) {
             const float* hb0 = cur + lanebase;
             float bq[4] = {hb0[0], hb0[1], hb0[kROWH], hb0[kROWH + 1]};  // B fragments of the first group
+            if (BURST && more) {
+#pragma unroll
+                for (int c = 0; c < kCC; ++c)
+#pragma unroll
+                    for (int f = 0; f < kNF; ++f) fvb[BURST ? c : 0][f] = xn[goff[f] >= 0 ? (cnext + c) * I3 + goff[f] : 0];
+            }
 #pragma unroll
             for (int ci = 0; ci < kCC; ++ci) {
                 // values loaded during the previous channel's MFMAs go to LDS now
                 if (ci > 0 && more) {
 #pragma unroll
-                    for (int f = 0; f < kNF; ++f) fill_store(f, nxt, ci - 1);
+                    for (int f = 0; f < kNF; ++f) {
+                        if (BURST) fv[f] = fvb[BURST ? ci - 1 : 0][f];
+                        fill_store(f, nxt, ci - 1);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
@@ -175,7 +187,7 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
                         bq[2] = hb[kROWH];
                         bq[3] = hb[kROWH + 1];
                     }
-                    if (more) {  // spread this channel's kNF copy loads over its 8 k-groups
+                    if (more && !BURST) {  // spread this channel's kNF copy loads over its 8 k-groups
 #pragma unroll
                         for (int f = 0; f < kNF; ++f)
                             if (f * 8 / kNF == j) fill_load(f, cnext + ci);
@@ -192,7 +204,10 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
             }
             if (more) {
 #pragma unroll
-                for (int f = 0; f < kNF; ++f) fill_store(f, nxt, kCC - 1);
+                for (int f = 0; f < kNF; ++f) {
+                    if (BURST) fv[f] = fvb[BURST ? kCC - 1 : 0][f];
+                    fill_store(f, nxt, kCC - 1);
+                }
             }
         } else if (more) {  // ablation: copy only
             for (int ci = 0; ci < kCC; ++ci) {
@@ -269,14 +284,19 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.dOD = FastDiv(g.OD);
     a.act = act;
     a.slope = slope;
-    a.debug = debug & 15;
+    a.debug = debug & 7;
+    const bool burst = (debug & 8) == 0;   // debug bit 3: spread the copy loads over the stage instead (A/B only)
     dim3 grid((unsigned)tiles, mtiles);
-    if (rows == 128 && variant == 2)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8>), grid, dim3(512), lds, stream, a);
-    else if (rows == 128)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4>), grid, dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4>), grid, dim3(256), lds, stream, a);
+    if (rows == 128 && variant == 2) {
+        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8, true>), grid, dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8, false>), grid, dim3(512), lds, stream, a);
+    } else if (rows == 128) {
+        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4, false>), grid, dim3(256), lds, stream, a);
+    } else {
+        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4, false>), grid, dim3(256), lds, stream, a);
+    }
     return 1;
 }
 

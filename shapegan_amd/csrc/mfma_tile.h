@@ -254,16 +254,39 @@ __global__ void __launch_bounds__(256) tile_gemm_kernel(LA la, LB lb, EPI epi, i
     }
 }
 
-// sums the split-K partials and hands each element to the real epilogue
+// sums the split-K partials and hands each element to the real epilogue.  One workgroup = 1024 consecutive columns of
+// one row (no per-element division); the partials of 4 columns are read as one dwordx4 when the row length allows it.
 template <class EPI>
 __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* ws, EPI epi, int M, int N, int splits) {
+    const int ncb = (N + 1023) >> 10;
+    const int i = blockIdx.x / ncb, j0 = (blockIdx.x - i * ncb) * 1024 + threadIdx.x * 4;
+    if (j0 >= N) return;
     const long total = (long)M * N;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int i = (int)(e / N), j = (int)(e % N);
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += ws[(long)s * total + e];
-        epi.store(epi.col(j), i, j, v);
+    const float* p = ws + (long)i * N + j0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((N & 3) == 0) {
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            const float4 q0 = *(const float4*)(p + (long)s * total), q1 = *(const float4*)(p + (long)(s + 1) * total);
+            const float4 q2 = *(const float4*)(p + (long)(s + 2) * total), q3 = *(const float4*)(p + (long)(s + 3) * total);
+            v[0] += (q0.x + q1.x) + (q2.x + q3.x);
+            v[1] += (q0.y + q1.y) + (q2.y + q3.y);
+            v[2] += (q0.z + q1.z) + (q2.z + q3.z);
+            v[3] += (q0.w + q1.w) + (q2.w + q3.w);
+        }
+        for (; s < splits; ++s) {
+            const float4 q = *(const float4*)(p + (long)s * total);
+            v[0] += q.x, v[1] += q.y, v[2] += q.z, v[3] += q.w;
+        }
+    } else {
+        for (int s = 0; s < splits; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < N) v[u] += p[(long)s * total + u];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (j0 + u < N) epi.store(epi.col(j0 + u), i, j0 + u, v[u]);
 }
 
 constexpr long kTargetBlocks = 512;  // >= 2 workgroups on each of the 256 CUs
@@ -306,11 +329,9 @@ static int launch_tile_gemm_t(LA la, LB lb, EPI epi, int M, int N, int K, int sp
         EpiWorkspace wepi{ws, M, N};
         hipLaunchKernelGGL((tile_gemm_kernel<TM, TN, LA, LB, EpiWorkspace>), grid, dim3(256), 0, st, la, lb, wepi, M, N,
                            K, kchunk);
-        long total = (long)M * N;
-        int fb = (int)((total + 255) / 256);
-        if (fb > 2048) fb = 2048;
-        hipLaunchKernelGGL((splitk_finalize_kernel<EPI>), dim3(fb), dim3(256), 0, st, (const float*)ws, epi, M, N,
-                           splitk);
+        const long fb = (long)M * ((N + 1023) >> 10);
+        hipLaunchKernelGGL((splitk_finalize_kernel<EPI>), dim3((unsigned)fb), dim3(256), 0, st, (const float*)ws, epi,
+                           M, N, splitk);
     }
     return 0;
 }

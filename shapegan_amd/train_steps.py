@@ -41,8 +41,11 @@ class WGANTrainer(object):
         self.c_opt.zero_grad()
         with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
             fake = self.generator(z)
-        out_fake = self.critic(fake)
-        out_real = self.critic(real)
+        # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
+        # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.
+        n_fake = fake.shape[0]
+        out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
+        out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean(out_fake) - ops.mean(out_real)
         self.c_bucket.arm()
         loss.backward()
@@ -219,8 +222,11 @@ class HybridWGANTrainer(object):
         self.c_opt.zero_grad()
         with torch.no_grad():
             fake = self.generate(z)
-        out_fake = self.critic(fake)
-        out_real = self.critic(real)
+        # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
+        # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.
+        n_fake = fake.shape[0]
+        out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
+        out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean(out_fake) - ops.mean(out_real)
         self.c_bucket.arm()
         loss.backward()
