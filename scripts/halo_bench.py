@@ -2,8 +2,9 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shapegan_amd import ops
-def timeit(fn, iters=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, iters=30):
+    for _ in range(10): fn()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters): fn()

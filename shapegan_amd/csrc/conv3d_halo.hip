@@ -38,7 +38,6 @@ struct HaloFwdArgs {
     FastDiv dntw, dnth, dOD;
     int act;
     float slope;
-    int debug;  // tuning experiments only: 1 = fill the halo once, 2 = skip the MFMAs
 };
 
 // Wp[(mt*G + g)*64 + lane] = float4{ W[mt*32 + (lane&31)][8g + 2j + (lane>>5)] , j = 0..3 }   (G = Cin*8 groups)
@@ -61,17 +60,21 @@ __global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __re
     }
 }
 
-// Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 8*TM MFMAs each):
-//   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1:
-//     each k-group issues one global load of the next box (9 per channel per thread), the values are written to LDS
-//     one channel (64*TM MFMAs) later, so neither the load latency nor the copy sits on the matrix pipe's critical path;
-//   * B fragments of group g+1 are read from LDS before the MFMAs of group g are issued; A fragments (packed weights,
-//     L2) are prefetched one group ahead; one barrier per stage.
-template <int TM, int NW, bool BURST>
+// Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 4*TM MFMAs each).  The loop body is ONE basic
+// block (no data-dependent branches), so that the compiler's s_waitcnt counts are exact and nothing drains the queues:
+//   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1.  All copy
+//     loads of the stage are issued at its top (vector loads return in order: only the first few weight loads then queue
+//     behind HBM-latency loads), the values are written to LDS one channel per channel of MFMAs.  Out-of-range voxels load
+//     a clamped address and store zero; threads outside the box store to an unused pad slot of the channel; the last
+//     stage re-copies its own channels into the idle buffer — no branch anywhere;
+//   * B fragments of group g+1 are read from LDS while the MFMAs of group g run; A fragments (packed weights, L2) sit in
+//     a ring of 8 groups; the weight pointer is wave-uniform (scalar base + lane offset); one barrier per stage.
+template <int TM, int NW>
 __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     constexpr int kFR = NW * 2;                          // halo rows copied per pass (one per half-wave)
     constexpr int kNF = (kHD * kHH + kFR - 1) / kFR;     // fill elements per thread per channel (72 rows)
     constexpr int ROWS = (NW / 2) * TM * 32;             // output channels per workgroup
+    constexpr int kRing = 8;
     extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][kCC][kHD][kHH][2][kHWH]
 
     uint32_t twi, thi, od, n, q1, q2;
@@ -81,7 +84,8 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     const int oh0 = thi * 8, ow0 = twi * 8;
     const int co0 = blockIdx.y * ROWS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
     const int p = wn * 32 + r, pw = p & 7, ph = p >> 3;  // position inside the 8x8 tile
     const int lanebase = 2 * ph * kROWH + kpar * kHWH + pw;
@@ -92,147 +96,127 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-    const long G = (long)a.Cin * 8;
-    const float4* wrow[TM];
+    const int G = a.Cin * 8;
+    const float4* wrow[TM];  // wave-uniform
 #pragma unroll
-    for (int t = 0; t < TM; ++t) wrow[t] = a.wp + ((long)(co0 / 32 + wm * TM + t) * G) * 64 + lane;
+    for (int t = 0; t < TM; ++t) wrow[t] = a.wp + ((long)(co0 / 32 + wm * TM + t) * G) * 64;
 
-    // ---- fill bookkeeping: element fl (0..8) of a channel is halo row 8*fl + tid/32, column tid%32 ----
+    // ---- fill bookkeeping: element f of a channel is halo row kFR*f + tid/32, column tid%32 ----
     const int I3 = a.g.ID * a.g.IH * a.g.IW;
     const float* xn = a.x + (long)n * a.g.Cx * I3;
     const int fl_w = tid & 31, frow = tid >> 5;
     const int iw = 2 * ow0 - 1 + fl_w;
     const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
     const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
-    int goff[kNF], loff[kNF];  // global offset inside a channel (-1: zero), LDS offset inside a channel (-1: none)
+    const int pad = (tid % (kHD * kHH * 2)) * kHWH + (kHWH - 1);  // column 9 of a half row: never read
+    unsigned goff[kNF];  // global offset inside a channel (0 when out of range: the value is replaced by zero)
+    int loff[kNF];       // LDS offset inside a channel
+    unsigned okmask = 0;
 #pragma unroll
     for (int f = 0; f < kNF; ++f) {
         const int row = kFR * f + frow, hd = row / kHH, hh = row - hd * kHH;
         const int id = 2 * (int)od - 1 + hd, ih = 2 * oh0 - 1 + hh;
         const bool inbox = fl_w < kHWF && row < kHD * kHH;
         const bool ok = inbox && wok && (unsigned)id < (unsigned)a.g.ID && (unsigned)ih < (unsigned)a.g.IH;
-        goff[f] = ok ? (id * a.g.IH + ih) * a.g.IW + iw : -1;
-        loff[f] = inbox ? hd * kROWD + hh * kROWH + lds_w : -1;
+        goff[f] = ok ? (unsigned)((id * a.g.IH + ih) * a.g.IW + iw) : 0u;
+        okmask |= ok ? (1u << f) : 0u;
+        loff[f] = inbox ? hd * kROWD + hh * kROWH + lds_w : pad;
     }
-    float fv[kNF];
-    auto fill_load = [&](int f, int cglob) {  // issue the load of element f of global channel cglob
-        fv[f] = xn[goff[f] >= 0 ? cglob * I3 + goff[f] : 0];
-    };
-    auto fill_store = [&](int f, float* buf, int ci) {
-        if (loff[f] >= 0) buf[ci * kHS + loff[f]] = goff[f] >= 0 ? fv[f] : 0.f;
-    };
-    // BURST: all copy loads of the next stage are issued at the top of the stage, so that only the first few weight
-    // loads queue behind HBM-latency loads (vector loads return in order); values are stored one channel per channel.
-    float fvb[BURST ? kCC : 1][kNF];
+    float fv[kCC][kNF];
 
-    // ---- prologue: box of stage 0 into buffer 0 ----
-    for (int ci = 0; ci < kCC; ++ci) {
+    // ---- prologue: box of stage 0 into buffer 0, first kRing weight groups ----
 #pragma unroll
-        for (int f = 0; f < kNF; ++f) fill_load(f, ci);
+    for (int c = 0; c < kCC; ++c)
 #pragma unroll
-        for (int f = 0; f < kNF; ++f) fill_store(f, halo, ci);
-    }
-    constexpr int kRing = 8;
-    // packed weights: a ring of kRing k-groups in flight.  Vector loads return in order, so a weight load issued after a
-    // copy load of x (HBM latency) cannot complete before it: 4 groups (~2000 matrix-pipe cycles) cover that latency.
+        for (int f = 0; f < kNF; ++f) fv[c][f] = (xn + (long)c * I3)[goff[f]];
     float4 aring[kRing][TM];
 #pragma unroll
     for (int u = 0; u < kRing; ++u)
 #pragma unroll
-        for (int t = 0; t < TM; ++t) aring[u][t] = wrow[t][u * 64];
-    long g = 0;
+        for (int t = 0; t < TM; ++t) aring[u][t] = (wrow[t] + (u < G ? u : G - 1) * 64)[lane];
+#pragma unroll
+    for (int c = 0; c < kCC; ++c)
+#pragma unroll
+        for (int f = 0; f < kNF; ++f) halo[c * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[c][f] : 0.f;
     __syncthreads();
 
     const int nstage = a.Cin / kCC;
+    int gbase = kRing;  // first group index to prefetch in this stage
     for (int s = 0; s < nstage; ++s) {
         const float* cur = halo + (s & 1) * (kCC * kHS);
         float* nxt = halo + ((s + 1) & 1) * (kCC * kHS);
-        const bool more = (s + 1 < nstage) && !(a.debug & 1);
-        const int cnext = (s + 1) * kCC;
-        if (!(a.debug & 2)) {
-            const float* hb0 = cur + lanebase;
-            float bq[4] = {hb0[0], hb0[1], hb0[kROWH], hb0[kROWH + 1]};  // B fragments of the first group
-            if (BURST && more) {
+        int cnext = (s + 1) * kCC;
+        cnext = cnext > a.Cin - kCC ? a.Cin - kCC : cnext;
+        const float* xs = xn + (long)cnext * I3;
+        const float* hb0 = cur + lanebase;
+        float bq[4] = {hb0[0], hb0[1], hb0[kROWH], hb0[kROWH + 1]};  // B fragments of the first group
 #pragma unroll
-                for (int c = 0; c < kCC; ++c)
+        for (int c = 0; c < kCC; ++c)
 #pragma unroll
-                    for (int f = 0; f < kNF; ++f) fvb[BURST ? c : 0][f] = xn[goff[f] >= 0 ? (cnext + c) * I3 + goff[f] : 0];
+            for (int f = 0; f < kNF; ++f) fv[c][f] = (xs + (long)c * I3)[goff[f]];
+        // sched_barrier(0): the machine scheduler otherwise sinks every load to just before its use (to save registers),
+        // which turns the ring / the early copy loads into load -> s_waitcnt vmcnt(0) -> use
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ci = 0; ci < kCC; ++ci) {
+            if (ci > 0) {  // the copy loads were issued >= 8 k-groups ago
+#pragma unroll
+                for (int f = 0; f < kNF; ++f) nxt[(ci - 1) * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[ci - 1][f] : 0.f;
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int ci = 0; ci < kCC; ++ci) {
-                // values loaded during the previous channel's MFMAs go to LDS now
-                if (ci > 0 && more) {
+            for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
+                float4 a_cur[TM];
 #pragma unroll
-                    for (int f = 0; f < kNF; ++f) {
-                        if (BURST) fv[f] = fvb[BURST ? ci - 1 : 0][f];
-                        fill_store(f, nxt, ci - 1);
-                    }
+                for (int t = 0; t < TM; ++t) a_cur[t] = aring[j % kRing][t];
+                int gi = gbase + ci * 8 + j;
+                gi = gi < G ? gi : G - 1;
+#pragma unroll
+                for (int t = 0; t < TM; ++t) aring[j % kRing][t] = (wrow[t] + (long)gi * 64)[lane];
+                const float b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
+                if (!(ci == kCC - 1 && j == 7)) {  // B fragments of the next group of this stage
+                    const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
+                    const float* hb = cur + lanebase + cin * kHS + (jn >> 1) * kROWD + (2 * (jn & 1)) * kROWH;
+                    bq[0] = hb[0];
+                    bq[1] = hb[1];
+                    bq[2] = hb[kROWH];
+                    bq[3] = hb[kROWH + 1];
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
-                    float4 a_cur[TM];
+                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, b0, acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < TM; ++t) a_cur[t] = aring[j % kRing][t];
-                    if (g + kRing < G) {
+                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, b1, acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < TM; ++t) aring[j % kRing][t] = wrow[t][(g + kRing) * 64];
-                    }
-                    ++g;
-                    const float b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
-                    if (!(ci == kCC - 1 && j == 7)) {  // B fragments of the next group of this stage
-                        const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
-                        const float* hb = cur + lanebase + cin * kHS + (jn >> 1) * kROWD + (2 * (jn & 1)) * kROWH;
-                        bq[0] = hb[0];
-                        bq[1] = hb[1];
-                        bq[2] = hb[kROWH];
-                        bq[3] = hb[kROWH + 1];
-                    }
-                    if (more && !BURST) {  // spread this channel's kNF copy loads over its 8 k-groups
+                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, b2, acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int f = 0; f < kNF; ++f)
-                            if (f * 8 / kNF == j) fill_load(f, cnext + ci);
-                    }
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, b0, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, b1, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, b2, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, b3, acc[t], 0, 0, 0);
-                }
-            }
-            if (more) {
-#pragma unroll
-                for (int f = 0; f < kNF; ++f) {
-                    if (BURST) fv[f] = fvb[BURST ? kCC - 1 : 0][f];
-                    fill_store(f, nxt, kCC - 1);
-                }
-            }
-        } else if (more) {  // ablation: copy only
-            for (int ci = 0; ci < kCC; ++ci) {
-#pragma unroll
-                for (int f = 0; f < kNF; ++f) fill_load(f, cnext + ci);
-#pragma unroll
-                for (int f = 0; f < kNF; ++f) fill_store(f, nxt, ci);
+                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, b3, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+#pragma unroll
+        for (int f = 0; f < kNF; ++f) nxt[(kCC - 1) * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[kCC - 1][f] : 0.f;
+        gbase += 8 * kCC;
         __syncthreads();  // next box complete and visible; everyone is done reading the current one
     }
 
-    // epilogue: y[n][co][od][oh0+ph][ow0+pw] = act(acc + bias[co])
+    // epilogue: y[n][co][od][oh0+ph][ow0+pw] = act(acc + bias[co]); all bias loads are issued before the first use
     const long O3 = (long)a.g.OD * a.g.OH * a.g.OW;
     float* yo = a.y + (long)n * a.Cout * O3 + ((long)od * a.g.OH + (oh0 + ph)) * a.g.OW + (ow0 + pw);
+    float bv[TM][16];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+            bv[t][q] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
+        }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-            if (co < a.Cout) {
-                float v = acc[t][q];
-                if (a.bias) v += a.bias[co];
-                yo[(long)co * O3] = sg_apply_act(v, a.act, a.slope);
-            }
+            if (co < a.Cout) yo[(long)co * O3] = sg_apply_act(acc[t][q] + bv[t][q], a.act, a.slope);
         }
     }
 }
@@ -284,19 +268,13 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.dOD = FastDiv(g.OD);
     a.act = act;
     a.slope = slope;
-    a.debug = debug & 7;
-    const bool burst = (debug & 8) == 0;   // debug bit 3: spread the copy loads over the stage instead (A/B only)
     dim3 grid((unsigned)tiles, mtiles);
-    if (rows == 128 && variant == 2) {
-        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8, true>), grid, dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8, false>), grid, dim3(512), lds, stream, a);
-    } else if (rows == 128) {
-        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4, true>), grid, dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4, false>), grid, dim3(256), lds, stream, a);
-    } else {
-        if (burst) hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4, true>), grid, dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4, false>), grid, dim3(256), lds, stream, a);
-    }
+    if (rows == 128 && variant == 2)
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8>), grid, dim3(512), lds, stream, a);
+    else if (rows == 128)
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4>), grid, dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4>), grid, dim3(256), lds, stream, a);
     return 1;
 }
 
@@ -322,6 +300,7 @@ struct DBox<1> {
 };
 constexpr int kDCC = 16;         // channels per stage: 16 k-groups, 128 MFMAs per wave
 constexpr int kDNF = 16;         // copy elements per thread per stage (3888 resp. 4000 box floats / 256 threads)
+constexpr int kDBUF = kDNF * 256; // floats per LDS buffer (box + unread tail)
 
 struct HaloDgradArgs {
     const float* dy;
@@ -367,7 +346,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     using BX = DBox<MODE>;
     constexpr int kDB = BX::CH;
-    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDCC][kDB]
+    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDBUF], a buffer = [kDCC][kDB] + tail
     const int par = blockIdx.z, pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
     uint32_t twi = 0, thi = 0, tdi = 0, n, q1, q2;
     if (MODE == 0) {
@@ -380,7 +359,8 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const int qd0 = tdi * 2, qh0 = thi * 8, qw0 = twi * 8;
     const int ci0 = blockIdx.y * 64;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
     // lane -> position inside a 32-position column tile; address of tap (td,th): lanebase + tn*TNOFF + (1-td)*PL + (1-th)*BW
     const int lpart = MODE == 0 ? (r >> 3) * BX::BW + (r & 7) : (r >> 4) * BX::PL + ((r >> 2) & 3) * BX::BW + (r & 3);
@@ -392,13 +372,15 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-    const long G = a.Cout;  // one k-group per output channel
-    const float4* wrow = a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64 + lane;
+    const int G = a.Cout;  // one k-group per output channel
+    const float4* wrow = a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64;  // wave-uniform
 
-    // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw) ----
+    // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw); a buffer
+    // holds kDNF*256 floats, so every thread stores all its elements (those beyond the box land in the unread tail) ----
     const int O3 = a.g.OD * a.g.OH * a.g.OW;
     const float* dyn = a.dy + (long)n * a.g.Cy * O3;
-    int goff[kDNF];  // offset from dyn of channel 0 of the stage (-1: zero, -2: beyond the box)
+    unsigned goff[kDNF];  // offset from dyn of channel 0 of the stage (0 when the value is replaced by zero)
+    unsigned okmask = 0;
 #pragma unroll
     for (int f = 0; f < kDNF; ++f) {
         const int e = tid + 256 * f;
@@ -410,33 +392,34 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         }
         const int hd = rem / BX::PL, hh = (rem - hd * BX::PL) / BX::BW, hw = rem % BX::BW;
         const int od = qd0 + pd - 1 + hd, oh = qh0 + ph - 1 + hh, ow = qw0 + pw - 1 + hw;
-        const bool ok = (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH && (unsigned)ow < (unsigned)a.g.OW &&
-                        (int)n + smp < a.batch;
-        goff[f] = e >= kDCC * kDB ? -2 : (ok ? (smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow : -1);
+        const bool ok = e < kDCC * kDB && (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH &&
+                        (unsigned)ow < (unsigned)a.g.OW && (int)n + smp < a.batch;
+        goff[f] = ok ? (unsigned)((smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow) : 0u;
+        okmask |= ok ? (1u << f) : 0u;
     }
     float fv[kDNF];
-    auto copy_load = [&](int f, int c0) { fv[f] = dyn[goff[f] >= 0 ? c0 * O3 + goff[f] : 0]; };
-    auto copy_store = [&](int f, float* buf) {
-        if (goff[f] != -2) buf[tid + 256 * f] = goff[f] >= 0 ? fv[f] : 0.f;
-    };
-
+    constexpr int kRing = 8;
+    float4 aring[kRing];
 #pragma unroll
-    for (int f = 0; f < kDNF; ++f) copy_load(f, 0);
+    for (int f = 0; f < kDNF; ++f) fv[f] = dyn[goff[f]];
 #pragma unroll
-    for (int f = 0; f < kDNF; ++f) copy_store(f, box);
-    float4 aring[4];
+    for (int u = 0; u < kRing; ++u) aring[u] = (wrow + (u < G ? u : G - 1) * 64)[lane];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) aring[u] = wrow[(u < G ? u : 0) * 64];
-    long g = 0;
+    for (int f = 0; f < kDNF; ++f) box[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
     __syncthreads();
 
+    // The stage loop body is one basic block (no data-dependent branch): copy loads of the next box at the top, their LDS
+    // stores in the second half of the stage, packed weights in a ring of 8 groups; sched_barriers keep the machine
+    // scheduler from sinking the loads to their uses (see conv_fwd_halo_kernel).
     constexpr int O00 = BX::PL + BX::BW, O01 = BX::PL, O10 = BX::BW, O11 = 0;  // (td,th) -> box offset
     const int nstage = a.Cout / kDCC;
+    int gbase = kRing;
     for (int s = 0; s < nstage; ++s) {
-        const float* cur = box + (s & 1) * (kDCC * kDB);
-        float* nxt = box + ((s + 1) & 1) * (kDCC * kDB);
-        const bool more = s + 1 < nstage;
-        const int cnext = (s + 1) * kDCC;
+        const float* cur = box + (s & 1) * kDBUF;
+        float* nxt = box + ((s + 1) & 1) * kDBUF;
+        int cnext = (s + 1) * kDCC;
+        cnext = cnext > a.Cout - kDCC ? a.Cout - kDCC : cnext;  // last stage: re-copy into the idle buffer
+        const float* dys = dyn + (long)cnext * O3;
         const float* hb0 = cur + lanebase;
         float bq[2][4];
 #pragma unroll
@@ -447,10 +430,14 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             bq[tn][3] = hb0[tn * BX::TNOFF + O11];   // j=3: td=1, th=1
         }
 #pragma unroll
+        for (int f = 0; f < kDNF; ++f) fv[f] = dys[goff[f]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int c = 0; c < kDCC; ++c) {  // one k-group per channel
-            const float4 a_cur = aring[c & 3];
-            if (g + 4 < G) aring[c & 3] = wrow[(g + 4) * 64];
-            ++g;
+            const float4 a_cur = aring[c % kRing];
+            int gi = gbase + c;
+            gi = gi < G ? gi : G - 1;
+            aring[c % kRing] = (wrow + (long)gi * 64)[lane];
             float b[2][4];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
@@ -466,14 +453,12 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                     bq[tn][3] = hb[tn * BX::TNOFF + O11];
                 }
             }
-            if (more) {
-                // copy schedule: loads of the next box in groups 0..11, each value stored 4 groups after its load
+            if (c >= kDCC / 2) {  // two of the 16 copied values per group
 #pragma unroll
-                for (int f = 0; f < kDNF; ++f) {
-                    if (f * 3 / 4 + 4 == c) copy_store(f, nxt);
-                    if (f * 3 / 4 == c) copy_load(f, cnext);
-                }
+                for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f)
+                    nxt[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[0][0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[1][0], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[0][1], acc[0], 0, 0, 0);
@@ -482,7 +467,9 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[1][2], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[0][3], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[1][3], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        gbase += kDCC;
         __syncthreads();
     }
 
@@ -491,6 +478,12 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const int nn = MODE == 0 ? (int)n : (int)n + wn;
     if (nn >= a.batch) return;
     float* out = a.dx + (long)nn * a.g.Cx * I3;
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+        bv[q] = a.bias ? a.bias[ci < a.Cin ? ci : a.Cin - 1] : 0.f;
+    }
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         int qd, qh, qw;
@@ -507,11 +500,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-            if (ci < a.Cin) {
-                float v = acc[tn][q];
-                if (a.bias) v += a.bias[ci];
-                out[(long)ci * I3 + pos] = sg_apply_act(v, a.act, a.slope);
-            }
+            if (ci < a.Cin) out[(long)ci * I3 + pos] = sg_apply_act(acc[tn][q] + bv[q], a.act, a.slope);
         }
     }
 }
@@ -554,10 +543,10 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     a.act = act;
     a.slope = slope;
     if (mode1) {
-        const size_t lds = (size_t)2 * kDCC * DBox<1>::CH * sizeof(float);
+        const size_t lds = (size_t)2 * kDBUF * sizeof(float);
         hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
     } else {
-        const size_t lds = (size_t)2 * kDCC * DBox<0>::CH * sizeof(float);
+        const size_t lds = (size_t)2 * kDBUF * sizeof(float);
         hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
     }
     return 1;
@@ -615,7 +604,8 @@ __global__ void __launch_bounds__(256) pack_wgrad_dy_kernel(const float* __restr
 
 __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wbox[];  // [2 buffers][2 channels][kHD][kWROWD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
     const int ci0 = blockIdx.x * 2;          // the two input channels (128 output columns) of this workgroup
     const int mt0 = blockIdx.y * 4;          // 128 output rows = 4 row tiles of 32
@@ -639,107 +629,128 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    // ---- copy bookkeeping: element f is (channel c = f / 9, row 8*(f%9) + tid/32, column tid%32) of the 2-channel box ----
+    // ---- copy bookkeeping: element f is (channel c = f / 9, row 8*(f%9) + tid/32, column tid%32) of the 2-channel box.
+    // Threads outside the box store to an unread pad slot (column 9 of a half row), out-of-range voxels load a clamped
+    // address and store zero: no branch in the stage loop ----
     const int I3 = a.g.ID * a.g.IH * a.g.IW;
     const int fl_w = tid & 31, frow = tid >> 5;
     const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
-    int rowoff[kWNF / 2];   // LDS offset of the row inside a channel (-1: none); identical for both channels
+    const int prow = (tid >> 1) % (kHD * kHH);
+    const int pad = (prow / kHH) * kWROWD + (prow % kHH) * kROWH + (tid & 1) * kHWH + (kHWH - 1);
+    int rowoff[kWNF / 2];   // LDS offset of the row inside a channel; identical for both channels
     int hdv[kWNF / 2], hhv[kWNF / 2];
+    unsigned inmask = 0;
 #pragma unroll
     for (int f = 0; f < kWNF / 2; ++f) {
         const int row = 8 * f + frow;
         hdv[f] = row / kHH;
         hhv[f] = row - hdv[f] * kHH;
-        rowoff[f] = (fl_w < kHWF && row < kHD * kHH) ? hdv[f] * kWROWD + hhv[f] * kROWH + lds_w : -1;
+        const bool inbox = fl_w < kHWF && row < kHD * kHH;
+        rowoff[f] = inbox ? hdv[f] * kWROWD + hhv[f] * kROWH + lds_w : pad;
+        inmask |= inbox ? (1u << f) : 0u;
     }
     float fv[kWNF];
-    int goff[kWNF];  // per stage: global offset or -1 (zero)
-    auto copy_prepare = [&](int sl) {  // geometry of slice sl -> goff[]
+    unsigned okmask = 0;
+    auto copy_issue = [&](int sl) {  // geometry of slice sl -> the kWNF loads of its box
         uint32_t twi, thi, od, n, q1, q2;
         a.dntw.divmod((uint32_t)sl, q1, twi);
         a.dnth.divmod(q1, q2, thi);
         a.dOD.divmod(q2, n, od);
         const int iw = 2 * (int)twi * 8 - 1 + fl_w;
         const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
-        const int nbase = (int)n * a.g.Cx * I3;
+        const float* xb = a.x + (long)n * a.g.Cx * I3;  // uniform
+        okmask = 0;
 #pragma unroll
         for (int f = 0; f < kWNF; ++f) {
             const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
             const int id = 2 * (int)od - 1 + hdv[fr], ih = 2 * (int)thi * 8 - 1 + hhv[fr];
-            const bool ok = wok && rowoff[fr] >= 0 && (ci0 + c) < a.Cin && (unsigned)id < (unsigned)a.g.ID &&
+            const bool ok = wok && ((inmask >> fr) & 1u) && (ci0 + c) < a.Cin && (unsigned)id < (unsigned)a.g.ID &&
                             (unsigned)ih < (unsigned)a.g.IH;
-            goff[f] = ok ? nbase + (ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw : -1;
+            const unsigned off = ok ? (unsigned)((ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw) : 0u;
+            okmask |= ok ? (1u << f) : 0u;
+            fv[f] = xb[off];
         }
     };
-    auto copy_load = [&](int f) { fv[f] = a.x[goff[f] >= 0 ? goff[f] : 0]; };
     auto copy_store = [&](int f, float* buf) {
         const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
-        if (rowoff[fr] >= 0) buf[c * kWHS + rowoff[fr]] = goff[f] >= 0 ? fv[f] : 0.f;
+        buf[c * kWHS + rowoff[fr]] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
     };
 
     const int nst = s_end - s_beg;
-    if (nst > 0) {
-        copy_prepare(s_beg);
+    constexpr int kRing = 8;  // A fragments: ring of 8 k-groups (one stage); group index runs over (slice, gq)
+    const float4* arow[2];    // wave-uniform
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) copy_load(f);
+    for (int t = 0; t < 2; ++t) arow[t] = a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64;
+    const int G = nst * 8;
+    if (nst > 0) {
+        copy_issue(s_beg);
+        float4 aring[kRing][2];
+#pragma unroll
+        for (int u = 0; u < kRing; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) aring[u][t] = (arow[t] + u * 64)[lane];
 #pragma unroll
         for (int f = 0; f < kWNF; ++f) copy_store(f, wbox);
-    }
-    // A fragments: ring of 4 k-groups; group index runs over (slice, gq)
-    const float4* arow[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) arow[t] = a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64 + lane;
-    const long G = (long)nst * 8;
-    float4 aring[4][2];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) aring[u][t] = arow[t][(u < G ? u : 0) * 64];
-    long g = 0;
-    __syncthreads();
+        __syncthreads();
 
-    for (int st = 0; st < nst; ++st) {
-        const float* cur = wbox + (st & 1) * (2 * kWHS);
-        float* nxt = wbox + ((st + 1) & 1) * (2 * kWHS);
-        const bool more = st + 1 < nst;
-        if (more) copy_prepare(s_beg + st + 1);
-#pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {   // k-group gq = output row ph of the 8x8 tile; j = column pair
-            float4 a_cur[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) a_cur[t] = aring[gq & 3][t];
-            if (g + 4 < G) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) aring[gq & 3][t] = arow[t][(g + 4) * 64];
-            }
-            ++g;
-            float b[2][4];
+        for (int st = 0; st < nst; ++st) {
+            const float* cur = wbox + (st & 1) * (2 * kWHS);
+            float* nxt = wbox + ((st + 1) & 1) * (2 * kWHS);
+            const int snext = st + 1 < nst ? st + 1 : st;   // last stage: re-copy into the idle buffer
+            float bq[2][4];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                const float* hb = cur + lanebase[tn] + 2 * gq * kROWH;
-                b[tn][0] = hb[0];
-                b[tn][1] = hb[2];
-                b[tn][2] = hb[4];
-                b[tn][3] = hb[6];
+                const float* hb = cur + lanebase[tn];
+                bq[tn][0] = hb[0];
+                bq[tn][1] = hb[2];
+                bq[tn][2] = hb[4];
+                bq[tn][3] = hb[6];
             }
-            if (more) {  // copy schedule: 18 loads in groups 0..5 (3 each), stores two groups later
+            copy_issue(s_beg + snext);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int f = 0; f < kWNF; ++f) {
-                    if (f / 3 + 2 == gq) copy_store(f, nxt);
-                    if (f / 3 == gq) copy_load(f);
+            for (int gq = 0; gq < 8; ++gq) {   // k-group gq = output row ph of the 8x8 tile; j = column pair
+                float4 a_cur[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a_cur[t] = aring[gq][t];
+                int gi = (st + 1) * 8 + gq;
+                gi = gi < G ? gi : G - 1;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) aring[gq][t] = (arow[t] + (long)gi * 64)[lane];
+                float b[2][4];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[tn][j] = bq[tn][j];
+                if (gq + 1 < 8) {
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const float* hb = cur + lanebase[tn] + 2 * (gq + 1) * kROWH;
+                        bq[tn][0] = hb[0];
+                        bq[tn][1] = hb[2];
+                        bq[tn][2] = hb[4];
+                        bq[tn][3] = hb[6];
+                    }
                 }
-            }
+                if (gq >= 4) {  // the 18 copied values go to LDS in the second half of the stage
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a0 = j == 0 ? a_cur[0].x : (j == 1 ? a_cur[0].y : (j == 2 ? a_cur[0].z : a_cur[0].w));
-                const float a1 = j == 0 ? a_cur[1].x : (j == 1 ? a_cur[1].y : (j == 2 ? a_cur[1].z : a_cur[1].w));
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[0][j], acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[0][j], acc[1][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[1][j], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[1][j], acc[1][1], 0, 0, 0);
+                    for (int f = 0; f < kWNF; ++f)
+                        if (f * 4 / kWNF + 4 == gq) copy_store(f, nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a0 = j == 0 ? a_cur[0].x : (j == 1 ? a_cur[0].y : (j == 2 ? a_cur[0].z : a_cur[0].w));
+                    const float a1 = j == 0 ? a_cur[1].x : (j == 1 ? a_cur[1].y : (j == 2 ? a_cur[1].z : a_cur[1].w));
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[0][j], acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[0][j], acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[1][j], acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[1][j], acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // epilogue: out[split][co][ci*64 + tap]
