@@ -3,6 +3,11 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shapegan_amd import ops
 
+def _warm_gpu():
+    a = torch.randn(4096, 4096, device="cuda")
+    for _ in range(200): a = (a @ a) * 1e-4
+    torch.cuda.synchronize()
+_warm_gpu()
 def timeit(fn, iters=30):
     for _ in range(10): fn()
     torch.cuda.synchronize()

@@ -17,6 +17,13 @@
 //   ~70 LDS writes per thread of staging.
 #include "conv_common.h"
 
+#ifndef SG_RING
+#define SG_RING 8
+#endif
+#ifndef SG_ABLATE
+#define SG_ABLATE 0   // tuning experiments only (scripts/ablate.sh): 1 no copy loads, 2 no copy, 4 no weight loads
+#endif
+
 namespace sg {
 
 // Fixed tile: 1 x 8 x 8 output positions (one D slice, 8 rows, 8 columns) -> halo box 4 x 18 x 18 input voxels.
@@ -62,19 +69,20 @@ __global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __re
 
 // Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 4*TM MFMAs each).  The loop body is ONE basic
 // block (no data-dependent branches), so that the compiler's s_waitcnt counts are exact and nothing drains the queues:
-//   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1.  All copy
-//     loads of the stage are issued at its top (vector loads return in order: only the first few weight loads then queue
-//     behind HBM-latency loads), the values are written to LDS one channel per channel of MFMAs.  Out-of-range voxels load
-//     a clamped address and store zero; threads outside the box store to an unused pad slot of the channel; the last
-//     stage re-copies its own channels into the idle buffer — no branch anywhere;
+//   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1: the copy
+//     loads are spread over the first 24 k-groups (all workgroups run in lock-step: a burst at the top of the stage is a
+//     chip-wide traffic jam once per stage, measured -8 %), each value goes to LDS 8 groups after its load.
+//     Out-of-range voxels load a clamped address and store zero; threads outside the box store to an unused pad slot of
+//     the channel; the last stage re-copies its own channels into the idle buffer — no branch anywhere;
 //   * B fragments of group g+1 are read from LDS while the MFMAs of group g run; A fragments (packed weights, L2) sit in
 //     a ring of 8 groups; the weight pointer is wave-uniform (scalar base + lane offset); one barrier per stage.
-template <int TM, int NW>
+template <int TM, int TN, int NW>
 __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     constexpr int kFR = NW * 2;                          // halo rows copied per pass (one per half-wave)
     constexpr int kNF = (kHD * kHH + kFR - 1) / kFR;     // fill elements per thread per channel (72 rows)
-    constexpr int ROWS = (NW / 2) * TM * 32;             // output channels per workgroup
-    constexpr int kRing = 8;
+    constexpr int WN = 2 / TN;                           // waves along the 64 positions (TN = 32-position tiles per wave)
+    constexpr int ROWS = (NW / WN) * TM * 32;            // output channels per workgroup
+    constexpr int kRing = SG_RING;
     extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][kCC][kHD][kHH][2][kHWH]
 
     uint32_t twi, thi, od, n, q1, q2;
@@ -86,15 +94,18 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
-    const int p = wn * 32 + r, pw = p & 7, ph = p >> 3;  // position inside the 8x8 tile
-    const int lanebase = 2 * ph * kROWH + kpar * kHWH + pw;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, kpar = lane >> 5;
+    // position inside the 8x8 tile of column tile tn: p = (wn*TN + tn)*32 + r -> ph = p >> 3, pw = p & 7
+    const int lanebase = 2 * (wn * TN * 4 + (r >> 3)) * kROWH + kpar * kHWH + (r & 7);
+    constexpr int kTNOFF = 2 * 4 * kROWH;  // LDS offset between the two column tiles of a wave (4 tile rows)
 
-    f32x16 acc[TM];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][u][q] = 0.f;
 
     const int G = a.Cin * 8;
     const float4* wrow[TM];  // wave-uniform
@@ -149,60 +160,75 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
         cnext = cnext > a.Cin - kCC ? a.Cin - kCC : cnext;
         const float* xs = xn + (long)cnext * I3;
         const float* hb0 = cur + lanebase;
-        float bq[4] = {hb0[0], hb0[1], hb0[kROWH], hb0[kROWH + 1]};  // B fragments of the first group
+        float bq[TN][4];  // B fragments of the first group
 #pragma unroll
-        for (int c = 0; c < kCC; ++c)
-#pragma unroll
-            for (int f = 0; f < kNF; ++f) fv[c][f] = (xs + (long)c * I3)[goff[f]];
+        for (int u = 0; u < TN; ++u) {
+            bq[u][0] = hb0[u * kTNOFF];
+            bq[u][1] = hb0[u * kTNOFF + 1];
+            bq[u][2] = hb0[u * kTNOFF + kROWH];
+            bq[u][3] = hb0[u * kTNOFF + kROWH + 1];
+        }
         // sched_barrier(0): the machine scheduler otherwise sinks every load to just before its use (to save registers),
         // which turns the ring / the early copy loads into load -> s_waitcnt vmcnt(0) -> use
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ci = 0; ci < kCC; ++ci) {
-            if (ci > 0) {  // the copy loads were issued >= 8 k-groups ago
-#pragma unroll
-                for (int f = 0; f < kNF; ++f) nxt[(ci - 1) * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[ci - 1][f] : 0.f;
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
                 float4 a_cur[TM];
 #pragma unroll
-                for (int t = 0; t < TM; ++t) a_cur[t] = aring[j % kRing][t];
+                for (int t = 0; t < TM; ++t) a_cur[t] = aring[(ci * 8 + j) % kRing][t];
                 int gi = gbase + ci * 8 + j;
                 gi = gi < G ? gi : G - 1;
 #pragma unroll
-                for (int t = 0; t < TM; ++t) aring[j % kRing][t] = (wrow[t] + (long)gi * 64)[lane];
-                const float b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
-                if (!(ci == kCC - 1 && j == 7)) {  // B fragments of the next group of this stage
+                for (int t = 0; t < TM; ++t)
+                    if (!(SG_ABLATE & 4)) aring[(ci * 8 + j) % kRing][t] = (wrow[t] + (long)gi * 64)[lane];
+                {  // copy of the next box: element e is loaded in group e*24/NE and stored 8 groups later
+                    constexpr int NE = kCC * kNF;
+                    const int gidx = ci * 8 + j;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int c = e / kNF, f = e % kNF;
+                        if (e * 24 / NE + 8 == gidx && !(SG_ABLATE & 2))
+                            nxt[c * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[c][f] : 0.f;
+                        if (e * 24 / NE == gidx && !(SG_ABLATE & 3)) fv[c][f] = (xs + (long)c * I3)[goff[f]];
+                    }
+                }
+                float b[TN][4];
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) b[u][k] = bq[u][k];
+                if (!(ci == kCC - 1 && j == 7) && !(SG_ABLATE & 16)) {  // B fragments of the next group of this stage
                     const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
                     const float* hb = cur + lanebase + cin * kHS + (jn >> 1) * kROWD + (2 * (jn & 1)) * kROWH;
-                    bq[0] = hb[0];
-                    bq[1] = hb[1];
-                    bq[2] = hb[kROWH];
-                    bq[3] = hb[kROWH + 1];
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) {
+                        bq[u][0] = hb[u * kTNOFF];
+                        bq[u][1] = hb[u * kTNOFF + 1];
+                        bq[u][2] = hb[u * kTNOFF + kROWH];
+                        bq[u][3] = hb[u * kTNOFF + kROWH + 1];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, b0, acc[t], 0, 0, 0);
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, b1, acc[t], 0, 0, 0);
+                    for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, b2, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, b3, acc[t], 0, 0, 0);
+                        for (int u = 0; u < TN; ++u) {
+                            const float av = k == 0 ? a_cur[t].x : (k == 1 ? a_cur[t].y : (k == 2 ? a_cur[t].z : a_cur[t].w));
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][k], acc[t][u], 0, 0, 0);
+                        }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#pragma unroll
-        for (int f = 0; f < kNF; ++f) nxt[(kCC - 1) * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[kCC - 1][f] : 0.f;
         gbase += 8 * kCC;
         __syncthreads();  // next box complete and visible; everyone is done reading the current one
     }
 
     // epilogue: y[n][co][od][oh0+ph][ow0+pw] = act(acc + bias[co]); all bias loads are issued before the first use
     const long O3 = (long)a.g.OD * a.g.OH * a.g.OW;
-    float* yo = a.y + (long)n * a.Cout * O3 + ((long)od * a.g.OH + (oh0 + ph)) * a.g.OW + (ow0 + pw);
     float bv[TM][16];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
@@ -212,11 +238,16 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
             bv[t][q] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
         }
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
+    for (int u = 0; u < TN; ++u) {
+        const int ph = (wn * TN + u) * 4 + (r >> 3), pw = r & 7;
+        float* yo = a.y + (long)n * a.Cout * O3 + ((long)od * a.g.OH + (oh0 + ph)) * a.g.OW + (ow0 + pw);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-            if (co < a.Cout) yo[(long)co * O3] = sg_apply_act(acc[t][q] + bv[t][q], a.act, a.slope);
+        for (int t = 0; t < TM; ++t) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+                if (co < a.Cout) yo[(long)co * O3] = sg_apply_act(acc[t][u][q] + bv[t][q], a.act, a.slope);
+            }
         }
     }
 }
@@ -242,8 +273,11 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     // below that the split-K gather kernel is faster
     if (!force && tiles * mtiles < 384) return 0;
     if (tiles >= (1L << 31)) return 0;
-    if (variant == 0) variant = (tiles * mtiles < 1024) ? 1 : 2;   // 0 = auto, 1 = 4 waves, 2 = 8 waves
-    const size_t lds = (size_t)2 * kCC * kHS * sizeof(float);
+    if (variant == 0) variant = 1;   // 1 = 4 waves x (32 rows x 64 positions), 2 = 8 waves x (32 x 32): A/B only
+    size_t lds = (size_t)2 * kCC * kHS * sizeof(float);
+    // Registers and LDS would admit 3 workgroups per CU; with fewer than ~4 rounds of workgroups that leaves a mostly
+    // idle last round (1024 workgroups: 768 + 256), so ask for enough LDS to cap the CU at 2 (debug bit 6: don't)
+    if (tiles * mtiles < 256 * 3 * 4 && !(debug & 64) && lds < 56 * 1024) lds = 56 * 1024;
 
     float4* wp = (float4*)workspace;
     {
@@ -270,11 +304,11 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.slope = slope;
     dim3 grid((unsigned)tiles, mtiles);
     if (rows == 128 && variant == 2)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8>), grid, dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 1, 8>), grid, dim3(512), lds, stream, a);
     else if (rows == 128)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 2, 4>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 1, 4>), grid, dim3(256), lds, stream, a);
     return 1;
 }
 
@@ -408,8 +442,8 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     for (int f = 0; f < kDNF; ++f) box[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
     __syncthreads();
 
-    // The stage loop body is one basic block (no data-dependent branch): copy loads of the next box at the top, their LDS
-    // stores in the second half of the stage, packed weights in a ring of 8 groups; sched_barriers keep the machine
+    // The stage loop body is one basic block (no data-dependent branch): copy loads of the next box spread over the first
+    // half of the stage, their LDS stores over the second half, packed weights in a ring of 8 groups; sched_barriers keep the machine
     // scheduler from sinking the loads to their uses (see conv_fwd_halo_kernel).
     constexpr int O00 = BX::PL + BX::BW, O01 = BX::PL, O10 = BX::BW, O11 = 0;  // (td,th) -> box offset
     const int nstage = a.Cout / kDCC;
@@ -429,8 +463,6 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             bq[tn][2] = hb0[tn * BX::TNOFF + O10];   // j=2: td=1, th=0
             bq[tn][3] = hb0[tn * BX::TNOFF + O11];   // j=3: td=1, th=1
         }
-#pragma unroll
-        for (int f = 0; f < kDNF; ++f) fv[f] = dys[goff[f]];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < kDCC; ++c) {  // one k-group per channel
@@ -453,7 +485,10 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                     bq[tn][3] = hb[tn * BX::TNOFF + O11];
                 }
             }
-            if (c >= kDCC / 2) {  // two of the 16 copied values per group
+            if (c < kDCC / 2) {  // copy of the next box: two loads per group in the first half of the stage ...
+#pragma unroll
+                for (int f = 2 * c; f < 2 * c + 2; ++f) fv[f] = dys[goff[f]];
+            } else {             // ... each value goes to LDS 8 groups after its load
 #pragma unroll
                 for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f)
                     nxt[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
@@ -651,14 +686,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     }
     float fv[kWNF];
     unsigned okmask = 0;
-    auto copy_issue = [&](int sl) {  // geometry of slice sl -> the kWNF loads of its box
+    unsigned goff[kWNF];
+    const float* xb = a.x;
+    auto copy_prepare = [&](int sl) {  // geometry of slice sl -> offsets / validity of the kWNF elements of its box
         uint32_t twi, thi, od, n, q1, q2;
         a.dntw.divmod((uint32_t)sl, q1, twi);
         a.dnth.divmod(q1, q2, thi);
         a.dOD.divmod(q2, n, od);
         const int iw = 2 * (int)twi * 8 - 1 + fl_w;
         const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
-        const float* xb = a.x + (long)n * a.g.Cx * I3;  // uniform
+        xb = a.x + (long)n * a.g.Cx * I3;  // uniform
         okmask = 0;
 #pragma unroll
         for (int f = 0; f < kWNF; ++f) {
@@ -666,9 +703,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
             const int id = 2 * (int)od - 1 + hdv[fr], ih = 2 * (int)thi * 8 - 1 + hhv[fr];
             const bool ok = wok && ((inmask >> fr) & 1u) && (ci0 + c) < a.Cin && (unsigned)id < (unsigned)a.g.ID &&
                             (unsigned)ih < (unsigned)a.g.IH;
-            const unsigned off = ok ? (unsigned)((ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw) : 0u;
+            goff[f] = ok ? (unsigned)((ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw) : 0u;
             okmask |= ok ? (1u << f) : 0u;
-            fv[f] = xb[off];
         }
     };
     auto copy_store = [&](int f, float* buf) {
@@ -683,7 +719,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     for (int t = 0; t < 2; ++t) arow[t] = a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64;
     const int G = nst * 8;
     if (nst > 0) {
-        copy_issue(s_beg);
+        copy_prepare(s_beg);
+#pragma unroll
+        for (int f = 0; f < kWNF; ++f) fv[f] = xb[goff[f]];
         float4 aring[kRing][2];
 #pragma unroll
         for (int u = 0; u < kRing; ++u)
@@ -706,7 +744,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 bq[tn][2] = hb[4];
                 bq[tn][3] = hb[6];
             }
-            copy_issue(s_beg + snext);
+            copy_prepare(s_beg + snext);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int gq = 0; gq < 8; ++gq) {   // k-group gq = output row ph of the 8x8 tile; j = column pair
@@ -732,10 +770,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                         bq[tn][3] = hb[6];
                     }
                 }
-                if (gq >= 4) {  // the 18 copied values go to LDS in the second half of the stage
+                // copy of the next box: loads spread over groups 0..3, LDS stores 4 groups later
 #pragma unroll
-                    for (int f = 0; f < kWNF; ++f)
-                        if (f * 4 / kWNF + 4 == gq) copy_store(f, nxt);
+                for (int f = 0; f < kWNF; ++f) {
+                    if (f * 4 / kWNF == gq) fv[f] = xb[goff[f]];
+                    if (f * 4 / kWNF + 4 == gq) copy_store(f, nxt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshapegan_hip.so")
+LIB_PATH = os.environ.get("SHAPEGAN_HIP_LIB") or os.path.join(_HERE, "libshapegan_hip.so")  # override: A/B builds
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
