@@ -380,5 +380,56 @@ class HybridProgressiveGANOracle(object):
         return loss.detach(), gp.detach()
 
 
+class ClassicGANOracle(object):
+    """train_gan.py:28-31,57-88 (SURVEY.md 8f rank 2): Adam 1e-3 generator, Adam 1e-5 discriminator with sigmoid + BCE;
+    per batch: one generator update, one discriminator update on fakes, one on reals."""
+
+    def __init__(self, g_state, d_state, g_lr=0.001, d_lr=0.00001):
+        self.G, self.D = clone_state(g_state), clone_state(d_state)
+        self.g_opt = torch.optim.Adam(params_of(self.G), lr=g_lr)
+        self.d_opt = torch.optim.Adam(params_of(self.D), lr=d_lr)
+
+    def generate(self, z):
+        return generator_forward(self.G, z, True)
+
+    def generator_step(self, z):
+        self.g_opt.zero_grad()
+        out = discriminator_forward(self.D, self.generate(z), True)
+        loss = -torch.mean(torch.log(out))
+        loss.backward()
+        self.g_opt.step()
+        return loss.detach()
+
+    def discriminator_fake_step(self, z):
+        self.d_opt.zero_grad()
+        out = discriminator_forward(self.D, self.generate(z).detach(), True)
+        loss = F.binary_cross_entropy(out, torch.zeros_like(out))
+        loss.backward()
+        self.d_opt.step()
+        return loss.detach(), out.detach()
+
+    def discriminator_real_step(self, real):
+        self.d_opt.zero_grad()
+        out = discriminator_forward(self.D, real, True)
+        loss = F.binary_cross_entropy(out, torch.ones_like(out))
+        loss.backward()
+        self.d_opt.step()
+        return loss.detach(), out.detach()
+
+
+class HybridGANOracle(ClassicGANOracle):
+    """train_hybrid_gan.py:43-46,64-67,77-125: the same cadence with an SDFNet generator sampled on the voxel grid.
+    (The reference keeps the generator graph in the fake-discriminator update and discards its gradients.)"""
+
+    def __init__(self, g_state, d_state, grid_points, resolution=32, g_lr=0.001, d_lr=0.00001):
+        ClassicGANOracle.__init__(self, g_state, d_state, g_lr, d_lr)
+        self.res, self.grid = resolution, grid_points
+
+    def generate(self, z):
+        pts = self.grid.repeat((z.shape[0], 1))
+        out = sdfnet_forward(self.G, pts, tile_latents(z, self.res ** 3))
+        return out.reshape(-1, self.res, self.res, self.res)
+
+
 def snapshot(P):
     return copy.deepcopy({k: v.detach().clone() for k, v in P.items()})

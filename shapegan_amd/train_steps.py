@@ -222,8 +222,7 @@ class HybridWGANTrainer(object):
         self.c_opt.zero_grad()
         with torch.no_grad():
             fake = self.generate(z)
-        # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
-        # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.
+        # one critic pass over the concatenated fake+real batch (train_hybrid_wgan.py:87-89), as in WGANTrainer
         n_fake = fake.shape[0]
         out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
         out_fake, out_real = out[:n_fake], out[n_fake:]
@@ -308,3 +307,75 @@ class HybridProgressiveGANTrainer(object):
         self.d_bucket.finish()
         self.d_opt.step()
         return loss.detach(), gp.detach()
+
+
+class ClassicGANTrainer(object):
+    """train_gan.py: gan.Generator (Adam 1e-3) against gan.Discriminator with its sigmoid
+    (Adam 1e-5, binary cross-entropy), batch 64; per batch one generator update (:57-67), one discriminator update on
+    fakes (:75-80) and one on reals (:82-86).  The BCE / log compositions act on [B] vectors (torch glue)."""
+
+    def __init__(self, generator, discriminator, g_lr=0.001, d_lr=0.00001):
+        self.generator, self.discriminator = generator, discriminator
+        discriminator.use_sigmoid = True
+        self.g_opt = optim.Adam(generator.parameters(), lr=g_lr)          # :28
+        self.d_opt = optim.Adam(discriminator.parameters(), lr=d_lr)      # :31
+        self.g_bucket, self.d_bucket = GradBucket(self.g_opt), GradBucket(self.d_opt)
+
+    def generate(self, z):
+        return self.generator(z)
+
+    def generator_step(self, z):
+        """:57-67 (the discriminator gradients the reference accumulates here are zeroed at :75; not computed)."""
+        self.g_opt.zero_grad()
+        fake = self.generate(z)
+        with frozen(self.discriminator):
+            out = self.discriminator(fake)
+        loss = -torch.mean(torch.log(out))
+        self.g_bucket.arm()
+        loss.backward()
+        self.g_bucket.finish()
+        self.g_opt.step()
+        return loss.detach()
+
+    def _discriminator_update(self, sample, target_value):
+        self.d_opt.zero_grad()
+        out = self.discriminator(sample)
+        loss = torch.nn.functional.binary_cross_entropy(out, torch.full_like(out, target_value))
+        self.d_bucket.arm()
+        loss.backward()
+        self.d_bucket.finish()
+        self.d_opt.step()
+        return loss.detach(), out.detach()
+
+    def discriminator_fake_step(self, z):
+        """:75-80."""
+        with torch.no_grad():
+            fake = self.generate(z)
+        return self._discriminator_update(fake, 0.0)
+
+    def discriminator_real_step(self, real):
+        """:82-86."""
+        return self._discriminator_update(real, 1.0)
+
+    def step(self, real, z_gen, z_disc):
+        self.generator_step(z_gen)
+        fake = self.discriminator_fake_step(z_disc)
+        return fake, self.discriminator_real_step(real)
+
+
+class HybridGANTrainer(ClassicGANTrainer):
+    """train_hybrid_gan.py: the same cadence with an SDFNet generator sampled on the 32^3 grid, batch 8 (:55).  The
+    reference keeps the generator graph in the fake-discriminator update (:103-108) and discards its gradients; they
+    are not computed here.  Per-shape latents replace sample_latent_codes' [B*R^3, L] tiling (:64-67)."""
+
+    def __init__(self, generator, discriminator, grid_points, resolution=32, g_lr=0.001, d_lr=0.00001):
+        ClassicGANTrainer.__init__(self, generator, discriminator, g_lr, d_lr)
+        self.res, self.grid = resolution, grid_points
+        self._tiled = {}
+
+    def generate(self, z):
+        count = z.shape[0]
+        if count not in self._tiled:
+            self._tiled[count] = self.grid.repeat((count, 1))
+        sdf = self.generator.forward_shapes(self._tiled[count], z, self.res ** 3)
+        return sdf.reshape(-1, self.res, self.res, self.res)

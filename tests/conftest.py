@@ -52,6 +52,11 @@ def golden_steps():
 
 
 @pytest.fixture(scope="session")
+def golden_steps_f2():
+    return Golden("steps_f2.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_sdf():
     return Golden("sdfnet_examples.npz")
 

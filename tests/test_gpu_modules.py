@@ -333,6 +333,86 @@ def test_hybrid_progressive_trajectory(golden_steps):
     _check_updates(g, g0, o32.G, o64.G, "progressive G", golden_steps, "prog/g_final")
 
 
+def test_classic_gan_trajectory(golden_steps_f2):
+    """SURVEY.md 8f rank 2, train_gan.py: generator update (-mean log D(G(z))), discriminator updates on fakes and on
+    reals (sigmoid + binary cross-entropy), Adam 1e-3 / 1e-5."""
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import ClassicGANTrainer
+    gd = golden_steps_f2
+    torch.manual_seed(61)
+    g, d = Generator(), Discriminator()
+    g0, d0 = _cpu_state(g), _cpu_state(d)
+    o32 = O.ClassicGANOracle(g0, d0)
+    o64 = O.ClassicGANOracle(_cpu_state(g, torch.float64), _cpu_state(d, torch.float64))
+    tr = ClassicGANTrainer(g, d)
+    real, zg, zd = (gd.t("gan/" + k) for k in ("real", "zg", "zd"))
+    gl = tr.generator_step(zg.cuda()).item()
+    (fl, of), (vl, ov) = tr.discriminator_fake_step(zd.cuda()), tr.discriminator_real_step(real.cuda())
+    for o, dt in ((o32, torch.float32), (o64, torch.float64)):
+        o.generator_step(zg.to(dt))
+        o.discriminator_fake_step(zd.to(dt))
+        o.discriminator_real_step(real.to(dt))
+    np.testing.assert_allclose([gl, fl.item(), vl.item()], gd["gan/losses"], rtol=2e-4, atol=1e-6)
+    close(of, gd.t("gan/out_fake"), rtol=1e-3, what="D(fake) vs reference fixture")
+    close(ov, gd.t("gan/out_real"), rtol=1e-3, what="D(real) vs reference fixture")
+    _check_updates(d, d0, o32.D, o64.D, "gan D", gd, "gan/d_final")
+    _check_updates(g, g0, o32.G, o64.G, "gan G", gd, "gan/g_final", max_frac=2e-2, outlier_cap=1.0, anchor_rtol=5e-2)
+
+
+def test_hybrid_gan_trajectory(golden_steps_f2):
+    """train_hybrid_gan.py: the same cadence with the SDFNet generator on the 32^3 grid."""
+    from shapegan_amd.model.gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import HybridGANTrainer
+    from shapegan_amd.util import get_voxel_coordinates
+    gd = golden_steps_f2
+    torch.manual_seed(62)
+    g, d = SDFNet(), Discriminator()
+    g0, d0 = _cpu_state(g), _cpu_state(d)
+    grid = torch.tensor(get_voxel_coordinates(32))
+    o32 = O.HybridGANOracle(g0, d0, grid)
+    o64 = O.HybridGANOracle(_cpu_state(g, torch.float64), _cpu_state(d, torch.float64), grid.double())
+    tr = HybridGANTrainer(g, d, grid.cuda())
+    real, zg, zd = (gd.t("hgan/" + k) for k in ("real", "zg", "zd"))
+    losses = [tr.generator_step(zg.cuda()).item(), tr.discriminator_fake_step(zd.cuda())[0].item(),
+              tr.discriminator_real_step(real.cuda())[0].item()]
+    for o, dt in ((o32, torch.float32), (o64, torch.float64)):
+        o.generator_step(zg.to(dt))
+        o.discriminator_fake_step(zd.to(dt))
+        o.discriminator_real_step(real.to(dt))
+    np.testing.assert_allclose(losses, gd["hgan/losses"], rtol=2e-4, atol=1e-6)
+    _check_updates(d, d0, o32.D, o64.D, "hybrid gan D", gd, "hgan/d_final")
+    _check_updates(g, g0, o32.G, o64.G, "hybrid gan G", gd, "hgan/g_final")
+
+
+def test_vae_trajectory(golden_steps_f2, monkeypatch):
+    """VAE branch of train_autoencoder.py (BN1d, two heads, reparameterisation, KLD), batch 4, two Adam steps; eps is
+    the reference's own draw (recorded in the fixture)."""
+    from shapegan_amd.model import autoencoder as ae_mod
+    from shapegan_amd.train_steps import AutoencoderTrainer
+    gd = golden_steps_f2
+    torch.manual_seed(63)
+    ae = ae_mod.Autoencoder(is_variational=True)
+    a0 = _cpu_state(ae)
+    o32, o64 = O.AutoencoderOracle(a0, True), O.AutoencoderOracle(_cpu_state(ae, torch.float64), True)
+    queue = [gd.t("vae/eps%d" % i) for i in range(2)]
+
+    class RecordedNormal(object):
+        def sample(self, shape):
+            return queue.pop(0)
+    monkeypatch.setattr(ae_mod, "standard_normal_distribution", RecordedNormal())
+    tr = AutoencoderTrainer(ae)
+    recs, r64 = [], []
+    for i in range(2):
+        b, eps = gd.t("vae/batch%d" % i), gd.t("vae/eps%d" % i)
+        recs.append(tr.step(b.cuda())[0].item())
+        o32.step(b, eps)
+        r64.append(o64.step(b.double(), eps.double())[0].item())
+    np.testing.assert_allclose(recs, gd["vae/losses"][0::2], rtol=1e-3)
+    np.testing.assert_allclose(recs, r64, rtol=1e-3)
+    _check_updates(ae, a0, o32.P, o64.P, "vae", gd, "vae/final", anchor_rtol=5e-2, max_frac=2e-2, outlier_cap=1.0)
+
+
 def test_dp_shards_sum_to_full_batch_gradient():
     """Distributed math on one GPU: averaged shard gradients == full-batch gradient for the BN-free
     critic, i.e. what one RCCL all-reduce of the flat buffers + grad_scale 1/G produces."""
