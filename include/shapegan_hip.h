@@ -149,6 +149,12 @@ int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, lo
                  float eps, long step, float grad_scale, hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
 
+/* ---- input pipeline -------------------------------------------------------------------------
+ * reference: VoxelDataset.__getitem__ (datasets.py:16-23): result.clamp_(-clamp, clamp); result /= clamp when
+ * rescale_sdf.  out = clamp(x, -clamp, clamp) / divisor on the device (divisor <= 0: no division); x == out allowed.
+ * Bit-exact with the reference's CPU arithmetic (NaN-propagating clamp, IEEE fp32 division). */
+int sg_voxel_prepare(const float* x, float* out, long n, float clamp, float divisor, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,47 @@ def main():
     st["vae/losses"] = np.array(losses)
     put(st, "vae/final", {k: summarize(v.float()) for k, v in A.state_dict().items()})
 
+    # ---- input pipeline: the reference's VoxelDataset on real files, and its create_batches
+    # generator executed from the reference's own source text (the script cannot be imported: it trains at import) ----
+    import ast
+    import tempfile
+    from shapegan_amd import datasets as native
+    sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    import datasets as ref_datasets
+    rng = np.random.RandomState(64)
+    raw = (rng.rand(5, 8, 8, 8).astype(np.float32) * 0.4 - 0.2)
+    raw[0, 0, 0, :6] = [np.nan, np.inf, -np.inf, 0.1, -0.1, np.float32(0.1) + np.float32(1e-8)]
+    with tempfile.TemporaryDirectory() as tmp:
+        names = []
+        for i in range(5):
+            names.append(os.path.join(tmp, "%c.npy" % "cadbe"[i]))
+            np.save(names[-1], raw[i])
+        for kw in (dict(), dict(rescale_sdf=False), dict(clamp=None)):
+            theirs, ours = ref_datasets.VoxelDataset(names, **kw), native.VoxelDataset(names, **kw)
+            for i in range(5):
+                assert np.array_equal(theirs[i].numpy(), ours[i].numpy(), equal_nan=True)
+        assert ref_datasets.VoxelDataset.glob(tmp + "/**.npy").files == native.VoxelDataset.glob(tmp + "/**.npy").files
+        st["vox/raw"] = raw
+        st["vox/rescaled"] = torch.stack([ref_datasets.VoxelDataset(names)[i] for i in range(5)]).numpy()
+        ds = ref_datasets.VoxelDataset(names)
+        ds.rescale_sdf = False
+        st["vox/clamped"] = torch.stack([ds[i] for i in range(5)]).numpy()
+    src = open(os.path.join(ref_import.REFERENCE_ROOT, "train_sdf_autodecoder.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "create_batches"][0]
+    code = compile(ast.Module(body=[fn], type_ignores=[]), "train_sdf_autodecoder.py", "exec")
+    for case, (count, batch) in enumerate(((1000, 64), (777, 50), (4096, 512))):
+        signs = np.random.RandomState(70 + case).rand(count) > (0.5, 0.3, 0.8)[case]
+        env = {"np": np, "signs": signs, "BATCH_SIZE": batch}
+        exec(code, env)
+        np.random.seed(700 + case)
+        theirs = [b.copy() for b in env["create_batches"]()]
+        np.random.seed(700 + case)
+        ours = list(native.create_batches(signs, batch))
+        assert len(theirs) == len(ours) and all(np.array_equal(a, b) for a, b in zip(theirs, ours))
+        st["batches/%d/signs" % case] = signs
+        st["batches/%d/flat" % case] = np.concatenate(theirs)
+        st["batches/%d/sizes" % case] = np.array([len(b) for b in theirs])
+
     np.savez_compressed(os.path.join(OUT, "steps_f2.npz"), **st)
     print("wrote steps_f2.npz with %d arrays" % len(st))
 

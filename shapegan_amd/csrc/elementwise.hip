@@ -98,6 +98,17 @@ __global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, long 
         p[e] = fminf(fmaxf(p[e], lo), hi);
 }
 
+// out = clamp(x, -c, c) [/ divisor]: VoxelDataset.__getitem__'s clamp_ and /= (datasets.py:19-22), NaN-propagating like
+// torch.clamp, true IEEE division like torch's `/= 0.1` (a reciprocal multiply differs in the last bit)
+__global__ void __launch_bounds__(256) voxel_prepare_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+                                                            float c, float divisor) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        float v = x[e];
+        v = v < -c ? -c : (v > c ? c : v);
+        out[e] = divisor > 0.f ? v / divisor : v;
+    }
+}
+
 // out = a*x + b*y   (y may be null)
 __global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                     float* __restrict__ out, long n, float a, float b) {
@@ -184,6 +195,12 @@ int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, lo
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream) {
     SG_CHECK_ARG(p && n > 0);
     hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, n, lo, hi);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_voxel_prepare(const float* x, float* out, long n, float clamp, float divisor, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && n > 0 && clamp >= 0.f);
+    hipLaunchKernelGGL(voxel_prepare_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, x, out, n, clamp, divisor);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

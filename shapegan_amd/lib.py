@@ -56,6 +56,7 @@ SIGNATURES = {
     "sg_rmsprop_step": (c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "sg_adam_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P]),
     "sg_clamp": (c_int, [_P, _L, _F, _F, _P]),
+    "sg_voxel_prepare": (c_int, [_P, _P, _L, _F, _F, _P]),
 }
 
 _lib = None

@@ -674,3 +674,12 @@ class GatherRows(Function):
 
 def gather_rows(table, idx):
     return GatherRows.apply(table, idx)
+
+
+def voxel_prepare(x, clamp, divisor, out=None):
+    """out = clamp(x, -clamp, clamp) / divisor on the device (VoxelDataset.__getitem__, datasets.py:19-22); divisor <= 0
+    skips the division.  In place when out is None."""
+    x = f32c(x)
+    out = x if out is None else out
+    check(_lib().sg_voxel_prepare(ptr(x), ptr(out), x.numel(), float(clamp), float(divisor), stream()), "voxel_prepare")
+    return out

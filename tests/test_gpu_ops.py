@@ -442,3 +442,47 @@ def test_conv_wgrad_halo_kernel(N, Ci, Co, O):
     F.conv3d(x, w, None, stride=2, padding=1).backward(dy)
     got = ops.conv_wgrad_halo_raw(dev(dy), dev(x), Ci)
     close(got, w.grad, what="wgrad halo vs oracle")
+
+
+# ---- input pipeline ---------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_voxel_prepare_bit_exact(golden_steps_f2):
+    """sg_voxel_prepare == the reference's CPU clamp_ + /= (datasets.py:19-22) bit for bit, NaN / inf included."""
+    from shapegan_amd import ops
+    g = golden_steps_f2
+    raw = torch.from_numpy(g["vox/raw"]).cuda()
+    got = ops.voxel_prepare(raw.clone(), 0.1, 0.1).cpu().numpy()
+    assert np.array_equal(got, g["vox/rescaled"], equal_nan=True)
+    got = ops.voxel_prepare(raw.clone(), 0.1, 0.0).cpu().numpy()
+    assert np.array_equal(got, g["vox/clamped"], equal_nan=True)
+    # full-size property: a 64^3 batch against torch's own CPU arithmetic
+    torch.manual_seed(0)
+    big = torch.rand(16, 64, 64, 64) * 0.5 - 0.25
+    want = big.clone().clamp_(-0.1, 0.1)
+    want /= 0.1
+    out = torch.empty_like(big, device="cuda")
+    ops.voxel_prepare(big.cuda(), 0.1, 0.1, out=out)
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["resident", "stream"])
+def test_voxel_batches_equal_dataloader(tmp_path, mode):
+    """Resident (HBM gather) and streaming (pinned double buffer) batch paths deliver exactly the batches
+    DataLoader(reference-style VoxelDataset, shuffle=True) delivers under the same seed: order, ragged last batch,
+    values bit for bit."""
+    from shapegan_amd.datasets import VoxelDataset
+    rng = np.random.RandomState(3)
+    for i in range(21):
+        np.save(str(tmp_path / ("m%02d.npy" % i)), (rng.rand(8, 8, 8).astype(np.float32) * 0.6 - 0.3))
+    ds = VoxelDataset.glob(str(tmp_path) + "/**.npy")
+    torch.manual_seed(77)
+    want = [b for b in torch.utils.data.DataLoader(ds, shuffle=True, batch_size=4)]
+    torch.manual_seed(77)
+    got = list(ds.resident().batches(4)) if mode == "resident" else list(ds.stream(4))
+    assert [tuple(b.shape) for b in got] == [tuple(b.shape) for b in want] and got[-1].shape[0] == 1
+    for a, b in zip(got, want):
+        assert a.is_cuda and torch.equal(a.cpu(), b)
+    torch.manual_seed(78)
+    dropped = list(ds.resident().batches(4, drop_last=True))
+    assert len(dropped) == 5 and all(b.shape[0] == 4 for b in dropped)

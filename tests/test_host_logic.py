@@ -150,3 +150,75 @@ def test_flat_optimizer_views_on_cpu():
     assert not f.coherent()
     f.zero_grad()  # ... and the optimizer re-attaches them
     assert f.coherent() and float(f.grad.abs().sum()) == 0.0
+
+
+# ---- input pipeline: host-side index work is bit-exact ---------------------------------------
+class _Ints(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return i
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_loader_index_order_matches_torch_dataloader(workers):
+    """ResidentVoxels / VoxelStream visit items in the order DataLoader(shuffle=True) would under the same global seed,
+    and leave the global RNG in the same state."""
+    from shapegan_amd.datasets import loader_index_order
+    for n, seed in ((37, 0), (1000, 123)):
+        torch.manual_seed(seed)
+        want = torch.cat([b for b in torch.utils.data.DataLoader(_Ints(n), shuffle=True, batch_size=8, num_workers=workers)])
+        after_ref = torch.rand(1)
+        torch.manual_seed(seed)
+        got = loader_index_order(n, True)
+        after = torch.rand(1)
+        assert torch.equal(got, want) and torch.equal(after, after_ref)
+    assert torch.equal(loader_index_order(5, False), torch.arange(5))
+    torch.manual_seed(9)
+    list(torch.utils.data.DataLoader(_Ints(5), shuffle=False, batch_size=2))
+    after_ref = torch.rand(1)
+    torch.manual_seed(9)
+    loader_index_order(5, False)
+    assert torch.equal(torch.rand(1), after_ref)
+
+
+def test_create_batches_matches_reference_fixture(golden_steps_f2):
+    """train_sdf_autodecoder.py:55-69, fixture produced by executing the reference's own function source."""
+    from shapegan_amd.datasets import create_batches
+    g = golden_steps_f2
+    for case, batch in enumerate((64, 50, 512)):
+        signs = g["batches/%d/signs" % case]
+        np.random.seed(700 + case)
+        got = list(create_batches(signs, batch))
+        assert [len(b) for b in got] == list(g["batches/%d/sizes" % case])
+        flat = np.concatenate(got)
+        assert np.array_equal(flat, g["batches/%d/flat" % case])
+        assert abs(int(signs[flat].sum()) * 2 - flat.size) == 0          # balanced signs
+
+
+def test_voxel_dataset_items_match_reference_fixture(golden_steps_f2, tmp_path):
+    """datasets.py:16-23 on real .npy files: clamp, optional rescale, NaN / inf / boundary values; glob is sorted."""
+    from shapegan_amd.datasets import VoxelDataset
+    g = golden_steps_f2
+    raw = g["vox/raw"]
+    for i, c in enumerate("cadbe"):
+        np.save(str(tmp_path / ("%s.npy" % c)), raw[i])
+    ordered = [str(tmp_path / ("%s.npy" % c)) for c in "cadbe"]
+    ds = VoxelDataset(ordered)
+    assert len(ds) == 5
+    for i in range(5):
+        assert np.array_equal(ds[i].numpy(), g["vox/rescaled"][i], equal_nan=True)
+    ds.rescale_sdf = False
+    for i in range(5):
+        assert np.array_equal(ds[i].numpy(), g["vox/clamped"][i], equal_nan=True)
+    assert np.array_equal(VoxelDataset(ordered, clamp=None)[1].numpy(), raw[1], equal_nan=True)
+    assert [os.path.basename(f) for f in VoxelDataset.glob(str(tmp_path) + "/**.npy").files] == ["a.npy", "b.npy", "c.npy", "d.npy", "e.npy"]
+    with pytest.raises(Exception):
+        VoxelDataset.glob(str(tmp_path) + "/nothing/**.npy")
+    split = tmp_path / "train.txt"
+    split.write_text("a\nmissing\nd\n")
+    assert [os.path.basename(f) for f in VoxelDataset.from_split(str(tmp_path) + "/{:s}.npy", str(split)).files] == ["a.npy", "d.npy"]
