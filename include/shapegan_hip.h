@@ -155,6 +155,32 @@ int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
  * Bit-exact with the reference's CPU arithmetic (NaN-propagating clamp, IEEE fp32 division). */
 int sg_voxel_prepare(const float* x, float* out, long n, float clamp, float divisor, hipStream_t stream);
 
+/* ---- PointNet-discriminator GAN family --------------------------------------------------------
+ * reference: model/point_sdf_net.py.  SDFGenerator (:49-119): x = lin(x) [+ z_lin(z) per shape]; LayerNorm; ReLU —
+ *   y[r] = act(gamma * normalise(x[r] + rowbias[r / rows_per_shape]) + beta), act in {none, relu}; rows may be strided
+ *   (ld*), so the skip concat `cat([x, pos])` (:100) is a 259-float row whose first 256 columns LayerNorm writes.
+ *   The backward returns dz (gradient of the pre-norm row, also of the per-shape bias rows) and dgamma / dbeta.
+ * PointNet (:11-47): `x.max(dim=-2)[0]` over the points of a shape: x [B,P,C] -> out [B,C] + argmax (first
+ *   occurrence); scatter = its adjoint (backward), gather = the adjoint of the scatter (double backward under the
+ *   gradient penalty, train_point_gan.py:61-70).
+ * sg_colsum_tall: out[b][c] = sum_r x[b*batch_stride + r*ld + c]: column sums of `batch` tall [rows, cols] matrices in
+ *   two deterministic passes (bias gradients of per-point Linear layers: rows = points; per-shape sums for the
+ *   z-injection gradient: batch = shapes). */
+int sg_layernorm_fwd(const float* x, long ldx, const float* rowbias, long rows_per_shape, const float* gamma,
+                     const float* beta, float* y, long ldy, float* mean, float* rstd, long R, int C, float eps, int act,
+                     hipStream_t stream);
+size_t sg_layernorm_bwd_workspace_bytes(long R, int C);
+int sg_layernorm_bwd(const float* x, long ldx, const float* rowbias, long rows_per_shape, const float* gamma, const float* y,
+                     long ldy, const float* dy, long lddy, const float* mean, const float* rstd, float* dz, long lddz,
+                     float* dgamma, float* dbeta, long R, int C, int act, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream);
+size_t sg_colsum_tall_workspace_bytes(long batch, long rows, int cols);
+int sg_colsum_tall(const float* x, float* out, long batch, long batch_stride, long rows, int cols, long ld, void* workspace,
+                   size_t workspace_bytes, hipStream_t stream);
+int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, hipStream_t stream);
+int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P, int C, hipStream_t stream);
+int sg_segmax_gather(const float* x, const int* idx, float* out, long B, long P, int C, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,5 +431,79 @@ class HybridGANOracle(ClassicGANOracle):
         return out.reshape(-1, self.res, self.res, self.res)
 
 
+# ---- PointNet-discriminator GAN family (model/point_sdf_net.py) -----------------------------------------------------
+def pointnet_forward(P, pos, dist):
+    """PointNet.forward, point_sdf_net.py:33-47 (dense path, batch=None)."""
+    dist = dist.unsqueeze(-1) if dist.size(-1) != 1 else dist
+    x = torch.cat([pos, dist], dim=-1)
+    for i in (0, 2, 4, 6):
+        x = F.linear(x, P["nn1.%d.weight" % i], P["nn1.%d.bias" % i])
+        if i < 6:
+            x = F.relu(x)
+    x = x.max(dim=-2)[0]
+    for i in (0, 2, 4):
+        x = F.linear(x, P["nn2.%d.weight" % i], P["nn2.%d.bias" % i])
+        if i < 4:
+            x = F.relu(x)
+    return x
+
+
+def sdf_generator_forward(P, pos, z, num_layers=8):
+    """SDFGenerator.forward, point_sdf_net.py:83-119 (norm=True, dropout 0)."""
+    x = pos
+    for i in range(num_layers):
+        if i == num_layers // 2:
+            x = torch.cat([x, pos], dim=-1)
+        x = F.linear(x, P["lins.%d.weight" % i], P["lins.%d.bias" % i])
+        if i == 0:
+            x = F.linear(z, P["z_lin1.weight"], P["z_lin1.bias"]).unsqueeze(1) + x
+        if i == num_layers // 2:
+            x = F.linear(z, P["z_lin2.weight"], P["z_lin2.bias"]).unsqueeze(1) + x
+        if i < num_layers - 1:
+            w = P["norms.%d.weight" % i]
+            x = F.relu(F.layer_norm(x, (w.shape[0],), w, P["norms.%d.bias" % i], 1e-5))
+    return x
+
+
+class PointGANOracle(object):
+    """train_point_gan.py:15-26,52-83."""
+
+    def __init__(self, g_state, d_state, lr=0.0001, gp_weight=10.0):
+        self.G, self.D = clone_state(g_state), clone_state(d_state)
+        self.g_opt = torch.optim.RMSprop(params_of(self.G), lr=lr)
+        self.d_opt = torch.optim.RMSprop(params_of(self.D), lr=lr)
+        self.gp_weight = gp_weight
+
+    def gradient_penalty(self, pos, dist, fake, alpha):
+        interpolated = alpha * dist + (1 - alpha) * fake
+        interpolated.requires_grad_(True)
+        out = pointnet_forward(self.D, pos, interpolated)
+        grad = torch.autograd.grad(out, interpolated, grad_outputs=torch.ones_like(out), create_graph=True,
+                                   retain_graph=True, only_inputs=True)[0]
+        grad_norm = grad.view(grad.size(0), -1).norm(dim=-1, p=2)
+        return self.gp_weight * ((grad_norm - 1).pow(2).mean())
+
+    def critic_step(self, uniform, z, alpha):
+        pos, dist = uniform[..., :3], uniform[..., 3:]
+        self.d_opt.zero_grad()
+        fake = sdf_generator_forward(self.G, pos, z)
+        out_real = pointnet_forward(self.D, pos, dist)
+        out_fake = pointnet_forward(self.D, pos, fake)
+        d_loss = out_fake.mean() - out_real.mean()
+        gp = self.gradient_penalty(pos, dist, fake, alpha)
+        (d_loss + gp).backward()
+        self.d_opt.step()
+        return d_loss.detach(), gp.detach()
+
+    def generator_step(self, uniform, z):
+        pos = uniform[..., :3]
+        self.g_opt.zero_grad()
+        fake = sdf_generator_forward(self.G, pos, z)
+        loss = -pointnet_forward(self.D, pos, fake).mean()
+        loss.backward()
+        self.g_opt.step()
+        return loss.detach()
+
+
 def snapshot(P):
     return copy.deepcopy({k: v.detach().clone() for k, v in P.items()})

@@ -1,0 +1,25 @@
+"""train_point_gan.py step times at the script's own (num_points, batch) stages: critic update (with GP) and generator update."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+from shapegan_amd.train_steps import PointGANTrainer
+
+def timeit(fn, iters=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+torch.manual_seed(0)
+G, D = SDFGenerator(128, 256, 8, True).cuda(), PointNet(1).cuda()
+tr = PointGANTrainer(G, D)
+for P, B in ((1024, 32), (4096, 32), (16384, 12), (32768, 6)):
+    u = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).cuda()
+    z, a = torch.randn(B, 128, device="cuda"), torch.rand(B, 1, 1, device="cuda")
+    tc = timeit(lambda: tr.critic_step(u, z, a))
+    tg = timeit(lambda: tr.generator_step(u, z))
+    # critic: G fwd (0.92 MF/pt) + 3 D passes fwd (0.34 MF/pt) + bwd/double-bwd ~ 2x + 3x; generator: 3x(G + D)
+    print("P=%5d B=%2d  critic+GP %.2f ms  generator %.2f ms  (%.2f Mpoints/s per critic update)" % (P, B, tc, tg, B * P / tc / 1e3), flush=True)

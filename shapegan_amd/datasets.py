@@ -187,3 +187,35 @@ def create_batches(signs, batch_size, rng=np.random):
     for b in range(full - 1):
         yield epoch[b * batch_size:(b + 1) * batch_size]
     yield epoch[(full - 1) * batch_size:]
+
+
+class PointDataset(object):
+    """datasets.py:53-92 (train_point_gan.py:28-29): per shape `<root>/uniform/<name>.npy` and `<root>/surface/<name>.npy`
+    ([M,4] xyz+sdf rows); an item is the SAME random subset of `num_points` rows of both (one np.random.choice draw per
+    item, with replacement, from the global numpy RNG — bit-exact index work under np.random.seed)."""
+
+    def __init__(self, root, filenames, num_points=1024, transform=None):
+        self.root = os.path.expanduser(os.path.join(os.path.normpath(root)))
+        self.filenames = filenames
+        self.num_points = num_points
+        assert 0 < self.num_points <= 64 ** 3
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def __getitem__(self, idx):
+        name = self.filenames[idx]
+        clouds = [torch.from_numpy(np.load(os.path.join(self.root, kind, '{}.npy'.format(name))))
+                  for kind in ('uniform', 'surface')]
+        rows = np.random.choice(clouds[0].size(0), self.num_points)
+        item = (clouds[0][rows], clouds[1][rows])
+        return item if self.transform is None else self.transform(item)
+
+    @staticmethod
+    def from_split(root, split, num_points=1024, transform=None):
+        with open(os.path.join(root, '{}.txt'.format(split)), 'r') as fh:
+            names = fh.read().split('\n')
+        if names and names[-1] == '':
+            names = names[:-1]
+        return PointDataset(root, names, num_points, transform)

@@ -1,0 +1,116 @@
+"""PointNet-discriminator GAN family (model/point_sdf_net.py): `PointNet` critic and `SDFGenerator` on HIP kernels.
+
+Same constructor arguments and state_dict keys as the reference (`nn1.{0,2,4,6}`, `nn2.{0,2,4}`; `lins.i`, `norms.i`,
+`z_lin1`, `z_lin2`, including the never-used last LayerNorm(1)), so checkpoints load either way.  The torch layer
+objects are parameter containers; every forward below runs through shapegan_amd.ops:
+  * per-point Linear (+ReLU): MFMA GEMM with bias / activation epilogue (`ops.linear`), closed under double backward;
+  * `lin(x) + z_lin(z).unsqueeze(1)`, LayerNorm, ReLU (:104-116): one `sg_layernorm_fwd` pass, the per-shape z row is
+    added on load — the [B,P,256] broadcast sum never exists; the skip concat `cat([x, pos])` (:100) is written by the
+    same pass as the tail of a 259-float row;
+  * `x.max(dim=-2)[0]` (:40): `sg_segmax_fwd` (+ scatter / gather adjoints for backward and double backward).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import ACT_NONE, ACT_RELU
+
+
+def _mlp(sizes):
+    mods = []
+    for i in range(len(sizes) - 1):
+        mods.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i + 2 < len(sizes):
+            mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+def _run_mlp(seq, x):
+    """Linear / ReLU chain of an nn.Sequential container on the GEMM kernel (activation fused into the epilogue)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        x = ops.linear(x, mods[i].weight, mods[i].bias, ACT_RELU if relu else ACT_NONE)
+        i += 2 if relu else 1
+    return x
+
+
+class PointNet(nn.Module):
+    """point_sdf_net.py:11-47: per-point MLP 4 -> 64 -> 128 -> 256 -> 512, max over the points of a shape, MLP
+    512 -> 256 -> 128 -> out_channels."""
+
+    def __init__(self, out_channels):
+        super(PointNet, self).__init__()
+        self.nn1 = _mlp([4, 64, 128, 256, 512])
+        self.nn2 = _mlp([512, 256, 128, out_channels])
+
+    def forward(self, pos, dist, batch=None):
+        if batch is not None:
+            raise NotImplementedError("ragged `batch` vectors (torch_scatter path, :42) are not on the training path")
+        dist = dist.unsqueeze(-1) if dist.size(-1) != 1 else dist
+        x = torch.cat([pos, dist], dim=-1)                      # [B,P,4] (16 B per point)
+        lead, P = x.shape[:-2], x.shape[-2]
+        h = _run_mlp(self.nn1, x.reshape(-1, 4))
+        h = ops.segmax(h.reshape(-1, P, h.shape[-1]))           # [B,512]
+        out = _run_mlp(self.nn2, h)
+        return out.reshape(tuple(lead) + (out.shape[-1],))
+
+
+class SDFGenerator(nn.Module):
+    """point_sdf_net.py:49-119: `num_layers` Linear layers of width `hidden_channels` with LayerNorm + ReLU, latent
+    injected as a per-shape bias after layers 0 and num_layers/2, the input positions concatenated again at
+    num_layers/2, last layer -> 1 channel without norm / activation."""
+
+    def __init__(self, latent_channels, hidden_channels, num_layers, norm=True, dropout=0.0):
+        super(SDFGenerator, self).__init__()
+        assert num_layers % 2 == 0
+        self.layers1 = None
+        self.layers2 = None
+        self.latent_channels = latent_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.norm = norm
+        self.dropout = dropout
+        self.lins = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        fan_in, fan_out = 3, hidden_channels
+        for i in range(num_layers):
+            self.lins.append(nn.Linear(fan_in, fan_out))
+            self.norms.append(nn.LayerNorm(fan_out))
+            fan_in = hidden_channels + 3 if i == num_layers // 2 - 1 else hidden_channels
+            if i == num_layers - 2:
+                fan_out = 1
+        self.z_lin1 = nn.Linear(latent_channels, hidden_channels)
+        self.z_lin2 = nn.Linear(latent_channels, hidden_channels)
+
+    def forward(self, pos, z):
+        pos = pos.unsqueeze(0) if pos.dim() == 2 else pos
+        assert pos.dim() == 3 and pos.size(-1) == 3
+        z = z.unsqueeze(0) if z.dim() == 1 else z
+        assert z.dim() == 2 and z.size(-1) == self.latent_channels
+        assert pos.size(0) == z.size(0)
+        if not self.norm or (self.dropout > 0.0 and self.training):
+            raise NotImplementedError("the native path covers the training configuration (norm=True, dropout=0.0)")
+        B, P = pos.shape[0], pos.shape[1]
+        half = self.num_layers // 2
+        pos2 = pos.reshape(B * P, 3)
+        x = pos2
+        for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
+            last = i == self.num_layers - 1
+            x = ops.linear(x, lin.weight, lin.bias)
+            if last:
+                zrow = None
+                if i == 0 or i == half:   # degenerate 2-layer nets only
+                    zrow = ops.linear(z, (self.z_lin1 if i == 0 else self.z_lin2).weight,
+                                      (self.z_lin1 if i == 0 else self.z_lin2).bias)
+                    x = x.reshape(B, P, -1) + zrow.unsqueeze(1)
+                break
+            zrow = None
+            if i == 0:
+                zrow = ops.linear(z, self.z_lin1.weight, self.z_lin1.bias)
+            elif i == half:
+                zrow = ops.linear(z, self.z_lin2.weight, self.z_lin2.bias)
+            tail = pos2 if i == half - 1 else None        # the next layer reads cat([x, pos])
+            x = ops.layernorm_act(x, zrow, P, norm.weight, norm.bias, norm.eps, ACT_RELU, tail)
+        return x.reshape(B, P, -1)

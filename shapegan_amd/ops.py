@@ -321,11 +321,23 @@ class Gemm(Function):
         return ga, gb, None, None
 
 
+def colsum_tall_raw(x, batch, batch_stride, rows, cols, ld):
+    """out[b][c] = sum_r x[b*batch_stride + r*ld + c] (two deterministic passes; rows = points)."""
+    lib = _lib()
+    out = torch.empty((batch, cols), dtype=torch.float32, device=x.device)
+    ws = workspace("colsum", lib.sg_colsum_tall_workspace_bytes(batch, rows, cols), x.device)
+    check(lib.sg_colsum_tall(ptr(x), ptr(out), batch, batch_stride, rows, cols, ld, ptr(ws), ws.numel(), stream()),
+          "colsum_tall")
+    return out
+
+
 class ColSum(Function):
     @staticmethod
     def forward(ctx, g):
         g = f32c(g)
         ctx.rows = g.shape[0]
+        if g.shape[0] > 256:   # per-point layers: one thread per column walking every row would serialise
+            return colsum_tall_raw(g, 1, 0, g.shape[0], g.shape[1], g.shape[1])[0]
         out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
         check(_lib().sg_colsum(ptr(g), ptr(out), g.shape[0], g.shape[1], g.shape[1], stream()), "colsum")
         return out
@@ -674,6 +686,117 @@ class GatherRows(Function):
 
 def gather_rows(table, idx):
     return GatherRows.apply(table, idx)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# PointNet-discriminator GAN family (model/point_sdf_net.py)
+# --------------------------------------------------------------------------------------------------------------
+class LayerNormAct(Function):
+    """y = act(layer_norm(x + rowbias[row // rows_per_shape])) for x [R,C] (point_sdf_net.py:104-116: `lin(x)`, the
+    z-injection `z_lin(z).unsqueeze(1) + x`, `norm`, `relu` in one pass).  With `tail` [R,T] the output is [R,C+T]
+    whose last T columns are a copy of tail: the skip concat `cat([x, pos])` (:100) without a second pass over x."""
+
+    @staticmethod
+    def forward(ctx, x, rowbias, rows_per_shape, gamma, beta, eps, act, tail):
+        x = f32c(x)
+        R, C = x.shape
+        T = 0 if tail is None else tail.shape[1]
+        y = torch.empty((R, C + T), dtype=torch.float32, device=x.device)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        rb = None if rowbias is None else f32c(rowbias)
+        check(_lib().sg_layernorm_fwd(ptr(x), C, ptr(rb), rows_per_shape, ptr(gamma), ptr(beta), ptr(y), C + T, ptr(mean),
+                                      ptr(rstd), R, C, eps, act, stream()), "layernorm_fwd")
+        if T:
+            y[:, C:] = tail
+        ctx.cfg = (R, C, T, rows_per_shape, act)
+        ctx.save_for_backward(x, rb, gamma, y, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, rb, gamma, y, mean, rstd = ctx.saved_tensors
+        R, C, T, rps, act = ctx.cfg
+        gy = f32c(gy)
+        lib = _lib()
+        dz = torch.empty((R, C), dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace("layernorm", lib.sg_layernorm_bwd_workspace_bytes(R, C), x.device)
+        check(lib.sg_layernorm_bwd(ptr(x), C, ptr(rb), rps, ptr(gamma), ptr(y), C + T, ptr(gy), C + T, ptr(mean), ptr(rstd),
+                                   ptr(dz), C, ptr(dgamma), ptr(dbeta), R, C, act, ptr(ws), ws.numel(), stream()),
+              "layernorm_bwd")
+        grb = None
+        if rb is not None and ctx.needs_input_grad[1]:
+            grb = colsum_tall_raw(dz, R // rps, rps * C, rps, C, C)
+        gtail = gy[:, C:] if (T and ctx.needs_input_grad[7]) else None
+        return dz, grb, None, dgamma, dbeta, None, None, gtail
+
+
+class SegMaxScatter(Function):
+    """dx[b,p,c] = dy[b,c] where p == idx[b,c], else 0 (the adjoint of the max over points); its own backward is the
+    gather at idx, so the gradient penalty's double backward (train_point_gan.py:61-70) stays on HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, dy, idx, P):
+        dy = f32c(dy)
+        B, C = dy.shape
+        dx = torch.empty((B, P, C), dtype=torch.float32, device=dy.device)
+        check(_lib().sg_segmax_scatter(ptr(dy), ptr(idx), ptr(dx), B, P, C, stream()), "segmax_scatter")
+        ctx.save_for_backward(idx)
+        return dx
+
+    @staticmethod
+    def backward(ctx, gdx):
+        (idx,) = ctx.saved_tensors
+        return SegMaxGather.apply(gdx, idx), None, None
+
+
+class SegMaxGather(Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = f32c(x)
+        B, P, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        check(_lib().sg_segmax_gather(ptr(x), ptr(idx), ptr(out), B, P, C, stream()), "segmax_gather")
+        ctx.P = P
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return SegMaxScatter.apply(g, idx, ctx.P), None
+
+
+class SegMax(Function):
+    """x [B,P,C] -> max over the P points of each shape (`x.max(dim=-2)[0]`, point_sdf_net.py:40)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = f32c(x)
+        B, P, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        check(_lib().sg_segmax_fwd(ptr(x), ptr(out), ptr(idx), B, P, C, stream()), "segmax_fwd")
+        ctx.P = P
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, g, _gidx):
+        (idx,) = ctx.saved_tensors
+        return SegMaxScatter.apply(g, idx, ctx.P)
+
+
+def segmax(x):
+    return SegMax.apply(x)[0]
+
+
+def layernorm_act(x, rowbias, rows_per_shape, gamma, beta, eps=1e-5, act=ACT_NONE, tail=None):
+    return LayerNormAct.apply(x, rowbias, rows_per_shape, gamma, beta, eps, act, tail)
 
 
 def voxel_prepare(x, clamp, divisor, out=None):

@@ -379,3 +379,58 @@ class HybridGANTrainer(ClassicGANTrainer):
             self._tiled[count] = self.grid.repeat((count, 1))
         sdf = self.generator.forward_shapes(self._tiled[count], z, self.res ** 3)
         return sdf.reshape(-1, self.res, self.res, self.res)
+
+
+class PointGANTrainer(object):
+    """train_point_gan.py: SDFGenerator (LayerNorm MLP, latent 128) against a PointNet critic on
+    [B, P, 4] point clouds, WGAN-GP (lambda 10) on the DISTANCE channel only, RMSprop 1e-4 for both; the critic is
+    updated on every batch, the generator on every 5th (:52-83)."""
+
+    def __init__(self, generator, critic, lr=0.0001, gp_weight=10.0):
+        self.generator, self.critic = generator, critic
+        self.g_opt = optim.RMSprop(generator.parameters(), lr=lr)    # :25
+        self.d_opt = optim.RMSprop(critic.parameters(), lr=lr)       # :26
+        self.g_bucket, self.d_bucket = GradBucket(self.g_opt), GradBucket(self.d_opt)
+        self.gp_weight = gp_weight
+
+    def gradient_penalty(self, pos, dist, fake, alpha):
+        """:61-70; `alpha` [B,1,1] replaces the on-device torch.rand."""
+        interpolated = alpha * dist + (1 - alpha) * fake
+        interpolated.requires_grad_(True)
+        out = self.critic(pos, interpolated)
+        grad = torch.autograd.grad(out, interpolated, grad_outputs=torch.ones_like(out), create_graph=True,
+                                   retain_graph=True, only_inputs=True)[0]
+        grad_norm = grad.reshape(grad.size(0), -1).norm(dim=-1, p=2)
+        return self.gp_weight * ((grad_norm - 1).pow(2).mean())
+
+    def critic_step(self, uniform, z, alpha):
+        """:52-74.  The reference keeps the generator graph here and discards its gradients (G_optimizer.zero_grad at
+        :77 precedes the only G_optimizer.step); they are not computed."""
+        pos, dist = uniform[..., :3], uniform[..., 3:]
+        self.d_opt.zero_grad()
+        with torch.no_grad():
+            fake = self.generator(pos, z)
+        out_real = self.critic(pos, dist)
+        out_fake = self.critic(pos, fake)
+        d_loss = ops.mean(out_fake) - ops.mean(out_real)
+        gp = self.gradient_penalty(pos, dist, fake, alpha)
+        loss = d_loss + gp
+        self.d_bucket.arm()
+        loss.backward()
+        self.d_bucket.finish()
+        self.d_opt.step()
+        return d_loss.detach(), gp.detach()
+
+    def generator_step(self, uniform, z):
+        """:76-83."""
+        pos = uniform[..., :3]
+        self.g_opt.zero_grad()
+        fake = self.generator(pos, z)
+        with frozen(self.critic):
+            out = self.critic(pos, fake)
+        loss = -ops.mean(out)
+        self.g_bucket.arm()
+        loss.backward()
+        self.g_bucket.finish()
+        self.g_opt.step()
+        return loss.detach()

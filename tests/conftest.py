@@ -57,6 +57,11 @@ def golden_steps_f2():
 
 
 @pytest.fixture(scope="session")
+def golden_steps_f4():
+    return Golden("steps_f4.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_sdf():
     return Golden("sdfnet_examples.npz")
 

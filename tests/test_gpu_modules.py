@@ -413,6 +413,62 @@ def test_vae_trajectory(golden_steps_f2, monkeypatch):
     _check_updates(ae, a0, o32.P, o64.P, "vae", gd, "vae/final", anchor_rtol=5e-2, max_frac=2e-2, outlier_cap=1.0)
 
 
+def test_point_gan_modules(golden_steps_f4):
+    """SDFGenerator / PointNet forward and parameter gradients vs the reference fixtures and the
+    fp64 oracle (P = 96 / 50: not multiples of the tile sizes)."""
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    gd = golden_steps_f4
+    torch.manual_seed(81)
+    G = SDFGenerator(128, 256, 8, True, dropout=0.0)
+    g0 = _cpu_state(G)
+    G = G.cuda()
+    pos, z, w = gd.t("gen/pos"), gd.t("gen/z"), gd.t("gen/w")
+    out = G(pos.cuda(), z.cuda())
+    close(out, gd.t("gen/out"), rtol=1e-4, atol=1e-5, what="SDFGenerator out vs reference fixture")
+    (out * w.cuda()).sum().backward()
+    P64 = O.clone_state({k: v.double() for k, v in g0.items()})
+    (O.sdf_generator_forward(P64, pos.double(), z.double()) * w.double()).sum().backward()
+    P32 = O.clone_state(g0)
+    (O.sdf_generator_forward(P32, pos, z) * w).sum().backward()
+    grads = gd.sub("gen/grad")
+    for k, p in G.named_parameters():
+        if k in grads:
+            check_against_oracles(p.grad, P32[k].grad, P64[k].grad, "SDFGenerator grad " + k, rtol=2e-4, noise_factor=8.0)
+            assert_summary_close(p.grad, grads[k], 2e-3, 1e-6, "SDFGenerator grad vs fixture " + k)
+    torch.manual_seed(82)
+    D = PointNet(out_channels=1).cuda()
+    out = D(gd.t("disc/pos").cuda(), gd.t("disc/dist").cuda())
+    close(out, gd.t("disc/out"), rtol=1e-4, atol=1e-6, what="PointNet out vs reference fixture")
+    out.sum().backward()
+    grads = gd.sub("disc/grad")
+    for k, p in D.named_parameters():
+        assert_summary_close(p.grad, grads[k], 1e-3, 1e-7, "PointNet grad vs fixture " + k)
+
+
+def test_point_gan_trajectory(golden_steps_f4):
+    """train_point_gan.py:52-83: critic update with the gradient penalty on the distance channel (double backward through
+    the max over points), then a generator update."""
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    gd = golden_steps_f4
+    torch.manual_seed(83)
+    g, d = SDFGenerator(128, 256, 8, True, dropout=0.0), PointNet(out_channels=1)
+    g0, d0 = _cpu_state(g), _cpu_state(d)
+    g, d = g.cuda(), d.cuda()
+    o32 = O.PointGANOracle(g0, d0)
+    o64 = O.PointGANOracle({k: v.double() for k, v in g0.items()}, {k: v.double() for k, v in d0.items()})
+    tr = PointGANTrainer(g, d)
+    uniform, z1, z2, alpha = (gd.t("step/" + k) for k in ("uniform", "z1", "z2", "alpha"))
+    dl, gp = tr.critic_step(uniform.cuda(), z1.cuda(), alpha.cuda())
+    gl = tr.generator_step(uniform.cuda(), z2.cuda())
+    for o, dt in ((o32, torch.float32), (o64, torch.float64)):
+        o.critic_step(uniform.to(dt), z1.to(dt), alpha.to(dt))
+        o.generator_step(uniform.to(dt), z2.to(dt))
+    np.testing.assert_allclose([dl.item(), gp.item(), gl.item()], gd["step/losses"], rtol=2e-4, atol=1e-6)
+    _check_updates(d, d0, o32.D, o64.D, "point gan critic", gd, "step/d_final")
+    _check_updates(g, g0, o32.G, o64.G, "point gan generator", gd, "step/g_final")
+
+
 def test_dp_shards_sum_to_full_batch_gradient():
     """Distributed math on one GPU: averaged shard gradients == full-batch gradient for the BN-free
     critic, i.e. what one RCCL all-reduce of the flat buffers + grad_scale 1/G produces."""

@@ -486,3 +486,82 @@ def test_voxel_batches_equal_dataloader(tmp_path, mode):
     torch.manual_seed(78)
     dropped = list(ds.resident().batches(4, drop_last=True))
     assert len(dropped) == 5 and all(b.shape[0] == 4 for b in dropped)
+
+
+# ---- PointNet-discriminator GAN family ---------------------------------------------------------
+@pytest.mark.parametrize("R,C,rps,tail,act", [(7, 256, 7, 0, 2), (300, 256, 100, 3, 2), (130, 64, 13, 0, 0), (64, 200, 64, 0, 2),
+                                              (4096, 256, 1024, 3, 2)])
+def test_layernorm_act(R, C, rps, tail, act):
+    """y = act(LN(x + zrow[r // rps])) (+ tail columns) and its backward vs torch fp64."""
+    from shapegan_amd import ops
+    torch.manual_seed(R + C)
+    B = R // rps
+    x = torch.randn(R, C) * 2 + 0.5
+    zb = torch.randn(B, C)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    t = torch.randn(R, tail) if tail else None
+    w = torch.randn(R, C + tail)
+
+    def ref(dt):
+        xs, zs, g, b = (v.to(dt).requires_grad_(True) for v in (x, zb, gamma, beta))
+        y = F.layer_norm(xs + zs.repeat_interleave(rps, 0), (C,), g, b, 1e-5)
+        y = F.relu(y) if act == 2 else y
+        if tail:
+            y = torch.cat([y, t.to(dt)], 1)
+        (y * w.to(dt)).sum().backward()
+        return y.detach(), xs.grad, zs.grad, g.grad, b.grad
+    want = ref(torch.float64)
+    xs, zs, g, b = (v.cuda().requires_grad_(True) for v in (x, zb, gamma, beta))
+    y = ops.layernorm_act(xs, zs, rps, g, b, 1e-5, act, None if t is None else t.cuda())
+    (y * w.cuda()).sum().backward()
+    got = (y.detach(), xs.grad, zs.grad, g.grad, b.grad)
+    for name, a, e in zip(("y", "dx", "dz", "dgamma", "dbeta"), got, want):
+        scale = float(e.abs().max()) + 1e-12
+        err = float((a.double().cpu() - e).abs().max()) / scale
+        assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize("B,P,C", [(3, 50, 512), (1, 1, 7), (2, 1000, 130), (6, 32768, 512)])
+def test_segmax_and_adjoints(B, P, C):
+    """max over points == torch.max(dim=-2) bit for bit (values AND first-occurrence indices, ties included); scatter
+    and gather are each other's adjoints; double backward through the pair works."""
+    from shapegan_amd import ops
+    torch.manual_seed(B * P + C)
+    x = torch.randn(B, P, C)
+    if P > 4:
+        x[:, 3] = x[:, 1]                      # exact ties: the first occurrence must win
+        x[0, 2, :] = x.max() + 1
+    want_v, want_i = x.max(dim=-2)
+    xs = x.cuda().requires_grad_(True)
+    out, idx = ops.SegMax.apply(xs)
+    assert torch.equal(out.cpu(), want_v)
+    if P > 4:
+        first = (x == want_v.unsqueeze(1)).float().argmax(dim=1)     # first index attaining the max
+        assert torch.equal(idx.cpu().long(), first)
+    w = torch.randn(B, C, device="cuda")
+    (out * w).sum().backward()
+    ref = torch.zeros(B, P, C)
+    ref.scatter_(1, idx.cpu().long().unsqueeze(1), w.cpu().unsqueeze(1))
+    assert torch.equal(xs.grad.cpu(), ref)
+    # adjointness <scatter(dy), u> == <dy, gather(u)> and double backward
+    u = torch.randn(B, P, C, device="cuda")
+    dy = torch.randn(B, C, device="cuda", requires_grad=True)
+    sc = ops.SegMaxScatter.apply(dy, idx, P)
+    lhs = (sc * u).sum()
+    rhs = (dy * ops.SegMaxGather.apply(u, idx)).sum()
+    np.testing.assert_allclose(lhs.item(), rhs.item(), rtol=1e-5)
+    (g,) = torch.autograd.grad(lhs, dy)
+    assert torch.equal(g, ops.SegMaxGather.apply(u, idx))
+
+
+def test_colsum_tall():
+    from shapegan_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(5, 3000, 70, device="cuda")
+    got = ops.colsum_tall_raw(x, 5, 3000 * 70, 3000, 70, 70)
+    np.testing.assert_allclose(got.cpu().numpy(), x.double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    g = torch.randn(100000, 256, device="cuda", requires_grad=True)
+    s = ops.ColSum.apply(g)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
+    s.sum().backward()
+    assert torch.equal(g.grad, torch.ones_like(g))

@@ -222,3 +222,27 @@ def test_voxel_dataset_items_match_reference_fixture(golden_steps_f2, tmp_path):
     split = tmp_path / "train.txt"
     split.write_text("a\nmissing\nd\n")
     assert [os.path.basename(f) for f in VoxelDataset.from_split(str(tmp_path) + "/{:s}.npy", str(split)).files] == ["a.npy", "d.npy"]
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present (GPU box)")
+def test_point_dataset_matches_reference(tmp_path):
+    """datasets.py:53-92 against the real class: same files, same np.random draws, same tensors."""
+    import importlib.util
+    from shapegan_amd.datasets import PointDataset
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(ref_import.REFERENCE_ROOT, "datasets.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(1)
+    for kind in ("uniform", "surface"):
+        os.makedirs(str(tmp_path / kind))
+        for name in ("s0", "s1", "s2"):
+            np.save(str(tmp_path / kind / (name + ".npy")), rng.rand(500, 4).astype(np.float32))
+    (tmp_path / "train.txt").write_text("s0\ns1\ns2\n")
+    theirs, ours = ref.PointDataset.from_split(str(tmp_path), "train", 64), PointDataset.from_split(str(tmp_path), "train", 64)
+    assert len(theirs) == len(ours) == 3 and theirs.filenames == ours.filenames
+    np.random.seed(11)
+    want = [theirs[i] for i in (2, 0, 1)]
+    np.random.seed(11)
+    got = [ours[i] for i in (2, 0, 1)]
+    for a, b in zip(want, got):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and b[0].shape == (64, 4)

@@ -188,6 +188,30 @@ def test_oracle_steps_match_golden_vae(golden_steps_f2):
         assert_summary_close(orc.P[k].float(), ref, 1e-5, 1e-8, k)
 
 
+def test_oracle_point_gan_matches_golden(golden_steps_f4):
+    """PointNet / SDFGenerator forwards and the train_point_gan.py steps, from seed-derived init."""
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    g = golden_steps_f4
+    torch.manual_seed(81)
+    G = SDFGenerator(128, 256, 8, True, dropout=0.0)
+    out = O.sdf_generator_forward(O.clone_state(G.state_dict()), g.t("gen/pos"), g.t("gen/z"))
+    np.testing.assert_array_equal(out.detach().numpy(), g["gen/out"])
+    torch.manual_seed(82)
+    D = PointNet(out_channels=1)
+    out = O.pointnet_forward(O.clone_state(D.state_dict()), g.t("disc/pos"), g.t("disc/dist"))
+    np.testing.assert_array_equal(out.detach().numpy(), g["disc/out"])
+    torch.manual_seed(83)
+    G, D = SDFGenerator(128, 256, 8, True, dropout=0.0), PointNet(out_channels=1)
+    orc = O.PointGANOracle(G.state_dict(), D.state_dict())
+    dl, gp = orc.critic_step(g.t("step/uniform"), g.t("step/z1"), g.t("step/alpha"))
+    gl = orc.generator_step(g.t("step/uniform"), g.t("step/z2"))
+    np.testing.assert_allclose([dl.item(), gp.item(), gl.item()], g["step/losses"], rtol=1e-5, atol=1e-7)
+    for k, ref in g.sub("step/d_final").items():
+        assert_summary_close(orc.D[k].float(), ref, 1e-5, 1e-8, k)
+    for k, ref in g.sub("step/g_final").items():
+        assert_summary_close(orc.G[k].float(), ref, 1e-5, 1e-8, k)
+
+
 def test_oracle_gradient_penalty_golden(golden_modules):
     from shapegan_amd.model.progressive_gan import Discriminator
     torch.manual_seed(41)
