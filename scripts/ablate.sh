@@ -5,9 +5,9 @@ cd "$(dirname "$0")/.."
 mkdir -p scripts/_abl
 for n in "$@"; do
   objs=""
-  for f in conv3d conv3d_halo gemm sdfnet batchnorm elementwise; do
+  for f in conv3d conv3d_halo gemm sdfnet batchnorm elementwise pointnet; do
     if [ $f = conv3d_halo ]; then
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSG_ABLATE=$((n % 100)) -DSG_RING=$((n >= 100 ? n / 100 : 8)) -c shapegan_amd/csrc/$f.hip -o scripts/_abl/${f}_$n.o
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSG_ABLATE=$n -c shapegan_amd/csrc/$f.hip -o scripts/_abl/${f}_$n.o
       objs="$objs scripts/_abl/${f}_$n.o"
     else
       objs="$objs shapegan_amd/csrc/_obj/$f.o"

@@ -67,23 +67,59 @@ __global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __re
     }
 }
 
-// Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 4*TM MFMAs each).  The loop body is ONE basic
+// ---- addressing helpers shared by the three halo kernels ---------------------------------------------------------
+// Every non-MFMA VALU instruction in the stage loop takes an issue slot away from the matrix pipe (measured: ~1 VALU op
+// per MFMA costs ~10 %), so the loops are written to need none:
+//   * global loads are raw BUFFER loads: scalar resource + a per-thread byte offset that never changes + a scalar
+//     offset that carries everything that does (channel, k-group) — no 64-bit vector address arithmetic; an element
+//     outside the tensor gets an offset beyond num_records and the hardware returns 0 (no select on the way to LDS);
+//   * LDS addresses are per-thread constants held in registers, everything else is an immediate offset: the stage loop
+//     is unrolled by two so that the double-buffer index is a compile-time constant.
+typedef __attribute__((address_space(3))) float lds_float;
+constexpr unsigned kBufRange = 0x80000000u;     // num_records of the buffer resources
+constexpr unsigned kBufOutside = 0x80000000u;   // byte offset that is out of range -> the load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)kBufRange, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    // bit_cast the WHOLE result: component access on the builtin's own vector type narrows the load to one dword
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <class T>
+__device__ __forceinline__ void pin_vgpr(T& v) {   // the value stays in its register (no rematerialising v_add in the loop)
+    asm volatile("" : "+v"(v));
+}
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+
+// Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 4*TN MFMAs each).  The loop body is ONE basic
 // block (no data-dependent branches), so that the compiler's s_waitcnt counts are exact and nothing drains the queues:
 //   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1: the copy
 //     loads are spread over the first 24 k-groups (all workgroups run in lock-step: a burst at the top of the stage is a
 //     chip-wide traffic jam once per stage, measured -8 %), each value goes to LDS 8 groups after its load.
-//     Out-of-range voxels load a clamped address and store zero; threads outside the box store to an unused pad slot of
-//     the channel; the last stage re-copies its own channels into the idle buffer — no branch anywhere;
+//     Threads outside the box store to an unused pad slot of the channel; the last stage re-copies its own channels
+//     into the idle buffer — no branch anywhere;
 //   * B fragments of group g+1 are read from LDS while the MFMAs of group g run; A fragments (packed weights, L2) sit in
-//     a ring of 8 groups; the weight pointer is wave-uniform (scalar base + lane offset); one barrier per stage.
-template <int TM, int TN, int NW>
+//     a ring of 8 groups; one barrier per stage.
+// Wave tile: 32 output channels x TN*32 positions (TN = 2: 4 waves cover 128 channels x 64 positions, two independent
+// accumulators per wave; TN = 1: 8 or 4 waves as rows x position halves).
+template <int TN, int NW>
 __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     constexpr int kFR = NW * 2;                          // halo rows copied per pass (one per half-wave)
     constexpr int kNF = (kHD * kHH + kFR - 1) / kFR;     // fill elements per thread per channel (72 rows)
-    constexpr int WN = 2 / TN;                           // waves along the 64 positions (TN = 32-position tiles per wave)
-    constexpr int ROWS = (NW / WN) * TM * 32;            // output channels per workgroup
+    constexpr int WN = 2 / TN;                           // waves along the 64 positions
+    constexpr int ROWS = (NW / WN) * 32;                 // output channels per workgroup
     constexpr int kRing = SG_RING;
+    constexpr int kBUF = kCC * kHS;                      // floats per LDS buffer
     extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][kCC][kHD][kHH][2][kHWH]
+    lds_float* const hl = (lds_float*)halo;
 
     uint32_t twi, thi, od, n, q1, q2;
     a.dntw.divmod(blockIdx.x, q1, twi);
@@ -95,78 +131,87 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, kpar = lane >> 5;
-    // position inside the 8x8 tile of column tile tn: p = (wn*TN + tn)*32 + r -> ph = p >> 3, pw = p & 7
+    // position inside the 8x8 tile of column tile u: p = (wn*TN + u)*32 + r -> ph = p >> 3, pw = p & 7
     const int lanebase = 2 * (wn * TN * 4 + (r >> 3)) * kROWH + kpar * kHWH + (r & 7);
     constexpr int kTNOFF = 2 * 4 * kROWH;  // LDS offset between the two column tiles of a wave (4 tile rows)
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int u = 0; u < TN; ++u)
 #pragma unroll
-        for (int u = 0; u < TN; ++u)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][u][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
 
-    const int G = a.Cin * 8;
-    const float4* wrow[TM];  // wave-uniform
+    // B-fragment read addresses: one register per (buffer, channel, kd); kh pair and column tile are immediates
+    const lds_float* bb[2][kCC][4];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) wrow[t] = a.wp + ((long)(co0 / 32 + wm * TM + t) * G) * 64;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < kCC; ++c)
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) {
+                bb[b][c][kd] = hl + b * kBUF + c * kHS + kd * kROWD + lanebase;
+                pin_vgpr(bb[b][c][kd]);
+            }
+
+    // packed weights of this wave's 32 rows: buffer resource on the row tile, lane offset fixed, k-group in the scalar offset
+    const int G = a.Cin * 8;
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + ((long)(co0 / 32 + wm) * G) * 64);
+    const unsigned wvoff = lane * 16;
 
     // ---- fill bookkeeping: element f of a channel is halo row kFR*f + tid/32, column tid%32 ----
     const int I3 = a.g.ID * a.g.IH * a.g.IW;
-    const float* xn = a.x + (long)n * a.g.Cx * I3;
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x + (long)n * a.g.Cx * I3);
     const int fl_w = tid & 31, frow = tid >> 5;
     const int iw = 2 * ow0 - 1 + fl_w;
     const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
     const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
     const int pad = (tid % (kHD * kHH * 2)) * kHWH + (kHWH - 1);  // column 9 of a half row: never read
-    unsigned goff[kNF];  // global offset inside a channel (0 when out of range: the value is replaced by zero)
-    int loff[kNF];       // LDS offset inside a channel
-    unsigned okmask = 0;
+    unsigned goff[kNF];   // byte offset inside a channel, kBufOutside for padding voxels (the load returns 0)
+    lds_float* sdst[kNF];  // LDS destination inside (buffer 0, channel 0)
 #pragma unroll
     for (int f = 0; f < kNF; ++f) {
         const int row = kFR * f + frow, hd = row / kHH, hh = row - hd * kHH;
         const int id = 2 * (int)od - 1 + hd, ih = 2 * oh0 - 1 + hh;
         const bool inbox = fl_w < kHWF && row < kHD * kHH;
         const bool ok = inbox && wok && (unsigned)id < (unsigned)a.g.ID && (unsigned)ih < (unsigned)a.g.IH;
-        goff[f] = ok ? (unsigned)((id * a.g.IH + ih) * a.g.IW + iw) : 0u;
-        okmask |= ok ? (1u << f) : 0u;
-        loff[f] = inbox ? hd * kROWD + hh * kROWH + lds_w : pad;
+        goff[f] = ok ? (unsigned)((id * a.g.IH + ih) * a.g.IW + iw) * 4u : kBufOutside;
+        sdst[f] = hl + (inbox ? hd * kROWD + hh * kROWH + lds_w : pad);
+        pin_vgpr(goff[f]);
+        pin_vgpr(sdst[f]);
     }
     float fv[kCC][kNF];
+    const unsigned chan_bytes = (unsigned)I3 * 4u;
 
     // ---- prologue: box of stage 0 into buffer 0, first kRing weight groups ----
 #pragma unroll
     for (int c = 0; c < kCC; ++c)
 #pragma unroll
-        for (int f = 0; f < kNF; ++f) fv[c][f] = (xn + (long)c * I3)[goff[f]];
-    float4 aring[kRing][TM];
+        for (int f = 0; f < kNF; ++f) fv[c][f] = buf_load(xres, goff[f], c * chan_bytes);
+    float4 aring[kRing];
 #pragma unroll
-    for (int u = 0; u < kRing; ++u)
-#pragma unroll
-        for (int t = 0; t < TM; ++t) aring[u][t] = (wrow[t] + (u < G ? u : G - 1) * 64)[lane];
+    for (int u = 0; u < kRing; ++u) aring[u] = buf_load4(wres, wvoff, (unsigned)(u < G ? u : G - 1) * 1024u);
 #pragma unroll
     for (int c = 0; c < kCC; ++c)
 #pragma unroll
-        for (int f = 0; f < kNF; ++f) halo[c * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[c][f] : 0.f;
+        for (int f = 0; f < kNF; ++f) sdst[f][c * kHS] = fv[c][f];
     __syncthreads();
 
     const int nstage = a.Cin / kCC;
     int gbase = kRing;  // first group index to prefetch in this stage
-    for (int s = 0; s < nstage; ++s) {
-        const float* cur = halo + (s & 1) * (kCC * kHS);
-        float* nxt = halo + ((s + 1) & 1) * (kCC * kHS);
+
+    auto stage = [&](auto tag, int s) {
+        constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
         int cnext = (s + 1) * kCC;
         cnext = cnext > a.Cin - kCC ? a.Cin - kCC : cnext;
-        const float* xs = xn + (long)cnext * I3;
-        const float* hb0 = cur + lanebase;
+        const unsigned xs = (unsigned)cnext * chan_bytes;
         float bq[TN][4];  // B fragments of the first group
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
-            bq[u][0] = hb0[u * kTNOFF];
-            bq[u][1] = hb0[u * kTNOFF + 1];
-            bq[u][2] = hb0[u * kTNOFF + kROWH];
-            bq[u][3] = hb0[u * kTNOFF + kROWH + 1];
+            const lds_float* hb = bb[CUR][0][0] + u * kTNOFF;
+            bq[u][0] = hb[0];
+            bq[u][1] = hb[1];
+            bq[u][2] = hb[kROWH];
+            bq[u][3] = hb[kROWH + 1];
         }
         // sched_barrier(0): the machine scheduler otherwise sinks every load to just before its use (to save registers),
         // which turns the ring / the early copy loads into load -> s_waitcnt vmcnt(0) -> use
@@ -175,23 +220,18 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
         for (int ci = 0; ci < kCC; ++ci) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // k-group j of channel ci: kd = j >> 1, kh pair = j & 1
-                float4 a_cur[TM];
-#pragma unroll
-                for (int t = 0; t < TM; ++t) a_cur[t] = aring[(ci * 8 + j) % kRing][t];
+                const float4 a_cur = aring[(ci * 8 + j) % kRing];
                 int gi = gbase + ci * 8 + j;
                 gi = gi < G ? gi : G - 1;
-#pragma unroll
-                for (int t = 0; t < TM; ++t)
-                    if (!(SG_ABLATE & 4)) aring[(ci * 8 + j) % kRing][t] = (wrow[t] + (long)gi * 64)[lane];
+                if (!(SG_ABLATE & 4)) aring[(ci * 8 + j) % kRing] = buf_load4(wres, wvoff, (unsigned)gi * 1024u);
                 {  // copy of the next box: element e is loaded in group e*24/NE and stored 8 groups later
                     constexpr int NE = kCC * kNF;
                     const int gidx = ci * 8 + j;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
                         const int c = e / kNF, f = e % kNF;
-                        if (e * 24 / NE + 8 == gidx && !(SG_ABLATE & 2))
-                            nxt[c * kHS + loff[f]] = ((okmask >> f) & 1u) ? fv[c][f] : 0.f;
-                        if (e * 24 / NE == gidx && !(SG_ABLATE & 3)) fv[c][f] = (xs + (long)c * I3)[goff[f]];
+                        if (e * 24 / NE + 8 == gidx && !(SG_ABLATE & 2)) sdst[f][NXT * kBUF + c * kHS] = fv[c][f];
+                        if (e * 24 / NE == gidx && !(SG_ABLATE & 3)) fv[c][f] = buf_load(xres, goff[f], xs + c * chan_bytes);
                     }
                 }
                 float b[TN][4];
@@ -201,7 +241,7 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
                     for (int k = 0; k < 4; ++k) b[u][k] = bq[u][k];
                 if (!(ci == kCC - 1 && j == 7) && !(SG_ABLATE & 16)) {  // B fragments of the next group of this stage
                     const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
-                    const float* hb = cur + lanebase + cin * kHS + (jn >> 1) * kROWD + (2 * (jn & 1)) * kROWH;
+                    const lds_float* hb = bb[CUR][cin][jn >> 1] + (2 * (jn & 1)) * kROWH;
 #pragma unroll
                     for (int u = 0; u < TN; ++u) {
                         bq[u][0] = hb[u * kTNOFF];
@@ -214,40 +254,38 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int t = 0; t < TM; ++t)
-#pragma unroll
-                        for (int u = 0; u < TN; ++u) {
-                            const float av = k == 0 ? a_cur[t].x : (k == 1 ? a_cur[t].y : (k == 2 ? a_cur[t].z : a_cur[t].w));
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][k], acc[t][u], 0, 0, 0);
-                        }
+                    for (int u = 0; u < TN; ++u) {
+                        const float av = k == 0 ? a_cur.x : (k == 1 ? a_cur.y : (k == 2 ? a_cur.z : a_cur.w));
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][k], acc[u], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         gbase += 8 * kCC;
         __syncthreads();  // next box complete and visible; everyone is done reading the current one
+    };
+    for (int s = 0; s + 1 < nstage; s += 2) {   // stages in pairs: the buffer index is a compile-time constant
+        stage(IntTag<0>(), s);
+        stage(IntTag<1>(), s + 1);
     }
+    if (nstage & 1) stage(IntTag<0>(), nstage - 1);
 
     // epilogue: y[n][co][od][oh0+ph][ow0+pw] = act(acc + bias[co]); all bias loads are issued before the first use
     const long O3 = (long)a.g.OD * a.g.OH * a.g.OW;
-    float bv[TM][16];
+    float bv[16];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-            bv[t][q] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
-        }
+    for (int q = 0; q < 16; ++q) {
+        const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+        bv[q] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
+    }
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int ph = (wn * TN + u) * 4 + (r >> 3), pw = r & 7;
         float* yo = a.y + (long)n * a.Cout * O3 + ((long)od * a.g.OH + (oh0 + ph)) * a.g.OW + (ow0 + pw);
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int co = co0 + (wm * TM + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-                if (co < a.Cout) yo[(long)co * O3] = sg_apply_act(acc[t][u][q] + bv[t][q], a.act, a.slope);
-            }
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+            if (co < a.Cout) yo[(long)co * O3] = sg_apply_act(acc[u][q] + bv[q], a.act, a.slope);
         }
     }
 }
@@ -259,6 +297,7 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
                  hipStream_t stream, int force, int debug) {
     // eligible: 8x8 position tiles exist, whole stages of 4 channels, enough output channels to fill 64-row MFMA tiles
     if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin % kCC != 0 || Cin < 8 || Cout < 32) return 0;
+    if ((long)g.Cx * g.ID * g.IH * g.IW * 4 >= (long)kBufRange || (long)Cin * 8 * 1024 >= (long)kBufRange) return 0;
     if (!workspace || workspace_bytes < halo_fwd_workspace_bytes(Cin, Cout)) return 0;
     if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
     // configuration: 128 output channels per workgroup as 8 waves x 1 tile (variant 0, more waves per SIMD to hide the
@@ -273,7 +312,7 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     // below that the split-K gather kernel is faster
     if (!force && tiles * mtiles < 384) return 0;
     if (tiles >= (1L << 31)) return 0;
-    if (variant == 0) variant = 1;   // 1 = 4 waves x (32 rows x 64 positions), 2 = 8 waves x (32 x 32): A/B only
+    if (variant == 0) variant = 2;   // 1 = 4 waves x (32 rows x 64 positions), 2 = 8 waves x (32 x 32): measured 143-146 vs 139-143 TF
     size_t lds = (size_t)2 * kCC * kHS * sizeof(float);
     // Registers and LDS would admit 3 workgroups per CU; with fewer than ~4 rounds of workgroups that leaves a mostly
     // idle last round (1024 workgroups: 768 + 256), so ask for enough LDS to cap the CU at 2 (debug bit 6: don't)
@@ -304,11 +343,11 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.slope = slope;
     dim3 grid((unsigned)tiles, mtiles);
     if (rows == 128 && variant == 2)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 1, 8>), grid, dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 8>), grid, dim3(512), lds, stream, a);
     else if (rows == 128)
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 2, 4>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<2, 4>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 1, 4>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_fwd_halo_kernel<1, 4>), grid, dim3(256), lds, stream, a);
     return 1;
 }
 
