@@ -445,15 +445,30 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
+    // No VALU work in the stage loop (see the addressing helpers above): buffer loads for dy and the weight image, one
+    // pinned LDS read address per (buffer, channel), stage loop unrolled by the buffer index.
+    lds_float* const bl = (lds_float*)box;
+    const lds_float* bb[2][kDCC];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < kDCC; ++c) {
+            bb[b][c] = bl + b * kDBUF + c * kDB + lanebase;
+            pin_vgpr(bb[b][c]);
+        }
+    lds_float* sdst = bl + tid;   // element f of a stage goes to sdst[256 f] (+ buffer)
+    pin_vgpr(sdst);
+
     const int G = a.Cout;  // one k-group per output channel
-    const float4* wrow = a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64);
+    const unsigned wvoff = lane * 16;
 
     // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw); a buffer
     // holds kDNF*256 floats, so every thread stores all its elements (those beyond the box land in the unread tail) ----
     const int O3 = a.g.OD * a.g.OH * a.g.OW;
-    const float* dyn = a.dy + (long)n * a.g.Cy * O3;
-    unsigned goff[kDNF];  // offset from dyn of channel 0 of the stage (0 when the value is replaced by zero)
-    unsigned okmask = 0;
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy + (long)n * a.g.Cy * O3);
+    const unsigned chan_bytes = (unsigned)O3 * 4u;
+    unsigned goff[kDNF];  // byte offset from channel 0 of the stage; kBufOutside where the box holds zero
 #pragma unroll
     for (int f = 0; f < kDNF; ++f) {
         const int e = tid + 256 * f;
@@ -467,40 +482,39 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         const int od = qd0 + pd - 1 + hd, oh = qh0 + ph - 1 + hh, ow = qw0 + pw - 1 + hw;
         const bool ok = e < kDCC * kDB && (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH &&
                         (unsigned)ow < (unsigned)a.g.OW && (int)n + smp < a.batch;
-        goff[f] = ok ? (unsigned)((smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow) : 0u;
-        okmask |= ok ? (1u << f) : 0u;
+        goff[f] = ok ? (unsigned)((smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow) * 4u : kBufOutside;
+        pin_vgpr(goff[f]);
     }
     float fv[kDNF];
     constexpr int kRing = 8;
     float4 aring[kRing];
 #pragma unroll
-    for (int f = 0; f < kDNF; ++f) fv[f] = dyn[goff[f]];
+    for (int f = 0; f < kDNF; ++f) fv[f] = buf_load(dres, goff[f], 0);
 #pragma unroll
-    for (int u = 0; u < kRing; ++u) aring[u] = (wrow + (u < G ? u : G - 1) * 64)[lane];
+    for (int u = 0; u < kRing; ++u) aring[u] = buf_load4(wres, wvoff, (unsigned)(u < G ? u : G - 1) * 1024u);
 #pragma unroll
-    for (int f = 0; f < kDNF; ++f) box[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
+    for (int f = 0; f < kDNF; ++f) sdst[256 * f] = fv[f];
     __syncthreads();
 
     // The stage loop body is one basic block (no data-dependent branch): copy loads of the next box spread over the first
-    // half of the stage, their LDS stores over the second half, packed weights in a ring of 8 groups; sched_barriers keep the machine
-    // scheduler from sinking the loads to their uses (see conv_fwd_halo_kernel).
+    // half of the stage, their LDS stores over the second half, packed weights in a ring of 8 groups; sched_barriers keep
+    // the machine scheduler from sinking the loads to their uses (see conv_fwd_halo_kernel).
     constexpr int O00 = BX::PL + BX::BW, O01 = BX::PL, O10 = BX::BW, O11 = 0;  // (td,th) -> box offset
     const int nstage = a.Cout / kDCC;
     int gbase = kRing;
-    for (int s = 0; s < nstage; ++s) {
-        const float* cur = box + (s & 1) * kDBUF;
-        float* nxt = box + ((s + 1) & 1) * kDBUF;
+    auto stage = [&](auto tag, int s) {
+        constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
         int cnext = (s + 1) * kDCC;
         cnext = cnext > a.Cout - kDCC ? a.Cout - kDCC : cnext;  // last stage: re-copy into the idle buffer
-        const float* dys = dyn + (long)cnext * O3;
-        const float* hb0 = cur + lanebase;
+        const unsigned dys = (unsigned)cnext * chan_bytes;
         float bq[2][4];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            bq[tn][0] = hb0[tn * BX::TNOFF + O00];   // j=0: td=0, th=0
-            bq[tn][1] = hb0[tn * BX::TNOFF + O01];   // j=1: td=0, th=1
-            bq[tn][2] = hb0[tn * BX::TNOFF + O10];   // j=2: td=1, th=0
-            bq[tn][3] = hb0[tn * BX::TNOFF + O11];   // j=3: td=1, th=1
+            const lds_float* hb = bb[CUR][0] + tn * BX::TNOFF;
+            bq[tn][0] = hb[O00];   // j=0: td=0, th=0
+            bq[tn][1] = hb[O01];   // j=1: td=0, th=1
+            bq[tn][2] = hb[O10];   // j=2: td=1, th=0
+            bq[tn][3] = hb[O11];   // j=3: td=1, th=1
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -508,29 +522,28 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             const float4 a_cur = aring[c % kRing];
             int gi = gbase + c;
             gi = gi < G ? gi : G - 1;
-            aring[c % kRing] = (wrow + (long)gi * 64)[lane];
+            aring[c % kRing] = buf_load4(wres, wvoff, (unsigned)gi * 1024u);
             float b[2][4];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[tn][j] = bq[tn][j];
             if (c + 1 < kDCC) {
-                const float* hb = hb0 + (c + 1) * kDB;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    bq[tn][0] = hb[tn * BX::TNOFF + O00];
-                    bq[tn][1] = hb[tn * BX::TNOFF + O01];
-                    bq[tn][2] = hb[tn * BX::TNOFF + O10];
-                    bq[tn][3] = hb[tn * BX::TNOFF + O11];
+                    const lds_float* hb = bb[CUR][c + 1] + tn * BX::TNOFF;
+                    bq[tn][0] = hb[O00];
+                    bq[tn][1] = hb[O01];
+                    bq[tn][2] = hb[O10];
+                    bq[tn][3] = hb[O11];
                 }
             }
             if (c < kDCC / 2) {  // copy of the next box: two loads per group in the first half of the stage ...
 #pragma unroll
-                for (int f = 2 * c; f < 2 * c + 2; ++f) fv[f] = dys[goff[f]];
+                for (int f = 2 * c; f < 2 * c + 2; ++f) fv[f] = buf_load(dres, goff[f], dys);
             } else {             // ... each value goes to LDS 8 groups after its load
 #pragma unroll
-                for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f)
-                    nxt[tid + 256 * f] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
+                for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f) sdst[NXT * kDBUF + 256 * f] = fv[f];
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[0][0], acc[0], 0, 0, 0);
@@ -545,7 +558,12 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         }
         gbase += kDCC;
         __syncthreads();
+    };
+    for (int s = 0; s + 1 < nstage; s += 2) {
+        stage(IntTag<0>(), s);
+        stage(IntTag<1>(), s + 1);
     }
+    if (nstage & 1) stage(IntTag<0>(), nstage - 1);
 
     // epilogue: dx[n'][ci][2 qd + pd][2 qh + ph][2 qw + pw] = act(acc + bias[ci])
     const long I3 = (long)a.g.ID * a.g.IH * a.g.IW;
@@ -589,6 +607,7 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     if (Cout % kDCC != 0 || Cin < 32) return 0;
     if (!workspace || workspace_bytes < halo_dgrad_workspace_bytes(Cin, Cout)) return 0;
     if ((long)batch * g.Cy * g.OD * g.OH * g.OW >= (1L << 31)) return 0;
+    if ((long)2 * g.Cy * g.OD * g.OH * g.OW * 4 >= (long)kBufRange || (long)Cout * 1024 >= (long)kBufRange) return 0;
     const int ntw = mode1 ? 1 : g.OW / 8, nth = mode1 ? 1 : g.OH / 8, ntd = mode1 ? 1 : g.OD / 2;
     const long tiles = mode1 ? (batch + 1) / 2 : (long)batch * ntd * nth * ntw;
     const int mtiles = (Cin + 63) / 64;
@@ -616,13 +635,18 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     a.dntd = FastDiv(ntd);
     a.act = act;
     a.slope = slope;
-    if (mode1) {
-        const size_t lds = (size_t)2 * kDBUF * sizeof(float);
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
-    } else {
-        const size_t lds = (size_t)2 * kDBUF * sizeof(float);
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    // registers admit 3 workgroups per CU; take 3 only when the grid then needs fewer CU-slots in total (a 2048-workgroup
+    // grid is 4 full rounds at 2 per CU but 2.67 rounds at 3): otherwise a larger LDS request caps the CU at 2
+    size_t lds = (size_t)2 * kDBUF * sizeof(float);
+    {
+        const long wgs = tiles * mtiles * 8;
+        const long cost2 = ((wgs + 511) / 512) * 2, cost3 = ((wgs + 767) / 768) * 3;
+        if (cost2 <= cost3) lds = 56 * 1024;
     }
+    if (mode1)
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
     return 1;
 }
 
@@ -704,80 +728,97 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     // ---- copy bookkeeping: element f is (channel c = f / 9, row 8*(f%9) + tid/32, column tid%32) of the 2-channel box.
-    // Threads outside the box store to an unread pad slot (column 9 of a half row), out-of-range voxels load a clamped
-    // address and store zero: no branch in the stage loop ----
+    // The box moves with the slice, so the global address has a per-thread part that never changes (voff: position inside
+    // the box and channel) and a per-stage part that is the same for every thread (scalar: sample, channel pair, box
+    // origin — folded into the buffer resource's base).  Whether an element is padding depends on the slice only
+    // through six edge flags (first / last tile in D, H, W): the element's class bits sit in bits 26..31 of `cls`, the
+    // stage's flags in the same bits of a scalar, and (cls & flags) | voff is >= num_records (2^26) exactly for padding —
+    // one v_and_or_b32 per element per stage is all the vector work the copy needs; the hardware returns 0 for those.
+    // Threads outside the box store to an unread pad slot (column 9 of a half row). ----
     const int I3 = a.g.ID * a.g.IH * a.g.IW;
     const int fl_w = tid & 31, frow = tid >> 5;
     const int lds_w = (fl_w & 1) * kHWH + (fl_w >> 1);
     const int prow = (tid >> 1) % (kHD * kHH);
     const int pad = (prow / kHH) * kWROWD + (prow % kHH) * kROWH + (tid & 1) * kHWH + (kHWH - 1);
-    int rowoff[kWNF / 2];   // LDS offset of the row inside a channel; identical for both channels
-    int hdv[kWNF / 2], hhv[kWNF / 2];
-    unsigned inmask = 0;
+    lds_float* const wl = (lds_float*)wbox;
+    lds_float* sdst[kWNF / 2];   // LDS destination of the row inside (buffer 0, channel 0); identical for both channels
+    unsigned voff[kWNF], cls[kWNF];
 #pragma unroll
     for (int f = 0; f < kWNF / 2; ++f) {
         const int row = 8 * f + frow;
-        hdv[f] = row / kHH;
-        hhv[f] = row - hdv[f] * kHH;
+        const int hd = row / kHH, hh = row - hd * kHH;
         const bool inbox = fl_w < kHWF && row < kHD * kHH;
-        rowoff[f] = inbox ? hdv[f] * kWROWD + hhv[f] * kROWH + lds_w : pad;
-        inmask |= inbox ? (1u << f) : 0u;
+        sdst[f] = wl + (inbox ? hd * kWROWD + hh * kROWH + lds_w : pad);
+        pin_vgpr(sdst[f]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bool ok = inbox && (ci0 + c) < a.Cin;
+            voff[c * (kWNF / 2) + f] = ok ? (unsigned)(c * I3 + (hd * a.g.IH + hh) * a.g.IW + fl_w) * 4u : kBufOutside;
+            cls[c * (kWNF / 2) + f] = (hd == 0 ? 1u << 26 : 0u) | (hd == kHD - 1 ? 1u << 27 : 0u) | (hh == 0 ? 1u << 28 : 0u) |
+                                      (hh == kHH - 1 ? 1u << 29 : 0u) | (fl_w == 0 ? 1u << 30 : 0u) |
+                                      (fl_w == kHWF - 1 ? 1u << 31 : 0u);
+            pin_vgpr(voff[c * (kWNF / 2) + f]);
+            pin_vgpr(cls[c * (kWNF / 2) + f]);
+        }
     }
     float fv[kWNF];
-    unsigned okmask = 0;
-    unsigned goff[kWNF];
-    const float* xb = a.x;
-    auto copy_prepare = [&](int sl) {  // geometry of slice sl -> offsets / validity of the kWNF elements of its box
+    unsigned eoff[kWNF];   // per stage: (cls & flags) | voff
+    __amdgpu_buffer_rsrc_t xres;
+    const int ntw_ = (int)a.g.OW / 8, nth_ = (int)a.g.OH / 8;
+    auto copy_prepare = [&](int sl) {  // slice sl -> resource base at the box origin + the padding offsets (scalar work + 18 VALU)
         uint32_t twi, thi, od, n, q1, q2;
         a.dntw.divmod((uint32_t)sl, q1, twi);
         a.dnth.divmod(q1, q2, thi);
         a.dOD.divmod(q2, n, od);
-        const int iw = 2 * (int)twi * 8 - 1 + fl_w;
-        const bool wok = fl_w < kHWF && (unsigned)iw < (unsigned)a.g.IW;
-        xb = a.x + (long)n * a.g.Cx * I3;  // uniform
-        okmask = 0;
+        const long origin = ((long)n * a.g.Cx + ci0) * I3 + ((2 * (long)od - 1) * a.g.IH + (16 * (long)thi - 1)) * a.g.IW +
+                            (16 * (long)twi - 1);   // may point before the tensor: those elements are padding
+        xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + origin), 0, 1 << 26, 0x00020000);
+        const unsigned flags = (od == 0 ? 1u << 26 : 0u) | ((int)od == a.g.OD - 1 ? 1u << 27 : 0u) | (thi == 0 ? 1u << 28 : 0u) |
+                               ((int)thi == nth_ - 1 ? 1u << 29 : 0u) | (twi == 0 ? 1u << 30 : 0u) |
+                               ((int)twi == ntw_ - 1 ? 1u << 31 : 0u);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) {
-            const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
-            const int id = 2 * (int)od - 1 + hdv[fr], ih = 2 * (int)thi * 8 - 1 + hhv[fr];
-            const bool ok = wok && ((inmask >> fr) & 1u) && (ci0 + c) < a.Cin && (unsigned)id < (unsigned)a.g.ID &&
-                            (unsigned)ih < (unsigned)a.g.IH;
-            goff[f] = ok ? (unsigned)((ci0 + c) * I3 + (id * a.g.IH + ih) * a.g.IW + iw) : 0u;
-            okmask |= ok ? (1u << f) : 0u;
-        }
-    };
-    auto copy_store = [&](int f, float* buf) {
-        const int c = f / (kWNF / 2), fr = f % (kWNF / 2);
-        buf[c * kWHS + rowoff[fr]] = ((okmask >> f) & 1u) ? fv[f] : 0.f;
+        for (int f = 0; f < kWNF; ++f) eoff[f] = (cls[f] & flags) | voff[f];
     };
 
     const int nst = s_end - s_beg;
     constexpr int kRing = 8;  // A fragments: ring of 8 k-groups (one stage); group index runs over (slice, gq)
-    const float4* arow[2];    // wave-uniform
-#pragma unroll
-    for (int t = 0; t < 2; ++t) arow[t] = a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64;
     const int G = nst * 8;
     if (nst > 0) {
+        __amdgpu_buffer_rsrc_t ares[2];   // packed dy of this wave's two 32-row tiles
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ares[t] = make_rsrc(a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64);
+        const unsigned avoff = lane * 16;
+        // B-fragment read addresses: (buffer, column tile, k-groups 0-3 / 4-7); the rest are immediates
+        const lds_float* bb[2][2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bb[b][tn][h] = wl + b * (2 * kWHS) + lanebase[tn] + h * (8 * kROWH);
+                    pin_vgpr(bb[b][tn][h]);
+                }
+
         copy_prepare(s_beg);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) fv[f] = xb[goff[f]];
+        for (int f = 0; f < kWNF; ++f) fv[f] = buf_load(xres, eoff[f], 0);
         float4 aring[kRing][2];
 #pragma unroll
         for (int u = 0; u < kRing; ++u)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) aring[u][t] = (arow[t] + u * 64)[lane];
+            for (int t = 0; t < 2; ++t) aring[u][t] = buf_load4(ares[t], avoff, (unsigned)(u < G ? u : G - 1) * 1024u);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) copy_store(f, wbox);
+        for (int f = 0; f < kWNF; ++f) sdst[f % (kWNF / 2)][(f / (kWNF / 2)) * kWHS] = fv[f];
         __syncthreads();
 
-        for (int st = 0; st < nst; ++st) {
-            const float* cur = wbox + (st & 1) * (2 * kWHS);
-            float* nxt = wbox + ((st + 1) & 1) * (2 * kWHS);
+        auto stage = [&](auto tag, int st) {
+            constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
             const int snext = st + 1 < nst ? st + 1 : st;   // last stage: re-copy into the idle buffer
             float bq[2][4];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                const float* hb = cur + lanebase[tn];
+                const lds_float* hb = bb[CUR][tn][0];
                 bq[tn][0] = hb[0];
                 bq[tn][1] = hb[2];
                 bq[tn][2] = hb[4];
@@ -793,7 +834,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 int gi = (st + 1) * 8 + gq;
                 gi = gi < G ? gi : G - 1;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) aring[gq][t] = (arow[t] + (long)gi * 64)[lane];
+                for (int t = 0; t < 2; ++t) aring[gq][t] = buf_load4(ares[t], avoff, (unsigned)gi * 1024u);
                 float b[2][4];
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
@@ -802,7 +843,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 if (gq + 1 < 8) {
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
-                        const float* hb = cur + lanebase[tn] + 2 * (gq + 1) * kROWH;
+                        const lds_float* hb = bb[CUR][tn][(gq + 1) >> 2] + 2 * ((gq + 1) & 3) * kROWH;
                         bq[tn][0] = hb[0];
                         bq[tn][1] = hb[2];
                         bq[tn][2] = hb[4];
@@ -812,8 +853,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 // copy of the next box: loads spread over groups 0..3, LDS stores 4 groups later
 #pragma unroll
                 for (int f = 0; f < kWNF; ++f) {
-                    if (f * 4 / kWNF == gq) fv[f] = xb[goff[f]];
-                    if (f * 4 / kWNF + 4 == gq) copy_store(f, nxt);
+                    if (f * 4 / kWNF == gq) fv[f] = buf_load(xres, eoff[f], 0);
+                    if (f * 4 / kWNF + 4 == gq) sdst[f % (kWNF / 2)][NXT * (2 * kWHS) + (f / (kWNF / 2)) * kWHS] = fv[f];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -828,7 +869,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
+        };
+        for (int st = 0; st + 1 < nst; st += 2) {
+            stage(IntTag<0>(), st);
+            stage(IntTag<1>(), st + 1);
         }
+        if (nst & 1) stage(IntTag<0>(), nst - 1);
     }
 
     // epilogue: out[split][co][ci*64 + tap]
