@@ -533,12 +533,12 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
 int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                                 int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                                 void* workspace, size_t workspace_bytes, int impl, hipStream_t stream) {
-    SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && impl == 1);
+    SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && (impl == 1 || impl == 3));
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: bad spatial dims");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad_impl")) return SG_ERR_ARG;
     const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
-                                  stream, 1);
+                                  stream, impl);   // 1: forced, 3: forced with 32-channel stages
     if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: shape not eligible for the LDS-halo kernel");
     SG_CHECK_LAUNCH();
     return SG_OK;

@@ -290,11 +290,186 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
     }
 }
 
+// ---- forward form on 4^3 output grids (8^3 inputs: Conv3d 128 -> 256 of the discriminators) ------------------------
+// The 1x8x8 tiling does not exist here; instead the WHOLE zero-padded sample (10^3 per channel) is the box and the 64
+// output voxels of the sample are the 64 columns of the workgroup.  The padding never changes, so it is written once
+// (zero fill of both buffers) and a stage copies only the 8^3 real voxels of its channels with fully coalesced loads.
+// Layout per channel: [10 d][10 h][even w | odd w] with the plane stride padded to 104 floats, which makes the 32-lane
+// fragment read (2 od x 4 oh x 4 ow, strides 208 / 20 / 1) conflict-free.
+// 8 waves: (K half) x (row tile pair) x (position half): waves 0-3 take channels 0-3 of every 8-channel stage, waves 4-7
+// channels 4-7 — a sample has only 64 output positions, so the second wave group comes from splitting K; the two
+// partial accumulators meet in LDS at the end.  Grid = batch x Cout/64.
+constexpr int k4HALF = 5, k4ROW = 10, k4PLANE = 104, k4CH = 10 * k4PLANE;   // 1040 floats per channel
+constexpr int k4CC = 8;                                                      // channels per stage
+constexpr int k4BUF = k4CC * k4CH;                                           // 8320 floats = 33 KB per buffer
+
+__global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
+    constexpr int kRing = 8;
+    extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][k4CC][k4CH]
+    lds_float* const hl = (lds_float*)halo;
+    const int n = blockIdx.x, co0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int p = wn * 32 + r, od = p >> 4, oh = (p >> 2) & 3, ow = p & 3;
+    const int lanebase = 2 * od * k4PLANE + 2 * oh * k4ROW + kpar * k4HALF + ow;
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+    // zero both buffers once: the halo padding is never written again
+    for (int e = tid; e < 2 * k4BUF; e += 512) hl[e] = 0.f;
+
+    const lds_float* bb[2][4][4];   // (buffer, own channel, kd)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) {
+                bb[b][c][kd] = hl + b * k4BUF + (kh * 4 + c) * k4CH + kd * k4PLANE + lanebase;
+                pin_vgpr(bb[b][c][kd]);
+            }
+    const int G = a.Cin * 8;
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + ((long)(co0 / 32 + wm) * G) * 64);
+    const unsigned wvoff = lane * 16;
+
+    // copy: a channel is 512 contiguous floats; thread t moves element t of each of the stage's 8 channels
+    const int I3 = 512;
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x + (long)n * a.g.Cx * I3);
+    unsigned xvoff = tid * 4;
+    lds_float* sdst = hl + ((tid >> 6) + 1) * k4PLANE + (((tid >> 3) & 7) + 1) * k4ROW + (((tid & 7) + 1) & 1) * k4HALF +
+                      (((tid & 7) + 1) >> 1);
+    pin_vgpr(xvoff);
+    pin_vgpr(sdst);
+    float fv[k4CC];
+    __syncthreads();   // zero fill done before the first real voxels land
+#pragma unroll
+    for (int c = 0; c < k4CC; ++c) fv[c] = buf_load(xres, xvoff, c * (I3 * 4));
+    // weight groups of this wave in order: stage s, own channel c, j -> group (s*8 + kh*4 + c)*8 + j = s*64 + kh*32 + (c*8+j)
+    const int nstage = a.Cin / k4CC, nq = nstage * 32;
+    auto group_of = [&](int q) {
+        q = q < nq ? q : nq - 1;
+        return (q >> 5) * 64 + kh * 32 + (q & 31);
+    };
+    float4 aring[kRing];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) aring[u] = buf_load4(wres, wvoff, (unsigned)group_of(u) * 1024u);
+#pragma unroll
+    for (int c = 0; c < k4CC; ++c) sdst[c * k4CH] = fv[c];
+    __syncthreads();
+
+    int qbase = kRing;
+    auto stage = [&](auto tag, int s) {
+        constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+        int cnext = (s + 1) * k4CC;
+        cnext = cnext > a.Cin - k4CC ? a.Cin - k4CC : cnext;
+        const unsigned xs = (unsigned)cnext * (I3 * 4);
+        float bq[4];
+        {
+            const lds_float* hb = bb[CUR][0][0];
+            bq[0] = hb[0];
+            bq[1] = hb[1];
+            bq[2] = hb[k4ROW];
+            bq[3] = hb[k4ROW + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int gidx = ci * 8 + j;
+                const float4 a_cur = aring[gidx % kRing];
+                aring[gidx % kRing] = buf_load4(wres, wvoff, (unsigned)group_of(qbase + gidx) * 1024u);
+                // copy of the next box: channel c is loaded in group 2c and stored in group 2c + 8
+#pragma unroll
+                for (int c = 0; c < k4CC; ++c) {
+                    if (2 * c + 8 == gidx) sdst[NXT * k4BUF + c * k4CH] = fv[c];
+                    if (2 * c == gidx) fv[c] = buf_load(xres, xvoff, xs + c * (I3 * 4));
+                }
+                float b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] = bq[k];
+                if (gidx + 1 < 32) {
+                    const int jn = (j + 1) & 7, cin = ci + ((j + 1) >> 3);
+                    const lds_float* hb = bb[CUR][cin][jn >> 1] + (2 * (jn & 1)) * k4ROW;
+                    bq[0] = hb[0];
+                    bq[1] = hb[1];
+                    bq[2] = hb[k4ROW];
+                    bq[3] = hb[k4ROW + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[3], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        qbase += 32;
+        __syncthreads();
+    };
+    for (int s = 0; s + 1 < nstage; s += 2) {
+        stage(IntTag<0>(), s);
+        stage(IntTag<1>(), s + 1);
+    }
+    if (nstage & 1) stage(IntTag<0>(), nstage - 1);
+
+    // the K halves meet in LDS (the boxes are dead after the last barrier): waves 4-7 park, waves 0-3 add and store
+    float* red = halo + ((wave & 3) * 16) * 64;
+    if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[q * 64 + lane] = acc[q];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    // y[n][co][p], p = od*16 + oh*4 + ow: 32 consecutive floats per (co, position half)
+    float* yo = a.y + (long)n * a.Cout * 64 + p;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+        if (co < a.Cout) {
+            const float bv = a.bias ? a.bias[co] : 0.f;
+            yo[(long)co * 64] = sg_apply_act(acc[q] + red[q * 64 + lane] + bv, a.act, a.slope);
+        }
+    }
+}
+
 size_t halo_fwd_workspace_bytes(int Cin, int Cout) { return (size_t)((Cout + 127) / 128) * 128 * Cin * 64 * sizeof(float); }
 
 int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                  const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                  hipStream_t stream, int force, int debug) {
+    // 4^3 outputs: the whole-sample box kernel (8-channel stages, 64-row tiles)
+    if (g.OD == 4 && g.OH == 4 && g.OW == 4) {
+        if (Cin % k4CC != 0 || Cin < 2 * k4CC || Cout < 32) return 0;
+        if (!workspace || workspace_bytes < halo_fwd_workspace_bytes(Cin, Cout)) return 0;
+        if ((long)g.Cx * 512 * 4 >= (long)kBufRange || (long)Cin * 8 * 1024 >= (long)kBufRange || batch > 65535 * 16) return 0;
+        const int mtiles = sg_cdiv(Cout, 64);
+        if (!force && (long)batch * mtiles < 256) return 0;
+        float4* wp = (float4*)workspace;
+        const int ntile = mtiles * 2;
+        const long total = (long)ntile * Cin * 8 * 64;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wp, Cout, Cin_total, Cin, ntile);
+        HaloFwdArgs a;
+        a.x = x;
+        a.wp = wp;
+        a.bias = bias;
+        a.y = y;
+        a.g = g;
+        a.Cin = Cin;
+        a.Cout = Cout;
+        a.nth = a.ntw = 1;
+        a.dntw = a.dnth = a.dOD = FastDiv(1);
+        a.act = act;
+        a.slope = slope;
+        hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles), dim3(512), (size_t)2 * k4BUF * sizeof(float),
+                           stream, a);
+        return 1;
+    }
     // eligible: 8x8 position tiles exist, whole stages of 4 channels, enough output channels to fill 64-row MFMA tiles
     if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin % kCC != 0 || Cin < 8 || Cout < 32) return 0;
     if ((long)g.Cx * g.ID * g.IH * g.IW * 4 >= (long)kBufRange || (long)Cin * 8 * 1024 >= (long)kBufRange) return 0;
@@ -371,9 +546,8 @@ template <>
 struct DBox<1> {
     static constexpr int BH = 5, BW = 5, PL = 25, CH = 250, TNOFF = 50, WNOFF = 125;
 };
-constexpr int kDCC = 16;         // channels per stage: 16 k-groups, 128 MFMAs per wave
-constexpr int kDNF = 16;         // copy elements per thread per stage (3888 resp. 4000 box floats / 256 threads)
-constexpr int kDBUF = kDNF * 256; // floats per LDS buffer (box + unread tail)
+// Channels per stage (template CC): 32 when the channel count allows (256 MFMAs per wave between barriers, 64 KB LDS),
+// else 16.  A stage copies CC * ~245 box floats = CC elements per thread into an LDS buffer of CC*256 floats.
 
 struct HaloDgradArgs {
     const float* dy;
@@ -415,8 +589,9 @@ __global__ void __launch_bounds__(256) pack_dgrad_frag_kernel(const float* __res
     }
 }
 
-template <int MODE>
+template <int MODE, int CC>
 __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
+    constexpr int kDCC = CC, kDNF = CC, kDBUF = CC * 256;   // channels per stage = copy elements per thread; floats per LDS buffer
     using BX = DBox<MODE>;
     constexpr int kDB = BX::CH;
     extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDBUF], a buffer = [kDCC][kDB] + tail
@@ -437,7 +612,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
     // lane -> position inside a 32-position column tile; address of tap (td,th): lanebase + tn*TNOFF + (1-td)*PL + (1-th)*BW
     const int lpart = MODE == 0 ? (r >> 3) * BX::BW + (r & 7) : (r >> 4) * BX::PL + ((r >> 2) & 3) * BX::BW + (r & 3);
-    const int lanebase = wn * BX::WNOFF + lpart + 1 - kpar;
+    const int lanebase = (SG_ABLATE & 256) ? r + 1 - kpar : wn * BX::WNOFF + lpart + 1 - kpar;
 
     f32x16 acc[2];
 #pragma unroll
@@ -604,7 +779,8 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    hipStream_t stream, int force) {
     const bool mode1 = g.OD == 4 && g.OH == 4 && g.OW == 4;
     if (!mode1 && (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0)) return 0;
-    if (Cout % kDCC != 0 || Cin < 32) return 0;
+    if (Cout % 16 != 0 || Cin < 32) return 0;
+    const int cc = (Cout % 32 == 0 && (force & 2)) ? 32 : 16;   // 32-channel stages measured 3 % slower (impl 3: A/B)
     if (!workspace || workspace_bytes < halo_dgrad_workspace_bytes(Cin, Cout)) return 0;
     if ((long)batch * g.Cy * g.OD * g.OH * g.OW >= (1L << 31)) return 0;
     if ((long)2 * g.Cy * g.OD * g.OH * g.OW * 4 >= (long)kBufRange || (long)Cout * 1024 >= (long)kBufRange) return 0;
@@ -637,16 +813,21 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     a.slope = slope;
     // registers admit 3 workgroups per CU; take 3 only when the grid then needs fewer CU-slots in total (a 2048-workgroup
     // grid is 4 full rounds at 2 per CU but 2.67 rounds at 3): otherwise a larger LDS request caps the CU at 2
-    size_t lds = (size_t)2 * kDBUF * sizeof(float);
-    {
+    size_t lds = (size_t)2 * cc * 256 * sizeof(float);
+    if (cc == 16) {
         const long wgs = tiles * mtiles * 8;
         const long cost2 = ((wgs + 511) / 512) * 2, cost3 = ((wgs + 767) / 768) * 3;
         if (cost2 <= cost3) lds = 56 * 1024;
     }
-    if (mode1)
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+    const dim3 grid((unsigned)tiles, mtiles, 8);
+    if (mode1 && cc == 32)
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1, 32>), grid, dim3(256), lds, stream, a);
+    else if (mode1)
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1, 16>), grid, dim3(256), lds, stream, a);
+    else if (cc == 32)
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0, 32>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), dim3((unsigned)tiles, mtiles, 8), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0, 16>), grid, dim3(256), lds, stream, a);
     return 1;
 }
 

@@ -37,11 +37,23 @@ struct GemmEpi {
 // sum over rows: out[j] = sum_i x[i*ld + j]   (bias gradients of Linear / 1^3 convs)
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
                                                      int cols, long ld) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
-    float s = 0.f;
-    for (int i = 0; i < rows; ++i) s += x[(long)i * ld + j];
-    out[j] = s;
+    // one workgroup per strip of 64 columns: 4 waves take interleaved rows (a single thread walking every row of its
+    // column is a chain of `rows` dependent loads: 23 us for a 128 x 256 bias-gradient matrix), LDS-reduced at the end
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < cols) {
+        int i = wave;
+        for (; i + 4 < rows; i += 8) {
+            s0 += x[(long)i * ld + j];
+            s1 += x[(long)(i + 4) * ld + j];
+        }
+        if (i < rows) s0 += x[(long)i * ld + j];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && j < cols) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // out[r] = sum_{e<len} x[r*ld + e]: one 256-thread workgroup per row (float4 stream, wave shuffles, LDS across waves).
@@ -124,7 +136,7 @@ int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long s
 
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream) {
     SG_CHECK_ARG(x && out && rows > 0 && cols > 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(sg_cdiv(cols, 256)), dim3(256), 0, stream, x, out, rows, cols, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3(sg_cdiv(cols, 64)), dim3(256), 0, stream, x, out, rows, cols, ld);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -68,15 +68,15 @@ def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
     return dx
 
 
-def conv_dgrad_halo_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
-    """dgrad through the forced LDS-halo kernel — tests and tuning only."""
+def conv_dgrad_halo_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, impl=1):
+    """dgrad through the forced LDS-halo kernel (impl 3: 32-channel stages) — tests and tuning only."""
     N, Co, OD, OH, OW = dy.shape
     Ct = w.shape[1]
     dx = torch.empty((N, cin, 2 * OD, 2 * OH, 2 * OW), dtype=torch.float32, device=dy.device)
     lib = _lib()
     ws = workspace("dgrad", lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes(Co, cin), dy.device)
     check(lib.sg_conv3d_k4s2p1_dgrad_impl(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH,
-                                          2 * OW, act, slope, ptr(ws), ws.numel(), 1, stream()), "conv3d_dgrad_impl")
+                                          2 * OW, act, slope, ptr(ws), ws.numel(), impl, stream()), "conv3d_dgrad_impl")
     return dx
 
 

@@ -370,7 +370,8 @@ def test_sdfnet_chairs_known_answers(golden_sdf, chairs_state):
 
 
 @pytest.mark.parametrize("N,Ci,Co,R", [(2, 64, 128, 16), (1, 8, 32, 16), (2, 24, 48, 16), (1, 32, 64, 32), (3, 16, 96, 16),
-                                       (1, 128, 256, 16), (1, 12, 40, 16), (2, 4 * 17, 130, 16)])
+                                       (1, 128, 256, 16), (1, 12, 40, 16), (2, 4 * 17, 130, 16),
+                                       (3, 128, 256, 8), (2, 16, 32, 8), (5, 24, 100, 8), (1, 40, 64, 8)])
 def test_conv_fwd_halo_kernel(N, Ci, Co, R):
     """The LDS-halo forward (forced, whatever the grid size) == the gather kernel == the oracle."""
     from shapegan_amd import ops
