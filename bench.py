@@ -34,9 +34,13 @@ CONV2_FLOP_PER_SAMPLE = 2.0 * 128 * 512 * 64 * 64
 def event_time_ms(fn, iters):
     """Average duration of fn() in ms, measured with HIP events on the stream the kernels are launched on."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(5):   # first launches pay code load / clock ramp
-        fn()
+    fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()   # warm up for ~0.2 s of work: the first launches pay code load and the clock ramp from idle
+    while time.perf_counter() - t0 < 0.2:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     start.record()
     for _ in range(iters):
         fn()

@@ -1077,6 +1077,184 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     }
 }
 
+// ---- wgrad form on 4^3 output grids (8^3 inputs) -----------------------------------------------------------------
+// Same structure as conv_wgrad_halo_kernel with the geometry of conv_fwd_halo4_kernel: a slice is a whole sample (its 64
+// output positions = 8 k-groups), the box is the zero-padded 10^3 sample of the workgroup's two input channels (padding
+// written once, a stage copies 2 x 512 contiguous floats), positions of a group: od = gq >> 1, oh = 2 (gq & 1) + (j >> 1),
+// ow = 2 (j & 1) + kpar.
+// ap[((mt*nslice + sl)*8 + gq)*64 + lane] = float4{ dy[sl][mt*32 + (lane&31)][pos(gq, j, lane>>5)], j = 0..3 }
+__global__ void __launch_bounds__(256) pack_wgrad_dy4_kernel(const float* __restrict__ dy, float4* __restrict__ ap, int Cout,
+                                                             int MT, int nslice) {
+    const long total = (long)MT * nslice * 8 * 64;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const int gq = (int)((e >> 6) & 7);
+        const long q = e >> 9;
+        const long sl = q % nslice;
+        const int mt = (int)(q / nslice);
+        const int co = mt * 32 + (lane & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < Cout) {
+            // j -> position offset (j >> 1) * 4 + 2 (j & 1): j = 0,1,2,3 -> +0, +2, +4, +6
+            const float* src = dy + (sl * Cout + co) * 64 + (gq >> 1) * 16 + (gq & 1) * 8 + (lane >> 5);
+            v = make_float4(src[0], src[2], src[4], src[6]);
+        }
+        ap[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) conv_wgrad_halo4_kernel(HaloWgradArgs a) {
+    constexpr int kBUF = 2 * k4CH;  // two channels per buffer
+    extern __shared__ __attribute__((aligned(16))) float wbox[];  // [2 buffers][2 channels][k4CH]
+    lds_float* const wl = (lds_float*)wbox;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int ci0 = blockIdx.x * 2, mt0 = blockIdx.y * 4, split = blockIdx.z;
+    const int s_beg = split * a.per_split, s_end = min(a.nslice, s_beg + a.per_split);
+    const int nst = s_end - s_beg;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    for (int e = tid; e < 2 * kBUF; e += 256) wl[e] = 0.f;   // the padding, once
+
+    if (nst > 0) {
+        // lane = tap of its column: col = wn*64 + tn*32 + r = (channel wn, tap tn*32 + r); one address per (buffer, tn, od)
+        const lds_float* bb[2][2][4];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int tap = tn * 32 + r, kd = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
+            const int lb = wn * k4CH + kd * k4PLANE + kh * k4ROW + (kw & 1) * k4HALF + (kw >> 1) + kpar;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int od = 0; od < 4; ++od) {
+                    bb[b][tn][od] = wl + b * kBUF + lb + od * (2 * k4PLANE);
+                    pin_vgpr(bb[b][tn][od]);
+                }
+        }
+        // copy: the two channels are 1024 contiguous floats of the sample; thread t moves elements t + 256 f
+        unsigned voff[4];
+        lds_float* sdst[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int e = tid + 256 * f, c = e >> 9, idx = e & 511;
+            const int id = idx >> 6, ih = (idx >> 3) & 7, iw = idx & 7;
+            voff[f] = (ci0 + c) < a.Cin ? (unsigned)e * 4u : kBufOutside;
+            sdst[f] = wl + c * k4CH + (id + 1) * k4PLANE + (ih + 1) * k4ROW + ((iw + 1) & 1) * k4HALF + ((iw + 1) >> 1);
+            pin_vgpr(voff[f]);
+            pin_vgpr(sdst[f]);
+        }
+        __amdgpu_buffer_rsrc_t ares[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ares[t] = make_rsrc(a.ap + ((long)(mt0 + wm * 2 + t) * a.nslice + s_beg) * 8 * 64);
+        const unsigned avoff = lane * 16;
+        const long slice_floats = (long)a.g.Cx * 512;
+        const float* xb = a.x + (long)s_beg * slice_floats + (long)ci0 * 512;
+        const int G = nst * 8;
+        constexpr int kRing = 8;
+        float fv[4];
+        __syncthreads();   // zero fill complete
+        {
+            const __amdgpu_buffer_rsrc_t xres = make_rsrc(xb);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fv[f] = buf_load(xres, voff[f], 0);
+        }
+        float4 aring[kRing][2];
+#pragma unroll
+        for (int u = 0; u < kRing; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) aring[u][t] = buf_load4(ares[t], avoff, (unsigned)(u < G ? u : G - 1) * 1024u);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *sdst[f] = fv[f];
+        __syncthreads();
+
+        auto stage = [&](auto tag, int st) {
+            constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+            const int snext = st + 1 < nst ? st + 1 : st;   // last stage: re-copy into the idle buffer
+            const __amdgpu_buffer_rsrc_t xres = make_rsrc(xb + (long)snext * slice_floats);
+            float bq[2][4];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const lds_float* hb = bb[CUR][tn][0];
+                bq[tn][0] = hb[0];
+                bq[tn][1] = hb[2];
+                bq[tn][2] = hb[2 * k4ROW];
+                bq[tn][3] = hb[2 * k4ROW + 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) {
+                float4 a_cur[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a_cur[t] = aring[gq][t];
+                int gi = (st + 1) * 8 + gq;
+                gi = gi < G ? gi : G - 1;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) aring[gq][t] = buf_load4(ares[t], avoff, (unsigned)gi * 1024u);
+                float b[2][4];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[tn][j] = bq[tn][j];
+                if (gq + 1 < 8) {
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const lds_float* hb = bb[CUR][tn][(gq + 1) >> 1] + ((gq + 1) & 1) * (4 * k4ROW);
+                        bq[tn][0] = hb[0];
+                        bq[tn][1] = hb[2];
+                        bq[tn][2] = hb[2 * k4ROW];
+                        bq[tn][3] = hb[2 * k4ROW + 2];
+                    }
+                }
+                if (gq < 4) fv[gq] = buf_load(xres, voff[gq], 0);                 // copy of the next sample: loads ...
+                else sdst[gq - 4][NXT * kBUF] = fv[gq - 4];                       // ... and stores 4 groups later
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a0 = j == 0 ? a_cur[0].x : (j == 1 ? a_cur[0].y : (j == 2 ? a_cur[0].z : a_cur[0].w));
+                    const float a1 = j == 0 ? a_cur[1].x : (j == 1 ? a_cur[1].y : (j == 2 ? a_cur[1].z : a_cur[1].w));
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[0][j], acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[0][j], acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[1][j], acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[1][j], acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int st = 0; st + 1 < nst; st += 2) {
+            stage(IntTag<0>(), st);
+            stage(IntTag<1>(), st + 1);
+        }
+        if (nst & 1) stage(IntTag<0>(), nst - 1);
+    }
+
+    // epilogue: out[split][co][ci*64 + tap]
+    float* out = a.ws + (long)split * a.Cout * a.ldw;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = wn * 64 + tn * 32 + r;
+        const int ci = ci0 + (col >> 6);
+        if (ci >= a.Cin) continue;
+        const long cbase = (long)ci * 64 + (col & 63);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = (mt0 + wm * 2 + t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+                if (co < a.Cout) out[(long)co * a.ldw + cbase] = acc[t][tn][q];
+            }
+        }
+    }
+}
+
 // sums the split partials [nsplit][Cout][Cin*64] into dw[Cout][Cin_total*64]
 __global__ void __launch_bounds__(256) wgrad_halo_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Cout, int ncol, long ldw, int nsplit) {
@@ -1089,8 +1267,10 @@ __global__ void __launch_bounds__(256) wgrad_halo_finalize_kernel(const float* _
     }
 }
 
+static bool wgrad_mode4(const ConvGeom& g) { return g.OD == 4 && g.OH == 4 && g.OW == 4; }
+
 static void wgrad_halo_plan(int batch, const ConvGeom& g, int Cin, int Cout, int& nslice, int& nsplit, int& mtiles) {
-    nslice = batch * g.OD * (g.OH / 8) * (g.OW / 8);
+    nslice = wgrad_mode4(g) ? batch : batch * g.OD * (g.OH / 8) * (g.OW / 8);   // 4^3 outputs: a slice is a sample
     mtiles = (Cout + 127) / 128;
     const int ntiles = ((Cin + 1) / 2) * mtiles;
     nsplit = (512 + ntiles - 1) / ntiles;
@@ -1099,7 +1279,7 @@ static void wgrad_halo_plan(int batch, const ConvGeom& g, int Cin, int Cout, int
 }
 
 size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
-    if (OH % 8 != 0 || OW % 8 != 0) return 0;
+    if ((OH % 8 != 0 || OW % 8 != 0) && !(OD == 4 && OH == 4 && OW == 4)) return 0;
     ConvGeom g;
     g.OD = OD;
     g.OH = OH;
@@ -1113,7 +1293,8 @@ size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, 
 
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
                    void* workspace, size_t workspace_bytes, hipStream_t stream, int force) {
-    if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin < 2 || Cout < 32) return 0;
+    const bool mode4 = wgrad_mode4(g);
+    if ((!mode4 && (g.OW % 8 != 0 || g.OH % 8 != 0)) || Cin < 2 || Cout < 32) return 0;
     if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
     int nslice, nsplit, mtiles;
     wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
@@ -1125,15 +1306,18 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     const int per_split = (nslice + nsplit - 1) / nsplit;
     nsplit = (nslice + per_split - 1) / per_split;
 
-    const FastDiv dntw(g.OW / 8), dnth(g.OH / 8), dOD(g.OD);
+    const FastDiv dntw(mode4 ? 1 : g.OW / 8), dnth(mode4 ? 1 : g.OH / 8), dOD(g.OD);
     float4* ap = (float4*)workspace;
     const size_t pack_floats4 = (size_t)mtiles * 4 * nslice * 8 * 64;
     float* part = (float*)(ap + pack_floats4);
     {
         int blocks = (int)((pack_floats4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(pack_wgrad_dy_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, g, Cout, mtiles * 4, nslice, dntw,
-                           dnth, dOD);
+        if (mode4)
+            hipLaunchKernelGGL(pack_wgrad_dy4_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, Cout, mtiles * 4, nslice);
+        else
+            hipLaunchKernelGGL(pack_wgrad_dy_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, g, Cout, mtiles * 4, nslice,
+                               dntw, dnth, dOD);
     }
     HaloWgradArgs a;
     a.ap = ap;
@@ -1150,8 +1334,13 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     const bool direct = nsplit == 1;
     a.ws = direct ? dw : part;
     a.ldw = direct ? (long)Cin_total * 64 : (long)Cin * 64;
-    const size_t lds = (size_t)2 * 2 * kWHS * sizeof(float);
-    hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256), lds, stream, a);
+    if (mode4) {
+        hipLaunchKernelGGL(conv_wgrad_halo4_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256),
+                           (size_t)2 * 2 * k4CH * sizeof(float), stream, a);
+    } else {
+        const size_t lds = (size_t)2 * 2 * kWHS * sizeof(float);
+        hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256), lds, stream, a);
+    }
     if (!direct) {
         const long total = (long)Cout * Cin * 64;
         int fb = (int)((total + 255) / 256);

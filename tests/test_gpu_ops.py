@@ -432,7 +432,8 @@ def test_sdfnet_segments_mode(S, N):
         close(p.grad, P[k].grad, rtol=2e-4, what="grad " + k)
 
 
-@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 3, 32, 8), (3, 16, 40, 8), (1, 8, 160, 16), (5, 2, 64, 8)])
+@pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 3, 32, 8), (3, 16, 40, 8), (1, 8, 160, 16), (5, 2, 64, 8),
+                                       (6, 128, 256, 4), (1, 3, 40, 4), (9, 16, 130, 4), (4, 2, 32, 4)])
 def test_conv_wgrad_halo_kernel(N, Ci, Co, O):
     """The LDS-halo weight gradient (forced) == autograd of ATen conv3d."""
     from shapegan_amd import ops
