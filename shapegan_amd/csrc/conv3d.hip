@@ -538,7 +538,7 @@ int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bi
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: bad spatial dims");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad_impl")) return SG_ERR_ARG;
     const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
-                                  stream, impl);   // 1: forced, 3: forced with 32-channel stages
+                                  stream, impl);   // 1: forced, 3: forced with one parity per workgroup
     if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: shape not eligible for the LDS-halo kernel");
     SG_CHECK_LAUNCH();
     return SG_OK;

@@ -546,8 +546,8 @@ template <>
 struct DBox<1> {
     static constexpr int BH = 5, BW = 5, PL = 25, CH = 250, TNOFF = 50, WNOFF = 125;
 };
-// Channels per stage (template CC): 32 when the channel count allows (256 MFMAs per wave between barriers, 64 KB LDS),
-// else 16.  A stage copies CC * ~245 box floats = CC elements per thread into an LDS buffer of CC*256 floats.
+// 16 channels per stage (32 measured 3 % slower): a stage copies 16 * ~245 box floats = 16 elements per thread into an
+// LDS buffer of 16*256 floats.
 
 struct HaloDgradArgs {
     const float* dy;
@@ -556,6 +556,7 @@ struct HaloDgradArgs {
     float* dx;
     ConvGeom g;
     int Cin, Cout, mtiles, batch;  // mtiles = row tiles (of 64) per parity
+    int ppw;                       // output parities per workgroup (1, 2, 4, 8)
     FastDiv dntw, dnth, dntd;
     int act;
     float slope;
@@ -589,13 +590,12 @@ __global__ void __launch_bounds__(256) pack_dgrad_frag_kernel(const float* __res
     }
 }
 
-template <int MODE, int CC>
+template <int MODE>
 __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
-    constexpr int kDCC = CC, kDNF = CC, kDBUF = CC * 256;   // channels per stage = copy elements per thread; floats per LDS buffer
+    constexpr int kDCC = 16, kDNF = 16, kDBUF = kDNF * 256;   // channels per stage = copy elements per thread; floats per LDS buffer
     using BX = DBox<MODE>;
     constexpr int kDB = BX::CH;
     extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kDBUF], a buffer = [kDCC][kDB] + tail
-    const int par = blockIdx.z, pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
     uint32_t twi = 0, thi = 0, tdi = 0, n, q1, q2;
     if (MODE == 0) {
         a.dntw.divmod(blockIdx.x, q1, twi);
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
     // lane -> position inside a 32-position column tile; address of tap (td,th): lanebase + tn*TNOFF + (1-td)*PL + (1-th)*BW
     const int lpart = MODE == 0 ? (r >> 3) * BX::BW + (r & 7) : (r >> 4) * BX::PL + ((r >> 2) & 3) * BX::BW + (r & 3);
-    const int lanebase = (SG_ABLATE & 256) ? r + 1 - kpar : wn * BX::WNOFF + lpart + 1 - kpar;
+    const int lanebase = wn * BX::WNOFF + lpart + 1 - kpar;
 
     f32x16 acc[2];
 #pragma unroll
@@ -634,16 +634,28 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     lds_float* sdst = bl + tid;   // element f of a stage goes to sdst[256 f] (+ buffer)
     pin_vgpr(sdst);
 
+    // A workgroup walks a.ppw output parities back to back (grid z = 8 / ppw): the copy / weight pipelines run straight
+    // through the parity boundaries, so only the first box load of the workgroup is exposed and the stores of a parity
+    // overlap the next one's MFMAs (one parity is only Cout/16 stages long).
     const int G = a.Cout;  // one k-group per output channel
-    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + (((long)par * (a.mtiles * 2) + (blockIdx.y * 2 + wm)) * G) * 64);
+    const int par0 = blockIdx.z * a.ppw, par_end = par0 + a.ppw;
+    const unsigned par_bytes = (unsigned)(a.mtiles * 2) * (unsigned)G * 1024u;   // weight image: [parity][row tile][G][64] float4
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + ((long)(blockIdx.y * 2 + wm) * G) * 64);
     const unsigned wvoff = lane * 16;
 
     // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw); a buffer
-    // holds kDNF*256 floats, so every thread stores all its elements (those beyond the box land in the unread tail) ----
+    // holds kDNF*256 floats, so every thread stores all its elements (those beyond the box land in the unread tail).
+    // The box of parity p starts at q0 + p - 1 in every dimension: against parity 0 the whole box moves by a SCALAR
+    // (it goes into the load's scalar offset), and an element is padding only through three edge conditions per
+    // dimension pair (low edge with p = 0, high edge with p = 1).  Each element keeps one word: offset for parity 0
+    // (biased so that it is never negative, < 2^26) | its edge classes in bits 26..31; the word AND (parity flags |
+    // 0x03ffffff) is the load offset, >= num_records (2^26) exactly for padding: 16 v_and per parity change. ----
     const int O3 = a.g.OD * a.g.OH * a.g.OW;
-    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy + (long)n * a.g.Cy * O3);
+    const int obias = (a.g.OH + 1) * a.g.OW + 1;   // elements: parity 0 reaches one plane + row + column before q0
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy + (long)n * a.g.Cy * O3 - obias), 0, 1 << 26, 0x00020000);
     const unsigned chan_bytes = (unsigned)O3 * 4u;
-    unsigned goff[kDNF];  // byte offset from channel 0 of the stage; kBufOutside where the box holds zero
+    unsigned gword[kDNF], goff[kDNF];
 #pragma unroll
     for (int f = 0; f < kDNF; ++f) {
         const int e = tid + 256 * f;
@@ -654,19 +666,79 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             rem -= smp * 125;
         }
         const int hd = rem / BX::PL, hh = (rem - hd * BX::PL) / BX::BW, hw = rem % BX::BW;
-        const int od = qd0 + pd - 1 + hd, oh = qh0 + ph - 1 + hh, ow = qw0 + pw - 1 + hw;
-        const bool ok = e < kDCC * kDB && (unsigned)od < (unsigned)a.g.OD && (unsigned)oh < (unsigned)a.g.OH &&
-                        (unsigned)ow < (unsigned)a.g.OW && (int)n + smp < a.batch;
-        goff[f] = ok ? (unsigned)((smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow) * 4u : kBufOutside;
-        pin_vgpr(goff[f]);
+        const int od = qd0 - 1 + hd, oh = qh0 - 1 + hh, ow = qw0 - 1 + hw;   // parity 0; parity bit p adds p
+        const bool never = e >= kDCC * kDB || (int)n + smp >= a.batch;
+        const unsigned cls = (od < 0 ? 1u << 26 : 0u) | (od + 1 >= a.g.OD ? 1u << 27 : 0u) | (oh < 0 ? 1u << 28 : 0u) |
+                             (oh + 1 >= a.g.OH ? 1u << 29 : 0u) | (ow < 0 ? 1u << 30 : 0u) | (ow + 1 >= a.g.OW ? 1u << 31 : 0u);
+        const int off0 = (smp * a.g.Cy + ci) * O3 + (od * a.g.OH + oh) * a.g.OW + ow + obias;   // >= 0
+        gword[f] = never ? 0xffffffffu : ((unsigned)off0 * 4u) | cls;
+        pin_vgpr(gword[f]);
     }
+    unsigned pshift = 0;   // scalar byte offset of the current parity's box against parity 0
+    auto set_goff = [&](int par) __attribute__((always_inline)) {
+        const int pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
+        // low-edge classes (bits 26,28,30) are padding when p = 0, high-edge classes (27,29,31) when p = 1
+        const unsigned mask = 0x03ffffffu | (pd ? 1u << 27 : 1u << 26) | (ph ? 1u << 29 : 1u << 28) | (pw ? 1u << 31 : 1u << 30);
+#pragma unroll
+        for (int f = 0; f < kDNF; ++f) goff[f] = gword[f] & mask;
+        pshift = (unsigned)((pd * a.g.OH + ph) * a.g.OW + pw) * 4u;
+    };
+    const long I3 = (long)a.g.ID * a.g.IH * a.g.IW;
+    // stores: buffer resource on the wave's sample, one lane offset per column tile (position of parity 0 + the kpar row),
+    // everything else (row block of 4 channels, parity shift) in the scalar offset
+    const int nn = MODE == 0 ? (int)n : (int)n + wn;
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)(nn < a.batch ? nn : 0) * a.g.Cx * I3);
+    const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.bias ? a.bias : a.dx);
+    unsigned ovoff[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        int qd, qh, qw;
+        if (MODE == 0) {
+            qd = qd0 + wn;
+            qh = qh0 + tn * 4 + (r >> 3);
+            qw = qw0 + (r & 7);
+        } else {
+            qd = 2 * tn + (r >> 4);
+            qh = (r >> 2) & 3;
+            qw = r & 3;
+        }
+        ovoff[tn] = (unsigned)(((2 * qd) * a.g.IH + 2 * qh) * a.g.IW + 2 * qw + 4 * kpar * (int)I3) * 4u;
+        pin_vgpr(ovoff[tn]);
+    }
+    const unsigned bvoff = kpar * 16;
+    auto write_parity = [&](int par) __attribute__((always_inline)) {   // dx[n'][ci][2q + p] = act(acc + bias[ci]); acc = 0
+        const int pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
+        const unsigned oshift = (unsigned)((pd * a.g.IH + ph) * a.g.IW + pw) * 4u;
+        if (nn < a.batch) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);   // scalar part of the channel; the lane adds 4*kpar
+                if (cis < a.Cin) {   // Cin % 8 == 0: the whole 8-channel block is in or out
+                    const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const float v = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff[tn],
+                                                              (int)((unsigned)cis * (unsigned)I3 * 4u + oshift), 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    };
+
+    set_goff(par0);
     float fv[kDNF];
-    constexpr int kRing = 8;
+    constexpr int kRing = 8;   // <= kDCC: the ring never reaches past the next stage
     float4 aring[kRing];
+    unsigned wcur = (unsigned)par0 * par_bytes;   // scalar byte offset of (parity, stage) in the weight image
 #pragma unroll
-    for (int f = 0; f < kDNF; ++f) fv[f] = buf_load(dres, goff[f], 0);
+    for (int f = 0; f < kDNF; ++f) fv[f] = buf_load(dres, goff[f], pshift);
 #pragma unroll
-    for (int u = 0; u < kRing; ++u) aring[u] = buf_load4(wres, wvoff, (unsigned)(u < G ? u : G - 1) * 1024u);
+    for (int u = 0; u < kRing; ++u) aring[u] = buf_load4(wres, wvoff, wcur + (unsigned)u * 1024u);
 #pragma unroll
     for (int f = 0; f < kDNF; ++f) sdst[256 * f] = fv[f];
     __syncthreads();
@@ -676,12 +748,10 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     // the machine scheduler from sinking the loads to their uses (see conv_fwd_halo_kernel).
     constexpr int O00 = BX::PL + BX::BW, O01 = BX::PL, O10 = BX::BW, O11 = 0;  // (td,th) -> box offset
     const int nstage = a.Cout / kDCC;
-    int gbase = kRing;
-    auto stage = [&](auto tag, int s) {
+    // dys: byte offset of the channels to copy (into the idle buffer) during this stage; wnext: weight offset of the stage
+    // that follows.  Both are scalars computed by the caller, the body itself is branch-free.
+    auto stage = [&](auto tag, unsigned dys, unsigned wnext) __attribute__((always_inline)) {
         constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
-        int cnext = (s + 1) * kDCC;
-        cnext = cnext > a.Cout - kDCC ? a.Cout - kDCC : cnext;  // last stage: re-copy into the idle buffer
-        const unsigned dys = (unsigned)cnext * chan_bytes;
         float bq[2][4];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
@@ -695,9 +765,8 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 #pragma unroll
         for (int c = 0; c < kDCC; ++c) {  // one k-group per channel
             const float4 a_cur = aring[c % kRing];
-            int gi = gbase + c;
-            gi = gi < G ? gi : G - 1;
-            aring[c % kRing] = buf_load4(wres, wvoff, (unsigned)gi * 1024u);
+            aring[c % kRing] = c + kRing < kDCC ? buf_load4(wres, wvoff, wcur + (unsigned)(c + kRing) * 1024u)
+                                                : buf_load4(wres, wvoff, wnext + (unsigned)(c + kRing - kDCC) * 1024u);
             float b[2][4];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
@@ -715,7 +784,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             }
             if (c < kDCC / 2) {  // copy of the next box: two loads per group in the first half of the stage ...
 #pragma unroll
-                for (int f = 2 * c; f < 2 * c + 2; ++f) fv[f] = buf_load(dres, goff[f], dys);
+                for (int f = 2 * c; f < 2 * c + 2; ++f) fv[f] = buf_load(dres, goff[f], dys + pshift);
             } else {             // ... each value goes to LDS 8 groups after its load
 #pragma unroll
                 for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f) sdst[NXT * kDBUF + 256 * f] = fv[f];
@@ -731,44 +800,24 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[1][3], acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        gbase += kDCC;
+        wcur = wnext;
         __syncthreads();
     };
-    for (int s = 0; s + 1 < nstage; s += 2) {
-        stage(IntTag<0>(), s);
-        stage(IntTag<1>(), s + 1);
-    }
-    if (nstage & 1) stage(IntTag<0>(), nstage - 1);
-
-    // epilogue: dx[n'][ci][2 qd + pd][2 qh + ph][2 qw + pw] = act(acc + bias[ci])
-    const long I3 = (long)a.g.ID * a.g.IH * a.g.IW;
-    const int nn = MODE == 0 ? (int)n : (int)n + wn;
-    if (nn >= a.batch) return;
-    float* out = a.dx + (long)nn * a.g.Cx * I3;
-    float bv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-        bv[q] = a.bias ? a.bias[ci < a.Cin ? ci : a.Cin - 1] : 0.f;
-    }
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        int qd, qh, qw;
-        if (MODE == 0) {
-            qd = qd0 + wn;
-            qh = qh0 + tn * 4 + (r >> 3);
-            qw = qw0 + (r & 7);
-        } else {
-            qd = 2 * tn + (r >> 4);
-            qh = (r >> 2) & 3;
-            qw = r & 3;
+    for (int par = par0; par < par_end; ++par) {
+        const bool more = par + 1 < par_end;
+        // the stage after this parity's last one: the next parity's first (new box origin) or, at the very end, the last
+        // stage again (copied into the idle buffer, never read)
+        const unsigned wlast = more ? (unsigned)(par + 1) * par_bytes : (unsigned)par * par_bytes + (unsigned)(nstage - 1) * kDCC * 1024u;
+        const unsigned dlast = more ? 0u : (unsigned)(nstage - 1) * kDCC * chan_bytes;
+        int s = 0;
+        for (; s + 1 < nstage; s += 2) {   // stages in pairs: the buffer index is a compile-time constant
+            stage(IntTag<0>(), (unsigned)(s + 1) * kDCC * chan_bytes, wcur + kDCC * 1024u);
+            const bool last = s + 2 == nstage;
+            if (last && more) set_goff(par + 1);
+            stage(IntTag<1>(), last ? dlast : (unsigned)(s + 2) * kDCC * chan_bytes, last ? wlast : wcur + kDCC * 1024u);
         }
-        const long pos = ((long)(2 * qd + pd) * a.g.IH + (2 * qh + ph)) * a.g.IW + (2 * qw + pw);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int ci = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
-            if (ci < a.Cin) out[(long)ci * I3 + pos] = sg_apply_act(acc[tn][q] + bv[q], a.act, a.slope);
-        }
+        if (s < nstage) stage(IntTag<0>(), dlast, wlast);   // odd stage count: only with one parity per workgroup
+        write_parity(par);
     }
 }
 
@@ -779,8 +828,8 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    hipStream_t stream, int force) {
     const bool mode1 = g.OD == 4 && g.OH == 4 && g.OW == 4;
     if (!mode1 && (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0)) return 0;
-    if (Cout % 16 != 0 || Cin < 32) return 0;
-    const int cc = (Cout % 32 == 0 && (force & 2)) ? 32 : 16;   // 32-channel stages measured 3 % slower (impl 3: A/B)
+    if (Cout % 16 != 0 || Cin < 32 || Cin % 8 != 0) return 0;
+    if (((long)2 * g.Cy * g.OD * g.OH * g.OW + (long)(g.OH + 1) * g.OW + 1) * 4 >= (1L << 26)) return 0;   // offset | class word
     if (!workspace || workspace_bytes < halo_dgrad_workspace_bytes(Cin, Cout)) return 0;
     if ((long)batch * g.Cy * g.OD * g.OH * g.OW >= (1L << 31)) return 0;
     if ((long)2 * g.Cy * g.OD * g.OH * g.OW * 4 >= (long)kBufRange || (long)Cout * 1024 >= (long)kBufRange) return 0;
@@ -811,23 +860,24 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     a.dntd = FastDiv(ntd);
     a.act = act;
     a.slope = slope;
+    // parities per workgroup: as many as keep >= 512 workgroups (2 per CU); force bit 1 (impl 3): one parity per workgroup
+    int ppw = 8;
+    while (ppw > 1 && (tiles * mtiles * (8 / ppw) < 512 || (force & 2) || (Cout / 16) % 2 != 0)) ppw >>= 1;
+    if ((long)8 * mtiles * 2 * Cout * 1024 >= (long)kBufRange) return 0;
+    a.ppw = ppw;
     // registers admit 3 workgroups per CU; take 3 only when the grid then needs fewer CU-slots in total (a 2048-workgroup
     // grid is 4 full rounds at 2 per CU but 2.67 rounds at 3): otherwise a larger LDS request caps the CU at 2
-    size_t lds = (size_t)2 * cc * 256 * sizeof(float);
-    if (cc == 16) {
-        const long wgs = tiles * mtiles * 8;
+    size_t lds = (size_t)2 * 16 * 256 * sizeof(float);
+    {
+        const long wgs = tiles * mtiles * (8 / ppw);
         const long cost2 = ((wgs + 511) / 512) * 2, cost3 = ((wgs + 767) / 768) * 3;
         if (cost2 <= cost3) lds = 56 * 1024;
     }
-    const dim3 grid((unsigned)tiles, mtiles, 8);
-    if (mode1 && cc == 32)
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1, 32>), grid, dim3(256), lds, stream, a);
-    else if (mode1)
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1, 16>), grid, dim3(256), lds, stream, a);
-    else if (cc == 32)
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0, 32>), grid, dim3(256), lds, stream, a);
+    const dim3 grid((unsigned)tiles, mtiles, 8 / ppw);
+    if (mode1)
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0, 16>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), grid, dim3(256), lds, stream, a);
     return 1;
 }
 

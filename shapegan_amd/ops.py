@@ -69,7 +69,7 @@ def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
 
 
 def conv_dgrad_halo_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, impl=1):
-    """dgrad through the forced LDS-halo kernel (impl 3: 32-channel stages) — tests and tuning only."""
+    """dgrad through the forced LDS-halo kernel (impl 3: one output parity per workgroup) — tests and tuning only."""
     N, Co, OD, OH, OW = dy.shape
     Ct = w.shape[1]
     dx = torch.empty((N, cin, 2 * OD, 2 * OH, 2 * OW), dtype=torch.float32, device=dy.device)
