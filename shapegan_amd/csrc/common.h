@@ -58,3 +58,30 @@ __device__ __forceinline__ double sg_wave_sum_d(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ---- zero-VALU addressing helpers (see conv3d_halo.hip for the rationale) ------------------------------------------
+namespace sg {
+typedef __attribute__((address_space(3))) float lds_float;
+constexpr unsigned kBufRange = 0x80000000u;     // num_records of the buffer resources
+constexpr unsigned kBufOutside = 0x80000000u;   // byte offset that is out of range -> the load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)kBufRange, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    // bit_cast the WHOLE result: component access on the builtin's own vector type narrows the load to one dword
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <class T>
+__device__ __forceinline__ void pin_vgpr(T& v) {   // the value stays in its register (no rematerialising v_add in the loop)
+    asm volatile("" : "+v"(v));
+}
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+}  // namespace sg

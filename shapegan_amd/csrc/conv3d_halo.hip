@@ -75,30 +75,6 @@ __global__ void __launch_bounds__(256) pack_fwd_weights_kernel(const float* __re
 //     outside the tensor gets an offset beyond num_records and the hardware returns 0 (no select on the way to LDS);
 //   * LDS addresses are per-thread constants held in registers, everything else is an immediate offset: the stage loop
 //     is unrolled by two so that the double-buffer index is a compile-time constant.
-typedef __attribute__((address_space(3))) float lds_float;
-constexpr unsigned kBufRange = 0x80000000u;     // num_records of the buffer resources
-constexpr unsigned kBufOutside = 0x80000000u;   // byte offset that is out of range -> the load returns 0
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)kBufRange, 0x00020000);
-}
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    // bit_cast the WHOLE result: component access on the builtin's own vector type narrows the load to one dword
-    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-template <class T>
-__device__ __forceinline__ void pin_vgpr(T& v) {   // the value stays in its register (no rematerialising v_add in the loop)
-    asm volatile("" : "+v"(v));
-}
-template <int V>
-struct IntTag {
-    static constexpr int value = V;
-};
-
 // Software pipeline per stage (4 input channels = 32 k-groups of 8 k, 4*TN MFMAs each).  The loop body is ONE basic
 // block (no data-dependent branches), so that the compiler's s_waitcnt counts are exact and nothing drains the queues:
 //   * the MFMAs of stage s read halo buffer s&1 while the SAME waves copy stage s+1's box into buffer (s+1)&1: the copy

@@ -112,25 +112,64 @@ static SdfPackLayout make_layout(int KU) {
     return L;
 }
 
-// acc[t] += A_tile(32 x K) * B(K x [t*32, t*32+32)) ; wp = this wave's packed A rows, Bs = LDS [K][ld]
+// acc[t] += A_tile(32 x K) * B(K x [t*32, t*32+32)) ; wp = this wave's packed A rows (wave-uniform), Bs = LDS [K][ld].
+// Software-pipelined like the conv halo kernels: A fragments come through a 4-deep ring of buffer loads (scalar base,
+// fixed lane offset, k-group in the scalar offset), the B fragments of k-group sq+1 are read from LDS (immediate offsets
+// from one running address) while the 4*NT MFMAs of group sq run; sched_barriers keep the loads where they are issued.
+// One VALU instruction (the LDS address step) per 4*NT MFMAs.
 template <int NT>
 __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __restrict__ wp, int nsq,
                                          const float* __restrict__ Bs, int ld, int lane) {
     const int r = lane & 31, kh = lane >> 5;
-    const float* bp = Bs + kh * ld + r;
-    float4 a_next = wp[lane];
-    for (int sq = 0; sq < nsq; ++sq) {
-        const float4 a = a_next;
-        if (sq + 1 < nsq) a_next = wp[(sq + 1) * 64 + lane];
+    // the packed rows are per wave: make the base a scalar so that the loads need no vector address arithmetic
+    const unsigned long long wq = (unsigned long long)wp;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wq), hi = __builtin_amdgcn_readfirstlane((unsigned)(wq >> 32));
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc((const void*)(((unsigned long long)hi << 32) | lo));
+    const unsigned wvoff = lane * 16;
+    const lds_float* bp = (const lds_float*)Bs + kh * ld + r;
+    const int last = nsq - 1;
+    float4 ar[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ar[u] = buf_load4(wres, wvoff, (unsigned)(u < last ? u : last) * 1024u);
+    float b[4][NT], bn[4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[j][t] = bp[j * 2 * ld + t * 32];
+    auto group = [&](float4 a, int sq) __attribute__((always_inline)) {
+        // B of the next group (the last group re-reads its own: no branch)
+        const lds_float* nb = bp + (sq < last ? 8 * ld : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[j][t] = nb[j * 2 * ld + t * 32];
+        bp = nb;
+        __builtin_amdgcn_sched_barrier(0);
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* bk = bp + (sq * 4 + j) * 2 * ld;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bk[t * 32], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[j][t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[j][t] = bn[j][t];
+    };
+    int sq = 0;
+    for (; sq + 4 <= nsq; sq += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 a = ar[u];
+            const int nx = sq + u + 4;
+            ar[u] = buf_load4(wres, wvoff, (unsigned)(nx < last ? nx : last) * 1024u);
+            group(a, sq + u);
         }
     }
+    // remainder (k not a multiple of 32): the ring already holds these groups
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (sq + u < nsq) group(ar[u], sq + u);
 }
 
 __device__ __forceinline__ int frag_row(int q, int kh) { return (q & 3) + 8 * (q >> 2) + 4 * kh; }
