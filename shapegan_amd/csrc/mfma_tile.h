@@ -289,6 +289,30 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* ws, E
         if (j0 + u < N) epi.store(epi.col(j0 + u), i, j0 + u, v[u]);
 }
 
+// many partials of a small matrix (Cin = 1 weight gradients: 512 partials of 64 x 64): one workgroup per 64 consecutive
+// elements, the 4 waves take interleaved partials and meet in LDS — 128 serial loads per thread instead of 512
+template <class EPI>
+__global__ void __launch_bounds__(256) splitk_finalize_deep_kernel(const float* ws, EPI epi, int M, int N, int splits) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long total = (long)M * N, e = (long)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int s = wave;
+        for (; s + 4 < splits; s += 8) {
+            s0 += ws[(long)s * total + e];
+            s1 += ws[(long)(s + 4) * total + e];
+        }
+        if (s < splits) s0 += ws[(long)s * total + e];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && e < total) {
+        const int i = (int)(e / N), j = (int)(e - (long)i * N);
+        epi.store(epi.col(j), i, j, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    }
+}
+
 constexpr long kTargetBlocks = 512;  // >= 2 workgroups on each of the 256 CUs
 
 struct TilePlan {
@@ -329,9 +353,14 @@ static int launch_tile_gemm_t(LA la, LB lb, EPI epi, int M, int N, int K, int sp
         EpiWorkspace wepi{ws, M, N};
         hipLaunchKernelGGL((tile_gemm_kernel<TM, TN, LA, LB, EpiWorkspace>), grid, dim3(256), 0, st, la, lb, wepi, M, N,
                            K, kchunk);
-        const long fb = (long)M * ((N + 1023) >> 10);
-        hipLaunchKernelGGL((splitk_finalize_kernel<EPI>), dim3((unsigned)fb), dim3(256), 0, st, (const float*)ws, epi,
-                           M, N, splitk);
+        if (splitk >= 32 && (long)M * N <= (1L << 18)) {
+            hipLaunchKernelGGL((splitk_finalize_deep_kernel<EPI>), dim3((unsigned)(((long)M * N + 63) / 64)), dim3(256), 0, st,
+                               (const float*)ws, epi, M, N, splitk);
+        } else {
+            const long fb = (long)M * ((N + 1023) >> 10);
+            hipLaunchKernelGGL((splitk_finalize_kernel<EPI>), dim3((unsigned)fb), dim3(256), 0, st, (const float*)ws, epi,
+                               M, N, splitk);
+        }
     }
     return 0;
 }
