@@ -117,7 +117,7 @@ static SdfPackLayout make_layout(int KU) {
 // fixed lane offset, k-group in the scalar offset), the B fragments of k-group sq+1 are read from LDS (immediate offsets
 // from one running address) while the 4*NT MFMAs of group sq run; sched_barriers keep the loads where they are issued.
 // One VALU instruction (the LDS address step) per 4*NT MFMAs.
-template <int NT>
+template <int NT, int RING = 4>
 __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __restrict__ wp, int nsq,
                                          const float* __restrict__ Bs, int ld, int lane) {
     const int r = lane & 31, kh = lane >> 5;
@@ -128,9 +128,9 @@ __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __rest
     const unsigned wvoff = lane * 16;
     const lds_float* bp = (const lds_float*)Bs + kh * ld + r;
     const int last = nsq - 1;
-    float4 ar[4];
+    float4 ar[RING];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ar[u] = buf_load4(wres, wvoff, (unsigned)(u < last ? u : last) * 1024u);
+    for (int u = 0; u < RING; ++u) ar[u] = buf_load4(wres, wvoff, (unsigned)(u < last ? u : last) * 1024u);
     float b[4][NT], bn[4][NT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -157,18 +157,18 @@ __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __rest
             for (int t = 0; t < NT; ++t) b[j][t] = bn[j][t];
     };
     int sq = 0;
-    for (; sq + 4 <= nsq; sq += 4) {
+    for (; sq + RING <= nsq; sq += RING) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RING; ++u) {
             const float4 a = ar[u];
-            const int nx = sq + u + 4;
+            const int nx = sq + u + RING;
             ar[u] = buf_load4(wres, wvoff, (unsigned)(nx < last ? nx : last) * 1024u);
             group(a, sq + u);
         }
     }
-    // remainder (k not a multiple of 32): the ring already holds these groups
+    // remainder (group count not a multiple of the ring): the ring already holds these groups
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < RING - 1; ++u)
         if (sq + u < nsq) group(ar[u], sq + u);
 }
 
@@ -381,14 +381,6 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
         dz8s[tid] = v;
     }
     __syncthreads();
-    {  // dH7 = w8 (x) dz8
-        const float* w8 = a.packed + a.lay.W8;
-        for (int e = tid; e < kH * P; e += 512) {
-            const int row = e / P, p = e - row * P;
-            Gs[e] = w8[row] * dz8s[p];
-        }
-    }
-    __syncthreads();
 
     f32x16 acc[NT];
     auto zero_acc = [&]() {
@@ -397,8 +389,77 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     };
-    // G <- G * (H_l > 0), also stored as dZ_l.  The H_l tile is fetched into registers one layer ahead (load_h is
-    // issued right after the previous mask, so its HBM latency hides behind that layer's W^T dZ GEMM).
+    // Each wave owns rows [32 wave, 32 wave + 32) of every dH_l in MFMA fragment layout (row = frag_row(q, kh), point =
+    // t*32 + r).  The ReLU mask, the dZ_l write-back and the bias-gradient partial sums happen right there in the GEMM
+    // epilogue: H_l is prefetched in the same layout while the GEMM runs (one lane offset + scalar offsets: buffer loads),
+    // so there is no separate pass over the LDS tile and its HBM latency is off the critical path.
+    const long lane_el = ((long)wave * 32 + 4 * kh) * a.ldn + p0 + r;   // element of (q = 0, t = 0) inside a layer image
+    const bool big = lane_el * 4 + 31L * a.ldn * 4 + 128 >= (1L << 31);  // (never at the supported sizes; keeps offsets 32-bit)
+    const unsigned hvoff = big ? 0u : (unsigned)(lane_el * 4);
+    bool pok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pok[t] = p0 + t * 32 + r < a.N;
+    float hf[16][NT];
+    auto load_h = [&](int layer) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t hres = make_rsrc(a.acts + (long)layer * kH * a.ldn);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                hf[q][t] = buf_load(hres, hvoff, (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4 + t * 128));
+    };
+    // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
+    auto mask_store = [&](int layer) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t zres = make_rsrc(a.dz + (long)layer * kH * a.ldn);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = wave * 32 + frag_row(q, kh);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
+                Gs[row * P + t * 32 + r] = g;
+                if (pok[t])
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)hvoff,
+                                                          (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4 + t * 128), 0);
+                rs += g;
+            }
+            if (a.bsum) {   // sum over the 32 lanes of the half-wave = the P points of this row
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+                if (r == 0) a.bsum[((long)layer * kH + row) * gridDim.x + blockIdx.x] = rs;
+            }
+        }
+    };
+
+    // dZ7 = (w8 (x) dz8) * (H7 > 0): the outer product is formed directly in fragment layout
+    load_h(6);
+    {
+        const float* w8 = a.packed + a.lay.W8;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float wv = w8[wave * 32 + frag_row(q, kh)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][q] = wv * dz8s[t * 32 + r];
+        }
+    }
+    mask_store(6);
+    __syncthreads();
+    auto back_step = [&](long toff, int layer) __attribute__((always_inline)) {  // dZ_layer+1 (LDS) -> dZ_layer (LDS, dz image)
+        load_h(layer);
+        zero_acc();
+        mlp_gemm<NT, 2>(acc, pk + (toff >> 2) + (long)wave * (kH / 8) * 64, kH / 8, Gs, P, lane);
+        __syncthreads();   // every wave is done reading the tile
+        mask_store(layer);
+        __syncthreads();
+    };
+    back_step(a.lay.T7, 5);    // dH6 -> dZ6
+    back_step(a.lay.T6, 4);    // dZ5
+    back_step(a.lay.T5x, 3);   // dZ4
+    back_step(a.lay.T4, 2);    // dZ3
+    back_step(a.lay.T3, 1);    // dZ2
+    back_step(a.lay.T2, 0);    // dZ1
+    // (element indexing of the dX part below)
     constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
     constexpr int RSTEP = 512 / P;
     const int mrow = tid / P, mp = tid % P;
@@ -406,50 +467,6 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
     const bool mok = mgp < a.N;
     const long moff = mok ? (long)mrow * a.ldn + mgp : 0;   // element 0 of this thread inside a layer's [256][ldn] image
     const long mstride = (long)RSTEP * a.ldn;
-    // G <- G * (H_l > 0), also stored as dZ_l.  (No register prefetch of H: with two workgroups per CU the other
-    // workgroup's MFMA phase covers this load; a prefetch array pushes the kernel past 128 VGPRs.)
-    auto mask_and_save = [&](int layer) {
-        const float* h = a.acts + (long)layer * kH * a.ldn + moff;
-        float* z = a.dz + (long)layer * kH * a.ldn + moff;
-#pragma unroll 8
-        for (int i = 0; i < HE; ++i) {
-            const float hv = h[mok ? i * mstride : 0];
-            const float g = (mok && hv > 0.f) ? Gs[tid + i * 512] : 0.f;
-            if (mok) z[i * mstride] = g;
-            Gs[tid + i * 512] = g;
-            if (P == 64 && a.bsum) {  // the 64 lanes of a wave hold the 64 points of row (wave + 8 i): bias-grad partial
-                const float rs = sg_wave_sum(g);
-                if (lane == 0) a.bsum[((long)layer * kH + wave + 8 * i) * gridDim.x + blockIdx.x] = rs;
-            }
-        }
-        __syncthreads();
-    };
-    auto back_step = [&](long toff) {  // G <- T_l * G
-        zero_acc();
-        mlp_gemm<NT>(acc, pk + (toff >> 2) + (long)wave * (kH / 8) * 64, kH / 8, Gs, P, lane);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = wave * 32 + frag_row(q, kh);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) Gs[row * P + t * 32 + r] = acc[t][q];
-        }
-        __syncthreads();
-    };
-
-    mask_and_save(6);          // dZ7
-    back_step(a.lay.T7);       // dH6
-    mask_and_save(5);          // dZ6
-    back_step(a.lay.T6);       // dH5
-    mask_and_save(4);          // dZ5
-    back_step(a.lay.T5x);      // dH4
-    mask_and_save(3);          // dZ4
-    back_step(a.lay.T4);
-    mask_and_save(2);          // dZ3
-    back_step(a.lay.T3);
-    mask_and_save(1);          // dZ2
-    back_step(a.lay.T2);
-    mask_and_save(0);          // dZ1
     // ---- input gradient dX = W1^T dZ1 + W5[:,256:]^T dZ5 (rows = input features, 32-row tiles round-robin over waves) ----
     // G holds dZ1 now; the dZ5 tile is read back from the dz image this workgroup wrote (L2-hot).  Accumulating both
     // products in registers and writing dx once needs neither LDS nor a read-modify-write.
