@@ -291,6 +291,133 @@ __global__ void __launch_bounds__(256) dgrad_out1_kernel(const float* __restrict
         }
 }
 
+// The same operator with LDS staging and register blocking, for grids that tile by 4 x 8 x 16 (every 16^3 / 32^3 layer):
+// a workgroup owns a 4x8x16 block of positions q of one sample; per stage it copies the (4+2)x(8+2)x(16+2) box of dy
+// of 8 channels into LDS (buffer loads, the hardware returns 0 outside the grid; double buffered), a thread owns TWO
+// neighbouring q along w = 2x2x4 outputs x 2: per channel it reads 9 rows of 4 consecutive dy values (18 ds_read_b64)
+// and takes the channel's 64 weights from scalar registers (s_load), 128 FMAs — the FMA pipe, not the load path, is
+// the limit.  Output rows are written as float4.
+constexpr int kO1D = 4, kO1H = 8, kO1W = 16;                       // q block
+constexpr int kO1BD = kO1D + 2, kO1BH = kO1H + 2, kO1BW = kO1W + 2;  // box
+constexpr int kO1CH = kO1BD * kO1BH * kO1BW;                       // 1080 floats per channel
+constexpr int kO1CC = 8;                                           // channels per stage
+constexpr int kO1NF = (kO1CH + 255) / 256;                         // copy elements per thread per channel
+
+__global__ void __launch_bounds__(256) dgrad_out1_tile_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ dx,
+                                                             ConvGeom g, int Cout, int Cin_total, int ntd, int nth, int ntw,
+                                                             int act, float slope) {
+    extern __shared__ __attribute__((aligned(16))) float box[];  // [2][kO1CC][kO1CH]
+    lds_float* const bl = (lds_float*)box;
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int twi = t % ntw; t /= ntw;
+    const int thi = t % nth; t /= nth;
+    const int tdi = t % ntd;
+    const int n = t / ntd;
+    const int qd0 = tdi * kO1D, qh0 = thi * kO1H, qw0 = twi * kO1W;
+    const int OHW = g.OH * g.OW, O3 = g.OD * OHW;
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(dy + (long)n * g.Cy * O3);
+    const unsigned chan_bytes = (unsigned)O3 * 4u;
+
+    unsigned goff[kO1NF];
+    lds_float* sdst[kO1NF];
+#pragma unroll
+    for (int f = 0; f < kO1NF; ++f) {
+        const int e = tid + 256 * f;
+        const int bd = e / (kO1BH * kO1BW), rem = e - bd * (kO1BH * kO1BW), bh = rem / kO1BW, bw = rem - bh * kO1BW;
+        const int od = qd0 - 1 + bd, oh = qh0 - 1 + bh, ow = qw0 - 1 + bw;
+        const bool ok = e < kO1CH && (unsigned)od < (unsigned)g.OD && (unsigned)oh < (unsigned)g.OH && (unsigned)ow < (unsigned)g.OW;
+        goff[f] = ok ? (unsigned)((od * g.OH + oh) * g.OW + ow) * 4u : kBufOutside;
+        sdst[f] = bl + (e < kO1CH ? e : kO1CH);   // one spare float behind each channel box takes the overshoot
+    }
+    // this thread's two positions: qw = 2 wq, 2 wq + 1
+    const int wq = tid & 7, hq = (tid >> 3) & 7, dq = tid >> 6;
+    const lds_float* rbase = bl + dq * (kO1BH * kO1BW) + hq * kO1BW + 2 * wq;
+
+    float acc[2][2][2][2];   // [q][pd][ph][pw]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (&acc[0][0][0][0])[i] = 0.f;
+
+    constexpr int kBUF = kO1CC * (kO1CH + 8);   // channel stride kO1CH + 8 keeps 8-byte alignment of the rows
+    constexpr int kCS = kO1CH + 8;
+    const int nstage = (Cout + kO1CC - 1) / kO1CC;
+    float fv[kO1CC][kO1NF];
+    auto issue = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < kO1CC; ++c) {
+            const int co = s * kO1CC + c;
+#pragma unroll
+            for (int f = 0; f < kO1NF; ++f) fv[c][f] = buf_load(dres, co < Cout ? goff[f] : kBufOutside, (unsigned)co * chan_bytes);
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < kO1CC; ++c)
+#pragma unroll
+            for (int f = 0; f < kO1NF; ++f) sdst[f][buf * kBUF + c * kCS] = fv[c][f];
+    };
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nstage;
+        if (more) issue(s + 1);
+#pragma unroll 2
+        for (int c = 0; c < kO1CC; ++c) {
+            const int co = s * kO1CC + c;
+            if (co >= Cout) break;
+            const float* wc = w + (long)co * Cin_total * 64;   // uniform address: scalar loads
+            float v[3][3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const lds_float* rp = rbase + cur * kBUF + c * kCS + a * (kO1BH * kO1BW) + b * kO1BW;
+                    v[a][b][0] = rp[0];
+                    v[a][b][1] = rp[1];
+                    v[a][b][2] = rp[2];
+                    v[a][b][3] = rp[3];
+                }
+            // neighbour index for (parity p, tap k): k=0 -> p 1, a 2 ; k=1 -> p 0, a 1 ; k=2 -> p 1, a 1 ; k=3 -> p 0, a 0
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) {
+                const int pd = (kd & 1) ? 0 : 1, ad = (kd == 0) ? 2 : (kd == 3 ? 0 : 1);
+#pragma unroll
+                for (int kh = 0; kh < 4; ++kh) {
+                    const int ph = (kh & 1) ? 0 : 1, ah = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
+                    const float w0 = wc[kd * 16 + kh * 4 + 0], w1 = wc[kd * 16 + kh * 4 + 1], w2 = wc[kd * 16 + kh * 4 + 2],
+                                w3 = wc[kd * 16 + kh * 4 + 3];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        acc[q][pd][ph][1] = fmaf(v[ad][ah][q + 2], w0, acc[q][pd][ph][1]);
+                        acc[q][pd][ph][0] = fmaf(v[ad][ah][q + 1], w1, acc[q][pd][ph][0]);
+                        acc[q][pd][ph][1] = fmaf(v[ad][ah][q + 1], w2, acc[q][pd][ph][1]);
+                        acc[q][pd][ph][0] = fmaf(v[ad][ah][q + 0], w3, acc[q][pd][ph][0]);
+                    }
+                }
+            }
+        }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+    float* out = dx + (long)n * g.Cx * g.ID * g.IH * g.IW;
+    const int qd = qd0 + dq, qh = qh0 + hq, qw = qw0 + 2 * wq;
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float4 o;
+            o.x = sg_apply_act(acc[0][pd][ph][0] + b0, act, slope);
+            o.y = sg_apply_act(acc[0][pd][ph][1] + b0, act, slope);
+            o.z = sg_apply_act(acc[1][pd][ph][0] + b0, act, slope);
+            o.w = sg_apply_act(acc[1][pd][ph][1] + b0, act, slope);
+            *reinterpret_cast<float4*>(out + ((long)(2 * qd + pd) * g.IH + (2 * qh + ph)) * g.IW + 2 * qw) = o;
+        }
+}
+
 // ---- wgrad -----------------------------------------------------------------------------------
 // A(i=co, k=(n,o)) = dy[n][co][o], lanes along k (positions).  Per k-tile each thread decodes its one position.
 struct WgradDyLoader {
@@ -476,6 +603,20 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
+    if (Cin == 1 && g.OD % kO1D == 0 && g.OH % kO1H == 0 && g.OW % kO1W == 0 && (long)g.Cy * g.O3() * 4 < (long)kBufRange) {
+        const int ntd = g.OD / kO1D, nth = g.OH / kO1H, ntw = g.OW / kO1W;
+        const size_t lds = (size_t)(2 * kO1CC * (kO1CH + 8) + 8) * sizeof(float);
+        static bool attr_set = false;   // > 48 KB of dynamic LDS needs the attribute once per process
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_out1_tile_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(dgrad_out1_tile_kernel, dim3((unsigned)((long)batch * ntd * nth * ntw)), dim3(256), lds, stream, dy, w,
+                           bias, dx, g, Cout, Cin_total, ntd, nth, ntw, act, slope);
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     if (Cin == 1 && Cout <= 512) {
         hipLaunchKernelGGL(dgrad_out1_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256),
                            (size_t)Cout * 64 * sizeof(float), stream, dy, w, bias, dx, g, Cout, Cin_total, (int)npos, act,
@@ -533,12 +674,13 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
 int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                                 int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                                 void* workspace, size_t workspace_bytes, int impl, hipStream_t stream) {
-    SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && (impl == 1 || impl == 3));
+    SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && (impl & 1) &&
+                 (impl == 1 || impl == 3 || impl == 9 || impl == 17 || impl == 33));
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: bad spatial dims");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad_impl")) return SG_ERR_ARG;
     const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
-                                  stream, impl);   // 1: forced, 3: forced with one parity per workgroup
+                                  stream, impl);   // 1: forced, 3: one parity per workgroup, 1 + 4 ppw: ppw parities
     if (rc != 1) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad_impl: shape not eligible for the LDS-halo kernel");
     SG_CHECK_LAUNCH();
     return SG_OK;

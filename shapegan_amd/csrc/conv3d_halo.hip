@@ -839,6 +839,7 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     // parities per workgroup: as many as keep >= 512 workgroups (2 per CU); force bit 1 (impl 3): one parity per workgroup
     int ppw = 8;
     while (ppw > 1 && (tiles * mtiles * (8 / ppw) < 512 || (force & 2) || (Cout / 16) % 2 != 0)) ppw >>= 1;
+    if ((force >> 2) && (Cout / 16) % 2 == 0) ppw = force >> 2;   // tests: impl = 1 + 4 * ppw forces 2, 4 or 8 parities
     if ((long)8 * mtiles * 2 * Cout * 1024 >= (long)kBufRange) return 0;
     a.ppw = ppw;
     // registers admit 3 workgroups per CU; take 3 only when the grid then needs fewer CU-slots in total (a 2048-workgroup

@@ -399,6 +399,10 @@ def test_conv_dgrad_halo_kernel(N, Ci, Co, O):
     ref = F.leaky_relu(F.conv_transpose3d(dy, w, b, stride=2, padding=1), 0.2)
     got = ops.conv_dgrad_halo_raw(dev(dy), dev(w), dev(b), Ci, ACT_LEAKY, 0.2)
     close(got, ref, what="dgrad halo vs oracle")
+    if (Co // 16) % 2 == 0:   # several output parities per workgroup (the large-grid configuration), forced
+        for ppw in (2, 4, 8):
+            got = ops.conv_dgrad_halo_raw(dev(dy), dev(w), dev(b), Ci, ACT_LEAKY, 0.2, impl=1 + 4 * ppw)
+            close(got, ref, what="dgrad halo, %d parities per workgroup" % ppw)
 
 
 @pytest.mark.parametrize("S,N", [(5, 700), (64, 20000), (3, 129), (300, 1000)])
