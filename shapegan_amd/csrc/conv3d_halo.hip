@@ -442,8 +442,14 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         a.dntw = a.dnth = a.dOD = FastDiv(1);
         a.act = act;
         a.slope = slope;
-        hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles), dim3(512), (size_t)2 * k4BUF * sizeof(float),
-                           stream, a);
+        const size_t lds4 = (size_t)2 * k4BUF * sizeof(float);   // 66.5 KB: above the default dynamic-LDS limit
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_halo4_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles), dim3(512), lds4, stream, a);
         return 1;
     }
     // eligible: 8x8 position tiles exist, whole stages of 4 channels, enough output channels to fill 64-row MFMA tiles
