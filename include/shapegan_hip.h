@@ -89,6 +89,11 @@ size_t sg_gemm_workspace_bytes(int M, int N);
 int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, long sci, long scj,
             const float* bias_i, const float* bias_j, int bias_j_shift, int M, int N, int K, int act, float slope,
             void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* C[M,N] = A[M,K] B[N,K]^T, K contiguous in both operands and K >> M, N: the SDFNet weight gradients dW_l = dZ_l H_{l-1}^T over
+ * the points of a batch (autograd of model/sdf_net.py:56-61).  Deterministic split-K; rows of C have stride ldc. */
+size_t sg_gemm_nt_workspace_bytes(int M, int N, long K);
+int sg_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, long K, void* workspace,
+               size_t workspace_bytes, hipStream_t stream);
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
 /* out[r*nseg + s] = sum of x[r*ld + e] over e in [seg_off[s], seg_off[s+1])  (per-shape sums of SDFNet dZ columns) */

@@ -76,6 +76,10 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned v
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ f32x4 buf_load4v(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 template <class T>
 __device__ __forceinline__ void pin_vgpr(T& v) {   // the value stays in its register (no rematerialising v_add in the loop)
     asm volatile("" : "+v"(v));

@@ -101,6 +101,190 @@ __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ x
     if (lane == 0) out[pair] = acc;
 }
 
+
+
+
+// ================================================================================================================
+// C[M,N] = A[M,K] * B[N,K]^T with K contiguous in both operands and K >> M, N: the SDFNet weight gradients
+// dW_l = dZ_l * H_{l-1}^T over the points of a batch (model/sdf_net.py:26-52 backward; 256 x 256 x 20 000 ... 4 M).
+// LDS-staged like the conv halo kernels and free of vector address arithmetic in the loop:
+//   * a workgroup owns a 128 x 128 tile of C and a K range (split-K, deterministic partials + finalize);
+//   * a stage is 32 k: each thread moves four 16-byte pieces of A and four of B (8 lanes cover one 128-byte row segment)
+//     with buffer loads — row in the scalar offset, rows beyond M / N get an out-of-range offset and read as 0 — and
+//     writes them to LDS as [k / 4][row][4]: the piece IS the unit, because the MFMA k index is only a summation index,
+//     lane (row, kh) can take k = 8 g + 4 kh + j for step j of group g in BOTH operands.  A fragment read is then one
+//     ds_read_b128 per 4 MFMA steps, contiguous over the 32 rows of a half-wave;
+//   * loads run two stages ahead (registers), LDS stores one stage ahead, one barrier per stage; the chunk stride is
+//     padded by 16 bytes so that the 8 pieces of a row segment land in different banks.
+constexpr int kNtKC = 32;                 // k per stage
+constexpr int kNtChunk = 128 * 4 + 4;     // floats per (k/4) chunk of one operand tile
+constexpr int kNtOp = 8 * kNtChunk;       // floats per operand tile per buffer
+
+struct GemmNtArgs {
+    const float* A;
+    const float* B;
+    float* out;      // partials [nsplit][M][N] (ldc = N) or C itself when nsplit == 1
+    long lda, ldb, ldc;
+    int M, N;
+    long K, kchunk;  // kchunk: multiple of kNtKC
+};
+
+__global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A | B][8][kNtChunk]
+    lds_float* const sl = (lds_float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kh = lane >> 5;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const long kbeg = (long)blockIdx.z * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const int nstage = (int)((kend - kbeg + kNtKC - 1) / kNtKC);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // copy: thread -> (row inside a 32-row pass, 16-byte piece kq of the 128-byte segment)
+    const int rowl = tid >> 3, kq = tid & 7;
+    const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.A + (long)i0 * a.lda + kbeg);
+    const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.B + (long)j0 * a.ldb + kbeg);
+    unsigned avoff[4], bvoff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 32 + rowl;   // the 32-row pass offset goes into the scalar offset (4 M-point rows: > 2^31 bytes)
+        avoff[p] = i0 + row < a.M ? (unsigned)(((long)rowl * a.lda + 4 * kq) * 4) : kBufOutside;
+        bvoff[p] = j0 + row < a.N ? (unsigned)(((long)rowl * a.ldb + 4 * kq) * 4) : kBufOutside;
+        pin_vgpr(avoff[p]);
+        pin_vgpr(bvoff[p]);
+    }
+    const unsigned pass_a = (unsigned)(32 * a.lda * 4), pass_b = (unsigned)(32 * a.ldb * 4);
+    lds_float* sdst = sl + kq * kNtChunk + rowl * 4;
+    pin_vgpr(sdst);
+    const lds_float* afrag = sl + kh * kNtChunk + (wm * 64 + r) * 4;
+    const lds_float* bfrag = sl + kNtOp + kh * kNtChunk + (wn * 64 + r) * 4;
+    pin_vgpr(afrag);
+    pin_vgpr(bfrag);
+
+    f32x4 ra[4], rb[4];   // pieces in flight (two stages ahead)
+    auto issue = [&](int s) __attribute__((always_inline)) {   // loads of stage s (clamped: a stage past the end re-reads the last)
+        const int sc = s < nstage ? s : nstage - 1;
+        const unsigned so = (unsigned)sc * (kNtKC * 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = buf_load4v(ares, avoff[p], so + (unsigned)p * pass_a);
+            rb[p] = buf_load4v(bres, bvoff[p], so + (unsigned)p * pass_b);
+        }
+    };
+    auto mask_tail = [&](int s) __attribute__((always_inline)) {   // zero the k >= kend part of the last stage
+        const long k = kbeg + (long)s * kNtKC + 4 * kq;
+        if (k + 4 > kend) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j >= kend) ra[p][j] = rb[p][j] = 0.f;
+            }
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *(lds_f32x4*)(sdst + buf * 2 * kNtOp + p * 128) = ra[p];
+            *(lds_f32x4*)(sdst + buf * 2 * kNtOp + kNtOp + p * 128) = rb[p];
+        }
+    };
+
+    if (nstage > 0) {
+        issue(0);
+        if (nstage == 1) mask_tail(0);
+        commit(0);
+        issue(1);
+        __syncthreads();
+        auto stage = [&](auto tag, int s) __attribute__((always_inline)) {
+            constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+            if (s + 1 == nstage - 1) mask_tail(s + 1);   // the pieces in registers belong to stage s + 1
+            commit(NXT);
+            issue(s + 2);
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + t * 128);
+                fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + t * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ca[2], cb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ca[t] = fa[t];
+                    cb[t] = fb[t];
+                }
+                if (g + 1 < 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                        fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a0 = ca[0][j], a1 = ca[1][j], b0 = cb[0][j], b1 = cb[1][j];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int s = 0; s + 1 < nstage; s += 2) {
+            stage(IntTag<0>(), s);
+            stage(IntTag<1>(), s + 1);
+        }
+        if (nstage & 1) stage(IntTag<0>(), nstage - 1);
+    }
+
+    float* out = a.out + (long)blockIdx.z * a.M * a.ldc;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int j = j0 + wn * 64 + tj * 32 + r;
+            if (j >= a.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = i0 + wm * 64 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (i < a.M) out[(long)i * a.ldc + j] = acc[ti][tj][q];
+            }
+        }
+}
+
+struct CopyEpi {   // finalize target: C[i][j], row stride ldc
+    float* c;
+    long ldc;
+    struct Col {
+        int j;
+    };
+    __device__ Col col(int j) const { return Col{j}; }
+    __device__ void store(const Col& cc, int i, int j, float v) const { c[(long)i * ldc + cc.j] = v; }
+};
+
+static void gemm_nt_plan(int M, int N, long K, int& nsplit, long& kchunk) {
+    const long tiles = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
+    long s = (512 + tiles - 1) / tiles;
+    const long maxs = K / (8 * kNtKC) > 0 ? K / (8 * kNtKC) : 1;   // >= 8 stages per workgroup
+    if (s > maxs) s = maxs;
+    if (s > 256) s = 256;
+    kchunk = ((K + s - 1) / s + kNtKC - 1) / kNtKC * kNtKC;
+    nsplit = (int)((K + kchunk - 1) / kchunk);
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -152,6 +336,56 @@ int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg
     SG_CHECK_ARG(x && out && seg_off && rows > 0 && nseg > 0);
     hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((rows * nseg + 3) / 4)), dim3(256), 0, stream, x, out, rows, ld,
                        seg_off, nseg);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+size_t sg_gemm_nt_workspace_bytes(int M, int N, long K) {
+    int nsplit;
+    long kchunk;
+    gemm_nt_plan(M, N, K, nsplit, kchunk);
+    return nsplit > 1 ? (size_t)nsplit * M * N * sizeof(float) : 0;
+}
+
+int sg_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, long K, void* workspace,
+               size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N);
+    SG_CHECK_ARG(31L * lda * 4 + 64 < (long)kBufRange && 31L * ldb * 4 + 64 < (long)kBufRange);   // lane offset
+    SG_CHECK_ARG(96L * lda * 4 + K * 4 < (1L << 32) && 96L * ldb * 4 + K * 4 < (1L << 32));       // scalar offset
+    int nsplit;
+    long kchunk;
+    gemm_nt_plan(M, N, K, nsplit, kchunk);
+    if (nsplit > 1 && (!workspace || workspace_bytes < (size_t)nsplit * M * N * sizeof(float)))
+        SG_FAIL(SG_ERR_WORKSPACE, "sg_gemm_nt: workspace too small");
+    GemmNtArgs a;
+    a.A = A;
+    a.B = B;
+    a.lda = lda;
+    a.ldb = ldb;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.kchunk = kchunk;
+    a.out = nsplit > 1 ? (float*)workspace : C;
+    a.ldc = nsplit > 1 ? N : ldc;
+    const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(sg_cdiv(N, 128), sg_cdiv(M, 128), nsplit), dim3(256), lds, stream, a);
+    if (nsplit > 1) {
+        CopyEpi epi{C, ldc};
+        if (nsplit >= 32 && (long)M * N <= (1L << 18)) {
+            hipLaunchKernelGGL((splitk_finalize_deep_kernel<CopyEpi>), dim3((unsigned)(((long)M * N + 63) / 64)), dim3(256), 0,
+                               stream, (const float*)workspace, epi, M, N, nsplit);
+        } else {
+            hipLaunchKernelGGL((splitk_finalize_kernel<CopyEpi>), dim3((unsigned)((long)M * ((N + 1023) >> 10))), dim3(256), 0,
+                               stream, (const float*)workspace, epi, M, N, nsplit);
+        }
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -138,6 +138,16 @@ def gemm_raw(a, ta, b, tb, bias_j=None, bias_shift=0, act=ACT_NONE, slope=0.0, o
     return out
 
 
+def gemm_nt_raw(a, b, out, M, N, K, lda, ldb, ldc, a_off=0, b_off=0, c_off=0):
+    """out[i, j] = sum_k a[i, k] * b[j, k] for K-contiguous operands with K >> M, N (the SDFNet weight gradients over the
+    points of a batch): the dedicated LDS-staged split-K kernel."""
+    lib = _lib()
+    ws = workspace("gemm_nt", lib.sg_gemm_nt_workspace_bytes(M, N, K), a.device)
+    check(lib.sg_gemm_nt(ptr(a) + 4 * a_off, lda, ptr(b) + 4 * b_off, ldb, ptr(out) + 4 * c_off, ldc, M, N, K, ptr(ws),
+                         ws.numel(), stream()), "gemm_nt")
+    return out
+
+
 def act_bwd_raw(y, dy, act, slope):
     dx = torch.empty_like(y)
     check(_lib().sg_act_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), act, slope, stream()), "act_bwd")
@@ -462,8 +472,7 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
 
     def wgrad_from_acts(layer_dz, act_idx, out, c_off=0, ldc=_H):
         # out[o, c_off + k] = sum_p dZ[o,p] * H[k,p]
-        gemm_raw(dz, False, acts, True, out=out, a_off=layer_dz * _H * ldn, b_off=act_idx * _H * ldn, M=_H, N=_H, K=N,
-                 lda=ldn, ldb=ldn, ldc=ldc, c_off=c_off)
+        gemm_nt_raw(dz, acts, out, _H, _H, N, ldn, ldn, ldc, a_off=layer_dz * _H * ldn, b_off=act_idx * _H * ldn, c_off=c_off)
 
     def wgrad_from_rows(layer_dz, rows, width, out, c_off, ldc):
         # out[o, c_off + k] = sum_p dZ[o,p] * rows[p,k]

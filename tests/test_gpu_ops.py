@@ -571,3 +571,20 @@ def test_colsum_tall():
     np.testing.assert_allclose(s.detach().cpu().numpy(), g.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
     s.sum().backward()
     assert torch.equal(g.grad, torch.ones_like(g))
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(256, 256, 20000, 20000), (256, 256, 4099, 4100), (70, 130, 1000, 1003), (256, 256, 31, 40),
+                                       (32, 256, 262144, 262144), (256, 256, 33, 33)])
+def test_gemm_nt_bigk(M, N, K, lda):
+    """C = A B^T for K-contiguous operands (SDFNet weight gradients): ragged M / N / K, K not a multiple of the stage or of
+    4, leading dimensions with padding, row-strided output."""
+    from shapegan_amd import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, lda, device="cuda")
+    b = torch.randn(N, lda, device="cuda")
+    out = torch.full((M, N + 5), 7.0, device="cuda")
+    ops.gemm_nt_raw(a, b, out, M, N, K, lda, lda, N + 5)
+    want = a[:, :K].double() @ b[:, :K].double().t()
+    err = float((out[:, :N].double() - want).abs().max()) / float(want.abs().max())
+    assert err < 2e-5, err
+    assert float((out[:, N:] - 7.0).abs().max()) == 0.0      # nothing written beyond the N columns
