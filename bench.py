@@ -119,7 +119,7 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
     t0 = time.perf_counter()
     orc.critic_step(reals[0], zs[0])            # warm-up (also sizes the sample)
     warm = time.perf_counter() - t0
-    nsteps = 2 if warm * 7 * 2 < 30 else 1
+    nsteps = max(1, min(6, int(15.0 / max(warm * 7, 1e-3))))   # ~15 s of CPU work (a 5+1 step is ~7 critic-step equivalents)
     t0 = time.perf_counter()
     for _ in range(nsteps):
         orc.step(reals, zs, zg)
