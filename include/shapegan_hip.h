@@ -119,6 +119,10 @@ int sg_bn_bwd(const float* dy, const float* x, const float* gamma, const float* 
  * double-backward (mask * gg) used by the WGAN-GP graph (train_hybrid_progressive_gan.py:102-111). */
 int sg_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);
 int sg_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, hipStream_t stream);
+/* dx = dy * act'(y) and rowsum[r] = sum of dx over row r of S voxels (r = sample * C + channel): the activation backward of a
+ * conv layer with the row sums its bias gradient needs, in one pass */
+int sg_act_bwd_rowsum(const float* y, const float* dy, float* dx, float* rowsum, long rows, long S, int act, float slope,
+                      hipStream_t stream);
 
 /* ---- K7: SDFNet fused MLP -------------------------------------------------------------------------------------
  * reference: SDFNet.forward, model/sdf_net.py:26-61 (+ autograd).  `params` = 16 device pointers in state_dict order

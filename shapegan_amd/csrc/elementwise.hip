@@ -28,6 +28,41 @@ __device__ __forceinline__ float act_grad_from_output(float y, float dy, int act
     }
 }
 
+// The same with the row sums of dx on the way out: row = one (sample, channel) image of S voxels, one workgroup per row.
+// The bias gradient of a convolution is the column sum of these row sums — the separate pass over dx is saved.
+__global__ void __launch_bounds__(256) act_bwd_rowsum_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, float* __restrict__ rowsum, long S,
+                                                             int act, float slope) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * S;
+    float s = 0.f;
+    if ((S & 3) == 0) {
+        const float4* y4 = reinterpret_cast<const float4*>(y + base);
+        const float4* g4 = reinterpret_cast<const float4*>(dy + base);
+        float4* d4 = reinterpret_cast<float4*>(dx + base);
+        for (long e = threadIdx.x; e < (S >> 2); e += 256) {
+            const float4 a = y4[e], g = g4[e];
+            float4 v;
+            v.x = act_grad_from_output(a.x, g.x, act, slope);
+            v.y = act_grad_from_output(a.y, g.y, act, slope);
+            v.z = act_grad_from_output(a.z, g.z, act, slope);
+            v.w = act_grad_from_output(a.w, g.w, act, slope);
+            d4[e] = v;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long e = threadIdx.x; e < S; e += 256) {
+            const float v = act_grad_from_output(y[base + e], dy[base + e], act, slope);
+            dx[base + e] = v;
+            s += v;
+        }
+    }
+    s = sg_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowsum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act,
                                                       float slope) {
     const long n4 = n >> 2;
@@ -171,6 +206,13 @@ int sg_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream
 int sg_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, hipStream_t stream) {
     SG_CHECK_ARG(y && dy && dx && n > 0);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, y, dy, dx, n, act, slope);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_act_bwd_rowsum(const float* y, const float* dy, float* dx, float* rowsum, long rows, long S, int act, float slope,
+                      hipStream_t stream) {
+    SG_CHECK_ARG(y && dy && dx && rowsum && rows > 0 && rows < (1L << 31) && S > 0);
+    hipLaunchKernelGGL(act_bwd_rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, stream, y, dy, dx, rowsum, S, act, slope);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

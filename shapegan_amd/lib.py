@@ -43,6 +43,7 @@ SIGNATURES = {
     "sg_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _Z, _P]),
     "sg_act_fwd": (c_int, [_P, _P, _L, _I, _F, _P]),
     "sg_act_bwd": (c_int, [_P, _P, _P, _L, _I, _F, _P]),
+    "sg_act_bwd_rowsum": (c_int, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
     "sg_sdfnet_packed_floats": (_Z, [_I]),
     "sg_sdfnet_pack": (c_int, [_P, _I, _I, _P, _P]),
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),

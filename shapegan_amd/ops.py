@@ -154,6 +154,20 @@ def act_bwd_raw(y, dy, act, slope):
     return dx
 
 
+def act_bwd_rowsum_raw(y, dy, act, slope):
+    """dz = dy * act'(y) for y [N,C,*S] together with the bias gradient sum over (N, S) of dz (one pass + a tiny column sum)."""
+    y, dy = f32c(y), f32c(dy)
+    N, C = y.shape[0], y.shape[1]
+    S = y.numel() // (N * C)
+    lib = _lib()
+    dz = torch.empty_like(y)
+    rows = torch.empty(N * C, dtype=torch.float32, device=y.device)
+    check(lib.sg_act_bwd_rowsum(ptr(y), ptr(dy), ptr(dz), ptr(rows), N * C, S, act, slope, stream()), "act_bwd_rowsum")
+    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    check(lib.sg_colsum(ptr(rows), ptr(gb), N, C, C, stream()), "colsum")
+    return dz, gb
+
+
 def act_fwd_raw(x, act, slope):
     y = torch.empty_like(x)
     check(_lib().sg_act_fwd(ptr(x), ptr(y), x.numel(), act, slope, stream()), "act_fwd")
@@ -246,10 +260,16 @@ class ConvFwd(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        gz = ActBwd.apply(y, gy, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gy
+        gb = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.act != ACT_NONE and want_b and not torch.is_grad_enabled() and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
+            gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope)     # plain backward: activation + bias sums in one pass
+        else:
+            gz = ActBwd.apply(y, gy, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gy
         gx = ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
         gw = ConvWgrad.apply(gz, x, w.shape[1]) if ctx.needs_input_grad[1] else None
-        gb = ChannelSum.apply(gz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if want_b and gb is None:
+            gb = ChannelSum.apply(gz)
         return gx, gw, gb, None, None
 
 
@@ -267,10 +287,16 @@ class ConvDgrad(Function):
     @staticmethod
     def backward(ctx, gdx):
         dy, w, dx = ctx.saved_tensors
-        gz = ActBwd.apply(dx, gdx, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gdx
+        g_b = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.act != ACT_NONE and want_b and not torch.is_grad_enabled() and dx.shape[2] * dx.shape[3] * dx.shape[4] >= 512:
+            gz, g_b = act_bwd_rowsum_raw(dx, gdx, ctx.act, ctx.slope)
+        else:
+            gz = ActBwd.apply(dx, gdx, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gdx
         g_dy = ConvFwd.apply(gz, w, None, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
         g_w = ConvWgrad.apply(dy, gz, w.shape[1]) if ctx.needs_input_grad[1] else None
-        g_b = ChannelSum.apply(gz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if want_b and g_b is None:
+            g_b = ChannelSum.apply(gz)
         return g_dy, g_w, g_b, None, None, None
 
 
