@@ -1329,6 +1329,7 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     const bool mode4 = wgrad_mode4(g);
     if ((!mode4 && (g.OW % 8 != 0 || g.OH % 8 != 0)) || Cin < 2 || Cout < 32) return 0;
     if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
+    if ((long)2 * g.ID * g.IH * g.IW * 4 >= (1L << 26)) return 0;   // box offset | edge-class word needs offsets below 2^26
     int nslice, nsplit, mtiles;
     wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
     const int ntiles = ((Cin + 1) / 2) * mtiles;
