@@ -156,6 +156,10 @@ int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float l
                     float grad_scale, float clip, hipStream_t stream);
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                  float eps, long step, float grad_scale, hipStream_t stream);
+/* Adam with the step counter (int64) and the two bias corrections (float[2]) in device memory: identical arithmetic, but
+ * the call has no host-side state that changes between steps, so a captured hipGraph of a training step replays it. */
+int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                     float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
 
 /* ---- input pipeline -------------------------------------------------------------------------

@@ -23,5 +23,8 @@ for npts, L in cases:
     ms_s = timeit(lambda: tr.step_sorted(idx))
     ms_g = timeit(lambda: tr.step_gathered(idx))
     t0 = time.perf_counter(); tr.step(idx); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+    if npts <= 65536:
+        trg = SDFAutoDecoderTrainer(SDFNet(latent_code_size=L), lat.detach().clone(), pts, sdf, pointcloud_size=pc, capturable=True)
+        print("   graphed step: %.3f ms" % timeit(lambda: trg.step_graphed(idx), 20), flush=True)
     flop = npts * (2.76e6 if L == 128 else 3.16e6)
     print("points %d L %d: %.3f ms/step (wall %.3f)  %.2f Mpoints/s  ~%.1f TFLOP/s   [sorted %.3f ms, gathered %.3f ms]" % (npts, L, ms, wall, npts / ms / 1e3, flop / ms / 1e9, ms_s, ms_g), flush=True)

@@ -128,6 +128,29 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Graph-capturable Adam: the step counter lives on the device.  One thread advances it and derives the two bias
+// corrections in double (as torch does on the host); the update kernel reads them from memory instead of its arguments.
+__global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restrict__ corr, float b1, float b2) {
+    const long long t = *step + 1;
+    *step = t;
+    corr[0] = (float)(1.0 - pow((double)b1, (double)t));
+    corr[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                       float b1, float b2, float eps, const float* __restrict__ corr,
+                                                       float gscale) {
+    const float step = lr / corr[0], bc2_sqrt = corr[1];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float gg = g[e] * gscale;
+        const float mm = b1 * m[e] + (1.f - b1) * gg;
+        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
 __global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, long n, float lo, float hi) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
         p[e] = fminf(fmaxf(p[e], lo), hi);
@@ -231,6 +254,15 @@ int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, lo
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                     float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream) {
+    SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_dev && corr_dev);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, stream, step_dev, corr_dev, beta1, beta2);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, (const float*)corr_dev, grad_scale);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

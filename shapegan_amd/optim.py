@@ -103,9 +103,16 @@ class RMSprop(_Base):
 
 
 class Adam(_Base):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam defaults.  capturable=True keeps the step counter on the device (sg_adam_step_dev) so that the
+    whole update can sit inside a captured graph; it needs every parameter's gradient in the flat buffer on every step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params)
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.capturable = capturable
+        if capturable:
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.f.flat.device)
+            self.corr_dev = torch.zeros(2, dtype=torch.float32, device=self.f.flat.device)
         self.exp_avg = torch.zeros_like(self.f.flat)
         self.exp_avg_sq = torch.zeros_like(self.f.flat)
         # torch keeps one step counter per parameter; a parameter that never had a grad never advances
@@ -116,7 +123,13 @@ class Adam(_Base):
         f = self.f
         base_p, base_m, base_v = f.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         uniform = f.coherent() and len(set(self.steps)) == 1
-        if uniform:
+        if self.capturable:
+            if not f.coherent():
+                raise RuntimeError("capturable Adam: every parameter must have its gradient in the flat buffer")
+            check(lib.sg_adam_step_dev(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
+                                       self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
+                                       self.grad_scale, stream()), "adam_step_dev")
+        elif uniform:
             self.steps = [s + 1 for s in self.steps]
             check(lib.sg_adam_step(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                    self.betas[1], self.eps, self.steps[0], self.grad_scale, stream()), "adam_step")

@@ -126,15 +126,41 @@ class AutoencoderTrainer(object):
 class SDFAutoDecoderTrainer(object):
     """train_sdf_autodecoder.py: DeepSDF auto-decoder, Adam(lr 1e-5) for the net and for the latent table."""
 
-    def __init__(self, sdf_net, latent_codes, points, sdf, pointcloud_size=200000, lr=1e-5, sigma=0.01, cutoff=0.1):
+    def __init__(self, sdf_net, latent_codes, points, sdf, pointcloud_size=200000, lr=1e-5, sigma=0.01, cutoff=0.1,
+                 capturable=False):
         self.net, self.latent_codes = sdf_net, latent_codes
         self.points = points
         self.sdf = sdf.clamp(-cutoff, cutoff)                         # :27
         self.pointcloud_size, self.sigma = pointcloud_size, sigma
         latent_codes.requires_grad = True                             # :42
-        self.net_opt = optim.Adam(sdf_net.parameters(), lr=lr)        # :44
-        self.lat_opt = optim.Adam([latent_codes], lr=lr)              # :45
+        # capturable: Adam keeps its step counter on the device, so step_graphed() can replay a captured step
+        self.net_opt = optim.Adam(sdf_net.parameters(), lr=lr, capturable=capturable)     # :44
+        self.lat_opt = optim.Adam([latent_codes], lr=lr, capturable=capturable)           # :45
         self.net_bucket, self.lat_bucket = GradBucket(self.net_opt), GradBucket(self.lat_opt)
+        self.capturable = capturable
+        self._graph, self._graph_idx, self._graph_loss, self._graph_calls = None, None, None, 0
+
+    def step_graphed(self, indices):
+        """step_gathered as ONE captured graph launch (single process only).  The reference's 20 000-point batch is
+        launch-bound (about 45 kernels, 1.2 ms eager of which the GPU is busy less than half); the first two calls
+        run eagerly (lazy initialisations), the third is captured and every call from then on is a replay.  The
+        returned loss tensor is overwritten by the next call."""
+        if not self.capturable or world_size() > 1:
+            raise RuntimeError("step_graphed needs SDFAutoDecoderTrainer(capturable=True) in a single process")
+        self._graph_calls += 1
+        if self._graph_calls <= 2:
+            return self.step_gathered(indices)
+        if self._graph is None or self._graph_idx.shape != indices.shape:
+            self._graph_idx = indices.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_loss = self.step_gathered(self._graph_idx)
+            self._graph = graph
+        else:
+            self._graph_idx.copy_(indices)
+        self._graph.replay()
+        return self._graph_loss
 
     def step(self, indices):
         """train_sdf_autodecoder.py:77-91 (with the integer floor division `:78` intends).
