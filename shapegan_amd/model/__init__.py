@@ -17,43 +17,58 @@ LATENT_CODES_FILENAME = os.path.join(MODEL_PATH, "sdf_net_latent_codes.to")
 LATENT_CODE_SIZE = 128
 
 
+def checkpoint_file(name, epoch=None):
+    """Where a module called `name` lives on disk: `models/<name>`, or for an epoch snapshot
+    `models/checkpoints/<stem>-epoch-%05d.<ext>` where <stem> is everything before the last dot
+    (model/__init__.py:25-34)."""
+    if epoch is None:
+        return os.path.join(MODEL_PATH, name)
+    stem, dot, ext = name.rpartition('.')
+    if not dot:
+        raise IndexError("checkpoint names need an extension: %r" % name)   # the reference indexes parts[-2]
+    return os.path.join(CHECKPOINT_PATH, "%s-epoch-%05d.%s" % (stem, epoch, ext))
+
+
 class Lambda(nn.Module):
-    """Parameter-free module around a callable (model/__init__.py:12-18)."""
+    """Parameter-free module around a callable (model/__init__.py:12-18); shows up in state_dict as nothing."""
 
     def __init__(self, function):
-        super().__init__()
+        nn.Module.__init__(self)
         self.function = function
 
     def forward(self, x):
         return self.function(x)
 
+    def extra_repr(self):
+        return getattr(self.function, "__name__", "callable")
+
 
 class SavableModule(nn.Module):
-    """nn.Module with the reference's checkpoint naming (model/__init__.py:20-47):
-    models/<filename>, models/checkpoints/<stem>-epoch-%05d.<ext>; optimizer state is never saved."""
+    """nn.Module with the reference's checkpoint protocol (model/__init__.py:20-47): a mutable `.filename`,
+    `get_filename(epoch, filename)`, `load(epoch)` (strict=False), `save(epoch)`, `.device`.  Optimizer state is never
+    part of a checkpoint, exactly as in the reference."""
 
     def __init__(self, filename):
-        super().__init__()
+        nn.Module.__init__(self)
         self.filename = filename
 
     def get_filename(self, epoch=None, filename=None):
-        name = self.filename if filename is None else filename
-        if epoch is None:
-            return os.path.join(MODEL_PATH, name)
-        parts = name.split('.')
-        parts[-2] += '-epoch-{:05d}'.format(epoch)
-        return os.path.join(CHECKPOINT_PATH, '.'.join(parts))
+        return checkpoint_file(self.filename if filename is None else filename, epoch)
 
     def load(self, epoch=None):
-        self.load_state_dict(torch.load(self.get_filename(epoch=epoch)), strict=False)
+        state = torch.load(self.get_filename(epoch=epoch))
+        self.load_state_dict(state, strict=False)
         from ..lib import bump_param_epoch
-        bump_param_epoch()
+        bump_param_epoch()   # packed weight images derived from the old values are stale now
 
     def save(self, epoch=None):
-        os.makedirs(CHECKPOINT_PATH if epoch is not None else MODEL_PATH, exist_ok=True)
-        # clone: parameters may be views into a flat optimizer buffer; keep the file per-tensor like the reference's
-        torch.save({k: v.detach().clone() for k, v in self.state_dict().items()}, self.get_filename(epoch=epoch))
+        target = self.get_filename(epoch=epoch)
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        # per-tensor clones: parameters may be views into a flat optimizer buffer, the file should not drag it along
+        torch.save({key: value.detach().clone() for key, value in self.state_dict().items()}, target)
 
     @property
     def device(self):
-        return next(self.parameters()).device
+        for parameter in self.parameters():
+            return parameter.device
+        raise StopIteration("module without parameters has no device")

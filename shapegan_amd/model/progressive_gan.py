@@ -19,35 +19,37 @@ FINAL_LAYER_FEATURES = 256
 
 
 def from_SDF(x, iteration):
-    """Reference semantics (model/progressive_gan.py:9-16): [B,R,R,R] -> [B,C,R,R,R] with C-1 zero channels.
-    Kept for callers that want the materialised tensor; the discriminator itself does not use it."""
-    resolution = RESOLUTIONS[iteration]
-    features = FEATURE_COUNTS[iteration]
-    x = x.reshape((-1, 1, resolution, resolution, resolution))
-    pad = torch.zeros((x.shape[0], features - 1, resolution, resolution, resolution), device=x.device)
-    return torch.cat((x, pad), dim=1)
+    """Reference semantics (model/progressive_gan.py:9-16, "fromRGB"): [B,R,R,R] -> [B,C,R,R,R], the grid on channel 0
+    and C-1 zero channels behind it.  Kept for callers that want the materialised tensor and for the fade-in blend;
+    the discriminator's own first stage never builds it."""
+    side, channels = RESOLUTIONS[iteration], FEATURE_COUNTS[iteration]
+    grid = x.reshape((-1, 1, side, side, side))
+    return torch.nn.functional.pad(grid, (0, 0, 0, 0, 0, 0, 0, channels - 1))   # zeros appended along the channel axis
+
+
+def _stage(cin, cout):
+    return nn.Sequential(nn.Conv3d(cin, cout, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(negative_slope=0.2))
 
 
 class Discriminator(SavableModule):
+    """model/progressive_gan.py:18-61.  Module creation order (head, then stages 0..3) is the reference's, so the default
+    initialisation under a given seed is bit-identical."""
+
     def __init__(self):
-        super().__init__(filename="hybrid_progressive_gan_discriminator_0.to")
-        self.iteration = 0
         self.filename_base = "hybrid_progressive_gan_discriminator_{:d}.to"
+        SavableModule.__init__(self, filename=self.filename_base.format(0))
+        self.iteration = 0
         self.fade_in_progress = 1
 
-        self.head = nn.Sequential(
-            Lambda(lambda t: t.reshape(-1, 64 * FINAL_LAYER_FEATURES)),
-            nn.Linear(64 * FINAL_LAYER_FEATURES, 128),
-            nn.LeakyReLU(negative_slope=0.2),
-            nn.Linear(128, 1),
-        )
+        flat = 64 * FINAL_LAYER_FEATURES
+        self.head = nn.Sequential(Lambda(lambda t: t.reshape(-1, flat)), nn.Linear(flat, 128),
+                                  nn.LeakyReLU(negative_slope=0.2), nn.Linear(128, 1))
+        widths = [FINAL_LAYER_FEATURES] + FEATURE_COUNTS          # stage i maps widths[i + 1] -> widths[i] channels
         self.optional_layers = nn.ModuleList()
-        for i, cin in enumerate(FEATURE_COUNTS):
-            cout = FEATURE_COUNTS[i - 1] if i > 0 else FINAL_LAYER_FEATURES
-            stage = nn.Sequential(nn.Conv3d(in_channels=cin, out_channels=cout, kernel_size=4, stride=2, padding=1),
-                                  nn.LeakyReLU(negative_slope=0.2))
+        for index in range(len(FEATURE_COUNTS)):
+            stage = _stage(widths[index + 1], widths[index])
             self.optional_layers.append(stage)
-            self.add_module('optional_layer_{:d}'.format(i), stage)
+            self.add_module('optional_layer_{:d}'.format(index), stage)    # second registration: both key sets exist
 
     def forward(self, x):
         it = self.iteration
@@ -68,4 +70,4 @@ class Discriminator(SavableModule):
 
     def set_iteration(self, value):
         self.iteration = value
-        self.filename = self.filename_base.format(self.iteration)
+        self.filename = self.filename_base.format(value)
