@@ -94,6 +94,12 @@ int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long s
 size_t sg_gemm_nt_workspace_bytes(int M, int N, long K);
 int sg_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, long K, void* workspace,
                size_t workspace_bytes, hipStream_t stream);
+/* up to 8 such products in one launch: member b multiplies A + a_off[b] with B + b_off[b] (element offsets, shared leading
+ * dimensions and sizes) into C + c_off[b] with row stride ldc[b] — all weight gradients of an SDFNet backward at once */
+size_t sg_gemm_nt_batched_workspace_bytes(int batch, int M, int N, long K);
+int sg_gemm_nt_batched(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
+                       const long* c_off, const long* ldc, int batch, int M, int N, long K, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream);
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
 /* out[r*nseg + s] = sum of x[r*ld + e] over e in [seg_off[s], seg_off[s+1])  (per-shape sums of SDFNet dZ columns) */

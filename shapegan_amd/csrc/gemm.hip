@@ -120,13 +120,16 @@ constexpr int kNtKC = 32;                 // k per stage
 constexpr int kNtChunk = 128 * 4 + 4;     // floats per (k/4) chunk of one operand tile
 constexpr int kNtOp = 8 * kNtChunk;       // floats per operand tile per buffer
 
+constexpr int kNtMaxBatch = 8;
 struct GemmNtArgs {
     const float* A;
     const float* B;
-    float* out;      // partials [nsplit][M][N] (ldc = N) or C itself when nsplit == 1
+    float* out;      // partials [batch][nsplit][M][N] (ldc = N) or C itself when nsplit == 1 and batch == 1
     long lda, ldb, ldc;
     int M, N;
     long K, kchunk;  // kchunk: multiple of kNtKC
+    int nsplit;      // grid z = batch * nsplit
+    long a_off[kNtMaxBatch], b_off[kNtMaxBatch];   // element offsets of the batch members' operands
 };
 
 __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
@@ -136,7 +139,8 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kh = lane >> 5;
     const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const long kbeg = (long)blockIdx.z * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const int bz = blockIdx.z / a.nsplit, sz = blockIdx.z - bz * a.nsplit;   // batch member, K split
+    const long kbeg = (long)sz * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
     const int nstage = (int)((kend - kbeg + kNtKC - 1) / kNtKC);
 
     f32x16 acc[2][2];
@@ -149,8 +153,8 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
 
     // copy: thread -> (row inside a 32-row pass, 16-byte piece kq of the 128-byte segment)
     const int rowl = tid >> 3, kq = tid & 7;
-    const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.A + (long)i0 * a.lda + kbeg);
-    const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.B + (long)j0 * a.ldb + kbeg);
+    const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.A + a.a_off[bz] + (long)i0 * a.lda + kbeg);
+    const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.B + a.b_off[bz] + (long)j0 * a.ldb + kbeg);
     unsigned avoff[4], bvoff[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
         if (nstage & 1) stage(IntTag<0>(), nstage - 1);
     }
 
-    float* out = a.out + (long)blockIdx.z * a.M * a.ldc;
+    float* out = a.out + (long)blockIdx.z * a.M * a.ldc;   // partial image (batch member, split); C itself if there is one
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -275,9 +279,37 @@ struct CopyEpi {   // finalize target: C[i][j], row stride ldc
     __device__ void store(const Col& cc, int i, int j, float v) const { c[(long)i * ldc + cc.j] = v; }
 };
 
-static void gemm_nt_plan(int M, int N, long K, int& nsplit, long& kchunk) {
-    const long tiles = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
-    long s = (512 + tiles - 1) / tiles;
+// C_b[i][j] = sum over the nsplit partials of batch member b; the members' outputs are given as element offsets from `c`
+struct GemmNtOut {
+    long c_off[kNtMaxBatch];
+    long ldc[kNtMaxBatch];
+};
+__global__ void __launch_bounds__(256) gemm_nt_finalize_kernel(const float* __restrict__ ws, float* __restrict__ c, GemmNtOut o,
+                                                               int M, int N, int nsplit) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const long total = (long)M * N, e = (long)blockIdx.x * 64 + lane;
+    const float* p = ws + (long)b * nsplit * total;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int s = wave;
+        for (; s + 4 < nsplit; s += 8) {
+            s0 += p[(long)s * total + e];
+            s1 += p[(long)(s + 4) * total + e];
+        }
+        if (s < nsplit) s0 += p[(long)s * total + e];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && e < total) {
+        const int i = (int)(e / N), j = (int)(e - (long)i * N);
+        c[o.c_off[b] + (long)i * o.ldc[b] + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
+}
+
+static void gemm_nt_plan(int M, int N, long K, int& nsplit, long& kchunk, int batch = 1) {
+    const long tiles = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128) * batch;
+    long s = 512 / tiles > 0 ? 512 / tiles : 1;   // at most 512 workgroups: one round at 2 per CU, no straggler round
     const long maxs = K / (8 * kNtKC) > 0 ? K / (8 * kNtKC) : 1;   // >= 8 stages per workgroup
     if (s > maxs) s = maxs;
     if (s > 256) s = 256;
@@ -340,6 +372,52 @@ int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg
     return SG_OK;
 }
 
+static int gemm_nt_launch(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
+                          const long* c_off, const long* ldc, int batch, int M, int N, long K, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream, const char* who) {
+    int nsplit;
+    long kchunk;
+    gemm_nt_plan(M, N, K, nsplit, kchunk, batch);
+    const bool direct = nsplit == 1 && batch == 1;
+    if (!direct && (!workspace || workspace_bytes < (size_t)batch * nsplit * M * N * sizeof(float)))
+        SG_FAIL(SG_ERR_WORKSPACE, "%s: workspace too small", who);
+    GemmNtArgs a;
+    a.A = A;
+    a.B = B;
+    a.lda = lda;
+    a.ldb = ldb;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.kchunk = kchunk;
+    a.nsplit = nsplit;
+    for (int b = 0; b < kNtMaxBatch; ++b) {
+        a.a_off[b] = b < batch ? a_off[b] : 0;
+        a.b_off[b] = b < batch ? b_off[b] : 0;
+    }
+    a.out = direct ? C + c_off[0] : (float*)workspace;
+    a.ldc = direct ? ldc[0] : N;
+    const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(sg_cdiv(N, 128), sg_cdiv(M, 128), batch * nsplit), dim3(256), lds, stream, a);
+    if (!direct) {
+        GemmNtOut o;
+        for (int b = 0; b < kNtMaxBatch; ++b) {
+            o.c_off[b] = b < batch ? c_off[b] : 0;
+            o.ldc[b] = b < batch ? ldc[b] : 0;
+        }
+        hipLaunchKernelGGL(gemm_nt_finalize_kernel, dim3((unsigned)(((long)M * N + 63) / 64), batch), dim3(256), 0, stream,
+                           (const float*)workspace, C, o, M, N, nsplit);
+    }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
 size_t sg_gemm_nt_workspace_bytes(int M, int N, long K) {
     int nsplit;
     long kchunk;
@@ -352,42 +430,28 @@ int sg_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, lon
     SG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N);
     SG_CHECK_ARG(31L * lda * 4 + 64 < (long)kBufRange && 31L * ldb * 4 + 64 < (long)kBufRange);   // lane offset
     SG_CHECK_ARG(96L * lda * 4 + K * 4 < (1L << 32) && 96L * ldb * 4 + K * 4 < (1L << 32));       // scalar offset
+    const long zero = 0;
+    return gemm_nt_launch(A, &zero, lda, B, &zero, ldb, C, &zero, &ldc, 1, M, N, K, workspace, workspace_bytes, stream,
+                          "sg_gemm_nt");
+}
+
+size_t sg_gemm_nt_batched_workspace_bytes(int batch, int M, int N, long K) {
     int nsplit;
     long kchunk;
-    gemm_nt_plan(M, N, K, nsplit, kchunk);
-    if (nsplit > 1 && (!workspace || workspace_bytes < (size_t)nsplit * M * N * sizeof(float)))
-        SG_FAIL(SG_ERR_WORKSPACE, "sg_gemm_nt: workspace too small");
-    GemmNtArgs a;
-    a.A = A;
-    a.B = B;
-    a.lda = lda;
-    a.ldb = ldb;
-    a.M = M;
-    a.N = N;
-    a.K = K;
-    a.kchunk = kchunk;
-    a.out = nsplit > 1 ? (float*)workspace : C;
-    a.ldc = nsplit > 1 ? N : ldc;
-    const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(sg_cdiv(N, 128), sg_cdiv(M, 128), nsplit), dim3(256), lds, stream, a);
-    if (nsplit > 1) {
-        CopyEpi epi{C, ldc};
-        if (nsplit >= 32 && (long)M * N <= (1L << 18)) {
-            hipLaunchKernelGGL((splitk_finalize_deep_kernel<CopyEpi>), dim3((unsigned)(((long)M * N + 63) / 64)), dim3(256), 0,
-                               stream, (const float*)workspace, epi, M, N, nsplit);
-        } else {
-            hipLaunchKernelGGL((splitk_finalize_kernel<CopyEpi>), dim3((unsigned)((long)M * ((N + 1023) >> 10))), dim3(256), 0,
-                               stream, (const float*)workspace, epi, M, N, nsplit);
-        }
-    }
-    SG_CHECK_LAUNCH();
-    return SG_OK;
+    gemm_nt_plan(M, N, K, nsplit, kchunk, batch);
+    return (size_t)batch * nsplit * M * N * sizeof(float);
+}
+
+int sg_gemm_nt_batched(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
+                       const long* c_off, const long* ldc, int batch, int M, int N, long K, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(A && B && C && a_off && b_off && c_off && ldc && batch > 0 && batch <= kNtMaxBatch);
+    SG_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K);
+    SG_CHECK_ARG(31L * lda * 4 + 64 < (long)kBufRange && 31L * ldb * 4 + 64 < (long)kBufRange);
+    SG_CHECK_ARG(96L * lda * 4 + K * 4 < (1L << 32) && 96L * ldb * 4 + K * 4 < (1L << 32));
+    for (int b = 0; b < batch; ++b) SG_CHECK_ARG(ldc[b] >= N);
+    return gemm_nt_launch(A, a_off, lda, B, b_off, ldb, C, c_off, ldc, batch, M, N, K, workspace, workspace_bytes, stream,
+                          "sg_gemm_nt_batched");
 }
 
 }  // extern "C"

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sg_voxel_prepare": (c_int, [_P, _P, _L, _F, _F, _P]),
     "sg_gemm_nt_workspace_bytes": (_Z, [_I, _I, _L]),
     "sg_gemm_nt": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _L, _P, _Z, _P]),
+    "sg_gemm_nt_batched_workspace_bytes": (_Z, [_I, _I, _I, _L]),
+    "sg_gemm_nt_batched": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _L, _P, _Z, _P]),
     "sg_layernorm_fwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _F, _I, _P]),
     "sg_layernorm_bwd_workspace_bytes": (_Z, [_L, _I]),
     "sg_layernorm_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P, _Z, _P]),

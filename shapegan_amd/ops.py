@@ -524,13 +524,23 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
     for rows, off, width in x_parts:
         wgrad_from_rows(0, rows, width, w1, off, kin_total)
         wgrad_from_rows(4, rows, width, w5, _H + off, _H + kin_total)
-    wgrad_from_acts(4, 3, w5, 0, _H + kin_total)
+    # the six 256 x 256 x N products dZ_l H_{l-1}^T in ONE launch (+ one finalize): layers2.0's hidden block, then layers
+    # 1.2/1.4/1.6/2.2/2.4
+    hidden = torch.empty((5, _H, _H), dtype=torch.float32, device=dev)
+    pairs = ((4, 3), (1, 0), (2, 1), (3, 2), (5, 4), (6, 5))
+    outs = [(w5, _H + kin_total)] + [(hidden[i], _H) for i in range(5)]
+    arr = ctypes.c_long * 6
+    a_off = arr(*[ldz * _H * ldn for ldz, _ in pairs])
+    b_off = arr(*[ai * _H * ldn for _, ai in pairs])
+    c_off = arr(*[(o.data_ptr() - w5.data_ptr()) // 4 for o, _ in outs])
+    ldcs = arr(*[ld for _, ld in outs])
+    ws = workspace("gemm_nt", lib.sg_gemm_nt_batched_workspace_bytes(6, _H, _H, N), dev)
+    check(lib.sg_gemm_nt_batched(ptr(dz), a_off, ldn, ptr(acts), b_off, ldn, ptr(w5), c_off, ldcs, 6, _H, _H, N, ptr(ws),
+                                 ws.numel(), stream()), "gemm_nt_batched")
     grads[0], grads[8] = w1, w5
     grads[1], grads[9] = bgrad(0), bgrad(4)
-    for pi, (ldz, ai) in zip((2, 4, 6, 10, 12), ((1, 0), (2, 1), (3, 2), (5, 4), (6, 5))):
-        g = torch.empty((_H, _H), dtype=torch.float32, device=dev)
-        wgrad_from_acts(ldz, ai, g)
-        grads[pi] = g
+    for i, (pi, (ldz, _)) in enumerate(zip((2, 4, 6, 10, 12), pairs[1:])):
+        grads[pi] = hidden[i]
         grads[pi + 1] = bgrad(ldz)
     # layers2.6: W8 [1,256], b8 [1]
     w8 = torch.empty((1, _H), dtype=torch.float32, device=dev)
