@@ -168,6 +168,44 @@ int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq
                      float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
 
+/* ---- K8/K9: loss compositions, gradient-penalty pieces, fade-in blend ---------------------------
+ * Each loss is one streaming pass + a finishing wave (deterministic, double partial sums) writing a device scalar;
+ * each backward is one elementwise pass that reads the upstream scalar gradient `gloss` from device memory.
+ * sg_loss_weighted_l1: get_reconstruction_loss, train_autoencoder.py:57-62 (neg_weight 32: d *= 32 where target < 0),
+ *   and with neg_weight 1 the DeepSDF data term mean|out - sdf|, train_sdf_autodecoder.py:88.
+ * sg_loss_kld: kld_loss, train_autoencoder.py:54-55.
+ * sg_loss_meansq: sum_r w_r |x_r|^2 / denom (w = 1 when row_weight is null): the latent regulariser
+ *   mean(batch_latent_codes^2), train_sdf_autodecoder.py:88 (row_weight = how often a shape occurs in the batch).
+ * sg_gradient_penalty: ((||g_b||_2 - 1)^2).mean() * weight over rows g_b of `grad` [B, M],
+ *   train_hybrid_progressive_gan.py:110-111, train_point_gan.py:68-70; sg_lerp_rows: alpha*real + (1-alpha)*fake (:105).
+ * sg_fade_blend: fade*x + half_scale*from_SDF(half) (model/progressive_gan.py:48-50): `half` [B,S] lands on channel 0 of
+ *   x [B,C,S], the C-1 zero channels of from_SDF are never built (x may be NULL: the embedding alone); sg_channel0 is its
+ *   adjoint w.r.t. `half`; sg_subsample2 / _adjoint: x_in[:, ::2, ::2, ::2] (bit-exact index work) and its adjoint. */
+size_t sg_loss_workspace_bytes(void);
+int sg_loss_weighted_l1_fwd(const float* out, const float* target, long n, float neg_weight, float* loss, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream);
+int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* gloss, float* dout, long n, float neg_weight,
+                            hipStream_t stream);
+int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream);
+int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* gloss, float* dmean, float* dlog_variance,
+                    long n, hipStream_t stream);
+int sg_loss_meansq_fwd(const float* x, const float* row_weight, long rows, int L, double denom, float* loss, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream);
+int sg_loss_meansq_bwd(const float* x, const float* row_weight, const float* gloss, float* dx, long rows, int L, double denom,
+                       hipStream_t stream);
+int sg_gradient_penalty_fwd(const float* grad, long B, long M, float weight, float* norms, float* loss, hipStream_t stream);
+int sg_gradient_penalty_bwd(const float* grad, const float* norms, const float* gloss, float* dgrad, long B, long M,
+                            float weight, hipStream_t stream);
+int sg_lerp_rows(const float* a, const float* b, const float* alpha, float* out, long B, long M, hipStream_t stream);
+int sg_fade_blend(const float* x, const float* half, float* out, long B, int C, long S, float fade, float half_scale,
+                  hipStream_t stream);
+int sg_channel0(const float* g, float* out, long B, int C, long S, float scale, hipStream_t stream);
+int sg_subsample2(const float* x, float* out, long B, int R, hipStream_t stream);
+int sg_subsample2_adjoint(const float* g, float* out, long B, int R, hipStream_t stream);
+/* second-order term of sg_act_bwd for tanh / sigmoid: out = ggx * dy * d(act'(y))/dy  (-2y resp. 1-2y) */
+int sg_act_bwd_dy(const float* y, const float* dy, const float* ggx, float* out, long n, int act, hipStream_t stream);
+
 /* ---- input pipeline -------------------------------------------------------------------------
  * reference: VoxelDataset.__getitem__ (datasets.py:16-23): result.clamp_(-clamp, clamp); result /= clamp when
  * rescale_sdf.  out = clamp(x, -clamp, clamp) / divisor on the device (divisor <= 0: no division); x == out allowed.
@@ -199,6 +237,14 @@ int sg_colsum_tall(const float* x, float* out, long batch, long batch_stride, lo
 int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, hipStream_t stream);
 int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P, int C, hipStream_t stream);
 int sg_segmax_gather(const float* x, const int* idx, float* out, long B, long P, int C, hipStream_t stream);
+/* torch_scatter.scatter_max over a ragged `batch` vector (model/point_sdf_net.py:42-43, train_point_gan_ref.py:109-110):
+ * out[b][c] = max over rows i with batch[i] == b of x[i][c] (0 for a segment without members, as torch_scatter), arg = the
+ * first row attaining it (-1 when empty); scatter = backward (zero-filled), gather = backward of the backward. */
+size_t sg_scatter_max_workspace_bytes(long B, int C);
+int sg_scatter_max_fwd(const float* x, const int64_t* batch, float* out, int* arg, long N, long B, int C, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream);
+int sg_scatter_max_scatter(const float* dy, const int* arg, float* dx, long N, long B, int C, hipStream_t stream);
+int sg_scatter_max_gather(const float* x, const int* arg, float* out, long N, long B, int C, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
 __device__ __forceinline__ float bn_act_grad(float xhat, float g, float b, float dy, int act, float slope) {
     if (act == SG_ACT_LEAKY) return (fmaf(g, xhat, b) > 0.f) ? dy : dy * slope;
     if (act == SG_ACT_RELU) return (fmaf(g, xhat, b) > 0.f) ? dy : 0.f;
+    if (act == SG_ACT_TANH) {   // derivative through the recomputed output, as the forward applied it (sg_apply_act)
+        const float y = tanhf(fmaf(g, xhat, b));
+        return dy * (1.f - y * y);
+    }
+    if (act == SG_ACT_SIGMOID) {
+        const float y = 1.f / (1.f + expf(-fmaf(g, xhat, b)));
+        return dy * y * (1.f - y);
+    }
     return dy;
 }
 

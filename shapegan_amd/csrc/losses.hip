@@ -1,0 +1,442 @@
+// shapegan_amd/csrc/losses.hip — the loss compositions and blends of the training scripts as single-pass HBM-bound kernels
+// (§8 row a13).
+//
+// Reference sites:
+//   get_reconstruction_loss   train_autoencoder.py:57-62   mean |d|, d = out - target, d *= 32 where target < 0
+//   kld_loss                  train_autoencoder.py:54-55   -0.5 * sum(1 + lv - mu^2 - exp(lv)) / numel
+//   DeepSDF loss              train_sdf_autodecoder.py:88  mean |out - sdf|  +  sigma * mean(z_batch^2)
+//   gradient penalty          train_hybrid_progressive_gan.py:103-111, train_point_gan.py:61-70
+//                             lerp alpha*real + (1-alpha)*fake;  ((||g_b||_2 - 1)^2).mean() * lambda
+//   fade-in blend             model/progressive_gan.py:48-50  fade*x + (1-fade)*from_SDF(x_in[:, ::2, ::2, ::2])
+//   scatter_max               model/point_sdf_net.py:42-43 (torch_scatter, ragged `batch` vector)
+// Reductions are two-stage and deterministic (per-workgroup double partials, one finishing wave); every backward is an
+// elementwise pass that reads the upstream scalar gradient from device memory (no host round trip).
+#include "common.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+constexpr int kRedBlocks = 512;
+
+static int red_grid(long n) {
+    long b = (n + 2047) / 2048;
+    if (b > kRedBlocks) b = kRedBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ void block_store_partial(double s, double* __restrict__ partial) {
+    __shared__ double red[4];
+    s = sg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) loss_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int nb,
+                                                        double scale) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+    s = sg_wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)(s * scale);
+}
+
+// ---- weighted L1 ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wl1_fwd_kernel(const float* __restrict__ o, const float* __restrict__ t, long n,
+                                                      float negw, double* __restrict__ partial) {
+    double s = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float tt = t[e];
+        float d = o[e] - tt;
+        if (tt < 0.f) d *= negw;
+        s += (double)fabsf(d);
+    }
+    block_store_partial(s, partial);
+}
+__global__ void __launch_bounds__(256) wl1_bwd_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                      const float* __restrict__ gloss, float* __restrict__ d_o, long n,
+                                                      float negw, float inv_n) {
+    const float g = gloss[0] * inv_n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float tt = t[e];
+        const float w = tt < 0.f ? negw : 1.f;
+        const float d = (o[e] - tt) * w;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        d_o[e] = g * sgn * w;
+    }
+}
+
+// ---- KL divergence of N(mu, exp(lv)) from N(0, 1) -----------------------------------------------------------------
+__global__ void __launch_bounds__(256) kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, long n,
+                                                      double* __restrict__ partial) {
+    double s = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float m = mu[e], l = lv[e];
+        s += (double)(1.f + l - m * m - expf(l));
+    }
+    block_store_partial(s, partial);
+}
+__global__ void __launch_bounds__(256) kld_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                      const float* __restrict__ gloss, float* __restrict__ dmu,
+                                                      float* __restrict__ dlv, long n, float inv_n) {
+    const float g = gloss[0] * inv_n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        dmu[e] = g * mu[e];
+        dlv[e] = -0.5f * g * (1.f - expf(lv[e]));
+    }
+}
+
+// ---- (row-weighted) mean of squares ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ roww, long n,
+                                                     int L, double* __restrict__ partial) {
+    double s = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = x[e];
+        s += (double)(roww ? roww[e / L] * v * v : v * v);
+    }
+    block_store_partial(s, partial);
+}
+__global__ void __launch_bounds__(256) sq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ roww,
+                                                     const float* __restrict__ gloss, float* __restrict__ dx, long n, int L,
+                                                     float scale2) {
+    const float g = gloss[0] * scale2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        dx[e] = (roww ? roww[e / L] : 1.f) * g * x[e];
+}
+
+// ---- gradient penalty ----------------------------------------------------------------------------------------------
+// one workgroup per sample row: norm_b = ||g_b||_2
+__global__ void __launch_bounds__(256) row_norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long M) {
+    const float* row = g + (long)blockIdx.x * M;
+    double s = 0;
+    if ((M & 3) == 0) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        for (long e = threadIdx.x; e < (M >> 2); e += 256) {
+            const float4 v = r4[e];
+            s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (long e = threadIdx.x; e < M; e += 256) s += (double)(row[e] * row[e]);
+    }
+    __shared__ double red[4];
+    s = sg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norms[blockIdx.x] = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void __launch_bounds__(64) gp_final_kernel(const float* __restrict__ norms, float* __restrict__ out, int B,
+                                                      float weight) {
+    double s = 0;
+    for (int i = threadIdx.x; i < B; i += 64) {
+        const double d = (double)norms[i] - 1.0;
+        s += d * d;
+    }
+    s = sg_wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)(s / B * (double)weight);
+}
+// d loss / d g[b, :] = gloss * weight * 2 (norm_b - 1) / B * g[b, :] / norm_b   (0 where norm_b == 0, as torch.norm's backward)
+__global__ void __launch_bounds__(256) gp_bwd_kernel(const float* __restrict__ g, const float* __restrict__ norms,
+                                                     const float* __restrict__ gloss, float* __restrict__ dg, long M,
+                                                     float coef) {
+    const float nb = norms[blockIdx.y];
+    const float c = nb > 0.f ? gloss[0] * coef * (nb - 1.f) / nb : 0.f;
+    const long base = (long)blockIdx.y * M;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M; e += (long)gridDim.x * 256) dg[base + e] = c * g[base + e];
+}
+
+// out[b, :] = alpha[b] * a[b, :] + (1 - alpha[b]) * b[b, :]   (two rounded products and one rounded sum, as the reference)
+__global__ void __launch_bounds__(256) lerp_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ alpha, float* __restrict__ out, long M) {
+    const float al = alpha[blockIdx.y], be = __fsub_rn(1.f, al);
+    const long base = (long)blockIdx.y * M;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M; e += (long)gridDim.x * 256)
+        out[base + e] = __fadd_rn(__fmul_rn(al, a[base + e]), __fmul_rn(be, b[base + e]));
+}
+
+// ---- fade-in blend -------------------------------------------------------------------------------------------------
+// out[b, c, s] = fade * x[b, c, s] + (c == 0 ? (1 - fade) * half[b, s] : 0);  x may be null (embedding only)
+__global__ void __launch_bounds__(256) fade_blend_kernel(const float* __restrict__ x, const float* __restrict__ half,
+                                                         float* __restrict__ out, int C, long S, float fade, float hscale) {
+    const long b = blockIdx.z;
+    const int c = blockIdx.y;
+    const long base = (b * C + c) * S;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < S; e += (long)gridDim.x * 256) {
+        float v = x ? __fmul_rn(fade, x[base + e]) : 0.f;
+        if (c == 0) v = __fadd_rn(v, __fmul_rn(hscale, half[b * S + e]));
+        out[base + e] = v;
+    }
+}
+// out[b, s] = a * g[b, 0, s]
+__global__ void __launch_bounds__(256) chan0_kernel(const float* __restrict__ g, float* __restrict__ out, int C, long S,
+                                                    float a) {
+    const long b = blockIdx.y;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < S; e += (long)gridDim.x * 256)
+        out[b * S + e] = a * g[b * C * S + e];
+}
+// nearest-neighbour x[:, ::2, ::2, ::2] of [B, R, R, R] grids and its adjoint (zeros at the odd positions)
+__global__ void __launch_bounds__(256) subsample2_kernel(const float* __restrict__ x, float* __restrict__ out, int R,
+                                                         long total) {
+    const int h = R >> 1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % h);
+        long r = e / h;
+        const int j = (int)(r % h);
+        r /= h;
+        const int i = (int)(r % h);
+        const long b = r / h;
+        out[e] = x[((b * R + 2 * i) * R + 2 * j) * R + 2 * k];
+    }
+}
+__global__ void __launch_bounds__(256) subsample2_adj_kernel(const float* __restrict__ g, float* __restrict__ out, int R,
+                                                             long total) {
+    const int h = R >> 1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % R);
+        long r = e / R;
+        const int j = (int)(r % R);
+        r /= R;
+        const int i = (int)(r % R);
+        const long b = r / R;
+        out[e] = ((i | j | k) & 1) ? 0.f : g[((b * h + (i >> 1)) * h + (j >> 1)) * h + (k >> 1)];
+    }
+}
+
+// ---- second-order term of tanh / sigmoid backward ------------------------------------------------------------------
+// ActBwd computes dx = dy * f'(.) through the OUTPUT y: d dx / d y = dy * (-2y) (tanh), dy * (1 - 2y) (sigmoid)
+__global__ void __launch_bounds__(256) act_bwd_dy_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                         const float* __restrict__ ggx, float* __restrict__ out, long n,
+                                                         int act) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float yy = y[e];
+        const float d = act == SG_ACT_TANH ? -2.f * yy : (act == SG_ACT_SIGMOID ? 1.f - 2.f * yy : 0.f);
+        out[e] = ggx[e] * dy[e] * d;
+    }
+}
+
+// ---- scatter_max over a ragged `batch` vector ---------------------------------------------------------------------
+// order-preserving float <-> uint map, so that atomicMax on the image is the float maximum
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__global__ void __launch_bounds__(256) fill_u32_kernel(unsigned* __restrict__ p, long n, unsigned v) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) p[e] = v;
+}
+__global__ void __launch_bounds__(256) scatter_max_pass1(const float* __restrict__ x, const int64_t* __restrict__ batch,
+                                                         unsigned* __restrict__ ord, long N, int C, long B) {
+    const long total = N * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / C;
+        const int c = (int)(e - i * C);
+        const long b = batch[i];
+        if (b >= 0 && b < B) atomicMax(&ord[b * C + c], f2ord(x[e]));
+    }
+}
+// first row that attains the maximum (deterministic: atomicMin over the row index)
+__global__ void __launch_bounds__(256) scatter_max_pass2(const float* __restrict__ x, const int64_t* __restrict__ batch,
+                                                         const unsigned* __restrict__ ord, int* __restrict__ arg, long N,
+                                                         int C, long B) {
+    const long total = N * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / C;
+        const int c = (int)(e - i * C);
+        const long b = batch[i];
+        if (b >= 0 && b < B && f2ord(x[e]) == ord[b * C + c]) atomicMin(&arg[b * C + c], (int)i);
+    }
+}
+__global__ void __launch_bounds__(256) scatter_max_finish(const unsigned* __restrict__ ord, int* __restrict__ arg,
+                                                          float* __restrict__ out, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const bool empty = arg[e] == 0x7fffffff;
+        out[e] = empty ? 0.f : ord2f(ord[e]);      // torch_scatter fills segments without a member with 0
+        if (empty) arg[e] = -1;
+    }
+}
+__global__ void __launch_bounds__(256) arg_scatter_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                                          float* __restrict__ dx, long BC, int C) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < BC; e += (long)gridDim.x * 256) {
+        const int i = arg[e];
+        if (i >= 0) dx[(long)i * C + (e % C)] = dy[e];     // (i, c) pairs are unique per (b, c): no conflicts
+    }
+}
+__global__ void __launch_bounds__(256) arg_gather_kernel(const float* __restrict__ x, const int* __restrict__ arg,
+                                                         float* __restrict__ out, long BC, int C) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < BC; e += (long)gridDim.x * 256) {
+        const int i = arg[e];
+        out[e] = i >= 0 ? x[(long)i * C + (e % C)] : 0.f;
+    }
+}
+
+static int ew_blocks(long n) {
+    long b = (n + 1023) / 1024;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+size_t sg_loss_workspace_bytes(void) { return kRedBlocks * sizeof(double); }
+
+#define SG_CHECK_WS()                                                             \
+    if (!workspace || workspace_bytes < sg_loss_workspace_bytes())                \
+    SG_FAIL(SG_ERR_WORKSPACE, "%s: workspace too small (need %zu bytes)", __func__, sg_loss_workspace_bytes())
+
+int sg_loss_weighted_l1_fwd(const float* out, const float* target, long n, float neg_weight, float* loss, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(out && target && loss && n > 0);
+    SG_CHECK_WS();
+    const int nb = red_grid(n);
+    hipLaunchKernelGGL(wl1_fwd_kernel, dim3(nb), dim3(256), 0, stream, out, target, n, neg_weight, (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, loss, nb, 1.0 / (double)n);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* gloss, float* dout, long n, float neg_weight,
+                            hipStream_t stream) {
+    SG_CHECK_ARG(out && target && gloss && dout && n > 0);
+    hipLaunchKernelGGL(wl1_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, out, target, gloss, dout, n, neg_weight,
+                       (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+    SG_CHECK_ARG(mean && log_variance && loss && n > 0);
+    SG_CHECK_WS();
+    const int nb = red_grid(n);
+    hipLaunchKernelGGL(kld_fwd_kernel, dim3(nb), dim3(256), 0, stream, mean, log_variance, n, (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, loss, nb, -0.5 / (double)n);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* gloss, float* dmean, float* dlog_variance,
+                    long n, hipStream_t stream) {
+    SG_CHECK_ARG(mean && log_variance && gloss && dmean && dlog_variance && n > 0);
+    hipLaunchKernelGGL(kld_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mean, log_variance, gloss, dmean,
+                       dlog_variance, n, (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_meansq_fwd(const float* x, const float* row_weight, long rows, int L, double denom, float* loss, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(x && loss && rows > 0 && L > 0 && denom > 0);
+    SG_CHECK_WS();
+    const long n = rows * L;
+    const int nb = red_grid(n);
+    hipLaunchKernelGGL(sq_fwd_kernel, dim3(nb), dim3(256), 0, stream, x, row_weight, n, L, (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, loss, nb, 1.0 / denom);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_meansq_bwd(const float* x, const float* row_weight, const float* gloss, float* dx, long rows, int L, double denom,
+                       hipStream_t stream) {
+    SG_CHECK_ARG(x && gloss && dx && rows > 0 && L > 0 && denom > 0);
+    const long n = rows * L;
+    hipLaunchKernelGGL(sq_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, row_weight, gloss, dx, n, L,
+                       (float)(2.0 / denom));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_gradient_penalty_fwd(const float* grad, long B, long M, float weight, float* norms, float* loss, hipStream_t stream) {
+    SG_CHECK_ARG(grad && norms && loss && B > 0 && B < 65536 && M > 0);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)B), dim3(256), 0, stream, grad, norms, M);
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)norms, loss, (int)B, weight);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_gradient_penalty_bwd(const float* grad, const float* norms, const float* gloss, float* dgrad, long B, long M,
+                            float weight, hipStream_t stream) {
+    SG_CHECK_ARG(grad && norms && gloss && dgrad && B > 0 && B < 65536 && M > 0);
+    long bx = (M + 2047) / 2048;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(gp_bwd_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, grad, norms, gloss, dgrad, M,
+                       (float)(2.0 * (double)weight / (double)B));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_lerp_rows(const float* a, const float* b, const float* alpha, float* out, long B, long M, hipStream_t stream) {
+    SG_CHECK_ARG(a && b && alpha && out && B > 0 && B < 65536 && M > 0);
+    long bx = (M + 2047) / 2048;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(lerp_rows_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, a, b, alpha, out, M);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_fade_blend(const float* x, const float* half, float* out, long B, int C, long S, float fade, float half_scale,
+                  hipStream_t stream) {
+    SG_CHECK_ARG(half && out && B > 0 && B < 65536 && C > 0 && C < 65536 && S > 0);
+    long bx = (S + 1023) / 1024;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(fade_blend_kernel, dim3((unsigned)bx, (unsigned)C, (unsigned)B), dim3(256), 0, stream, x, half, out, C,
+                       S, fade, half_scale);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_channel0(const float* g, float* out, long B, int C, long S, float scale, hipStream_t stream) {
+    SG_CHECK_ARG(g && out && B > 0 && B < 65536 && C > 0 && S > 0);
+    long bx = (S + 1023) / 1024;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(chan0_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, g, out, C, S, scale);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_subsample2(const float* x, float* out, long B, int R, hipStream_t stream) {
+    SG_CHECK_ARG(x && out && B > 0 && R >= 2 && (R & 1) == 0);
+    const long total = B * (R / 2) * (R / 2) * (R / 2);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, out, R, total);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_subsample2_adjoint(const float* g, float* out, long B, int R, hipStream_t stream) {
+    SG_CHECK_ARG(g && out && B > 0 && R >= 2 && (R & 1) == 0);
+    const long total = B * (long)R * R * R;
+    hipLaunchKernelGGL(subsample2_adj_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, g, out, R, total);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_act_bwd_dy(const float* y, const float* dy, const float* ggx, float* out, long n, int act, hipStream_t stream) {
+    SG_CHECK_ARG(y && dy && ggx && out && n > 0 && (act == SG_ACT_TANH || act == SG_ACT_SIGMOID));
+    hipLaunchKernelGGL(act_bwd_dy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, ggx, out, n, act);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+size_t sg_scatter_max_workspace_bytes(long B, int C) { return (size_t)B * C * sizeof(unsigned); }
+int sg_scatter_max_fwd(const float* x, const int64_t* batch, float* out, int* arg, long N, long B, int C, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(x && batch && out && arg && N > 0 && N < (1L << 31) && B > 0 && C > 0);
+    if (!workspace || workspace_bytes < sg_scatter_max_workspace_bytes(B, C))
+        SG_FAIL(SG_ERR_WORKSPACE, "sg_scatter_max_fwd: workspace too small");
+    unsigned* ord = (unsigned*)workspace;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(ew_blocks(B * C)), dim3(256), 0, stream, ord, B * C, 0u);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(ew_blocks(B * C)), dim3(256), 0, stream, (unsigned*)arg, B * C, 0x7fffffffu);
+    hipLaunchKernelGGL(scatter_max_pass1, dim3(ew_blocks(N * C)), dim3(256), 0, stream, x, batch, ord, N, C, B);
+    hipLaunchKernelGGL(scatter_max_pass2, dim3(ew_blocks(N * C)), dim3(256), 0, stream, x, batch, (const unsigned*)ord, arg,
+                       N, C, B);
+    hipLaunchKernelGGL(scatter_max_finish, dim3(ew_blocks(B * C)), dim3(256), 0, stream, (const unsigned*)ord, arg, out,
+                       B * C);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_scatter_max_scatter(const float* dy, const int* arg, float* dx, long N, long B, int C, hipStream_t stream) {
+    SG_CHECK_ARG(dy && arg && dx && N > 0 && B > 0 && C > 0);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(ew_blocks(N * C)), dim3(256), 0, stream, (unsigned*)dx, N * C, 0u);
+    hipLaunchKernelGGL(arg_scatter_kernel, dim3(ew_blocks(B * C)), dim3(256), 0, stream, dy, arg, dx, B * C, C);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_scatter_max_gather(const float* x, const int* arg, float* out, long N, long B, int C, hipStream_t stream) {
+    SG_CHECK_ARG(x && arg && out && N > 0 && B > 0 && C > 0);
+    hipLaunchKernelGGL(arg_gather_kernel, dim3(ew_blocks(B * C)), dim3(256), 0, stream, x, arg, out, B * C, C);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -5,7 +5,7 @@ fails, this module raises.  Signatures mirror include/shapegan_hip.h one to one.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SHAPEGAN_HIP_LIB") or os.path.join(_HERE, "libshapega
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
-_P, _I, _L, _F, _Z = c_void_p, c_int, c_long, c_float, c_size_t
+_P, _I, _L, _F, _Z, _D = c_void_p, c_int, c_long, c_float, c_size_t, c_double
 
 # name -> (restype, argtypes); every symbol include/shapegan_hip.h declares
 SIGNATURES = {
@@ -71,6 +71,25 @@ SIGNATURES = {
     "sg_segmax_fwd": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "sg_segmax_scatter": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "sg_segmax_gather": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "sg_loss_workspace_bytes": (_Z, []),
+    "sg_loss_weighted_l1_fwd": (c_int, [_P, _P, _L, _F, _P, _P, _Z, _P]),
+    "sg_loss_weighted_l1_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _P]),
+    "sg_loss_kld_fwd": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
+    "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
+    "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),
+    "sg_loss_meansq_bwd": (c_int, [_P, _P, _P, _P, _L, _I, _D, _P]),
+    "sg_gradient_penalty_fwd": (c_int, [_P, _L, _L, _F, _P, _P, _P]),
+    "sg_gradient_penalty_bwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
+    "sg_lerp_rows": (c_int, [_P, _P, _P, _P, _L, _L, _P]),
+    "sg_fade_blend": (c_int, [_P, _P, _P, _L, _I, _L, _F, _F, _P]),
+    "sg_channel0": (c_int, [_P, _P, _L, _I, _L, _F, _P]),
+    "sg_subsample2": (c_int, [_P, _P, _L, _I, _P]),
+    "sg_subsample2_adjoint": (c_int, [_P, _P, _L, _I, _P]),
+    "sg_act_bwd_dy": (c_int, [_P, _P, _P, _P, _L, _I, _P]),
+    "sg_scatter_max_workspace_bytes": (_Z, [_L, _I]),
+    "sg_scatter_max_fwd": (c_int, [_P, _P, _P, _P, _L, _L, _I, _P, _Z, _P]),
+    "sg_scatter_max_scatter": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "sg_scatter_max_gather": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
 }
 
 _lib = None

@@ -46,10 +46,13 @@ class PointNet(nn.Module):
         self.nn2 = _mlp([512, 256, 128, out_channels])
 
     def forward(self, pos, dist, batch=None):
-        if batch is not None:
-            raise NotImplementedError("ragged `batch` vectors (torch_scatter path, :42) are not on the training path")
         dist = dist.unsqueeze(-1) if dist.size(-1) != 1 else dist
         x = torch.cat([pos, dist], dim=-1)                      # [B,P,4] (16 B per point)
+        if batch is not None:
+            # ragged point sets (train_point_gan_ref.py:31-52): x [N,4], batch [N] names each point's shape
+            h = _run_mlp(self.nn1, x.reshape(-1, 4))
+            h = ops.scatter_max(h, batch.reshape(-1))           # [B,512], torch_scatter.scatter_max(...)[0]  (:42)
+            return _run_mlp(self.nn2, h)
         lead, P = x.shape[:-2], x.shape[-2]
         h = _run_mlp(self.nn1, x.reshape(-1, 4))
         h = ops.segmax(h.reshape(-1, P, h.shape[-1]))           # [B,512]

@@ -61,9 +61,8 @@ class Discriminator(SavableModule):
         x = ops.conv3d_k4s2p1(x, conv.weight, conv.bias, ACT_LEAKY, 0.2)
         if (self.fade_in_progress < 1.0) and it > 0:
             # blend with the nearest-neighbour downsampled input injected on channel 0 (progressive_gan.py:48-50)
-            half = x_in.reshape((-1, res, res, res))[:, ::2, ::2, ::2]
-            x2 = from_SDF(half, it - 1)
-            x = self.fade_in_progress * x + (1.0 - self.fade_in_progress) * x2
+            # one fused pass: the nearest-neighbour subsample lands on channel 0, from_SDF's zero channels are not built
+            x = ops.fade_blend(x, x_in.reshape((-1, res, res, res)), self.fade_in_progress)
         for i in range(it - 1, -1, -1):
             x = run_stack(self.optional_layers[i], x, self.training)
         return run_stack(self.head, x, self.training).squeeze()

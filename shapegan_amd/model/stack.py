@@ -54,7 +54,10 @@ def _producer(m, x, act, slope):
 
 def _batchnorm(m, x, act, slope, training):
     use_batch_stats = training or not m.track_running_stats
-    momentum = 0.1 if m.momentum is None else m.momentum
+    if m.momentum is None:
+        # torch switches to a cumulative moving average (factor 1/num_batches_tracked) here; no reference model uses it
+        raise NotImplementedError("shapegan_amd BatchNorm: momentum=None (cumulative average) is not implemented")
+    momentum = m.momentum
     return ops.BatchNormAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var,
                                   m.num_batches_tracked if use_batch_stats else None, use_batch_stats, m.eps, momentum,
                                   act, slope)

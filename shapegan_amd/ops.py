@@ -202,14 +202,22 @@ class ActBwd(Function):
         y, dy = f32c(y), f32c(dy)
         ctx.act, ctx.slope = act, slope
         ctx.save_for_backward(y)
+        ctx.dy = dy if act in (ACT_TANH, ACT_SIGMOID) else None
         return act_bwd_raw(y, dy, act, slope)
 
     @staticmethod
     def backward(ctx, ggx):
         (y,) = ctx.saved_tensors
         g_dy = ActBwd.apply(y, ggx, ctx.act, ctx.slope) if ctx.needs_input_grad[1] else None
-        # d/dy is zero almost everywhere for LeakyReLU/ReLU (the only activations on double-backward paths)
-        return None, g_dy, None, None
+        g_y = None
+        if ctx.needs_input_grad[0] and ctx.act in (ACT_TANH, ACT_SIGMOID):
+            # d/dy of dy*(1-y^2) resp. dy*y*(1-y): the second-order term of a double backward through tanh / sigmoid
+            # (zero almost everywhere for LeakyReLU / ReLU).  Needs dy, which forward did not have to keep otherwise.
+            dy = ctx.dy
+            g_y = torch.empty_like(y)
+            check(_lib().sg_act_bwd_dy(ptr(y), ptr(f32c(dy.detach())), ptr(f32c(ggx.detach())), ptr(g_y), y.numel(), ctx.act,
+                                       stream()), "act_bwd_dy")
+        return g_y, g_dy, None, None
 
 
 class Act(Function):
@@ -851,3 +859,307 @@ def voxel_prepare(x, clamp, divisor, out=None):
     out = x if out is None else out
     check(_lib().sg_voxel_prepare(ptr(x), ptr(out), x.numel(), float(clamp), float(divisor), stream()), "voxel_prepare")
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# loss compositions, gradient-penalty pieces, fade-in blend (K8 / K9)
+# --------------------------------------------------------------------------------------------------------------
+def _loss_ws(device):
+    return workspace("loss", _lib().sg_loss_workspace_bytes(), device)
+
+
+class WeightedL1(Function):
+    """mean(|d|), d = out - target, d *= neg_weight where target < 0 (get_reconstruction_loss, train_autoencoder.py:57-62;
+    neg_weight 1: the DeepSDF data term mean|out - sdf|, train_sdf_autodecoder.py:88)."""
+
+    @staticmethod
+    def forward(ctx, out, target, neg_weight):
+        out, target = f32c(out), f32c(target.detach())
+        if out.shape != target.shape:
+            raise RuntimeError("weighted_l1: shape mismatch %s vs %s" % (tuple(out.shape), tuple(target.shape)))
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        ws = _loss_ws(out.device)
+        check(_lib().sg_loss_weighted_l1_fwd(ptr(out), ptr(target), out.numel(), neg_weight, ptr(loss), ptr(ws), ws.numel(),
+                                             stream()), "loss_weighted_l1_fwd")
+        ctx.neg_weight = neg_weight
+        ctx.save_for_backward(out, target)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        out, target = ctx.saved_tensors
+        d = torch.empty_like(out)
+        check(_lib().sg_loss_weighted_l1_bwd(ptr(out), ptr(target), ptr(f32c(g)), ptr(d), out.numel(), ctx.neg_weight,
+                                             stream()), "loss_weighted_l1_bwd")
+        return d, None, None
+
+
+def weighted_l1(out, target, neg_weight=1.0):
+    return WeightedL1.apply(out, target, float(neg_weight))
+
+
+class KLD(Function):
+    """-0.5 * sum(1 + lv - mu^2 - exp(lv)) / numel (kld_loss, train_autoencoder.py:54-55)."""
+
+    @staticmethod
+    def forward(ctx, mean, log_variance):
+        mean, log_variance = f32c(mean), f32c(log_variance)
+        loss = torch.empty((), dtype=torch.float32, device=mean.device)
+        ws = _loss_ws(mean.device)
+        check(_lib().sg_loss_kld_fwd(ptr(mean), ptr(log_variance), mean.numel(), ptr(loss), ptr(ws), ws.numel(), stream()),
+              "loss_kld_fwd")
+        ctx.save_for_backward(mean, log_variance)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        mean, lv = ctx.saved_tensors
+        dm, dl = torch.empty_like(mean), torch.empty_like(lv)
+        check(_lib().sg_loss_kld_bwd(ptr(mean), ptr(lv), ptr(f32c(g)), ptr(dm), ptr(dl), mean.numel(), stream()),
+              "loss_kld_bwd")
+        return dm, dl
+
+
+def kld(mean, log_variance):
+    return KLD.apply(mean, log_variance)
+
+
+class MeanSq(Function):
+    """sum_r w_r |x_r|^2 / denom for x [rows, L] (w = 1 without row_weight): the latent regulariser
+    mean(batch_latent_codes^2) of train_sdf_autodecoder.py:88 — over the gathered rows (row_weight None, denom = numel) or
+    over the latent table with row_weight = how often each shape occurs in the batch (denom = batch * L)."""
+
+    @staticmethod
+    def forward(ctx, x, row_weight, denom):
+        x = f32c(x)
+        rows, width = x.shape
+        rw = None if row_weight is None else f32c(row_weight)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = _loss_ws(x.device)
+        check(_lib().sg_loss_meansq_fwd(ptr(x), ptr(rw), rows, width, float(denom), ptr(loss), ptr(ws), ws.numel(),
+                                        stream()), "loss_meansq_fwd")
+        ctx.denom = float(denom)
+        ctx.save_for_backward(x, rw)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, rw = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(_lib().sg_loss_meansq_bwd(ptr(x), ptr(rw), ptr(f32c(g)), ptr(dx), x.shape[0], x.shape[1], ctx.denom,
+                                        stream()), "loss_meansq_bwd")
+        return dx, None, None
+
+
+def mean_sq(x, row_weight=None, denom=None):
+    x2 = x.reshape(x.shape[0], -1) if x.dim() != 2 else x
+    return MeanSq.apply(x2, row_weight, float(x.numel() if denom is None else denom))
+
+
+class GradientPenalty(Function):
+    """((||g_b||_2 - 1)^2).mean() * weight over the per-sample rows of `gradients`
+    (train_hybrid_progressive_gan.py:110-111, train_point_gan.py:68-70)."""
+
+    @staticmethod
+    def forward(ctx, gradients, weight):
+        B = gradients.shape[0]
+        g2 = f32c(gradients).reshape(B, -1)
+        norms = torch.empty(B, dtype=torch.float32, device=g2.device)
+        loss = torch.empty((), dtype=torch.float32, device=g2.device)
+        check(_lib().sg_gradient_penalty_fwd(ptr(g2), B, g2.shape[1], weight, ptr(norms), ptr(loss), stream()),
+              "gradient_penalty_fwd")
+        ctx.weight, ctx.shape = weight, gradients.shape
+        ctx.save_for_backward(g2, norms)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g2, norms = ctx.saved_tensors
+        dg = torch.empty_like(g2)
+        check(_lib().sg_gradient_penalty_bwd(ptr(g2), ptr(norms), ptr(f32c(g)), ptr(dg), g2.shape[0], g2.shape[1],
+                                             ctx.weight, stream()), "gradient_penalty_bwd")
+        return dg.reshape(ctx.shape), None
+
+
+def gradient_penalty(gradients, weight):
+    return GradientPenalty.apply(gradients, float(weight))
+
+
+def lerp_rows(a, b, alpha):
+    """alpha[b] * a[b] + (1 - alpha[b]) * b[b] per sample (train_hybrid_progressive_gan.py:103-105); no autograd: the
+    reference detaches both operands and makes the result a leaf."""
+    B = a.shape[0]
+    a2, b2 = f32c(a.detach()).reshape(B, -1), f32c(b.detach()).reshape(B, -1)
+    al = f32c(alpha.detach()).reshape(-1)
+    if al.numel() != B or a2.shape != b2.shape:
+        raise RuntimeError("lerp_rows: need one alpha per sample and equal shapes")
+    out = torch.empty_like(a2)
+    check(_lib().sg_lerp_rows(ptr(a2), ptr(b2), ptr(al), ptr(out), B, a2.shape[1], stream()), "lerp_rows")
+    return out.reshape(a.shape)
+
+
+class Scale(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        x = f32c(x)
+        ctx.a = a
+        out = torch.empty_like(x)
+        check(_lib().sg_axpby(ptr(x), None, ptr(out), x.numel(), a, 0.0, stream()), "axpby")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return Scale.apply(g, ctx.a), None
+
+
+class Chan0(Function):
+    """out[b, s] = a * g[b, 0, s] for g [B, C, S...]; adjoint of the channel-0 embedding."""
+
+    @staticmethod
+    def forward(ctx, g, a):
+        g = f32c(g)
+        B, C = g.shape[0], g.shape[1]
+        S = g.numel() // (B * C)
+        out = torch.empty((B,) + tuple(g.shape[2:]), dtype=torch.float32, device=g.device)
+        check(_lib().sg_channel0(ptr(g), ptr(out), B, C, S, a, stream()), "channel0")
+        ctx.a, ctx.C = a, C
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        return FadeBlend.apply(None, gg, ctx.C, 0.0, ctx.a), None
+
+
+class FadeBlend(Function):
+    """fade * x + half_scale * from_SDF(half) (model/progressive_gan.py:48-50) with x [B,C,r,r,r], half [B,r,r,r]: the
+    C-1 zero channels of from_SDF are never built.  x None: the embedding alone (the adjoint of Chan0).  Linear in both
+    operands, backward written with Scale / Chan0, so the gradient penalty's double backward passes through."""
+
+    @staticmethod
+    def forward(ctx, x, half, C, fade, half_scale):
+        half = f32c(half)
+        B = half.shape[0]
+        S = half.numel() // B
+        if x is not None:
+            x = f32c(x)
+            if x.shape[0] != B or x.shape[1] != C or x.numel() != B * C * S:
+                raise RuntimeError("fade_blend: x %s does not match half %s" % (tuple(x.shape), tuple(half.shape)))
+        out = torch.empty((B, C) + tuple(half.shape[1:]), dtype=torch.float32, device=half.device)
+        check(_lib().sg_fade_blend(ptr(x), ptr(half), ptr(out), B, C, S, fade, half_scale, stream()), "fade_blend")
+        ctx.cfg = (x is not None, fade, half_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        has_x, fade, hs = ctx.cfg
+        gx = Scale.apply(g, fade) if (has_x and ctx.needs_input_grad[0]) else None
+        gh = Chan0.apply(g, hs) if ctx.needs_input_grad[1] else None
+        return gx, gh, None, None, None
+
+
+class Subsample2(Function):
+    """x[:, ::2, ::2, ::2] of [B,R,R,R] grids (model/progressive_gan.py:49; index work, bit-exact)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = f32c(x)
+        B, R = x.shape[0], x.shape[-1]
+        out = torch.empty((B, R // 2, R // 2, R // 2), dtype=torch.float32, device=x.device)
+        check(_lib().sg_subsample2(ptr(x), ptr(out), B, R, stream()), "subsample2")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return Subsample2Adjoint.apply(g)
+
+
+class Subsample2Adjoint(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = f32c(g)
+        B, h = g.shape[0], g.shape[-1]
+        out = torch.empty((B, 2 * h, 2 * h, 2 * h), dtype=torch.float32, device=g.device)
+        check(_lib().sg_subsample2_adjoint(ptr(g), ptr(out), B, 2 * h, stream()), "subsample2_adjoint")
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        return Subsample2.apply(gg)
+
+
+def fade_blend(x, x_in, fade):
+    """The progressive discriminator's fade-in (model/progressive_gan.py:48-50): x [B,C,r,r,r] from the new stage, x_in
+    [B,2r,2r,2r] the stage's input grid."""
+    half = Subsample2.apply(x_in)
+    return FadeBlend.apply(x, half, x.shape[1], float(fade), float(1.0 - fade))
+
+
+class ScatterMaxScatter(Function):
+    @staticmethod
+    def forward(ctx, dy, arg, N):
+        dy = f32c(dy)
+        B, C = dy.shape
+        dx = torch.empty((N, C), dtype=torch.float32, device=dy.device)
+        check(_lib().sg_scatter_max_scatter(ptr(dy), ptr(arg), ptr(dx), N, B, C, stream()), "scatter_max_scatter")
+        ctx.save_for_backward(arg)
+        return dx
+
+    @staticmethod
+    def backward(ctx, gdx):
+        (arg,) = ctx.saved_tensors
+        return ScatterMaxGather.apply(gdx, arg), None, None
+
+
+class ScatterMaxGather(Function):
+    @staticmethod
+    def forward(ctx, x, arg):
+        x = f32c(x)
+        N, C = x.shape
+        B = arg.shape[0]
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        check(_lib().sg_scatter_max_gather(ptr(x), ptr(arg), ptr(out), N, B, C, stream()), "scatter_max_gather")
+        ctx.N = N
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return ScatterMaxScatter.apply(g, arg, ctx.N), None
+
+
+class ScatterMax(Function):
+    """torch_scatter.scatter_max(x, batch, dim=-2)[0] for x [N,C] and a ragged int64 `batch` vector
+    (model/point_sdf_net.py:42-43): out [B,C], B = dim_size; empty segments give 0."""
+
+    @staticmethod
+    def forward(ctx, x, batch, B):
+        x = f32c(x)
+        N, C = x.shape
+        lib = _lib()
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        ws = workspace("scatter_max", lib.sg_scatter_max_workspace_bytes(B, C), x.device)
+        check(lib.sg_scatter_max_fwd(ptr(x), ptr(batch), ptr(out), ptr(arg), N, B, C, ptr(ws), ws.numel(), stream()),
+              "scatter_max_fwd")
+        ctx.N = N
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _garg):
+        (arg,) = ctx.saved_tensors
+        return ScatterMaxScatter.apply(g, arg, ctx.N), None, None
+
+
+def scatter_max(x, batch, dim_size=None):
+    if batch.dtype != torch.int64:
+        batch = batch.long()
+    if dim_size is None:
+        dim_size = int(batch.max().item()) + 1
+    return ScatterMax.apply(x, batch.contiguous(), int(dim_size))

@@ -48,6 +48,28 @@ class _Flat(object):
     def coherent(self):
         return all(self.grad_view_ok(i) for i in range(len(self.params)))
 
+    def adopt_grads(self):
+        """Copies every parameter's live .grad into its flat slice and re-attaches the view (a parameter without a
+        gradient contributes zeros), so that the flat buffer is what the exchange and the update both see."""
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if self.grad_view_ok(i):
+                continue
+            n = p.numel()
+            if p.grad is None:
+                self.grad[o:o + n].zero_()
+            else:
+                self.grad[o:o + n].copy_(p.grad.reshape(-1))
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def check_storage(self):
+        """module.to()/.cuda()/.float() after the optimizer was built re-allocates p.data: the flat buffer would be
+        updated while the module computes with the orphaned copy.  Fail instead."""
+        base = self.flat.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * o:
+                raise RuntimeError("optimizer: a parameter no longer lives in the flat buffer (module.to()/.float() "
+                                   "after constructing the optimizer?); rebuild the optimizer")
+
     def zero_grad(self):
         """Zeroes the flat gradient buffer and re-attaches views that were dropped (e.g. by module.zero_grad())."""
         self.grad.zero_()
@@ -94,6 +116,7 @@ class RMSprop(_Base):
 
     def step(self):
         lib = L.load()
+        self.f.check_storage()
         base_p, base_s = self.f.flat.data_ptr(), self.square_avg.data_ptr()
         for seg in self._segments():
             o, n, g = seg[0], seg[1], seg[2]
@@ -121,6 +144,7 @@ class Adam(_Base):
     def step(self):
         lib = L.load()
         f = self.f
+        f.check_storage()
         base_p, base_m, base_v = f.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         uniform = f.coherent() and len(set(self.steps)) == 1
         if self.capturable:

@@ -94,6 +94,13 @@ class GradBucket(object):
         """Call right after loss.backward(): exchanges whatever has not gone out yet and waits."""
         self.armed = False
         if world_size() > 1:
+            if not self.opt.f.coherent():
+                # module.zero_grad() (grads -> None) or an out-of-place accumulation detached p.grad from the flat
+                # buffer: the optimizer would step on p.grad while the exchange summed a stale buffer.  Pull the live
+                # gradients back into their slices first (a tail slice that already went out is no longer valid).
+                if getattr(self, "tail_done", False):
+                    raise RuntimeError("GradBucket: gradient views changed after the early slice was exchanged")
+                self.opt.f.adopt_grads()
             if getattr(self, "tail_done", False):
                 a, _ = self.tail
                 self.works.append(dist.all_reduce(self.opt.flat_grad[:a], op=dist.ReduceOp.SUM, async_op=True))

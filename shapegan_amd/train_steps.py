@@ -9,7 +9,7 @@ import contextlib
 
 import torch
 
-from . import ops, optim
+from . import lib, ops, optim
 from .parallel import GradBucket, allreduce_tensor_, world_size
 
 
@@ -79,14 +79,12 @@ class WGANTrainer(object):
 
 def reconstruction_loss(output, target):
     """train_autoencoder.py:57-62: mean |d|, d = output - target, d *= 32 where target < 0."""
-    difference = output - target
-    difference = torch.where(target < 0, difference * 32, difference)
-    return torch.mean(torch.abs(difference))
+    return ops.weighted_l1(output, target.reshape(output.shape), 32.0)     # one streaming pass (sg_loss_weighted_l1)
 
 
 def kld_loss(mean, log_variance):
     """train_autoencoder.py:54-55."""
-    return -0.5 * torch.sum(1 + log_variance - mean.pow(2) - log_variance.exp()) / mean.nelement()
+    return ops.kld(mean, log_variance)
 
 
 def voxel_difference(output, target):
@@ -160,6 +158,9 @@ class SDFAutoDecoderTrainer(object):
         else:
             self._graph_idx.copy_(indices)
         self._graph.replay()
+        # the captured Adam kernels rewrite the parameters through raw pointers: neither tensor._version nor the
+        # epoch moved, so derived weight images (ops._PackCache) would otherwise survive the replay
+        lib.bump_param_epoch()
         return self._graph_loss
 
     def step(self, indices):
@@ -186,11 +187,12 @@ class SDFAutoDecoderTrainer(object):
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
         batch_points = ops.gather_rows(self.points, indices)
-        batch_sdf = self.sdf[indices]
+        batch_sdf = ops.gather_rows(self.sdf.unsqueeze(1), indices).squeeze(1)
         output = self.net.forward_segments(batch_points, self.latent_codes, model_indices.int(), seg_off)
         n, width = indices.shape[0], self.latent_codes.shape[1]
-        reg = (counts.to(torch.float32).unsqueeze(1) * torch.pow(self.latent_codes, 2)).sum() / (n * width)
-        loss = torch.mean(torch.abs(output - batch_sdf)) + self.sigma * reg
+        # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator
+        reg = ops.mean_sq(self.latent_codes, counts.to(torch.float32), n * width / self.sigma)
+        loss = ops.weighted_l1(output, batch_sdf) + reg
         loss.backward()
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
@@ -206,9 +208,9 @@ class SDFAutoDecoderTrainer(object):
         self.lat_opt.zero_grad()
         batch_latent = ops.gather_rows(self.latent_codes, model_indices)
         batch_points = ops.gather_rows(self.points, indices)
-        batch_sdf = self.sdf[indices]
+        batch_sdf = ops.gather_rows(self.sdf.unsqueeze(1), indices).squeeze(1)
         output = self.net(batch_points, batch_latent)
-        loss = torch.mean(torch.abs(output - batch_sdf)) + self.sigma * torch.mean(torch.pow(batch_latent, 2))
+        loss = ops.weighted_l1(output, batch_sdf) + ops.mean_sq(batch_latent, None, batch_latent.numel() / self.sigma)
         loss.backward()
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
@@ -298,13 +300,12 @@ class HybridProgressiveGANTrainer(object):
 
     def gradient_penalty(self, real, fake, alpha):
         """train_hybrid_progressive_gan.py:102-111; `alpha` [B,1,1,1] replaces the on-device torch.rand."""
-        alpha = alpha.expand(real.shape)
-        interpolated = alpha * real + ((1 - alpha) * fake)
+        interpolated = ops.lerp_rows(real, fake, alpha)
         interpolated.requires_grad = True
         out = self.discriminator(interpolated)
         gradients = torch.autograd.grad(outputs=out, inputs=interpolated, grad_outputs=torch.ones_like(out),
                                         create_graph=True, retain_graph=True, only_inputs=True)[0]
-        return ((gradients.norm(2, dim=(1, 2, 3)) - 1) ** 2).mean() * self.gp_weight
+        return ops.gradient_penalty(gradients, self.gp_weight)
 
     def generator_step(self, z):
         """:135-149."""
@@ -421,13 +422,12 @@ class PointGANTrainer(object):
 
     def gradient_penalty(self, pos, dist, fake, alpha):
         """:61-70; `alpha` [B,1,1] replaces the on-device torch.rand."""
-        interpolated = alpha * dist + (1 - alpha) * fake
+        interpolated = ops.lerp_rows(dist, fake, alpha)
         interpolated.requires_grad_(True)
         out = self.critic(pos, interpolated)
         grad = torch.autograd.grad(out, interpolated, grad_outputs=torch.ones_like(out), create_graph=True,
                                    retain_graph=True, only_inputs=True)[0]
-        grad_norm = grad.reshape(grad.size(0), -1).norm(dim=-1, p=2)
-        return self.gp_weight * ((grad_norm - 1).pow(2).mean())
+        return ops.gradient_penalty(grad, self.gp_weight)
 
     def critic_step(self, uniform, z, alpha):
         """:52-74.  The reference keeps the generator graph here and discards its gradients (G_optimizer.zero_grad at
