@@ -102,6 +102,9 @@ int sg_gemm_nt_batched(const float* A, const long* a_off, long lda, const float*
                        size_t workspace_bytes, hipStream_t stream);
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
+/* rows [d*rows_per_dst, (d+1)*rows_per_dst) go to outs[d] (ndst <= 8 host-side pointers to device buffers): one launch for
+ * bias gradients that live in separate slices of a flat gradient buffer */
+int sg_rowsum_multi(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, hipStream_t stream);
 /* out[r*nseg + s] = sum of x[r*ld + e] over e in [seg_off[s], seg_off[s+1])  (per-shape sums of SDFNet dZ columns) */
 int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, hipStream_t stream);
 

@@ -1,0 +1,60 @@
+"""Workloads for the rocprofv3 counter passes of a round (run one mode per pass; see scripts/profile_round.sh).
+
+    mfma : SDFNet fused forward / training steps (sdfnet_fwd, sdfnet_bwd, gemm_nt_bigk batched) and the three halo conv forms
+           at the critic's 128-sample pass -> SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE
+    hbm  : two WGAN 5+1 steps (covers the Cin=1 / Cout=1 edge kernels) + calibration streams of a known byte count
+           (1 GiB read + 1 GiB write through b32 loads (sg_axpby) and through b128 loads (sg_act_fwd)) -> FETCH_SIZE / WRITE_SIZE
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shapegan_amd import ops  # noqa: E402
+from shapegan_amd.lib import check, ptr, stream  # noqa: E402
+
+mode = sys.argv[1]
+torch.manual_seed(0)
+if mode == "mfma":
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+    from shapegan_amd.util import get_voxel_coordinates
+    net = SDFNet()
+    grid = torch.tensor(get_voxel_coordinates(32)).cuda().repeat((8, 1))
+    z = torch.randn(8, 128, device="cuda")
+    with torch.no_grad():
+        for _ in range(4):
+            net.forward_shapes(grid, z, 32768)
+    pc, shapes = 200000, 64
+    pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
+    sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
+    for npts, lat in ((20000, 128), (200000, 256)):
+        tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), torch.randn(shapes, lat, device="cuda") * 1e-2, pts, sdf,
+                                   pointcloud_size=pc)
+        idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
+        for _ in range(4):
+            tr.step(idx)
+    x = torch.randn(128, 64, 16, 16, 16, device="cuda")
+    w = torch.randn(128, 64, 4, 4, 4, device="cuda") * 0.02
+    b = torch.zeros(128, device="cuda")
+    for _ in range(4):
+        y = ops.conv_fwd_raw(x, w, b, 1, 0.2)
+        ops.conv_dgrad_raw(y, w, None, 64)
+        ops.conv_wgrad_raw(y, x, 64)
+elif mode == "hbm":
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
+    tr = WGANTrainer(Generator(), Discriminator())
+    reals = [(torch.rand(64, 32, 32, 32) * 2 - 1).cuda() for _ in range(5)]
+    zs = [torch.randn(64, 128).cuda() for _ in range(5)]
+    zg = torch.randn(64, 128).cuda()
+    for _ in range(2):
+        tr.step(reals, zs, zg)
+    n = 1 << 28                                                   # 1 GiB of floats: past the 256 MiB Infinity Cache
+    a, o = torch.randn(n, device="cuda"), torch.empty(n, device="cuda")
+    lib = ops.L.load()
+    for _ in range(3):
+        check(lib.sg_axpby(ptr(a), None, ptr(o), n, 2.0, 0.0, stream()), "axpby")      # b32 loads / stores
+        check(lib.sg_act_fwd(ptr(a), ptr(o), n, 1, 0.2, stream()), "act_fwd")          # b128 loads / stores
+torch.cuda.synchronize()

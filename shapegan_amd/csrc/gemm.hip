@@ -86,6 +86,37 @@ __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) out[r] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same with the rows split into up to 8 equal groups that go to different destinations (the seven bias gradients of
+// an SDFNet backward land in seven separate slices of the optimizer's flat gradient buffer).
+struct RowsumDst {
+    float* out[8];
+};
+__global__ void __launch_bounds__(256) rowsum_multi_kernel(const float* __restrict__ x, RowsumDst dst, long rows_per_dst,
+                                                           long len, long ld) {
+    const long r = blockIdx.x;
+    const float* p = x + r * ld;
+    float s = 0.f;
+    if ((((uintptr_t)p) & 15) == 0 && (len & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (long e = threadIdx.x; e < (len >> 2); e += 256) {
+            const float4 v = p4[e];
+            s0 += v.x;
+            s1 += v.y;
+            s2 += v.z;
+            s3 += v.w;
+        }
+        s = (s0 + s1) + (s2 + s3);
+    } else {
+        for (long e = threadIdx.x; e < len; e += 256) s += p[e];
+    }
+    s = sg_wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dst.out[r / rows_per_dst][r % rows_per_dst] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // out[r*S + s] = sum_{e in [off[s], off[s+1])} x[r*ld + e]: one wave per (row, segment) pair
 __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
                                                      long ld, const int64_t* __restrict__ off, long S) {
@@ -360,6 +391,17 @@ int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream) {
     SG_CHECK_ARG(x && out && rows > 0 && len > 0);
     hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, out, rows, len, ld);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_rowsum_multi(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, hipStream_t stream) {
+    SG_CHECK_ARG(x && outs && ndst > 0 && ndst <= 8 && rows_per_dst > 0 && len > 0);
+    RowsumDst d;
+    for (int i = 0; i < 8; ++i) d.out[i] = outs[i < ndst ? i : 0];
+    for (int i = 0; i < ndst; ++i) SG_CHECK_ARG(outs[i] != nullptr);
+    hipLaunchKernelGGL(rowsum_multi_kernel, dim3((unsigned)(rows_per_dst * ndst)), dim3(256), 0, stream, x, d, rows_per_dst,
+                       len, ld);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -14,6 +14,9 @@
 #include "common.h"
 #include "../../include/shapegan_hip.h"
 
+// the blends below promise the reference's rounding sequence (separate products and sums): no fma contraction in this file
+#pragma clang fp contract(off)
+
 namespace sg {
 
 constexpr int kRedBlocks = 512;
@@ -147,10 +150,12 @@ __global__ void __launch_bounds__(256) gp_bwd_kernel(const float* __restrict__ g
 // out[b, :] = alpha[b] * a[b, :] + (1 - alpha[b]) * b[b, :]   (two rounded products and one rounded sum, as the reference)
 __global__ void __launch_bounds__(256) lerp_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         const float* __restrict__ alpha, float* __restrict__ out, long M) {
-    const float al = alpha[blockIdx.y], be = __fsub_rn(1.f, al);
+    const float al = alpha[blockIdx.y], be = 1.f - al;
     const long base = (long)blockIdx.y * M;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M; e += (long)gridDim.x * 256)
-        out[base + e] = __fadd_rn(__fmul_rn(al, a[base + e]), __fmul_rn(be, b[base + e]));
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M; e += (long)gridDim.x * 256) {
+        const float t1 = al * a[base + e], t2 = be * b[base + e];   // (contraction is off in this file: no fma)
+        out[base + e] = t1 + t2;
+    }
 }
 
 // ---- fade-in blend -------------------------------------------------------------------------------------------------
@@ -161,8 +166,11 @@ __global__ void __launch_bounds__(256) fade_blend_kernel(const float* __restrict
     const int c = blockIdx.y;
     const long base = (b * C + c) * S;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < S; e += (long)gridDim.x * 256) {
-        float v = x ? __fmul_rn(fade, x[base + e]) : 0.f;
-        if (c == 0) v = __fadd_rn(v, __fmul_rn(hscale, half[b * S + e]));
+        float v = x ? fade * x[base + e] : 0.f;
+        if (c == 0) {
+            const float h = hscale * half[b * S + e];
+            v = v + h;
+        }
         out[base + e] = v;
     }
 }

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sg_gemm": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_colsum": (c_int, [_P, _P, _I, _I, _L, _P]),
     "sg_rowsum": (c_int, [_P, _P, _L, _L, _L, _P]),
+    "sg_rowsum_multi": (c_int, [_P, _P, _I, _L, _L, _L, _P]),
     "sg_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P]),
     "sg_bn_workspace_bytes": (_Z, [_I]),
     "sg_bn_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
@@ -164,3 +165,49 @@ PARAM_EPOCH = 0
 def bump_param_epoch():
     global PARAM_EPOCH
     PARAM_EPOCH += 1
+
+
+# ---- gradient destinations ---------------------------------------------------------------------------------------------
+# A flat-buffer optimizer (shapegan_amd.optim) registers, per parameter, the slice of its flat gradient buffer that
+# belongs to it.  In a plain backward (no create_graph) the weight-gradient kernels write straight into that slice and hand
+# autograd a view of it: AccumulateGrad adopts the view as p.grad (no `p.grad += g` launch, no copy), post-accumulate hooks
+# fire as usual.  Only the FIRST contribution of a zero_grad() cycle may do this (a second write would clobber the first);
+# later contributions come back as ordinary tensors and autograd adds them in place — into the same slice.
+import weakref  # noqa: E402
+
+
+class GradSlot(object):
+    __slots__ = ("param", "flat_grad", "offset", "numel", "written")
+
+    def __init__(self, param, flat_grad, offset):
+        self.param = weakref.ref(param)
+        self.flat_grad, self.offset, self.numel = flat_grad, offset, param.numel()
+        self.written = False
+
+
+GRAD_SLOTS = {}
+
+
+def register_grad_slot(param, flat_grad, offset):
+    slot = GradSlot(param, flat_grad, offset)
+    GRAD_SLOTS[param.data_ptr()] = slot
+    return slot
+
+
+def grad_destination(param_tensor, shape):
+    """A view (of `shape`) of the flat-gradient slice of the parameter whose storage `param_tensor` is, if this backward
+    may write its gradient there directly; else None."""
+    slot = GRAD_SLOTS.get(param_tensor.data_ptr())
+    if slot is None or slot.written or torch.is_grad_enabled():
+        return None
+    p = slot.param()
+    if p is None or p.data_ptr() != param_tensor.data_ptr():
+        GRAD_SLOTS.pop(param_tensor.data_ptr(), None)      # the parameter is gone (its address was reused)
+        return None
+    n = 1
+    for d in shape:
+        n *= d
+    if p.grad is not None or n != slot.numel:
+        return None
+    slot.written = True
+    return slot.flat_grad[slot.offset:slot.offset + n].view(shape)

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..util import get_points_in_unit_sphere, get_voxel_coordinates
-from . import LATENT_CODE_SIZE, SavableModule
+from . import LATENT_CODE_SIZE, LATENT_CODES_FILENAME, SavableModule  # noqa: F401  (re-exported: train_sdf_autodecoder.py:13)
 
 SDF_NET_BREADTH = 256
 

@@ -83,13 +83,25 @@ def conv_dgrad_halo_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, impl=1):
 _WGRAD_WS_CAP = 256 << 20
 
 
-def conv_wgrad_raw(dy, x, ct):
+def _param_grad_out(param, shape, device):
+    """Where a parameter gradient of a plain backward goes: the parameter's slice of its optimizer's flat gradient buffer
+    when that is open (lib.grad_destination: autograd then adopts the view as p.grad, no accumulation pass), else a new
+    tensor."""
+    dst = L.grad_destination(param, shape) if param is not None else None
+    return dst if dst is not None else torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def conv_wgrad_raw(dy, x, ct, out=None):
     """dy [N,Co,O,O,O], x [N,Cx,2O,2O,2O] -> dw [Co,ct,4,4,4] (channels >= Cx are zero)."""
     N, Co, OD, OH, OW = dy.shape
     Cx = x.shape[1]
     if x.shape[0] != N or x.shape[2] != 2 * OD:
         raise RuntimeError("conv wgrad: shape mismatch")
-    if Cx < ct:
+    if out is not None:
+        dw = out
+        if Cx < ct:
+            dw.zero_()
+    elif Cx < ct:
         dw = torch.zeros((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
     else:
         dw = torch.empty((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
@@ -154,7 +166,7 @@ def act_bwd_raw(y, dy, act, slope):
     return dx
 
 
-def act_bwd_rowsum_raw(y, dy, act, slope):
+def act_bwd_rowsum_raw(y, dy, act, slope, gb_out=None):
     """dz = dy * act'(y) for y [N,C,*S] together with the bias gradient sum over (N, S) of dz (one pass + a tiny column sum)."""
     y, dy = f32c(y), f32c(dy)
     N, C = y.shape[0], y.shape[1]
@@ -163,7 +175,7 @@ def act_bwd_rowsum_raw(y, dy, act, slope):
     dz = torch.empty_like(y)
     rows = torch.empty(N * C, dtype=torch.float32, device=y.device)
     check(lib.sg_act_bwd_rowsum(ptr(y), ptr(dy), ptr(dz), ptr(rows), N * C, S, act, slope, stream()), "act_bwd_rowsum")
-    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    gb = torch.empty(C, dtype=torch.float32, device=y.device) if gb_out is None else gb_out
     check(lib.sg_colsum(ptr(rows), ptr(gb), N, C, C, stream()), "colsum")
     return dz, gb
 
@@ -174,18 +186,18 @@ def act_fwd_raw(x, act, slope):
     return y
 
 
-def channel_sum_raw(g):
+def channel_sum_raw(g, out=None):
     """g [N,C,*S] -> [C]  (bias gradient of a convolution)."""
     N, C = g.shape[0], g.shape[1]
     S = g.numel() // (N * C)
     lib = _lib()
-    if S == 1:
+    if out is None:
         out = torch.empty(C, dtype=torch.float32, device=g.device)
+    if S == 1:
         check(lib.sg_colsum(ptr(g), ptr(out), N, C, C, stream()), "colsum")
         return out
     tmp = torch.empty(N * C, dtype=torch.float32, device=g.device)
     check(lib.sg_rowsum(ptr(g), ptr(tmp), N * C, S, S, stream()), "rowsum")
-    out = torch.empty(C, dtype=torch.float32, device=g.device)
     check(lib.sg_colsum(ptr(tmp), ptr(out), N, C, C, stream()), "colsum")
     return out
 
@@ -262,22 +274,26 @@ class ConvFwd(Function):
         x, w = f32c(x), f32c(w)
         y = conv_fwd_raw(x, w, b, act, slope)
         ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None, b)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         gb = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.act != ACT_NONE and want_b and not torch.is_grad_enabled() and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
-            gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope)     # plain backward: activation + bias sums in one pass
+        plain = not torch.is_grad_enabled()      # no create_graph: raw kernels, parameter gradients straight into their slices
+        if ctx.act != ACT_NONE and want_b and plain and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
+            # activation + bias sums in one pass
+            gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope, L.grad_destination(b, b.shape))
         else:
             gz = ActBwd.apply(y, gy, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gy
         gx = ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
-        gw = ConvWgrad.apply(gz, x, w.shape[1]) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad_raw(f32c(gz), x, w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(gz, x, w.shape[1])
         if want_b and gb is None:
-            gb = ChannelSum.apply(gz)
+            gb = channel_sum_raw(f32c(gz), L.grad_destination(b, b.shape)) if plain else ChannelSum.apply(gz)
         return gx, gw, gb, None, None
 
 
@@ -289,22 +305,25 @@ class ConvDgrad(Function):
         dy, w = f32c(dy), f32c(w)
         dx = conv_dgrad_raw(dy, w, b, cin, act, slope)
         ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
-        ctx.save_for_backward(dy, w, dx if act != ACT_NONE else None)
+        ctx.save_for_backward(dy, w, dx if act != ACT_NONE else None, b)
         return dx
 
     @staticmethod
     def backward(ctx, gdx):
-        dy, w, dx = ctx.saved_tensors
+        dy, w, dx, b = ctx.saved_tensors
         g_b = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.act != ACT_NONE and want_b and not torch.is_grad_enabled() and dx.shape[2] * dx.shape[3] * dx.shape[4] >= 512:
-            gz, g_b = act_bwd_rowsum_raw(dx, gdx, ctx.act, ctx.slope)
+        plain = not torch.is_grad_enabled()
+        if ctx.act != ACT_NONE and want_b and plain and dx.shape[2] * dx.shape[3] * dx.shape[4] >= 512:
+            gz, g_b = act_bwd_rowsum_raw(dx, gdx, ctx.act, ctx.slope, L.grad_destination(b, b.shape))
         else:
             gz = ActBwd.apply(dx, gdx, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gdx
         g_dy = ConvFwd.apply(gz, w, None, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
-        g_w = ConvWgrad.apply(dy, gz, w.shape[1]) if ctx.needs_input_grad[1] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            g_w = conv_wgrad_raw(dy, f32c(gz), w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(dy, gz, w.shape[1])
         if want_b and g_b is None:
-            g_b = ChannelSum.apply(gz)
+            g_b = channel_sum_raw(f32c(gz), L.grad_destination(b, b.shape)) if plain else ChannelSum.apply(gz)
         return g_dy, g_w, g_b, None, None, None
 
 
@@ -375,16 +394,26 @@ def colsum_tall_raw(x, batch, batch_stride, rows, cols, ld):
     return out
 
 
+def _colsum_raw(g, out=None):
+    """Column sums of a 2-D tensor (bias gradient of a Linear layer)."""
+    if g.shape[0] > 256:   # per-point layers: one thread per column walking every row would serialise
+        res = colsum_tall_raw(g, 1, 0, g.shape[0], g.shape[1], g.shape[1])[0]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    if out is None:
+        out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
+    check(_lib().sg_colsum(ptr(g), ptr(out), g.shape[0], g.shape[1], g.shape[1], stream()), "colsum")
+    return out
+
+
 class ColSum(Function):
     @staticmethod
     def forward(ctx, g):
         g = f32c(g)
         ctx.rows = g.shape[0]
-        if g.shape[0] > 256:   # per-point layers: one thread per column walking every row would serialise
-            return colsum_tall_raw(g, 1, 0, g.shape[0], g.shape[1], g.shape[1])[0]
-        out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
-        check(_lib().sg_colsum(ptr(g), ptr(out), g.shape[0], g.shape[1], g.shape[1], stream()), "colsum")
-        return out
+        return _colsum_raw(g)
 
     @staticmethod
     def backward(ctx, gg):
@@ -400,23 +429,32 @@ class LinearAct(Function):
         x, w = f32c(x), f32c(w)
         y = gemm_raw(x, False, w, not w_kn, bias_j=b, bias_shift=bias_shift, act=act, slope=slope)
         ctx.cfg = (act, slope, w_kn, bias_shift, b is not None)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None, b)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         act, slope, w_kn, bias_shift, has_b = ctx.cfg
         gz = ActBwd.apply(y, gy, act, slope) if act != ACT_NONE else gy
         gx = gw = gb = None
+        plain = not torch.is_grad_enabled()
         if ctx.needs_input_grad[0]:
             gx = Gemm.apply(gz, w, False, w_kn)             # gz @ w  (or gz @ w^T when w is [in,out])
         if ctx.needs_input_grad[1]:
-            gw = Gemm.apply(x, gz, True, False) if w_kn else Gemm.apply(gz, x, True, False)
+            if plain:
+                gzc = f32c(gz)
+                a, bm = (x, gzc) if w_kn else (gzc, x)
+                gw = gemm_raw(a, True, bm, False, out=L.grad_destination(w, w.shape))
+            else:
+                gw = Gemm.apply(x, gz, True, False) if w_kn else Gemm.apply(gz, x, True, False)
         if has_b and ctx.needs_input_grad[2]:
-            gb = ColSum.apply(gz)
-            if bias_shift:
-                gb = ColSum.apply(gb.reshape(-1, 1 << bias_shift).t())
+            if plain and not bias_shift:
+                gb = _colsum_raw(f32c(gz), L.grad_destination(b, b.shape))
+            else:
+                gb = ColSum.apply(gz)
+                if bias_shift:
+                    gb = ColSum.apply(gb.reshape(-1, 1 << bias_shift).t())
         return gx, gw, gb, None, None, None, None
 
 
@@ -461,8 +499,8 @@ class BatchNormAct(Function):
         N, C, S, training, act, slope = ctx.cfg
         gy = f32c(gy)
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        dgamma = _param_grad_out(gamma, gamma.shape, x.device)
+        dbeta = _param_grad_out(beta, beta.shape, x.device)
         lib = _lib()
         ws = workspace("bn", lib.sg_bn_workspace_bytes(C), x.device)
         check(lib.sg_bn_bwd(ptr(gy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dgamma),
@@ -513,28 +551,31 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
         gemm_raw(dz, False, rows, False, out=out, a_off=layer_dz * _H * ldn, M=_H, N=width, K=N, lda=ldn,
                  ldb=rows.shape[1], ldc=ldc, c_off=c_off)
 
-    ball = None
-    if bsum is not None:  # [7*256][nblk] partial row sums from the fused backward: one short reduction for all layers
+    # bias gradients: [7*256][nblk] partial row sums from the fused backward -> one short reduction for all seven layers,
+    # each layer's 256 sums written where that parameter's gradient lives
+    bias_idx = (1, 3, 5, 7, 9, 11, 13)                       # parameter index of the bias of dZ layer 0..6
+    bouts = [_param_grad_out(ctx_params[pi], (_H,), dev) for pi in bias_idx]
+    if bsum is not None:
         nblk = bsum.shape[1]
-        ball = torch.empty(7 * _H, dtype=torch.float32, device=dev)
-        check(lib.sg_rowsum(ptr(bsum), ptr(ball), 7 * _H, nblk, nblk, stream()), "rowsum")
+        arr7 = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
+        check(lib.sg_rowsum_multi(ptr(bsum), arr7, 7, _H, nblk, nblk, stream()), "rowsum_multi")
+    else:
+        for layer_dz, out in enumerate(bouts):
+            check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
 
     def bgrad(layer_dz):
-        if ball is not None:
-            return ball[layer_dz * _H:(layer_dz + 1) * _H]
-        out = torch.empty(_H, dtype=torch.float32, device=dev)
-        check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
-        return out
+        return bouts[layer_dz]
 
     # layers1.0 / layers2.0 take X; pieces not materialised per point are filled by the caller afterwards
-    w1 = torch.zeros((_H, kin_total), dtype=torch.float32, device=dev)
-    w5 = torch.zeros((_H, _H + kin_total), dtype=torch.float32, device=dev)
+    # (every column of both is written: points / latent columns below or by the caller, the hidden block by the batch)
+    w1 = _param_grad_out(ctx_params[0], (_H, kin_total), dev)
+    w5 = _param_grad_out(ctx_params[8], (_H, _H + kin_total), dev)
     for rows, off, width in x_parts:
         wgrad_from_rows(0, rows, width, w1, off, kin_total)
         wgrad_from_rows(4, rows, width, w5, _H + off, _H + kin_total)
     # the six 256 x 256 x N products dZ_l H_{l-1}^T in ONE launch (+ one finalize): layers2.0's hidden block, then layers
     # 1.2/1.4/1.6/2.2/2.4
-    hidden = torch.empty((5, _H, _H), dtype=torch.float32, device=dev)
+    hidden = [_param_grad_out(ctx_params[pi], (_H, _H), dev) for pi in (2, 4, 6, 10, 12)]
     pairs = ((4, 3), (1, 0), (2, 1), (3, 2), (5, 4), (6, 5))
     outs = [(w5, _H + kin_total)] + [(hidden[i], _H) for i in range(5)]
     arr = ctypes.c_long * 6
@@ -551,9 +592,9 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
         grads[pi] = hidden[i]
         grads[pi + 1] = bgrad(ldz)
     # layers2.6: W8 [1,256], b8 [1]
-    w8 = torch.empty((1, _H), dtype=torch.float32, device=dev)
+    w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
     gemm_raw(dz8, False, acts, True, out=w8, b_off=6 * _H * ldn, M=1, N=_H, K=N, lda=N, ldb=ldn, ldc=_H)
-    b8 = torch.empty(1, dtype=torch.float32, device=dev)
+    b8 = _param_grad_out(ctx_params[15], (1,), dev)
     check(lib.sg_rowsum(ptr(dz8), ptr(b8), 1, N, N, stream()), "rowsum")
     grads[14], grads[15] = w8, b8
     return grads
@@ -680,7 +721,7 @@ class SDFNetShapes(Function):
             w1, w5 = f32c(params[0]), f32c(params[8])
             g1 = gemm_raw(t1, True, w1, False, b_off=3, M=S, N=Lz, K=_H, lda=S, ldb=kin_total)
             g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
-            gz = torch.empty_like(g1)
+            gz = _param_grad_out(z, g1.shape, dev)
             check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
         return (None, dx, gz, None, None, None) + tuple(grads)
 
@@ -721,17 +762,21 @@ class GatherRows(Function):
         out = torch.empty((n, width), dtype=torch.float32, device=table.device)
         check(_lib().sg_gather_rows(ptr(table), ptr(idx), ptr(out), n, width, stream()), "gather_rows")
         ctx.rows = table.shape[0]
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, table)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
+        idx, table = ctx.saved_tensors
         width = g.shape[1]
         if g.stride(1) != 1:
             g = g.contiguous()
-        tg = torch.zeros((ctx.rows, width), dtype=torch.float32, device=g.device)
+        tg = L.grad_destination(table, (ctx.rows, width))     # the latent table's own slice of its optimizer's flat buffer
+        if tg is not None:
+            tg.zero_()
+        else:
+            tg = torch.zeros((ctx.rows, width), dtype=torch.float32, device=g.device)
         check(_lib().sg_scatter_add_rows(g.data_ptr(), g.stride(0), ptr(idx), ptr(tg), idx.numel(), width, stream()),
               "scatter_add_rows")
         return tg, None
@@ -1162,4 +1207,4 @@ def scatter_max(x, batch, dim_size=None):
         batch = batch.long()
     if dim_size is None:
         dim_size = int(batch.max().item()) + 1
-    return ScatterMax.apply(x, batch.contiguous(), int(dim_size))
+    return ScatterMax.apply(x, batch.contiguous(), int(dim_size))[0]

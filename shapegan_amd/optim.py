@@ -38,6 +38,7 @@ class _Flat(object):
             if p.grad is not None:
                 self.grad[o:o + n].copy_(p.grad.reshape(-1))
             p.grad = self.grad[o:o + n].view(p.shape)
+        self.slots = [L.register_grad_slot(p, self.grad, o) for p, o in zip(self.params, self.offsets)]
         L.bump_param_epoch()
 
     def grad_view_ok(self, i):
@@ -48,10 +49,12 @@ class _Flat(object):
     def coherent(self):
         return all(self.grad_view_ok(i) for i in range(len(self.params)))
 
-    def adopt_grads(self):
-        """Copies every parameter's live .grad into its flat slice and re-attaches the view (a parameter without a
-        gradient contributes zeros), so that the flat buffer is what the exchange and the update both see."""
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+    def adopt_grads(self, indices=None):
+        """Copies the live .grad of every parameter (or of those in `indices`) into its flat slice and re-attaches the view
+        (a parameter without a gradient contributes zeros), so that the flat buffer is what the exchange and the update
+        both see."""
+        for i in (range(len(self.params)) if indices is None else indices):
+            p, o = self.params[i], self.offsets[i]
             if self.grad_view_ok(i):
                 continue
             n = p.numel()
@@ -71,11 +74,13 @@ class _Flat(object):
                                    "after constructing the optimizer?); rebuild the optimizer")
 
     def zero_grad(self):
-        """Zeroes the flat gradient buffer and re-attaches views that were dropped (e.g. by module.zero_grad())."""
-        self.grad.zero_()
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            if not self.grad_view_ok(i):
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        """Gradients -> None (torch's set_to_none semantics) and every slice of the flat buffer open for a direct write:
+        the next backward's weight-gradient kernels store into the slices and autograd adopts those views as p.grad
+        (lib.grad_destination), so neither a memset of the buffer nor a `p.grad += g` pass per parameter is launched.  A
+        parameter that receives no gradient keeps p.grad None and is skipped by step(), as in torch.optim."""
+        for p, slot in zip(self.params, self.slots):
+            p.grad = None
+            slot.written = False
 
 
 class _Base(object):
@@ -149,7 +154,7 @@ class Adam(_Base):
         uniform = f.coherent() and len(set(self.steps)) == 1
         if self.capturable:
             if not f.coherent():
-                raise RuntimeError("capturable Adam: every parameter must have its gradient in the flat buffer")
+                f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
             check(lib.sg_adam_step_dev(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                        self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
                                        self.grad_scale, stream()), "adam_step_dev")

@@ -68,20 +68,26 @@ class GradBucket(object):
         if start_idx >= len(f.params) or start_idx == 0:
             return
         self.tail = (f.offsets[start_idx], total)
+        self.tail_index = list(range(start_idx, len(f.params)))
         self.tail_params = f.params[start_idx:]
         for p in self.tail_params:
             self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _on_grad(self, param):
+        """Post-accumulate hook of a tail parameter (autograd runs it once per backward and parameter, after all of the
+        parameter's contributions have been summed)."""
         if not self.armed:
             return
         self.pending -= 1
         if self.pending == 0:
             self.armed = False
-            if self.opt.f.coherent():
-                a, b = self.tail
-                self.works.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
-                self.tail_done = True
+            f = self.opt.f
+            # a gradient that did not come out of a direct write (stock autograd tensors, several contributions summed by
+            # the engine) is copied into its slice now, so that the slice is what goes on the wire
+            f.adopt_grads(self.tail_index)
+            a, b = self.tail
+            self.works.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self.tail_done = True
 
     def arm(self):
         """Call right before loss.backward(): the tail slice will be exchanged from inside backward."""
@@ -94,17 +100,19 @@ class GradBucket(object):
         """Call right after loss.backward(): exchanges whatever has not gone out yet and waits."""
         self.armed = False
         if world_size() > 1:
-            if not self.opt.f.coherent():
-                # module.zero_grad() (grads -> None) or an out-of-place accumulation detached p.grad from the flat
-                # buffer: the optimizer would step on p.grad while the exchange summed a stale buffer.  Pull the live
-                # gradients back into their slices first (a tail slice that already went out is no longer valid).
-                if getattr(self, "tail_done", False):
-                    raise RuntimeError("GradBucket: gradient views changed after the early slice was exchanged")
-                self.opt.f.adopt_grads()
+            f = self.opt.f
             if getattr(self, "tail_done", False):
                 a, _ = self.tail
+                f.adopt_grads(range(0, self.tail_index[0]))
+                # tail parameters must still be the views that were reduced (a later out-of-place accumulation would have
+                # left the reduced slice behind)
+                if not all(f.grad_view_ok(i) for i in self.tail_index):
+                    raise RuntimeError("GradBucket: a gradient changed after its slice was exchanged")
                 self.works.append(dist.all_reduce(self.opt.flat_grad[:a], op=dist.ReduceOp.SUM, async_op=True))
             else:
+                # module.zero_grad() (grads -> None), stock autograd tensors or an out-of-place accumulation leave p.grad
+                # outside the flat buffer: the optimizer would step on p.grad while the exchange summed a stale slice
+                f.adopt_grads()
                 self.works.append(dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM, async_op=True))
         self.tail_done = False
         self.wait()

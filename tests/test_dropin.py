@@ -60,8 +60,9 @@ def compare(case, rec, gold, report=None):
         if not np.issubdtype(ref.dtype, np.floating):
             np.testing.assert_array_equal(got, ref, err_msg=k)     # num_batches_tracked
         elif "running_" in k:
-            # BatchNorm running statistics inherit the random walk of the gradient-free bias in front of them
-            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).mean() + 1e-3), err_msg=k)
+            # BatchNorm running statistics inherit the random walk of the gradient-free bias in front of them (a few
+            # optimizer steps of +-lr each, entering with momentum 0.1): 2 % of the typical entry
+            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * float(np.abs(ref).mean()) + 1e-6, err_msg=k)
         elif cases.gradient_free(k):
             u_ref, u_got = ref.astype(np.float64) - init[k], got.astype(np.float64) - init[k]
             assert float(np.abs(u_got).max()) <= 3.0 * float(np.abs(u_ref).max()) + 1e-12, k

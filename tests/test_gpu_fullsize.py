@@ -43,11 +43,16 @@ def test_conv3d_full_size_vs_aten(N, Ci, Co, R):
     w = torch.randn(Co, Ci, 4, 4, 4) / (Ci * 64) ** 0.5
     b = torch.randn(Co) * 0.1
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    y_ref = F.leaky_relu(F.conv3d(xr, wr, br, stride=2, padding=1), 0.2)
+    y_ref = F.conv3d(xr, wr, br, stride=2, padding=1)
     dy = torch.randn_like(y_ref)
     y_ref.backward(dy)
     xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    y = ops.conv3d_k4s2p1(xg, wg, bg, ACT_LEAKY, 0.2)
+    # the fused LeakyReLU epilogue: forward only (a mask flip at an output within rounding of 0 is legitimate in fp32 and
+    # moves a 64 x 64 block of the weight gradient by a finite amount, so gradients are compared on the linear op;
+    # the mask itself is covered at small sizes in test_gpu_ops.py)
+    with torch.no_grad():
+        close(ops.conv3d_k4s2p1(xg, wg, bg, ACT_LEAKY, 0.2), F.leaky_relu(y_ref, 0.2), what="forward + LeakyReLU")
+    y = ops.conv3d_k4s2p1(xg, wg, bg)
     close(y, y_ref, what="forward")
     y.backward(dy.cuda())
     close(xg.grad, xr.grad, what="input gradient")
@@ -81,40 +86,47 @@ def _state(module):
     return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
 
 
+def _state64(module):
+    return {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu().clone())
+            for k, v in module.state_dict().items()}
+
+
 def test_wgan_batch64_update_vs_oracle():
     """BASELINE configs[1]: one critic update and one generator update of train_wgan.py:60-84 at batch 64 against WGANOracle
     on the same inputs — critic loss, the 64 critic scores of each side, every gradient, the generator's BatchNorm running
-    statistics."""
+    statistics.  Gradients are sums over up to 128 x 4096 products with heavy cancellation, so the comparison is the one the
+    trajectory tests use: as close to the fp64 oracle as 1e-4 of the tensor's scale plus 4x the fp32 oracle's own error."""
+    from test_gpu_modules import check_against_oracles
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
     torch.manual_seed(0)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     g, c = Generator(), Discriminator()
-    orc = O.WGANOracle(_state(g), _state(c))
+    o32, o64 = O.WGANOracle(_state(g), _state(c)), O.WGANOracle(_state64(g), _state64(c))
     tr = WGANTrainer(g, c)
     gen = torch.Generator().manual_seed(1000)
     real = torch.rand(64, 32, 32, 32, generator=gen) * 2 - 1
     z, zg = torch.randn(64, 128, generator=gen), torch.randn(64, 128, generator=gen)
     loss, out_fake, out_real = tr.critic_step(real.cuda(), z.cuda())
-    loss_ref, of_ref, or_ref = orc.critic_step(real, z)
-    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=RTOL, atol=1e-7)
-    close(out_fake, of_ref, what="critic(fake)")
-    close(out_real, or_ref, what="critic(real)")
-    grads = dict(zip([k for k, _ in c.named_parameters()], [p.grad for _, p in c.named_parameters()]))
-    for k, p in c.named_parameters():
-        close_mostly(grads[k], orc.C[k].grad, rtol=2e-4, what="critic grad " + k)
+    grads = {k: p.grad.detach().clone() for k, p in c.named_parameters()}
+    r32, r64 = o32.critic_step(real, z), o64.critic_step(real.double(), z.double())
+    np.testing.assert_allclose(loss.item(), r64[0].item(), rtol=RTOL, atol=1e-7)
+    check_against_oracles(out_fake, r32[1], r64[1], "critic(fake)")
+    check_against_oracles(out_real, r32[2], r64[2], "critic(real)")
+    gscale = max(float(o64.C[k].grad.abs().mean()) for k in grads)
+    # (128 samples x up to 64 x 4096 LeakyReLU outputs per layer: a few more kink flips than in the small cases -> 0.3 %)
+    for k in grads:
+        check_against_oracles(grads[k], o32.C[k].grad, o64.C[k].grad, "critic grad " + k, gscale=gscale, max_frac=3e-3)
     gl, out = tr.generator_step(zg.cuda())
-    gl_ref, out_ref = orc.generator_step(zg)
-    np.testing.assert_allclose(gl.item(), gl_ref.item(), rtol=RTOL, atol=1e-7)
-    close(out, out_ref, what="critic(generator(z))")
+    g32, g64 = o32.generator_step(zg), o64.generator_step(zg.double())
+    np.testing.assert_allclose(gl.item(), g64[0].item(), rtol=RTOL, atol=1e-7)
+    check_against_oracles(out, g32[1], g64[1], "critic(generator(z))")
+    gscale = max(float(v.grad.abs().mean()) for k, v in o64.G.items() if v.requires_grad)
     for k, p in g.named_parameters():
-        ref = orc.G[k].grad
-        if k.endswith("bias") and k.split(".")[1] in ("0", "3", "6"):
-            continue     # conv bias in front of a training-mode BatchNorm: mathematically zero gradient, pure rounding noise
-        close_mostly(p.grad, ref, rtol=3e-4, max_bad_frac=2e-3, what="generator grad " + k)
+        check_against_oracles(p.grad, o32.G[k].grad, o64.G[k].grad, "generator grad " + k, gscale=gscale, max_frac=3e-3)
     for k, v in g.state_dict().items():
         if "running_" in k:
-            close(v, orc.G[k], rtol=1e-4, what=k)
+            check_against_oracles(v, o32.G[k], o64.G[k], k)
 
 
 def test_sdf_autodecoder_200k_L256_step_vs_oracle():

@@ -112,7 +112,8 @@ def test_lerp_rows_bit_exact():
     ref = a * real + ((1 - a) * fake)                                         # train_hybrid_progressive_gan.py:104-105
     got = ops.lerp_rows(real.cuda(), fake.cuda(), alpha.cuda())
     assert got.shape == real.shape and not got.requires_grad
-    assert torch.equal(got.cpu(), ref)
+    diff = (got.cpu() - ref).abs()
+    assert torch.equal(got.cpu(), ref), "%d entries differ, max %.3e" % (int((diff > 0).sum()), float(diff.max()))
 
 
 @pytest.mark.parametrize("B,shape", [(16, (32, 32, 32)), (5, (7, 3)), (3, (1000,))])
@@ -256,6 +257,9 @@ def test_double_backward_through_sigmoid_discriminator(use_sigmoid):
     close_mostly(g, g_ref, what="input gradient")
     ((g.norm(2, dim=(1, 2, 3)) - 1) ** 2).mean().backward()
     for k, p in d.named_parameters():
+        if P[k].grad is None:                      # the last bias never enters dD/dx
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+            continue
         close_mostly(p.grad, P[k].grad, rtol=2e-4, what="double-backward grad " + k)
 
 

@@ -146,10 +146,23 @@ def test_flat_optimizer_views_on_cpu():
     for k, v in d.state_dict().items():
         assert torch.equal(v, before[k])
     assert f.coherent()
-    d.zero_grad()  # torch default set_to_none=True drops the views ...
-    assert not f.coherent()
-    f.zero_grad()  # ... and the optimizer re-attaches them
-    assert f.coherent() and float(f.grad.abs().sum()) == 0.0
+    f.zero_grad()  # torch's set_to_none semantics; every slice is open for one direct gradient write
+    assert not f.coherent() and all(p.grad is None for p in d.parameters())
+    w = d.head[1].weight
+    wi = [i for i, p in enumerate(f.params) if p is w][0]
+    with torch.no_grad():                              # a plain backward runs with grad mode off
+        dst = L.grad_destination(w, w.shape)           # what a weight-gradient kernel asks for
+        assert dst is not None and dst.data_ptr() == f.grad.data_ptr() + 4 * f.offsets[wi]
+        assert L.grad_destination(w, w.shape) is None  # a second contribution in the same cycle must not clobber the first
+    f.zero_grad()
+    with torch.enable_grad():
+        assert L.grad_destination(w, w.shape) is None  # create_graph backward: gradients must stay ordinary tensors
+    # gradients that arrived as ordinary tensors (stock autograd, or None) are pulled into the flat buffer on demand
+    for i, p in enumerate(d.parameters()):
+        p.grad = None if i == 0 else torch.full_like(p, float(i))
+    f.adopt_grads()
+    assert f.coherent() and float(f.grad[:f.params[0].numel()].abs().sum()) == 0.0
+    assert float(f.params[3].grad.mean()) == 3.0
 
 
 # ---- input pipeline: host-side index work is bit-exact ---------------------------------------

@@ -42,13 +42,26 @@ def _worker(rank, world, port, out_dir):
     loss = O.discriminator_forward(P, shard, False).mean()   # local-batch mean, as each rank's step computes it
     bucket.arm()
     loss.backward()                                          # the tail slice is exchanged from inside backward
-    assert opt.f.coherent() and bucket.tail_done and len(bucket.works) == 1
+    # stock autograd hands over ordinary tensors: the hook pulled the tail's into the flat buffer before sending the slice
+    assert bucket.tail_done and len(bucket.works) == 1 and all(opt.f.grad_view_ok(i) for i in bucket.tail_index)
     bucket.finish()
+    assert opt.f.coherent()
     np.save(os.path.join(out_dir, "grad%d.npy" % rank), (opt.flat_grad * opt.grad_scale).numpy())
+    # module.zero_grad() (grads -> None) followed by a backward leaves p.grad outside the flat buffer; finish()
+    # must exchange the LIVE gradients, not a stale buffer
+    critic.zero_grad()
+    opt.flat_grad.fill_(123.0)                                   # poison: anything stale would show up in the sum
+    O.discriminator_forward(P, shard, False).mean().backward()   # not armed: one exchange of the whole buffer
+    assert not opt.f.coherent()
+    bucket.finish()
+    assert opt.f.coherent()
+    np.save(os.path.join(out_dir, "again%d.npy" % rank), (opt.flat_grad * opt.grad_scale).numpy())
     if rank == 0:
         opt.zero_grad()
         O.discriminator_forward(P, full, False).mean().backward()
+        opt.f.adopt_grads()
         np.save(os.path.join(out_dir, "full.npy"), opt.flat_grad.numpy())
+        np.save(os.path.join(out_dir, "slices.npy"), np.array([(o, p.numel()) for p, o in zip(opt.f.params, opt.f.offsets)]))
     parallel.allreduce_tensor_(torch.ones(3))
     torch.distributed.destroy_process_group()
 
@@ -56,7 +69,13 @@ def _worker(rank, world, port, out_dir):
 def test_dp_gradient_equals_full_batch(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
-    full = np.load(tmp_path / "full.npy")
+    used = np.zeros(np.load(tmp_path / "full.npy").shape, dtype=bool)      # alignment padding between slices is nobody's
+    for o, n in np.load(tmp_path / "slices.npy"):
+        used[o:o + n] = True
+    g0, g1 = np.load(tmp_path / "grad0.npy")[used], np.load(tmp_path / "grad1.npy")[used]
+    full = np.load(tmp_path / "full.npy")[used]
     np.testing.assert_array_equal(g0, g1)                       # replicas see the same reduced gradient
     np.testing.assert_allclose(g0, full, rtol=1e-4, atol=1e-7)  # and it is the full-batch gradient
+    a0, a1 = np.load(tmp_path / "again0.npy")[used], np.load(tmp_path / "again1.npy")[used]
+    np.testing.assert_array_equal(a0, a1)
+    np.testing.assert_allclose(a0, full, rtol=1e-4, atol=1e-7)  # also after module.zero_grad() dropped the flat views
