@@ -3,15 +3,26 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config wgan|hybrid_progressive|hybrid_wgan|sdf]
 
-A "step" is one pass of the train_wgan.py cadence over synthetic data that is already resident in HBM: five critic
-updates (generator forward, two critic forward+backward, fused RMSprop + weight clip) and one generator update
-(train_wgan.py:39,60-84), 32^3 voxel grids, batch 64 per GPU, fp32.  With N GPUs every rank runs the same per-GPU
-workload (weak scaling) and each optimizer update all-reduces one flat gradient buffer over RCCL.
-Rank 0 prints ONE JSON line (schema in the task contract) including `roofline` for the dominant kernel (the
-64->128 channel Conv3d forward implicit GEMM, timed alone with HIP events on the launch stream), the SDFNet
-Mpoints/s figures, and — at N=1 — `cpu_baseline`: the CPU oracle's time for the same step on the host cores.
+Default workload (`--config wgan`, BASELINE configs[1], the configuration the metric is quoted on): one "step" is one pass
+of the train_wgan.py cadence over synthetic data already resident in HBM — five critic updates (generator forward, one
+critic forward+backward over fake+real, fused RMSprop + weight clip) and one generator update (train_wgan.py:39,60-84),
+32^3 voxel grids, batch 64 per GPU, fp32.  With N GPUs every rank runs the same per-GPU workload (weak scaling) and each
+optimizer update all-reduces one flat gradient buffer over RCCL.  The other configs are the remaining BASELINE workloads
+behind the same harness (the multi-GPU ones are `hybrid_progressive` = configs[3] and `hybrid_wgan` = configs[4]):
+    hybrid_progressive  train_hybrid_progressive_gan.py iteration 3 (64^3), batch 16/GPU, WGAN-GP: 5 discriminator + 1 generator updates
+    hybrid_wgan         train_hybrid_wgan.py 32^3, batch 8/GPU: 5 critic + 1 generator updates
+    sdf                 train_sdf_autodecoder.py, latent 256, 200 000 points per step per GPU (value in Mpoints/s)
+
+Rank 0 prints ONE JSON line (schema in the task contract).  At N=1 with the default config it carries
+  `roofline`      the kernel that takes the largest share of the step (Conv3d 128->64 input-gradient / ConvTranspose3d forward
+                  implicit GEMM, `conv_dgrad_halo_kernel<0>`: 22 % of the step), timed alone with HIP events on the launch
+                  stream at the critic's 128-sample shape, plus `kernels`: the same measurement for every conv form of the
+                  step (MFMA-bound ones against the fp32 MFMA peak, Cin=1 / Cout=1 edge layers against HBM),
+  `sdfnet`        the SDFNet half of the metric (fused forward, both auto-decoder training configs) with algorithmic AND
+                  executed FLOP rates,
+  `cpu_baseline`  the CPU oracle's time for the same step on the host cores and the GPU-vs-oracle loss agreement.
 """
 import argparse
 import json
@@ -26,9 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 TB/s achievable)
 BATCH = 64
-# forward GFLOP of the dominant kernel: Conv3d 64->128, k4 s2 p1, 16^3 -> 8^3, per sample
-CONV2_FLOP_PER_SAMPLE = 2.0 * 128 * 512 * 64 * 64
 
 
 def event_time_ms(fn, iters):
@@ -49,37 +59,91 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
-def roofline_conv():
+def conv_kernel_table():
+    """Every conv form of the WGAN step at the shape it runs with in the critic update (fake+real = 128 samples) or the
+    generator (64 samples), timed through the C-ABI entry (weight-image packs included).  flop = 2*Cout*Cin*64 per output
+    voxel; bytes = each operand once."""
     from shapegan_amd import ops
-    # the critic runs fake and real as one 2*BATCH pass (5 of the step's 7 launches of this layer); the timed call is
-    # the C-ABI entry, i.e. the weight-image pack (~1 % of the time) plus the MFMA kernel
     nb = 2 * BATCH
-    x = torch.randn(nb, 64, 16, 16, 16, device="cuda")
-    w = torch.randn(128, 64, 4, 4, 4, device="cuda") * 0.02
-    b = torch.zeros(128, device="cuda")
-    ms = event_time_ms(lambda: ops.conv_fwd_raw(x, w, b, 1, 0.2), 30)
-    flop = CONV2_FLOP_PER_SAMPLE * nb
-    achieved = flop / (ms * 1e-3) / 1e12
-    # HBM bytes per launch of this kernel: PMC counters cannot be read in-process, so the figure measured with
-    # rocprofv3 (--pmc FETCH_SIZE / WRITE_SIZE, separate passes, guide corrections) is read from profiles/
-    traffic = None
+    rows = []
+
+    def mfma(name, kernel, flop, fn):
+        ms = event_time_ms(fn, 20)
+        tf = flop / (ms * 1e-3) / 1e12
+        rows.append({"name": name, "kernel": kernel, "bound": "mfma", "flop": flop, "us": round(ms * 1e3, 1),
+                     "tflops": round(tf, 1), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+
+    def hbm(name, kernel, nbytes, flop, fn):
+        ms = event_time_ms(fn, 20)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"name": name, "kernel": kernel, "bound": "hbm", "bytes": nbytes, "flop": flop, "us": round(ms * 1e3, 1),
+                     "gb_per_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+
+    x16 = torch.randn(nb, 64, 16, 16, 16, device="cuda")
+    w2 = torch.randn(128, 64, 4, 4, 4, device="cuda") * 0.02
+    b2 = torch.zeros(128, device="cuda")
+    y8 = torch.randn(nb, 128, 8, 8, 8, device="cuda")
+    f2 = 2.0 * 128 * 64 * 64 * 512 * nb
+    mfma("Conv3d 64->128 input-gradient / ConvT forward, 8^3 -> 16^3, 128 samples", "conv_dgrad_halo_kernel<0>", f2,
+         lambda: ops.conv_dgrad_raw(y8, w2, None, 64))
+    mfma("Conv3d 64->128 forward, 16^3 -> 8^3, 128 samples", "conv_fwd_halo_kernel<1,8>", f2,
+         lambda: ops.conv_fwd_raw(x16, w2, b2, 1, 0.2))
+    mfma("Conv3d 64->128 weight-gradient, 128 samples", "conv_wgrad_halo_kernel", f2, lambda: ops.conv_wgrad_raw(y8, x16, 64))
+    x8 = torch.randn(nb, 128, 8, 8, 8, device="cuda")
+    w3 = torch.randn(256, 128, 4, 4, 4, device="cuda") * 0.02
+    b3 = torch.zeros(256, device="cuda")
+    y4 = torch.randn(nb, 256, 4, 4, 4, device="cuda")
+    f3 = 2.0 * 256 * 128 * 64 * 64 * nb
+    mfma("Conv3d 128->256 forward, 8^3 -> 4^3, 128 samples", "conv_fwd_halo4_kernel", f3, lambda: ops.conv_fwd_raw(x8, w3, b3, 1, 0.2))
+    mfma("Conv3d 128->256 input-gradient / ConvT forward, 4^3 -> 8^3, 128 samples", "conv_dgrad_halo_kernel<1>", f3,
+         lambda: ops.conv_dgrad_raw(y4, w3, None, 128))
+    mfma("Conv3d 128->256 weight-gradient, 128 samples", "conv_wgrad_halo4_kernel", f3, lambda: ops.conv_wgrad_raw(y4, x8, 128))
+    # HBM-bound edge layers (one channel on one side)
+    x32 = torch.randn(nb, 1, 32, 32, 32, device="cuda")
+    w1 = torch.randn(64, 1, 4, 4, 4, device="cuda") * 0.1
+    b1 = torch.zeros(64, device="cuda")
+    y16 = torch.randn(nb, 64, 16, 16, 16, device="cuda")
+    f1 = 2.0 * 64 * 64 * 4096 * nb
+    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv1 forward", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
+        lambda: ops.conv_fwd_raw(x32, w1, b1, 1, 0.2))
+    hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv1 wgrad", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
+        lambda: ops.conv_wgrad_raw(y16, x32, 1))
+    y16g = y16[:BATCH].contiguous()
+    hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "dgrad_out1", 4.0 * (y16g.numel() + BATCH * 32768 + w1.numel()),
+        f1 / 2, lambda: ops.conv_dgrad_raw(y16g, w1, None, 1))
+    return rows
+
+
+def roofline_and_kernels():
+    rows = conv_kernel_table()
+    dom = rows[0]   # conv_dgrad_halo_kernel<0>: the largest share of the step's kernel time (profiles/r02_wgan_step_kernel_stats.csv)
+    traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (cannot be read in-process)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_conv_fwd_halo_hbm.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_hbm.json")) as fh:
             traffic = float(json.load(fh)["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "mfma", "kernel": "conv_fwd_halo_kernel (Conv3d 64->128 k4 s2 p1 forward, 16^3 -> 8^3, 128 samples = critic pass over fake+real; the largest GEMM of the step)",
-            "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
-            "flop_per_launch": flop}
+    roof = {"bound": "mfma", "kernel": dom["kernel"] + " (" + dom["name"] + "; the largest share of the step's kernel time)",
+            "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+            "launch_ms": round(dom["us"] / 1e3, 4), "flop_per_launch": dom["flop"]}
+    return roof, rows
+
+
+def sdf_flops(latent):
+    """(algorithmic, executed) forward FLOP per point: SURVEY.md 8d's count of the reference's cat+Linear layers, and what the
+    kernels execute once the latent columns of layers1.0 / layers2.0 are folded into per-shape bias vectors."""
+    algorithmic = 2 * ((3 + latent) * 256 + 3 * 256 * 256 + (259 + latent) * 256 + 2 * 256 * 256 + 256)
+    executed = algorithmic - 2 * 2 * latent * 256
+    return algorithmic, executed
 
 
 def sdfnet_numbers():
     """SDFNet half of the metric.  Forward: a 32^3 x 8 grid pass (config 5's generator forward).  Training: one
     auto-decoder step (train_sdf_autodecoder.py:77-91: gather, fused forward, L1+reg loss, fused backward, weight-grad
     GEMMs, two Adam updates) at the reference's 20 000 points/step with latent 128, and at BASELINE configs[2]'s
-    200 000 points/step with latent 256.  FLOP/point from SURVEY.md 8d (921 088 fwd at L=128, 1 052 160 at L=256,
-    ~3x for a training step)."""
+    200 000 points/step with latent 256.  Rates are given twice: against the reference's algorithmic FLOP count (SURVEY.md
+    8d: forward, x3 for a training step) and against the FLOPs the kernels execute (the per-shape latent fold removes the
+    latent columns of two layers; the 20 000-point step keeps per-point latents and executes everything)."""
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     from shapegan_amd.util import get_voxel_coordinates
@@ -90,25 +154,35 @@ def sdfnet_numbers():
     with torch.no_grad():
         ms_fwd = event_time_ms(lambda: net.forward_shapes(grid, z, 32768), 10)
     n_fwd = 8 * 32768
-    fwd_tflops = n_fwd * 921088 / (ms_fwd * 1e-3) / 1e12
-    out = {"fwd_mpoints_per_s": round(n_fwd / ms_fwd / 1e3, 2), "fwd_tflops": round(fwd_tflops, 2),
-           "fwd_frac_of_f32_mfma_peak": round(fwd_tflops / F32_MFMA_PEAK_TFLOPS, 4)}
+    alg, exe = sdf_flops(128)
+    out = {"fwd_mpoints_per_s": round(n_fwd / ms_fwd / 1e3, 2),
+           "fwd_tflops_algorithmic": round(n_fwd * alg / (ms_fwd * 1e-3) / 1e12, 2),
+           "fwd_tflops_executed": round(n_fwd * exe / (ms_fwd * 1e-3) / 1e12, 2),
+           "fwd_frac_of_f32_mfma_peak_algorithmic": round(n_fwd * alg / (ms_fwd * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+           "fwd_frac_of_f32_mfma_peak_executed": round(n_fwd * exe / (ms_fwd * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     pc, shapes = 200000, 64
     pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
     sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
-    for tag, npts, lat, flop_pt in (("train_ref_20k_L128", 20000, 128, 3 * 921088), ("train_cfg_200k_L256", 200000, 256, 3 * 1052160)):
+    for tag, npts, lat, folded in (("train_ref_20k_L128", 20000, 128, False), ("train_cfg_200k_L256", 200000, 256, True)):
         table = torch.randn(shapes, lat, device="cuda") * 1e-2
         tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
         idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
         ms = event_time_ms(lambda: tr.step(idx), 10)
+        alg, exe = sdf_flops(lat)
+        exe = exe if folded else alg
         out[tag] = {"mpoints_per_s": round(npts / ms / 1e3, 3), "ms_per_step": round(ms, 3),
-                    "tflops": round(npts * flop_pt / (ms * 1e-3) / 1e12, 2)}
+                    "tflops_algorithmic": round(npts * 3 * alg / (ms * 1e-3) / 1e12, 2),
+                    "tflops_executed": round(npts * 3 * exe / (ms * 1e-3) / 1e12, 2),
+                    "frac_of_f32_mfma_peak_executed": round(npts * 3 * exe / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     return out
 
 
 def cpu_baseline(reals, zs, zg, g_state, c_state):
-    """The CPU oracle (torch fp32 ops = the reference's own arithmetic engine, all host cores) on the same step."""
+    """The CPU oracle (torch fp32 ops = the reference's own arithmetic engine, a PORT of the step body, not the reference's
+    module classes) on the same step, plus the agreement of the GPU path with it on the first critic update."""
     from oracle import torch_oracle as O
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
     # oneDNN's conv3d backward stops scaling past ~32 threads on the GPU box's 256-core host (measured: 0.49 s per
     # critic update at 16-32 threads, 1.6 s at 128, 15 s at 256): use the fastest setting and report it as `cores`
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -117,8 +191,17 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
     zs = [z.cpu() for z in zs]
     zg = zg.cpu()
     t0 = time.perf_counter()
-    orc.critic_step(reals[0], zs[0])            # warm-up (also sizes the sample)
+    ref = orc.critic_step(reals[0], zs[0])      # warm-up (also sizes the sample) and the parity reference
     warm = time.perf_counter() - t0
+    # the same update on the GPU from the same initial state: loss and the 2 x 64 critic scores
+    g, c = Generator(), Discriminator()
+    g.load_state_dict(g_state)
+    c.load_state_dict(c_state)
+    got = WGANTrainer(g, c).critic_step(reals[0].cuda(), zs[0].cuda())
+    scores_ref = torch.cat([ref[1], ref[2]])
+    scores = torch.cat([got[1], got[2]]).cpu()
+    rel = float((scores - scores_ref).abs().max() / scores_ref.abs().mean())
+    loss_rel = abs(float(got[0]) - float(ref[0])) / max(abs(float(ref[0])), 1e-30)
     nsteps = max(1, min(6, int(15.0 / max(warm * 7, 1e-3))))   # ~15 s of CPU work (a 5+1 step is ~7 critic-step equivalents)
     t0 = time.perf_counter()
     for _ in range(nsteps):
@@ -126,7 +209,101 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
     dt = time.perf_counter() - t0
     return {"value": round(nsteps / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d full 5+1 WGAN step(s) at batch 64 after 1 warm-up critic update, oracle/torch_oracle.py "
-                      "WGANOracle on torch CPU fp32" % nsteps}
+                      "WGANOracle on torch CPU fp32" % nsteps,
+            "gpu_vs_oracle": {"critic_scores_max_err_over_mean_abs": rel, "critic_loss_rel_err": loss_rel,
+                              "what": "first critic update at batch 64 from the same initial state and inputs"}}
+
+
+# ---- workloads -----------------------------------------------------------------------------------------------------------
+def make_wgan(rank):
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
+    torch.manual_seed(0)                        # identical replicas on every rank
+    generator, critic = Generator(), Discriminator()
+    state = ({k: v.detach().cpu().clone() for k, v in generator.state_dict().items()},
+             {k: v.detach().cpu().clone() for k, v in critic.state_dict().items()})
+    trainer = WGANTrainer(generator, critic)
+    gen = torch.Generator().manual_seed(1000 + rank)   # per-rank synthetic data (batch axis sharded)
+    reals = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(5)]
+    zs = [torch.randn(BATCH, 128, generator=gen).cuda() for _ in range(5)]
+    zg = torch.randn(BATCH, 128, generator=gen).cuda()
+    info = {"metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
+            "unit": "steps/s", "units_per_step": 1.0,
+            "workload": "train_wgan.py 32^3 voxel WGAN, fp32, batch=64 synthetic SDF grids (BASELINE configs[1])",
+            "batch": BATCH, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1}}
+    return (lambda: trainer.step(reals, zs, zg)), info, (reals, zs, zg, state)
+
+
+def make_hybrid_progressive(rank):
+    from shapegan_amd.model.progressive_gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import HybridProgressiveGANTrainer
+    from shapegan_amd.util import get_voxel_coordinates
+    torch.manual_seed(0)
+    R, B = 64, 16
+    g, d = SDFNet(), Discriminator().cuda()
+    d.set_iteration(3)
+    tr = HybridProgressiveGANTrainer(g, d, torch.tensor(get_voxel_coordinates(R)).cuda(), R)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    reals = [(torch.rand(B, R, R, R, generator=gen) * 2 - 1).cuda() for _ in range(5)]
+    zs = [torch.randn(B, 128, generator=gen).cuda() for _ in range(6)]
+    alphas = [torch.rand(B, 1, 1, 1, generator=gen).cuda() for _ in range(5)]
+
+    def step():   # train_hybrid_progressive_gan.py:120-166: generator on every 5th batch (first), discriminator on every batch
+        tr.generator_step(zs[5])
+        for real, z, alpha in zip(reals, zs, alphas):
+            tr.discriminator_step(real, z, alpha)
+    info = {"metric": "hybrid progressive WGAN-GP train steps/sec @64^3 (1 generator + 5 discriminator updates, batch 16/GPU)",
+            "unit": "steps/s", "units_per_step": 1.0,
+            "workload": "train_hybrid_progressive_gan.py iteration=3 (64^3), SDFNet generator + progressive 3D-CNN discriminator, "
+                        "WGAN-GP double backward, fp32, batch=16 (BASELINE configs[3])",
+            "batch": B, "extra": {"discriminator_updates_per_step": 5, "generator_updates_per_step": 1}}
+    return step, info, None
+
+
+def make_hybrid_wgan(rank):
+    from shapegan_amd.model.gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import HybridWGANTrainer
+    from shapegan_amd.util import get_voxel_coordinates
+    torch.manual_seed(0)
+    B = 8
+    tr = HybridWGANTrainer(SDFNet(), Discriminator(), torch.tensor(get_voxel_coordinates(32)).cuda())
+    gen = torch.Generator().manual_seed(1000 + rank)
+    reals = [(torch.rand(B, 32, 32, 32, generator=gen) * 0.2 - 0.1).cuda() for _ in range(5)]
+    zs = [torch.randn(B, 128, generator=gen).cuda() for _ in range(6)]
+
+    def step():   # train_hybrid_wgan.py:78-115: critic on every batch, generator on every 5th
+        for i, (real, z) in enumerate(zip(reals, zs)):
+            tr.critic_step(real, z)
+            if i == 0:
+                tr.generator_step(zs[5])
+    info = {"metric": "hybrid WGAN train steps/sec @32^3 (5 critic + 1 generator updates, batch 8/GPU)", "unit": "steps/s",
+            "units_per_step": 1.0,
+            "workload": "train_hybrid_wgan.py, SDFNet generator sampled to 32^3 + 3D-CNN critic, fp32, batch=8 (BASELINE configs[4])",
+            "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1}}
+    return step, info, None
+
+
+def make_sdf(rank):
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+    torch.manual_seed(0)
+    pc, shapes, lat, npts = 200000, 64, 256, 200000
+    gen = torch.Generator().manual_seed(1000 + rank)
+    pts = (torch.rand(shapes * pc, 3, generator=gen) * 2 - 1).cuda()
+    sdf = (torch.rand(shapes * pc, generator=gen) * 0.2 - 0.1).cuda()
+    table = (torch.randn(shapes, lat, generator=torch.Generator().manual_seed(7)) * 1e-2).cuda()   # replicated table
+    tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
+    idx = torch.randint(0, shapes * pc, (npts,), generator=gen).cuda()
+    info = {"metric": "SDFNet auto-decoder training Mpoints/sec (train_sdf_autodecoder.py, latent 256, 200 000 points/step/GPU)",
+            "unit": "Mpoints/s", "units_per_step": npts / 1e6,
+            "workload": "train_sdf_autodecoder.py DeepSDF, latent=256, 200k (xyz,sdf) points/step, fp32 (BASELINE configs[2])",
+            "batch": npts, "extra": {}}
+    return (lambda: tr.step(idx)), info, None
+
+
+WORKLOADS = {"wgan": make_wgan, "hybrid_progressive": make_hybrid_progressive, "hybrid_wgan": make_hybrid_wgan, "sdf": make_sdf}
 
 
 def main():
@@ -134,6 +311,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="wgan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / SDFNet side measurements")
     args = ap.parse_args()
@@ -142,18 +320,7 @@ def main():
     rank, world, local = parallel.init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local % torch.cuda.device_count())
-    from shapegan_amd.model.gan import Discriminator, Generator
-    from shapegan_amd.train_steps import WGANTrainer
-
-    torch.manual_seed(0)                        # identical replicas on every rank
-    generator, critic = Generator(), Discriminator()
-    g_state = {k: v.detach().cpu().clone() for k, v in generator.state_dict().items()}
-    c_state = {k: v.detach().cpu().clone() for k, v in critic.state_dict().items()}
-    trainer = WGANTrainer(generator, critic)
-    gen = torch.Generator().manual_seed(1000 + rank)   # per-rank synthetic data (batch axis sharded)
-    reals = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(5)]
-    zs = [torch.randn(BATCH, 128, generator=gen).cuda() for _ in range(5)]
-    zg = torch.randn(BATCH, 128, generator=gen).cuda()
+    step, info, wgan_data = WORKLOADS[args.config](rank)
 
     def sync():
         if world > 1:
@@ -161,11 +328,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(reals, zs, zg)
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(reals, zs, zg)
+        step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -174,21 +341,22 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        config = {"workload": info["workload"], "global_batch": info["batch"] * world, "parallelism": "dp%d" % world}
+        config.update(info["extra"])
         line = {
-            "metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
-            "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train_wgan.py 32^3 voxel WGAN, fp32, batch=64 synthetic SDF grids (BASELINE configs[1])",
-                       "global_batch": BATCH * world, "critic_updates_per_step": 5, "generator_updates_per_step": 1,
-                       "parallelism": "dp%d" % world},
-            "critic_updates_per_s": round(world * args.steps * 5 / elapsed, 3),
+            "metric": info["metric"], "value": round(world * args.steps * info["units_per_step"] / elapsed, 4),
+            "unit": info["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config,
         }
-        if not args.no_extras:
-            line["roofline"] = roofline_conv()
-            line["sdfnet"] = sdfnet_numbers()
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(reals, zs, zg, g_state, c_state)
+        if args.config == "wgan":
+            line["critic_updates_per_s"] = round(world * args.steps * 5 / elapsed, 3)
+            if not args.no_extras:
+                line["roofline"], line["kernels"] = roofline_and_kernels()
+                line["sdfnet"] = sdfnet_numbers()
+            if world == 1 and not args.no_cpu_baseline:
+                reals, zs, zg, (g_state, c_state) = wgan_data
+                line["cpu_baseline"] = cpu_baseline(reals, zs, zg, g_state, c_state)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -249,6 +249,22 @@ int sg_scatter_max_fwd(const float* x, const int64_t* batch, float* out, int* ar
 int sg_scatter_max_scatter(const float* dy, const int* arg, float* dx, long N, long B, int C, hipStream_t stream);
 int sg_scatter_max_gather(const float* x, const int* arg, float* out, long N, long B, int C, hipStream_t stream);
 
+/* ---- data-parallel gradient exchange: libshapegan_comm.so ----------------------------------------------
+ * reference: nn.DataParallel's gradient reduce-add, train_hybrid_progressive_gan.py:62-68.  One process per GPU; one
+ * ncclAllReduce(sum, fp32) of a slice of the flat gradient buffer per call, on the communicator's own stream, ordered after
+ * the work already enqueued on `compute_stream` (sg_allreduce_launch) — backward kernels enqueued afterwards overlap with it;
+ * sg_allreduce_wait makes `compute_stream` wait for every exchange launched so far.  No host synchronisation.  The library
+ * owns the communicator, its stream and two events between init and destroy; buffers stay the caller's.  Rank 0 makes the
+ * unique id (sg_allreduce_unique_id) and distributes it out of band (a file, MPI, torch.distributed's store). */
+typedef struct sg_comm sg_comm;
+const char* sg_comm_last_error(void);
+size_t sg_allreduce_unique_id_bytes(void);
+int sg_allreduce_unique_id(void* id_out, size_t bytes);
+int sg_allreduce_init(sg_comm** comm, int rank, int world, const void* unique_id, size_t id_bytes, int device);
+int sg_allreduce_launch(sg_comm* comm, float* buf, long count, hipStream_t compute_stream);
+int sg_allreduce_wait(sg_comm* comm, hipStream_t compute_stream);
+int sg_allreduce_destroy(sg_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

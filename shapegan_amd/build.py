@@ -65,7 +65,26 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    build_comm(force, verbose)
     return LIB
+
+
+COMM_LIB = os.path.join(HERE, "libshapegan_comm.so")
+
+
+def build_comm(force=False, verbose=True):
+    """libshapegan_comm.so: the RCCL gradient exchange of the C ABI (csrc/comm.cpp), linked against the ROCm RCCL."""
+    src = os.path.join(CSRC, "comm.cpp")
+    if not (force or _stale(COMM_LIB, [src, HEADERS[-1]])):
+        return COMM_LIB
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", COMM_LIB, "-L/opt/rocm/lib", "-lrccl",
+           "-lamdhip64"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libshapegan_comm.so failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return COMM_LIB
 
 
 if __name__ == "__main__":

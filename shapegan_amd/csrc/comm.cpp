@@ -1,0 +1,112 @@
+// shapegan_amd/csrc/comm.cpp — the gradient exchange of the data-parallel path behind the C ABI: RCCL all-reduce of the flat
+// fp32 gradient buffer of one network per optimizer step, stream-ordered, without torch.distributed on the hot path.
+//
+// Reference: nn.DataParallel's reduce-add of replica gradients (train_hybrid_progressive_gan.py:62-68) — here one process per
+// GPU, identical replicas, one (or two: tail slice early, head slice at the end of backward) ncclAllReduce(sum) per update;
+// the 1/world factor is applied by the optimizer kernel (grad_scale).  Built into its own library (libshapegan_comm.so) so
+// that single-GPU users of libshapegan_hip.so do not need RCCL.
+//
+// Ordering: every communicator owns a side stream.  sg_allreduce_launch records an event on the caller's compute stream,
+// makes the side stream wait for it (the slice's gradients are complete), and enqueues the all-reduce there — later backward
+// kernels on the compute stream overlap with it.  sg_allreduce_wait makes the compute stream wait for everything enqueued so
+// far.  No host synchronisation anywhere.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/shapegan_hip.h"
+
+struct sg_comm {
+    ncclComm_t comm;
+    hipStream_t side;
+    hipEvent_t ready, done;
+    int rank, world, device;
+    int pending;
+};
+
+static thread_local char g_comm_err[512];
+#define COMM_FAIL(...)                               \
+    do {                                             \
+        snprintf(g_comm_err, 512, __VA_ARGS__);      \
+        return -2;                                   \
+    } while (0)
+#define COMM_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) COMM_FAIL("%s: %s failed: %s", __func__, #call, hipGetErrorString(e__)); \
+    } while (0)
+#define COMM_NCCL(call)                                                                        \
+    do {                                                                                       \
+        ncclResult_t r__ = (call);                                                             \
+        if (r__ != ncclSuccess) COMM_FAIL("%s: %s failed: %s", __func__, #call, ncclGetErrorString(r__)); \
+    } while (0)
+
+extern "C" {
+
+const char* sg_comm_last_error(void) { return g_comm_err; }
+
+size_t sg_allreduce_unique_id_bytes(void) { return sizeof(ncclUniqueId); }
+
+int sg_allreduce_unique_id(void* id_out, size_t bytes) {
+    if (!id_out || bytes < sizeof(ncclUniqueId)) COMM_FAIL("sg_allreduce_unique_id: need %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    COMM_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int sg_allreduce_init(sg_comm** out, int rank, int world, const void* unique_id, size_t id_bytes, int device) {
+    if (!out || !unique_id || id_bytes < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world)
+        COMM_FAIL("sg_allreduce_init: bad argument");
+    COMM_HIP(hipSetDevice(device));
+    sg_comm* c = new sg_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    c->pending = 0;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        COMM_FAIL("sg_allreduce_init: ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    COMM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    COMM_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    COMM_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    *out = c;
+    return 0;
+}
+
+int sg_allreduce_launch(sg_comm* c, float* buf, long count, hipStream_t compute_stream) {
+    if (!c || !buf || count <= 0) COMM_FAIL("sg_allreduce_launch: bad argument");
+    COMM_HIP(hipEventRecord(c->ready, compute_stream));
+    COMM_HIP(hipStreamWaitEvent(c->side, c->ready, 0));
+    COMM_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, c->side));
+    c->pending++;
+    return 0;
+}
+
+int sg_allreduce_wait(sg_comm* c, hipStream_t compute_stream) {
+    if (!c) COMM_FAIL("sg_allreduce_wait: bad argument");
+    if (c->pending) {
+        COMM_HIP(hipEventRecord(c->done, c->side));
+        COMM_HIP(hipStreamWaitEvent(compute_stream, c->done, 0));
+        c->pending = 0;
+    }
+    return 0;
+}
+
+int sg_allreduce_destroy(sg_comm* c) {
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->side);
+    (void)ncclCommDestroy(c->comm);
+    (void)hipEventDestroy(c->ready);
+    (void)hipEventDestroy(c->done);
+    (void)hipStreamDestroy(c->side);
+    delete c;
+    return 0;
+}
+
+}  // extern "C"

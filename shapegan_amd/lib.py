@@ -93,6 +93,41 @@ SIGNATURES = {
     "sg_scatter_max_gather": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
 }
 
+# libshapegan_comm.so (RCCL gradient exchange; loaded only by data-parallel runs that ask for it)
+COMM_PATH = os.path.join(_HERE, "libshapegan_comm.so")
+COMM_SIGNATURES = {
+    "sg_comm_last_error": (c_char_p, []),
+    "sg_allreduce_unique_id_bytes": (_Z, []),
+    "sg_allreduce_unique_id": (c_int, [_P, _Z]),
+    "sg_allreduce_init": (c_int, [_P, _I, _I, _P, _Z, _I]),
+    "sg_allreduce_launch": (c_int, [_P, _P, _L, _P]),
+    "sg_allreduce_wait": (c_int, [_P, _P]),
+    "sg_allreduce_destroy": (c_int, [_P]),
+}
+_comm = None
+
+
+def load_comm():
+    """Loads libshapegan_comm.so (once).  Raises if it has not been built."""
+    global _comm
+    if _comm is None:
+        if not os.path.exists(COMM_PATH):
+            raise RuntimeError("libshapegan_comm.so is missing at %s — build it with `python -m shapegan_amd.build`" % COMM_PATH)
+        lib = ctypes.CDLL(COMM_PATH)
+        for name, (res, args) in COMM_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _comm = lib
+    return _comm
+
+
+def check_comm(rc, what=""):
+    if rc != 0:
+        msg = load_comm().sg_comm_last_error()
+        raise RuntimeError("shapegan_comm %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
 _lib = None
 
 

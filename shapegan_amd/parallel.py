@@ -33,6 +33,63 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class NativeComm(object):
+    """The C-ABI gradient exchange (include/shapegan_hip.h: sg_allreduce_*, libshapegan_comm.so): an RCCL communicator with
+    its own stream; `launch` enqueues an in-place all-reduce(sum) of a contiguous fp32 CUDA tensor ordered after the current
+    stream's work, `wait` makes the current stream wait for everything launched — no torch.distributed on the hot path.
+    torch.distributed is used once, as the out-of-band channel for the 128-byte RCCL unique id."""
+
+    def __init__(self, rank=None, world=None, device=None, unique_id=None):
+        import ctypes
+        from . import lib as L
+        self.L, self.lib = L, L.load_comm()
+        rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
+        world = world_size() if world is None else world
+        device = torch.cuda.current_device() if device is None else device
+        nbytes = self.lib.sg_allreduce_unique_id_bytes()
+        if unique_id is None:
+            buf = ctypes.create_string_buffer(nbytes)
+            if rank == 0:
+                L.check_comm(self.lib.sg_allreduce_unique_id(buf, nbytes), "unique_id")
+            box = [buf.raw]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        handle = ctypes.c_void_p()
+        L.check_comm(self.lib.sg_allreduce_init(ctypes.byref(handle), rank, world, unique_id, len(unique_id), device), "init")
+        self.handle, self.rank, self.world = handle, rank, world
+
+    def launch(self, t):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise RuntimeError("NativeComm.launch needs a contiguous fp32 CUDA tensor")
+        self.L.check_comm(self.lib.sg_allreduce_launch(self.handle, t.data_ptr(), t.numel(),
+                                                       torch.cuda.current_stream().cuda_stream), "launch")
+
+    def wait(self):
+        self.L.check_comm(self.lib.sg_allreduce_wait(self.handle, torch.cuda.current_stream().cuda_stream), "wait")
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.sg_allreduce_destroy(self.handle)
+            self.handle = None
+
+
+_native = None
+
+
+def native_comm():
+    """The process-wide NativeComm when SG_NATIVE_ALLREDUCE=1 and the tensors live on GPUs, else None (torch.distributed
+    carries the exchange: "nccl" = RCCL on ROCm, "gloo" in the CPU tests)."""
+    global _native
+    if os.environ.get("SG_NATIVE_ALLREDUCE", "0") != "1" or not torch.cuda.is_available() or world_size() < 2:
+        return None
+    if dist.get_backend() != "nccl":
+        return None          # several ranks on one GPU (gloo functional checks): RCCL cannot form that communicator
+    if _native is None:
+        _native = NativeComm()
+    return _native
+
+
 class GradBucket(object):
     """Gradient exchange of one optimizer: its flat fp32 gradient buffer is summed across ranks in (at most) two
     contiguous slices.  The TAIL slice holds the parameters whose gradients autograd finishes FIRST (the deepest
@@ -52,6 +109,7 @@ class GradBucket(object):
         self.tail = None            # (start, end) element range of the early slice
         self.tail_params = []
         self.hooks = []
+        self.native = native_comm()
         optimizer.grad_scale = 1.0 / world_size()
         if overlap and world_size() > 1:
             self._plan(tail_fraction)
@@ -86,7 +144,7 @@ class GradBucket(object):
             # the engine) is copied into its slice now, so that the slice is what goes on the wire
             f.adopt_grads(self.tail_index)
             a, b = self.tail
-            self.works.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self._exchange(self.opt.flat_grad[a:b])
             self.tail_done = True
 
     def arm(self):
@@ -108,18 +166,29 @@ class GradBucket(object):
                 # left the reduced slice behind)
                 if not all(f.grad_view_ok(i) for i in self.tail_index):
                     raise RuntimeError("GradBucket: a gradient changed after its slice was exchanged")
-                self.works.append(dist.all_reduce(self.opt.flat_grad[:a], op=dist.ReduceOp.SUM, async_op=True))
+                self._exchange(self.opt.flat_grad[:a])
             else:
                 # module.zero_grad() (grads -> None), stock autograd tensors or an out-of-place accumulation leave p.grad
                 # outside the flat buffer: the optimizer would step on p.grad while the exchange summed a stale slice
                 f.adopt_grads()
-                self.works.append(dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM, async_op=True))
+                self._exchange(self.opt.flat_grad)
         self.tail_done = False
         self.wait()
 
+    def _exchange(self, t):
+        """In-place SUM of a slice of the flat gradient buffer across ranks, asynchronous w.r.t. the compute stream."""
+        if self.native is not None:
+            self.native.launch(t)
+            self.works.append(None)
+        else:
+            self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
     def wait(self):
+        if self.native is not None and self.works:
+            self.native.wait()
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
         self.works = []
 
     def allreduce(self):

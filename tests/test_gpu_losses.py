@@ -413,3 +413,23 @@ def test_graph_replay_invalidates_weight_packs():
     with torch.no_grad():
         expect = fresh.forward_shapes(probe, z, 512)
     assert torch.equal(after, expect)
+
+
+# ---- C-ABI RCCL exchange (sg_allreduce_*) -----------------------------------------------------------------------
+def test_native_allreduce_single_rank_stream_order():
+    """libshapegan_comm.so on the one GPU of this box: communicator of world size 1 (all a single-GPU box can form), the
+    exchange runs on the communicator's stream AFTER the producer kernel on the compute stream, and the compute stream sees the
+    result after sg_allreduce_wait.  Sum over one rank = identity."""
+    from shapegan_amd.parallel import NativeComm
+    comm = NativeComm(rank=0, world=1)
+    n = 1 << 24
+    x = torch.zeros(n, device="cuda")
+    for it in range(3):
+        x.add_(1.5)                    # producer on the compute stream
+        comm.launch(x[: n // 2])       # two slices of the flat buffer, like the tail / head exchange
+        comm.launch(x[n // 2:])
+        comm.wait()
+        y = x * 2.0                    # consumer on the compute stream
+        assert float(y[0]) == 3.0 * (it + 1) and float(y[-1]) == 3.0 * (it + 1)
+    torch.cuda.synchronize()
+    comm.close()

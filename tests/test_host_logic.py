@@ -25,11 +25,13 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "shapegan_hip.h")).read()
     declared = set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", header, flags=re.I))
     assert len(declared) >= 30
-    lib = ctypes.CDLL(L.LIB_PATH)
+    lib, comm = ctypes.CDLL(L.LIB_PATH), ctypes.CDLL(L.COMM_PATH)
     for name in sorted(declared):
-        assert hasattr(lib, name), "missing export: " + name
-    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+        home = comm if name in L.COMM_SIGNATURES else lib       # the RCCL exchange lives in libshapegan_comm.so
+        assert hasattr(home, name), "missing export: " + name
+    assert declared == set(L.SIGNATURES) | set(L.COMM_SIGNATURES), (declared ^ (set(L.SIGNATURES) | set(L.COMM_SIGNATURES)))
     assert L.load().sg_abi_version() == 1
+    assert L.load_comm().sg_allreduce_unique_id_bytes() == 128
 
 
 def test_missing_library_fails_loudly(monkeypatch):
