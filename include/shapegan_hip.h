@@ -54,6 +54,9 @@ int sg_conv3d_k4s2p1_fwd_impl(const float* x, const float* w, const float* bias,
                               void* workspace, size_t workspace_bytes, int impl, int debug, hipStream_t stream);
 /* dx[batch,Cx(first Cin channels),ID,IH,IW] = conv^T(dy, w) (+bias[ci], act: used when this is a ConvTranspose fwd) */
 size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin);
+/* the same with the batch and the output grid of the convolution (O = I/2): also covers the tap-plane scratch of the
+ * one-channel layers (Cin == 1: ConvTranspose3d(C -> 1) forward / Conv3d(1 -> C) input gradient) */
+size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(int batch, int Cin, int Cout, int OD, int OH, int OW);
 int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                            int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                            void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -19,6 +19,8 @@
 // Double backward (WGAN-GP, train_hybrid_progressive_gan.py:102-111) needs nothing else because the
 // convolution is bilinear in (x, W).
 #include "mfma_tile.h"
+#include <stdlib.h>
+
 #include "conv_common.h"
 #include "../../include/shapegan_hip.h"
 
@@ -508,8 +510,20 @@ using namespace sg;
 
 extern "C" {
 
+// A/B switch for the edge-layer kernels of conv3d_edge.hip (SG_NO_EDGE=1 restores the previous kernels)
+static bool edge_enabled() {
+    static const bool on = !(getenv("SG_NO_EDGE") && getenv("SG_NO_EDGE")[0] == '1');
+    return on;
+}
+
 size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) {
     const size_t a = (size_t)8 * Cout * 8 * Cin * sizeof(float), b = halo_dgrad_workspace_bytes(Cin, Cout);
+    return a > b ? a : b;
+}
+
+size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(int batch, int Cin, int Cout, int OD, int OH, int OW) {
+    const size_t a = sg_conv3d_k4s2p1_dgrad_workspace_bytes(Cout, Cin);
+    const size_t b = (Cin == 1 && Cout <= 64) ? edge_dgrad_workspace_bytes(batch, OD, OH, OW) : 0;
     return a > b ? a : b;
 }
 
@@ -517,7 +531,9 @@ size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int batch, int Cin, int Cout, int 
     // gather kernel: up to 16 split-K partials of the [Cout, Cin*64] weight gradient; LDS-halo kernel: packed dy + partials
     const size_t a = (size_t)16 * Cout * Cin * 64 * sizeof(float);
     const size_t b = halo_wgrad_workspace_bytes(batch, Cin, Cout, OD, OH, OW);
-    return a > b ? a : b;
+    const size_t c = (Cin == 1 && Cout <= 64) ? edge_wgrad_workspace_bytes(batch, OD, OH, OW) : 0;
+    const size_t ab = a > b ? a : b;
+    return ab > c ? ab : c;
 }
 
 size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
@@ -527,7 +543,9 @@ size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD
     const size_t tiles = ((size_t)batch * OD * OH * OW + 63) / 64 * ((Cout + 63) / 64);
     const size_t splitk = tiles >= 512 ? 0 : per * 8 * sizeof(float);
     const size_t pack = halo_fwd_workspace_bytes(Cin, Cout);
-    return splitk > pack ? splitk : pack;
+    const size_t edge = (Cin == 1 && Cout <= 64) ? edge_fwd_workspace_bytes(batch, OD, OH, OW) : 0;
+    const size_t sp = splitk > pack ? splitk : pack;
+    return sp > edge ? sp : edge;
 }
 
 static int check_sizes(const ConvGeom& g, int batch, const char* who) {
@@ -545,6 +563,11 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_fwd")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
+    if (Cin == 1 && edge_enabled() &&
+        edge_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes, stream) == 1) {
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     {
         const int rc = halo_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
                                     stream);
@@ -603,6 +626,11 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
+    if (Cin == 1 && edge_enabled() &&
+        edge_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes, stream) == 1) {
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     if (Cin == 1 && g.OD % kO1D == 0 && g.OH % kO1H == 0 && g.OW % kO1W == 0 && (long)g.Cy * g.O3() * 4 < (long)kBufRange) {
         const int ntd = g.OD / kO1D, nth = g.OH / kO1H, ntw = g.OW / kO1W;
         const size_t lds = (size_t)(2 * kO1CC * (kO1CH + 8) + 8) * sizeof(float);
@@ -708,6 +736,11 @@ int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
+    if (Cin == 1 && edge_enabled() &&
+        edge_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace ? workspace_bytes : 0, stream) == 1) {
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     {
         const int rc = halo_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace ? workspace_bytes : 0,
                                       stream, 0);

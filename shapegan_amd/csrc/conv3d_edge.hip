@@ -1,0 +1,537 @@
+// shapegan_amd/csrc/conv3d_edge.hip — the k4/s2/p1 layers with ONE channel on the voxel-grid side (gfx950 only):
+//   gan.Discriminator.layers[0]  Conv3d(1 -> 64)   (model/gan.py:49), progressive stage `it` on from_SDF's single real channel
+//   (model/progressive_gan.py:38), Autoencoder.encoder[0] Conv3d(1 -> 24) (model/autoencoder.py:16): forward + weight gradient;
+//   gan.Generator.layers[9] ConvTranspose3d(64 -> 1) (model/gan.py:21), Autoencoder.decoder's ConvTranspose3d(24 -> 1)
+//   (model/autoencoder.py:63): forward = the input gradient of the Conv3d(1 -> C) form.
+//
+// These layers move 64x more activation bytes than grid bytes and are HBM-bound (28 flop/B): SURVEY.md 8d asks for HBM GB/s
+// here.  Each output/operand is touched once; the small 1-channel grid is re-read from L1/L2.
+//
+//   forward  (conv_fwd_c1_kernel)    GEMM rows = positions, cols = Cout (<= 64), K = 64 taps.  The grid is zero-padded once into the
+//            workspace (one small pass), so a lane's patch values are plain 8-byte loads at lane_base + (kd, kh) scalar offset:
+//            no masks, no LDS, no VALU in the loop.  The 64 x 64 weight matrix lives in registers as MFMA B fragments for the
+//            whole kernel; a wave walks position tiles of 32, the patch loads of the next tile are issued before the MFMAs of
+//            the current one.  K is ordered (kd, kh, kw-pair) so that lane half h owns taps kw = 2h, 2h+1 (one b64 load).
+//            Positions are the ROWS of the product so that 4 accumulator registers are 4 consecutive positions of one channel:
+//            16-byte stores (row-per-lane dword stores were store-issue bound).
+//   wgrad    (conv_wgrad_c1_kernel)  GEMM M = Cout, N = 64 taps, K = positions (split over all waves, deterministic two-level
+//            reduction).  The dy tile of a pass ([Cout][32 positions]) is copied with fully coalesced 16-byte loads, transposed
+//            through a wave-private LDS tile and read back as fragments; the patch operand comes from the same padded grid
+//            (lane = tap, stride-2 gather served by L1).
+//   dgrad    (tapplane_gemm_kernel + col2im_c1_kernel)  out[2q+p] = sum_co sum_t dy[co][q+d] w[co][k]: first the 64 tap planes
+//            S[k][q] = sum_co w[co][k] dy[co][q] (a dense GEMM rows = positions, cols = 64 taps, K = Cout; a 1-row GEMM per
+//            parity would waste 31/32 of every MFMA), then each output gathers its 8 taps from the planes (every plane element
+//            is used exactly once; the planes stay in the 256 MB Infinity Cache between the two kernels).
+#include <stdlib.h>
+
+#include "conv_common.h"
+#include "../../include/shapegan_hip.h"
+
+namespace sg {
+
+// ---- zero-padded copy of channel 0: xp[n][d+1][h+1][w+1] = x[n][0][d][h][w] ------------------------------------------------------
+__global__ void __launch_bounds__(256) pad1_kernel(const float* __restrict__ x, float* __restrict__ xp, int D, int H, int W,
+                                                   long sample_stride, long total) {
+    const int Wp = W + 2, Hp = H + 2, Dp = D + 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int w = (int)(e % Wp);
+        long r = e / Wp;
+        const int h = (int)(r % Hp);
+        r /= Hp;
+        const int d = (int)(r % Dp);
+        const long n = r / Dp;
+        const bool in = w >= 1 && w <= W && h >= 1 && h <= H && d >= 1 && d <= D;
+        xp[e] = in ? x[n * sample_stride + ((long)(d - 1) * H + (h - 1)) * W + (w - 1)] : 0.f;
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+struct EdgeFwdArgs {
+    const float* xp;    // [batch][Dp][Hp][Wp]
+    const float* w;     // [Cout][Cin_total][64], channel 0 used
+    const float* bias;  // [Cout] or null
+    float* y;           // [batch][Cy][O3]
+    int OD, OH, OW, Hp, Wp, Cout, Cy, Cin_total;
+    long xp_sample;     // floats per padded sample
+    int tiles_per_sample, total_tiles;
+    FastDiv dtps, dOW, dOH;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z,
+                                           float w) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    v.x = __builtin_bit_cast(unsigned, x);
+    v.y = __builtin_bit_cast(unsigned, y);
+    v.z = __builtin_bit_cast(unsigned, z);
+    v.w = __builtin_bit_cast(unsigned, w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}
+
+// D[row = position][col = channel]: the patch values are the A operand, the weights the B operand, so that a lane ends up
+// with 4 consecutive positions of ONE channel per 4 accumulator registers -> 16-byte stores (4x fewer store instructions than
+// channel-major rows, which were store-issue bound).
+template <int NT>   // column tiles of 32 output channels (1 or 2)
+__global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh2 = lane >> 5;
+    // B fragments: wfr[nt][kd*4+kh][j] = W[32 nt + r][0][kd][kh][2*kh2 + j]
+    float wfr[NT][16][2], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + r, coc = co < a.Cout ? co : a.Cout - 1;   // clamped row, masked by a multiply: no branches
+        const float keep = co < a.Cout ? 1.f : 0.f;
+        bl[nt] = a.bias ? keep * a.bias[coc] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wfr[nt][g][j] = keep * a.w[(long)coc * a.Cin_total * 64 + g * 4 + 2 * kh2 + j];
+    }
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.xp);
+    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.y);
+    const unsigned O3 = (unsigned)(a.OD * a.OH * a.OW);
+    unsigned soff[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) soff[g] = (unsigned)(((g >> 2) * a.Hp + (g & 3)) * a.Wp) * 4u;
+
+    const int nwaves = gridDim.x * 4;
+    int t = blockIdx.x * 4 + wave;
+    // xoff: this lane's patch origin (position tile*32 + r); yoff[nt]: this lane's channel row at the tile's first position
+    auto lane_offsets = [&](int tile, unsigned& xoff, unsigned (&yoff)[NT]) __attribute__((always_inline)) {
+        uint32_t n, tp, q1, ow, oh, od;
+        a.dtps.divmod((uint32_t)tile, n, tp);
+        const uint32_t p = tp * 32 + r;
+        a.dOW.divmod(p, q1, ow);
+        a.dOH.divmod(q1, od, oh);
+        xoff = (unsigned)((long)n * a.xp_sample + ((long)(2 * od) * a.Hp + 2 * oh) * a.Wp + 2 * ow + 2 * kh2) * 4u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            yoff[nt] = nt * 32 + r < a.Cout ? (unsigned)(((long)n * a.Cy + nt * 32 + r) * O3 + tp * 32 + 4 * kh2) * 4u : kBufOutside;
+    };
+    if (t >= a.total_tiles) return;
+    unsigned xoff, yoff[NT];
+    lane_offsets(t, xoff, yoff);
+    f32x2 bcur[16], bnext[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) bcur[g] = buf_load2(xres, xoff, soff[g]);
+    for (; t < a.total_tiles; t += nwaves) {
+        const int tn = t + nwaves;
+        unsigned xoff_n = xoff, yoff_n[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) yoff_n[nt] = yoff[nt];
+        if (tn < a.total_tiles) lane_offsets(tn, xoff_n, yoff_n);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) bnext[g] = buf_load2(xres, xoff_n, soff[g]);   // the last tile re-reads itself (unused)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[g].x, wfr[nt][g][0], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[g].y, wfr[nt][g][1], acc[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // rows of D = positions (q & 3) + 8 (q >> 2) + 4 kh2: registers 4c .. 4c+3 are 4 consecutive positions.
+        // One uniform branch per tile on the activation (LeakyReLU / none inline, the transcendental ones out of line).
+        auto store_tile = [&](auto fn) __attribute__((always_inline)) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    buf_store4(yres, yoff[nt], 32u * c, fn(acc[nt][4 * c] + bl[nt]), fn(acc[nt][4 * c + 1] + bl[nt]),
+                               fn(acc[nt][4 * c + 2] + bl[nt]), fn(acc[nt][4 * c + 3] + bl[nt]));
+        };
+        if (a.act == SG_ACT_NONE) {
+            store_tile([](float v) { return v; });
+        } else if (a.act == SG_ACT_LEAKY) {
+            const float sl = a.slope;
+            store_tile([sl](float v) { return v > 0.f ? v : v * sl; });
+        } else {
+            const int act = a.act;
+            const float sl = a.slope;
+            store_tile([act, sl](float v) { return sg_apply_act(v, act, sl); });
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) bcur[g] = bnext[g];
+        xoff = xoff_n;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) yoff[nt] = yoff_n[nt];
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------------
+struct EdgeWgradArgs {
+    const float* dy;    // [batch][Cy][O3]
+    const float* xp;    // padded grid
+    float* partial;     // [gridDim.x][64*64]
+    int OD, OH, OW, Hp, Wp, Cout, Cy;
+    long xp_sample;
+    int passes_per_sample, total_passes;   // a pass = 32 consecutive positions of one sample
+    FastDiv dpps, dOW16, dOH;               // dOW16: OW / 16 row segments per row
+};
+
+// dy rows are staged through LDS: the MFMA wants A[row = channel][k = position] with only two k per instruction, so direct
+// fragment loads would touch one 128-byte line per lane; instead the wave copies its [32 MT channels][32 positions] tile with
+// fully coalesced 16-byte loads (8 lanes per 128-byte row segment), stores it as [row][36] (conflict-free for the fragment
+// reads) and reads 16 consecutive positions per lane back as four ds_read_b128.
+template <int MT>
+__global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
+    constexpr int kLd = 36;                       // floats per staged row
+    constexpr int kStage = MT * 32 * kLd;         // floats per wave
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // staging (<= 4 x 2304 floats), then the cross-wave sum
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh2 = lane >> 5;
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy);
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.xp);
+    const unsigned O3 = (unsigned)(a.OD * a.OH * a.OW);
+    float* stage = lds + wave * kStage;
+    // copy lane -> (row within a group of 8, 16-byte column)
+    const int crow = lane >> 3, ccol = (lane & 7) * 4;
+    unsigned tapoff[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int tap = nt * 32 + r, kd = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
+        tapoff[nt] = (unsigned)((kd * a.Hp + kh) * a.Wp + kw) * 4u;
+    }
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
+
+    const int nwaves = gridDim.x * 4;
+    f32x4 cv[MT * 4];     // this lane's pieces of the dy tile
+    float bv[2][16];
+    auto issue = [&](int ps) __attribute__((always_inline)) {
+        uint32_t n, pp, seg, q1, od, oh;
+        a.dpps.divmod((uint32_t)ps, n, pp);
+        const unsigned dbase = (unsigned)((long)n * a.Cy * O3 + pp * 32 + ccol) * 4u;
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int co = i * 8 + crow;
+            cv[i] = buf_load4v(dres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
+        }
+        const uint32_t p0 = pp * 32 + 16 * kh2;   // this lane half's 16 positions: one row segment (od, oh, ow0 .. ow0+15)
+        a.dOW16.divmod(p0 >> 4, q1, seg);
+        a.dOH.divmod(q1, od, oh);
+        const unsigned xbase = (unsigned)((long)n * a.xp_sample + ((long)(2 * od) * a.Hp + 2 * oh) * a.Wp + 32 * seg) * 4u;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bv[nt][j] = buf_load(xres, xbase + tapoff[nt], 8u * j);
+    };
+    int ps = blockIdx.x * 4 + wave;
+    if (ps < a.total_passes) issue(ps);
+    for (; ps < a.total_passes; ps += nwaves) {
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(stage + (i * 8 + crow) * kLd + ccol) = cv[i];
+        float bc[2][16];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bc[nt][j] = bv[nt][j];
+        f32x4 av[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) av[mt][c] = *reinterpret_cast<const f32x4*>(stage + (mt * 32 + r) * kLd + 16 * kh2 + 4 * c);
+        if (ps + nwaves < a.total_passes) issue(ps + nwaves);   // next pass's global loads fly during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j >> 2][j & 3], bc[nt][j], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // cross-wave sum in a fixed order, then one partial tile per workgroup
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh2;
+                lds[wave * 4096 + row * 64 + nt * 32 + r] = acc[mt][nt][q];
+            }
+    __syncthreads();
+    float* out = a.partial + (long)blockIdx.x * 4096;
+    for (int e = threadIdx.x; e < MT * 32 * 64; e += 256)
+        out[e] = (lds[e] + lds[4096 + e]) + (lds[2 * 4096 + e] + lds[3 * 4096 + e]);
+}
+
+// dw[co][0][tap] = sum over workgroup partials; 256 threads = 4 partial groups x 64 outputs, fixed summation order
+__global__ void __launch_bounds__(256) wgrad_c1_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                int nparts, int Cout, int Cin_total) {
+    __shared__ float red[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg_ = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int p = sg_; p < nparts; p += 4) s += partial[(long)p * 4096 + e];
+    red[sg_][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sg_ == 0) {
+        const int co = e >> 6, tap = e & 63;
+        if (co < Cout) dw[((long)co * Cin_total) * 64 + tap] = (red[0][tap] + red[1][tap]) + (red[2][tap] + red[3][tap]);
+    }
+}
+
+// ---- input gradient: tap planes + col2im ----------------------------------------------------------------------------------
+struct TapPlaneArgs {
+    const float* dy;   // [batch][Cy][O3]
+    const float* w;    // [Cout][Cin_total][64], channel 0
+    float* S;          // [batch][64][O3]
+    int Cout, Cy, Cin_total;
+    unsigned O3;
+    int tiles_per_sample, total_tiles;
+    FastDiv dtps;
+};
+
+template <int NS>   // channel pairs: Cout <= 2 NS
+__global__ void __launch_bounds__(256) tapplane_gemm_kernel(TapPlaneArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh2 = lane >> 5;
+    // B fragments (columns = taps): wfr[nt][s] = W[co = 2s + kh2][0][tap = 32 nt + r]
+    float wfr[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int co = 2 * s + kh2, coc = co < a.Cout ? co : a.Cout - 1;
+        const float keep = co < a.Cout ? 1.f : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wfr[nt][s] = keep * a.w[(long)coc * a.Cin_total * 64 + nt * 32 + r];
+    }
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy);
+    const __amdgpu_buffer_rsrc_t sres = make_rsrc(a.S);
+    const int nwaves = gridDim.x * 4;
+    for (int t = blockIdx.x * 4 + wave; t < a.total_tiles; t += nwaves) {
+        uint32_t n, tp;
+        a.dtps.divmod((uint32_t)t, n, tp);
+        // A operand (rows = positions): dy[n][co = 2s + kh2][tile*32 + r]
+        const unsigned doff = (unsigned)(((long)n * a.Cy + kh2) * a.O3 + tp * 32 + r) * 4u;
+        float av[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) av[s] = buf_load(dres, 2 * s + kh2 < a.Cout ? doff : kBufOutside, (unsigned)(2 * s) * a.O3 * 4u);
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wfr[0][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wfr[1][s], acc[1], 0, 0, 0);
+        }
+        // S[n][tap = 32 nt + r][tile*32 + 8c + 4 kh2 + (0..3)]
+        const unsigned soff = (unsigned)(((long)n * 64 + r) * a.O3 + tp * 32 + 4 * kh2) * 4u;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                buf_store4(sres, soff, (unsigned)(nt * 32) * a.O3 * 4u + 32u * c, acc[nt][4 * c], acc[nt][4 * c + 1],
+                           acc[nt][4 * c + 2], acc[nt][4 * c + 3]);
+    }
+}
+
+// out[n][2q + p] = act(bias + sum over the 8 taps of parity p of S[n][k][q + delta]); per dimension: parity 0 takes tap 1 at
+// q and tap 3 at q-1, parity 1 takes tap 0 at q+1 and tap 2 at q (conv3d.hip, dgrad_out1_kernel).  One thread per q.
+__global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict__ S, const float* __restrict__ bias,
+                                                        float* __restrict__ dx, ConvGeom g, long dx_sample, int total, int act,
+                                                        float slope) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    int n, qd, qh, qw;
+    decode_pos(g, (uint32_t)j, n, qd, qh, qw);
+    const int OHW = g.OH * g.OW;
+    const long O3 = (long)g.OD * OHW;
+    const float* Sn = S + (long)n * 64 * O3;
+    float acc[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) (&acc[0][0][0])[i] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+        const int pd = (kd & 1) ? 0 : 1, dd = (kd == 0) ? 1 : (kd == 3 ? -1 : 0);
+        const int od = qd + dd;
+        if ((unsigned)od >= (unsigned)g.OD) continue;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int ph = (kh & 1) ? 0 : 1, dh = (kh == 0) ? 1 : (kh == 3 ? -1 : 0);
+            const int oh = qh + dh;
+            if ((unsigned)oh >= (unsigned)g.OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int pw = (kw & 1) ? 0 : 1, dw_ = (kw == 0) ? 1 : (kw == 3 ? -1 : 0);
+                const int ow = qw + dw_;
+                if ((unsigned)ow >= (unsigned)g.OW) continue;
+                acc[pd][ph][pw] += Sn[(long)(kd * 16 + kh * 4 + kw) * O3 + (long)od * OHW + oh * g.OW + ow];
+            }
+        }
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+    float* out = dx + (long)n * dx_sample;
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float2 o;
+            o.x = sg_apply_act(acc[pd][ph][0] + b0, act, slope);
+            o.y = sg_apply_act(acc[pd][ph][1] + b0, act, slope);
+            *reinterpret_cast<float2*>(out + ((long)(2 * qd + pd) * g.IH + (2 * qh + ph)) * g.IW + 2 * qw) = o;
+        }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+static size_t padded_floats(int batch, const ConvGeom& g) { return (size_t)batch * (g.ID + 2) * (g.IH + 2) * (g.IW + 2); }
+
+size_t edge_fwd_workspace_bytes(int batch, int OD, int OH, int OW) {
+    return (size_t)batch * (2 * OD + 2) * (2 * OH + 2) * (2 * OW + 2) * sizeof(float);
+}
+size_t edge_wgrad_workspace_bytes(int batch, int OD, int OH, int OW) {
+    return edge_fwd_workspace_bytes(batch, OD, OH, OW) + (size_t)512 * 4096 * sizeof(float);
+}
+size_t edge_dgrad_workspace_bytes(int batch, int OD, int OH, int OW) { return (size_t)batch * 64 * OD * OH * OW * sizeof(float); }
+
+static void launch_pad(const float* x, float* xp, int batch, const ConvGeom& g, hipStream_t stream) {
+    const long total = (long)padded_floats(batch, g);
+    long blocks = (total + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, xp, g.ID, g.IH, g.IW, (long)g.Cx * g.I3(),
+                       total);
+}
+
+// Conv3d(1 -> Cout <= 64) forward.  Returns 1 if handled, 0 if not eligible.
+int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                 const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream, int force) {
+    const long O3 = g.O3();
+    if (Cin != 1 || Cout > 64 || O3 % 32 != 0) return 0;
+    if (!force && (long)batch * O3 < 65536) return 0;   // small problems: the generic kernel's launch is as good
+    if (!workspace || workspace_bytes < edge_fwd_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
+    if (padded_floats(batch, g) * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
+    float* xp = (float*)workspace;
+    launch_pad(x, xp, batch, g, stream);
+    EdgeFwdArgs a;
+    a.xp = xp;
+    a.w = w;
+    a.bias = bias;
+    a.y = y;
+    a.OD = g.OD;
+    a.OH = g.OH;
+    a.OW = g.OW;
+    a.Hp = g.IH + 2;
+    a.Wp = g.IW + 2;
+    a.Cout = Cout;
+    a.Cy = g.Cy;
+    a.Cin_total = Cin_total;
+    a.xp_sample = (long)(g.ID + 2) * (g.IH + 2) * (g.IW + 2);
+    a.tiles_per_sample = (int)(O3 / 32);
+    a.total_tiles = batch * a.tiles_per_sample;
+    a.dtps = FastDiv((uint32_t)a.tiles_per_sample);
+    a.dOW = FastDiv((uint32_t)g.OW);
+    a.dOH = FastDiv((uint32_t)g.OH);
+    a.act = act;
+    a.slope = slope;
+    int wgs = (a.total_tiles + 3) / 4;
+    if (wgs > 512) wgs = 512;
+    {
+        const char* dbg = getenv("SG_EDGE_DEBUG");
+        const int d = dbg ? atoi(dbg) : 0;
+        if (d & 1) wgs = wgs > 256 ? 256 : wgs;
+        if (d & 2) (void)hipStreamSynchronize(stream);
+        if (d & 4) wgs = wgs > 128 ? 128 : wgs;
+    }
+    if (Cout > 32)
+        hipLaunchKernelGGL((conv_fwd_c1_kernel<2>), dim3(wgs), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_c1_kernel<1>), dim3(wgs), dim3(256), 0, stream, a);
+    return 1;
+}
+
+// Conv3d(1 -> Cout <= 64) weight gradient (channel 0 of dw; the caller zeroes the rest when Cin_total > 1).
+int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force) {
+    const long O3 = g.O3();
+    if (Cin != 1 || Cout > 64 || g.OW % 16 != 0) return 0;
+    if (!force && (long)batch * O3 < 65536) return 0;
+    if (!workspace || workspace_bytes < edge_wgrad_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
+    if (padded_floats(batch, g) * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
+    float* xp = (float*)workspace;
+    float* partial = xp + padded_floats(batch, g);
+    launch_pad(x, xp, batch, g, stream);
+    EdgeWgradArgs a;
+    a.dy = dy;
+    a.xp = xp;
+    a.partial = partial;
+    a.OD = g.OD;
+    a.OH = g.OH;
+    a.OW = g.OW;
+    a.Hp = g.IH + 2;
+    a.Wp = g.IW + 2;
+    a.Cout = Cout;
+    a.Cy = g.Cy;
+    a.xp_sample = (long)(g.ID + 2) * (g.IH + 2) * (g.IW + 2);
+    a.passes_per_sample = (int)(O3 / 32);
+    a.total_passes = batch * a.passes_per_sample;
+    a.dpps = FastDiv((uint32_t)a.passes_per_sample);
+    a.dOW16 = FastDiv((uint32_t)(g.OW / 16));
+    a.dOH = FastDiv((uint32_t)g.OH);
+    int wgs = (a.total_passes + 3) / 4;
+    if (wgs > 512) wgs = 512;
+    if (Cout > 32)
+        hipLaunchKernelGGL((conv_wgrad_c1_kernel<2>), dim3(wgs), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_c1_kernel<1>), dim3(wgs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(wgrad_c1_finalize_kernel, dim3(64), dim3(256), 0, stream, (const float*)partial, dw, wgs, Cout, Cin_total);
+    return 1;
+}
+
+// Conv3d(1 -> Cout <= 64) input gradient = ConvTranspose3d(Cout -> 1) forward: dx [batch][Cx][I3] (channel 0 written).
+int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                   const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream, int force) {
+    const long O3 = g.O3();
+    if (Cin != 1 || Cout > 64 || O3 % 32 != 0) return 0;
+    if (!force && (long)batch * O3 < 65536) return 0;
+    if (!workspace || workspace_bytes < edge_dgrad_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
+    if ((size_t)batch * 64 * O3 * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
+    TapPlaneArgs a;
+    a.dy = dy;
+    a.w = w;
+    a.S = (float*)workspace;
+    a.Cout = Cout;
+    a.Cy = g.Cy;
+    a.Cin_total = Cin_total;
+    a.O3 = (unsigned)O3;
+    a.tiles_per_sample = (int)(O3 / 32);
+    a.total_tiles = batch * a.tiles_per_sample;
+    a.dtps = FastDiv((uint32_t)a.tiles_per_sample);
+    int wgs = (a.total_tiles + 3) / 4;
+    if (wgs > 1024) wgs = 1024;
+    if (Cout <= 16)
+        hipLaunchKernelGGL((tapplane_gemm_kernel<8>), dim3(wgs), dim3(256), 0, stream, a);
+    else if (Cout <= 32)
+        hipLaunchKernelGGL((tapplane_gemm_kernel<16>), dim3(wgs), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((tapplane_gemm_kernel<32>), dim3(wgs), dim3(256), 0, stream, a);
+    const int total = (int)((long)batch * O3);
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)workspace, bias, dx, g,
+                       (long)g.Cx * g.I3(), total, act, slope);
+    return 1;
+}
+
+}  // namespace sg

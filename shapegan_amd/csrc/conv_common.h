@@ -74,4 +74,17 @@ size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, 
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
                    void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0);
 
+// conv3d_edge.hip: layers with one channel on the voxel-grid side (Cin == 1).  Same return convention as the halo_*_try.
+size_t edge_fwd_workspace_bytes(int batch, int OD, int OH, int OW);
+size_t edge_wgrad_workspace_bytes(int batch, int OD, int OH, int OW);
+size_t edge_dgrad_workspace_bytes(int batch, int OD, int OH, int OW);
+int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                 const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream, int force = 0);
+int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0);
+int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                   const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream, int force = 0);
+
 }  // namespace sg

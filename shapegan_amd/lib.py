@@ -24,6 +24,7 @@ SIGNATURES = {
     "sg_conv3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_conv3d_k4s2p1_fwd_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _I, _P]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
+    "sg_conv3d_k4s2p1_dgrad_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_conv3d_k4s2p1_dgrad_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "sg_conv3d_k4s2p1_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),

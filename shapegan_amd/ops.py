@@ -61,7 +61,7 @@ def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
         raise RuntimeError("conv dgrad: shape mismatch")
     dx = torch.empty((N, cin, 2 * OD, 2 * OH, 2 * OW), dtype=torch.float32, device=dy.device)
     lib = _lib()
-    nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes(Co, cin)
+    nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(N, cin, Co, OD, OH, OW)
     ws = workspace("dgrad", nb, dy.device)
     check(lib.sg_conv3d_k4s2p1_dgrad(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
                                      act, slope, ptr(ws), ws.numel(), stream()), "conv3d_dgrad")
