@@ -18,6 +18,51 @@ import torch.nn.functional as F
 LATENT_CODE_SIZE = 128  # model/__init__.py:10
 
 
+class kink_control(object):
+    """Context manager around oracle forwards that deals with LeakyReLU / ReLU kinks.  At a kink the derivative is
+    discontinuous: two correct fp32 implementations whose pre-activations differ in the last bits take different branches,
+    and their gradients then differ by a finite amount (one flipped element of a conv layer moves a whole [Cin x taps] block
+    of the weight gradient below it and, through the input gradient, everything further down).
+
+    record_below=t : `fragile` collects (call index, flat element indices) of the pre-activations with |z| < t * mean|z| of
+                     their layer — the elements whose branch fp32 rounding can decide either way.
+    flips={call: indices} : those elements take the OTHER branch (value and derivative), i.e. the oracle evaluates the
+                     network for the sign pattern an implementation with slightly different rounding would see."""
+
+    def __init__(self, record_below=None, flips=None):
+        self.record_below, self.flips = record_below, flips or {}
+        self.fragile = []
+
+    def __enter__(self):
+        self._saved = (F.leaky_relu, F.relu)
+        self._call = 0
+
+        def watch(fn, leaky):
+            def wrapped(z, *a, **k):
+                i = self._call
+                self._call += 1
+                if self.record_below is not None:
+                    with torch.no_grad():
+                        near = (z.abs() < self.record_below * z.abs().mean()).reshape(-1).nonzero().flatten()
+                    if near.numel():
+                        self.fragile.append((i, near))
+                y = fn(z, *a, **k)
+                if i in self.flips:
+                    slope = (a[0] if a else k.get("negative_slope", 0.01)) if leaky else 0.0
+                    other = torch.where(z > 0, z * slope, z)
+                    m = torch.zeros(z.numel(), dtype=z.dtype)
+                    m[self.flips[i]] = 1
+                    y = y + (other - y) * m.reshape(z.shape)
+                return y
+            return wrapped
+        F.leaky_relu, F.relu = watch(F.leaky_relu, True), watch(F.relu, False)
+        return self
+
+    def __exit__(self, *exc):
+        F.leaky_relu, F.relu = self._saved
+        return False
+
+
 def clone_state(sd, requires_grad=True, device="cpu"):
     """Deep copy of a state_dict onto `device`; float tensors become leaves that require grad (buffers do not)."""
     out = {}

@@ -511,9 +511,9 @@ using namespace sg;
 extern "C" {
 
 // A/B switch for the edge-layer kernels of conv3d_edge.hip (SG_NO_EDGE=1 restores the previous kernels)
-static bool edge_enabled() {
-    static const bool on = !(getenv("SG_NO_EDGE") && getenv("SG_NO_EDGE")[0] == '1');
-    return on;
+static bool edge_enabled(int which = 7) {   // SG_NO_EDGE = bit mask: 1 forward, 2 input gradient, 4 weight gradient
+    static const int off = getenv("SG_NO_EDGE") ? atoi(getenv("SG_NO_EDGE")) : 0;
+    return (off & which) == 0;
 }
 
 size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes(int Cout, int Cin) {
@@ -563,7 +563,7 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_fwd")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    if (Cin == 1 && edge_enabled() &&
+    if (Cin == 1 && edge_enabled(1) &&
         edge_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes, stream) == 1) {
         SG_CHECK_LAUNCH();
         return SG_OK;
@@ -626,7 +626,7 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_dgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    if (Cin == 1 && edge_enabled() &&
+    if (Cin == 1 && edge_enabled(2) &&
         edge_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes, stream) == 1) {
         SG_CHECK_LAUNCH();
         return SG_OK;
@@ -736,7 +736,7 @@ int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad: spatial dims must be even and >= 2");
     if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad")) return SG_ERR_ARG;
     const long npos = (long)batch * g.O3();
-    if (Cin == 1 && edge_enabled() &&
+    if (Cin == 1 && edge_enabled(4) &&
         edge_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace ? workspace_bytes : 0, stream) == 1) {
         SG_CHECK_LAUNCH();
         return SG_OK;

