@@ -66,7 +66,25 @@ def build(force=False, verbose=True):
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     build_comm(force, verbose)
+    build_cpu(force, verbose)
     return LIB
+
+
+CPU_LIB = os.path.join(HERE, "libshapegan_cpu.so")
+
+
+def build_cpu(force=False, verbose=True):
+    """libshapegan_cpu.so: the plain-C++ twin of the C ABI (csrc_cpu/shapegan_cpu.cpp), g++ + OpenMP, no GPU code."""
+    src = os.path.join(HERE, "csrc_cpu", "shapegan_cpu.cpp")
+    if not (force or _stale(CPU_LIB, [src])):
+        return CPU_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wall", src, "-o", CPU_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libshapegan_cpu.so failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return CPU_LIB
 
 
 COMM_LIB = os.path.join(HERE, "libshapegan_comm.so")

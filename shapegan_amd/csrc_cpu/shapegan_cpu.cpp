@@ -1,0 +1,855 @@
+// shapegan_amd/csrc_cpu/shapegan_cpu.cpp — libshapegan_cpu.so: the plain-C++ twin of the C ABI (include/shapegan_hip.h).
+//
+// SURVEY.md 8b asks for "a CPU twin (`*_cpu`) of each [entry point] for the no-GPU config and unit tests"; BASELINE configs[0]
+// is `train_autoencoder.py classic ... on CPU (plumbing, no GPU)`.  Every function here is `sg_<name>_cpu` with the argument
+// list of `sg_<name>` (the stream and workspace arguments are accepted and ignored; pointers are host pointers).  It is a
+// SEPARATE implementation written against the header's contracts — straightforward loops with OpenMP over the outer index,
+// no tiling heroics: correctness plumbing, not a performance path — and it shares no code with oracle/ (test infrastructure)
+// or with the HIP kernels.  The Python shells pick it only for tensors that live on the CPU (shapegan_amd/lib.py); GPU
+// tensors never come here and there is no fallback in either direction.
+//
+// Opaque-buffer contracts it keeps compatible with the sizes the HIP library reports (host-side helpers, callable without a
+// GPU): sg_sdfnet_packed_floats (this twin stores the plain weights at the front of the buffer), sg_sdfnet_bwd_blocks
+// (bias partials: column 0 carries the row sums, the other columns zeros).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+typedef void* hipStream_t_;
+#define SG_OK 0
+#define SG_ERR_ARG (-1)
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+
+static thread_local char g_err[512];
+#define CPU_CHECK(cond)                                                                  \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            snprintf(g_err, sizeof(g_err), "%s: bad argument: %s", __func__, #cond);     \
+            return SG_ERR_ARG;                                                           \
+        }                                                                                \
+    } while (0)
+
+static inline float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case ACT_LEAKY: return v > 0.f ? v : v * slope;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_TANH: return tanhf(v);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+static inline float act_grad_out(float y, float dy, int act, float slope) {   // derivative through the activation OUTPUT
+    switch (act) {
+        case ACT_LEAKY: return y > 0.f ? dy : dy * slope;
+        case ACT_RELU: return y > 0.f ? dy : 0.f;
+        case ACT_TANH: return dy * (1.f - y * y);
+        case ACT_SIGMOID: return dy * y * (1.f - y);
+        default: return dy;
+    }
+}
+
+extern "C" {
+
+const char* sg_cpu_last_error(void) { return g_err; }
+
+// ---- K1 / K2: Conv3d / ConvTranspose3d (kernel 4, stride 2, padding 1) ------------------------------------------------
+int sg_conv3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                             int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void*, size_t, void*) {
+    CPU_CHECK(x && w && y && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && !(ID & 1) && !(IH & 1) && !(IW & 1));
+    const int OD = ID / 2, OH = IH / 2, OW = IW / 2;
+    const long I3 = (long)ID * IH * IW, O3 = (long)OD * OH * OW;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < batch; ++n)
+        for (int co = 0; co < Cout; ++co) {
+            float* yo = y + ((long)n * Cout + co) * O3;
+            const float b = bias ? bias[co] : 0.f;
+            for (long e = 0; e < O3; ++e) yo[e] = b;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float* xi = x + ((long)n * Cx + ci) * I3;
+                const float* wk = w + ((long)co * Cin_total + ci) * 64;
+                for (int kd = 0; kd < 4; ++kd)
+                    for (int kh = 0; kh < 4; ++kh)
+                        for (int kw = 0; kw < 4; ++kw) {
+                            const float wv = wk[kd * 16 + kh * 4 + kw];
+                            const int ow0 = kw == 0 ? 1 : 0, ow1 = kw == 3 ? OW - 1 : OW;   // 0 <= 2ow + kw - 1 < IW
+                            for (int od = 0; od < OD; ++od) {
+                                const int id = 2 * od + kd - 1;
+                                if ((unsigned)id >= (unsigned)ID) continue;
+                                for (int oh = 0; oh < OH; ++oh) {
+                                    const int ih = 2 * oh + kh - 1;
+                                    if ((unsigned)ih >= (unsigned)IH) continue;
+                                    const float* xr = xi + ((long)id * IH + ih) * IW + kw - 1;
+                                    float* yr = yo + ((long)od * OH + oh) * OW;
+                                    for (int ow = ow0; ow < ow1; ++ow) yr[ow] += wv * xr[2 * ow];
+                                }
+                            }
+                        }
+            }
+            if (act != ACT_NONE)
+                for (long e = 0; e < O3; ++e) yo[e] = apply_act(yo[e], act, slope);
+        }
+    return SG_OK;
+}
+
+int sg_conv3d_k4s2p1_dgrad_cpu(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                               int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void*, size_t,
+                               void*) {
+    CPU_CHECK(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && !(ID & 1) && !(IH & 1) && !(IW & 1));
+    const int OD = ID / 2, OH = IH / 2, OW = IW / 2;
+    const long I3 = (long)ID * IH * IW, O3 = (long)OD * OH * OW;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < batch; ++n)
+        for (int ci = 0; ci < Cin; ++ci) {
+            float* xo = dx + ((long)n * Cx + ci) * I3;
+            const float b = bias ? bias[ci] : 0.f;
+            for (long e = 0; e < I3; ++e) xo[e] = b;
+            for (int co = 0; co < Cout; ++co) {
+                const float* yo = dy + ((long)n * Cout + co) * O3;
+                const float* wk = w + ((long)co * Cin_total + ci) * 64;
+                for (int kd = 0; kd < 4; ++kd)
+                    for (int kh = 0; kh < 4; ++kh)
+                        for (int kw = 0; kw < 4; ++kw) {
+                            const float wv = wk[kd * 16 + kh * 4 + kw];
+                            const int ow0 = kw == 0 ? 1 : 0, ow1 = kw == 3 ? OW - 1 : OW;
+                            for (int od = 0; od < OD; ++od) {
+                                const int id = 2 * od + kd - 1;
+                                if ((unsigned)id >= (unsigned)ID) continue;
+                                for (int oh = 0; oh < OH; ++oh) {
+                                    const int ih = 2 * oh + kh - 1;
+                                    if ((unsigned)ih >= (unsigned)IH) continue;
+                                    float* xr = xo + ((long)id * IH + ih) * IW + kw - 1;
+                                    const float* yr = yo + ((long)od * OH + oh) * OW;
+                                    for (int ow = ow0; ow < ow1; ++ow) xr[2 * ow] += wv * yr[ow];
+                                }
+                            }
+                        }
+            }
+            if (act != ACT_NONE)
+                for (long e = 0; e < I3; ++e) xo[e] = apply_act(xo[e], act, slope);
+        }
+    return SG_OK;
+}
+
+int sg_conv3d_k4s2p1_wgrad_cpu(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx, int Cout,
+                               int ID, int IH, int IW, void*, size_t, void*) {
+    CPU_CHECK(dy && x && dw && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && !(ID & 1) && !(IH & 1) && !(IW & 1));
+    const int OD = ID / 2, OH = IH / 2, OW = IW / 2;
+    const long I3 = (long)ID * IH * IW, O3 = (long)OD * OH * OW;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            double acc[64];
+            for (int k = 0; k < 64; ++k) acc[k] = 0.0;
+            for (int n = 0; n < batch; ++n) {
+                const float* yo = dy + ((long)n * Cout + co) * O3;
+                const float* xi = x + ((long)n * Cx + ci) * I3;
+                for (int kd = 0; kd < 4; ++kd)
+                    for (int kh = 0; kh < 4; ++kh)
+                        for (int kw = 0; kw < 4; ++kw) {
+                            const int ow0 = kw == 0 ? 1 : 0, ow1 = kw == 3 ? OW - 1 : OW;
+                            float s = 0.f;
+                            for (int od = 0; od < OD; ++od) {
+                                const int id = 2 * od + kd - 1;
+                                if ((unsigned)id >= (unsigned)ID) continue;
+                                for (int oh = 0; oh < OH; ++oh) {
+                                    const int ih = 2 * oh + kh - 1;
+                                    if ((unsigned)ih >= (unsigned)IH) continue;
+                                    const float* xr = xi + ((long)id * IH + ih) * IW + kw - 1;
+                                    const float* yr = yo + ((long)od * OH + oh) * OW;
+                                    float r = 0.f;
+                                    for (int ow = ow0; ow < ow1; ++ow) r += yr[ow] * xr[2 * ow];
+                                    s += r;
+                                }
+                            }
+                            acc[kd * 16 + kh * 4 + kw] += (double)s;
+                        }
+            }
+            float* d = dw + ((long)co * Cin_total + ci) * 64;
+            for (int k = 0; k < 64; ++k) d[k] = (float)acc[k];
+        }
+    return SG_OK;
+}
+
+int sg_convT3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
+                              int ID, int IH, int IW, int act, float slope, void* ws, size_t wb, void* st) {
+    return sg_conv3d_k4s2p1_dgrad_cpu(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act, slope, ws,
+                                      wb, st);
+}
+int sg_convT3d_k4s2p1_dgrad_cpu(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
+                                int IW, void* ws, size_t wb, void* st) {
+    return sg_conv3d_k4s2p1_fwd_cpu(dy, w, nullptr, dx, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, ACT_NONE, 0.f,
+                                    ws, wb, st);
+}
+int sg_convT3d_k4s2p1_wgrad_cpu(const float* dy, const float* x, float* dw, int batch, int Cin_T, int Cout_T, int ID, int IH,
+                                int IW, void* ws, size_t wb, void* st) {
+    return sg_conv3d_k4s2p1_wgrad_cpu(x, dy, dw, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, ws, wb, st);
+}
+
+// ---- K3 / K6: GEMM family -------------------------------------------------------------------------------------------------
+int sg_gemm_cpu(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, long sci, long scj,
+                const float* bias_i, const float* bias_j, int bias_j_shift, int M, int N, int K, int act, float slope, void*,
+                size_t, void*) {
+    CPU_CHECK(A && B && C && M > 0 && N > 0 && K > 0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; ++i) {
+        std::vector<double> row(N, 0.0);
+        for (int k = 0; k < K; ++k) {
+            const double a = A[i * sai + k * sak];
+            const float* bk = B + k * sbk;
+            for (int j = 0; j < N; ++j) row[j] += a * (double)bk[j * sbj];
+        }
+        for (int j = 0; j < N; ++j) {
+            float v = (float)row[j] + (bias_i ? bias_i[i] : 0.f) + (bias_j ? bias_j[j >> bias_j_shift] : 0.f);
+            C[i * sci + j * scj] = apply_act(v, act, slope);
+        }
+    }
+    return SG_OK;
+}
+int sg_gemm_nt_cpu(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, long K, void*, size_t,
+                   void*) {
+    CPU_CHECK(A && B && C && M > 0 && N > 0 && K > 0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            const float *a = A + i * lda, *b = B + j * ldb;
+            double s = 0;
+            for (long k = 0; k < K; ++k) s += (double)a[k] * (double)b[k];
+            C[i * ldc + j] = (float)s;
+        }
+    return SG_OK;
+}
+int sg_gemm_nt_batched_cpu(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
+                           const long* c_off, const long* ldc, int batch, int M, int N, long K, void* ws, size_t wb, void* st) {
+    CPU_CHECK(A && B && C && a_off && b_off && c_off && ldc && batch > 0 && batch <= 8);
+    for (int b = 0; b < batch; ++b) {
+        const int rc = sg_gemm_nt_cpu(A + a_off[b], lda, B + b_off[b], ldb, C + c_off[b], ldc[b], M, N, K, ws, wb, st);
+        if (rc) return rc;
+    }
+    return SG_OK;
+}
+int sg_colsum_cpu(const float* x, float* out, int rows, int cols, long ld, void*) {
+    CPU_CHECK(x && out && rows > 0 && cols > 0);
+    for (int j = 0; j < cols; ++j) {
+        double s = 0;
+        for (int i = 0; i < rows; ++i) s += x[i * ld + j];
+        out[j] = (float)s;
+    }
+    return SG_OK;
+}
+int sg_rowsum_cpu(const float* x, float* out, long rows, long len, long ld, void*) {
+    CPU_CHECK(x && out && rows > 0 && len > 0);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        double s = 0;
+        for (long e = 0; e < len; ++e) s += x[r * ld + e];
+        out[r] = (float)s;
+    }
+    return SG_OK;
+}
+int sg_rowsum_multi_cpu(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, void* st) {
+    CPU_CHECK(x && outs && ndst > 0 && ndst <= 8);
+    for (int d = 0; d < ndst; ++d) {
+        const int rc = sg_rowsum_cpu(x + (long)d * rows_per_dst * ld, outs[d], rows_per_dst, len, ld, st);
+        if (rc) return rc;
+    }
+    return SG_OK;
+}
+int sg_segsum_cpu(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, void*) {
+    CPU_CHECK(x && out && seg_off && rows > 0 && nseg > 0);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r)
+        for (long s = 0; s < nseg; ++s) {
+            double acc = 0;
+            for (long e = seg_off[s]; e < seg_off[s + 1]; ++e) acc += x[r * ld + e];
+            out[r * nseg + s] = (float)acc;
+        }
+    return SG_OK;
+}
+int sg_colsum_tall_cpu(const float* x, float* out, long batch, long batch_stride, long rows, int cols, long ld, void*, size_t,
+                       void*) {
+    CPU_CHECK(x && out && batch > 0 && rows > 0 && cols > 0);
+    for (long b = 0; b < batch; ++b)
+        for (int c = 0; c < cols; ++c) {
+            double s = 0;
+            for (long r = 0; r < rows; ++r) s += x[b * batch_stride + r * ld + c];
+            out[b * cols + c] = (float)s;
+        }
+    return SG_OK;
+}
+
+// ---- K4: BatchNorm ---------------------------------------------------------------------------------------------------------
+int sg_bn_train_fwd_cpu(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S, float eps,
+                        float momentum, int act, float slope, void*, size_t, void*) {
+    CPU_CHECK(x && gamma && beta && y && save_mean && save_invstd && N > 0 && C > 0 && S > 0);
+    const double cnt = (double)N * S;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+        double s = 0, s2 = 0;
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) s += p[e];
+        }
+        const double mu = s / cnt;
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) s2 += (p[e] - mu) * (p[e] - mu);
+        }
+        const double var = s2 / cnt;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[c] = (float)mu;
+        save_invstd[c] = is;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(cnt > 1 ? s2 / (cnt - 1) : var);
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            float* q = y + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) q[e] = apply_act(gamma[c] * ((p[e] - (float)mu) * is) + beta[c], act, slope);
+        }
+    }
+    if (num_batches_tracked) *num_batches_tracked += 1;
+    return SG_OK;
+}
+int sg_bn_eval_fwd_cpu(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,
+                       const float* running_var, float* save_mean, float* save_invstd, int N, int C, long S, float eps, int act,
+                       float slope, void*) {
+    CPU_CHECK(x && gamma && beta && y && running_mean && running_var && save_mean && save_invstd && N > 0 && C > 0 && S > 0);
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+        const float mu = running_mean[c], is = 1.f / sqrtf(running_var[c] + eps);
+        save_mean[c] = mu;
+        save_invstd[c] = is;
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            float* q = y + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) q[e] = apply_act(gamma[c] * ((p[e] - mu) * is) + beta[c], act, slope);
+        }
+    }
+    return SG_OK;
+}
+int sg_bn_bwd_cpu(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                  const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, long S, int train, int act,
+                  float slope, void*, size_t, void*) {
+    CPU_CHECK(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && N > 0 && C > 0 && S > 0);
+    const double cnt = (double)N * S;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+        const float mu = save_mean[c], is = save_invstd[c], g = gamma[c], b = beta[c];
+        double s1 = 0, s2 = 0;
+        for (int n = 0; n < N; ++n) {
+            const long base = ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) {
+                const float xh = (x[base + e] - mu) * is;
+                const float gg = act_grad_out(apply_act(g * xh + b, act, slope), dy[base + e], act, slope);
+                s1 += gg;
+                s2 += (double)gg * xh;
+            }
+        }
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
+        for (int n = 0; n < N; ++n) {
+            const long base = ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) {
+                const float xh = (x[base + e] - mu) * is;
+                const float gg = act_grad_out(apply_act(g * xh + b, act, slope), dy[base + e], act, slope);
+                dx[base + e] = g * is * (train ? gg - m1 - xh * m2 : gg);
+            }
+        }
+    }
+    return SG_OK;
+}
+
+// ---- K5: activations ---------------------------------------------------------------------------------------------------------
+int sg_act_fwd_cpu(const float* x, float* y, long n, int act, float slope, void*) {
+    CPU_CHECK(x && y && n > 0);
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < n; ++e) y[e] = apply_act(x[e], act, slope);
+    return SG_OK;
+}
+int sg_act_bwd_cpu(const float* y, const float* dy, float* dx, long n, int act, float slope, void*) {
+    CPU_CHECK(y && dy && dx && n > 0);
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < n; ++e) dx[e] = act_grad_out(y[e], dy[e], act, slope);
+    return SG_OK;
+}
+int sg_act_bwd_rowsum_cpu(const float* y, const float* dy, float* dx, float* rowsum, long rows, long S, int act, float slope, void*) {
+    CPU_CHECK(y && dy && dx && rowsum && rows > 0 && S > 0);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        double s = 0;
+        for (long e = r * S; e < (r + 1) * S; ++e) {
+            dx[e] = act_grad_out(y[e], dy[e], act, slope);
+            s += dx[e];
+        }
+        rowsum[r] = (float)s;
+    }
+    return SG_OK;
+}
+int sg_act_bwd_dy_cpu(const float* y, const float* dy, const float* ggx, float* out, long n, int act, void*) {
+    CPU_CHECK(y && dy && ggx && out && n > 0 && (act == ACT_TANH || act == ACT_SIGMOID));
+    for (long e = 0; e < n; ++e) out[e] = ggx[e] * dy[e] * (act == ACT_TANH ? -2.f * y[e] : 1.f - 2.f * y[e]);
+    return SG_OK;
+}
+
+// ---- K7: SDFNet ------------------------------------------------------------------------------------------------------------
+// packed buffer of this twin (all row-major): W1k [256][KU] | W2 W3 W4 [256][256] | W5x [256][256] | W5i [256][KU] | W6 W7 |
+// w8 [256] | b1..b7 [7][256] | b8
+struct CpuSdf {
+    int KU;
+    const float *W1k, *W2, *W3, *W4, *W5x, *W5i, *W6, *W7, *w8, *b, *b8;
+};
+static CpuSdf sdf_view(const float* p, int KU) {
+    CpuSdf v;
+    v.KU = KU;
+    v.W1k = p;
+    p += 256L * KU;
+    v.W2 = p; p += 65536;
+    v.W3 = p; p += 65536;
+    v.W4 = p; p += 65536;
+    v.W5x = p; p += 65536;
+    v.W5i = p; p += 256L * KU;
+    v.W6 = p; p += 65536;
+    v.W7 = p; p += 65536;
+    v.w8 = p; p += 256;
+    v.b = p; p += 7 * 256;
+    v.b8 = p;
+    return v;
+}
+int sg_sdfnet_pack_cpu(const float* const* params, int latent, int kin_used, float* packed, void*) {
+    CPU_CHECK(params && packed && latent >= 0 && kin_used >= 3 && kin_used <= 3 + latent);
+    const int kin = 3 + latent;
+    float* p = packed;
+    for (int o = 0; o < 256; ++o) memcpy(p + (long)o * kin_used, params[0] + (long)o * kin, sizeof(float) * kin_used);
+    p += 256L * kin_used;
+    for (int l = 1; l <= 3; ++l, p += 65536) memcpy(p, params[2 * l], sizeof(float) * 65536);
+    for (int o = 0; o < 256; ++o) memcpy(p + o * 256, params[8] + (long)o * (256 + kin), sizeof(float) * 256);
+    p += 65536;
+    for (int o = 0; o < 256; ++o) memcpy(p + (long)o * kin_used, params[8] + (long)o * (256 + kin) + 256, sizeof(float) * kin_used);
+    p += 256L * kin_used;
+    for (int l = 5; l <= 6; ++l, p += 65536) memcpy(p, params[2 * l], sizeof(float) * 65536);
+    memcpy(p, params[14], sizeof(float) * 256);
+    p += 256;
+    for (int l = 0; l < 7; ++l, p += 256) memcpy(p, params[2 * l + 1], sizeof(float) * 256);
+    p[0] = params[15][0];
+    return SG_OK;
+}
+// out[o] = relu?(b[o] + sum_k W[o][k] in[k]) for one point
+static inline void dense(const float* W, int K, const float* in, const float* b, float* out, bool relu, bool accumulate) {
+    for (int o = 0; o < 256; ++o) {
+        const float* w = W + (long)o * K;
+        float s = accumulate ? out[o] : (b ? b[o] : 0.f);
+        for (int k = 0; k < K; ++k) s += w[k] * in[k];
+        out[o] = s;
+    }
+    if (relu)
+        for (int o = 0; o < 256; ++o) out[o] = out[o] > 0.f ? out[o] : 0.f;
+}
+int sg_sdfnet_fwd_cpu(const float* points, long points_period, const float* latent, const int64_t* latent_idx, int latent_size,
+                      const float* packed, int kin_used, const float* zb1, const float* zb5, long points_per_shape,
+                      const int* shape_index, float* out, float* acts, long ldn, long N, void*) {
+    CPU_CHECK(points && packed && out && N > 0 && kin_used >= 3 && (kin_used == 3 || latent) && ((zb1 != nullptr) == (zb5 != nullptr)));
+    CPU_CHECK(!zb1 || shape_index || points_per_shape > 0);
+    const CpuSdf v = sdf_view(packed, kin_used);
+    const int KU = kin_used, L = latent_size;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < N; ++p) {
+        float xin[3 + 1024], h[256], h2[256];
+        const long pi = points_period > 0 ? p % points_period : p;
+        for (int c = 0; c < 3; ++c) xin[c] = points[pi * 3 + c];
+        if (KU > 3) {
+            const long row = latent_idx ? latent_idx[p] : p;
+            for (int k = 0; k < KU - 3; ++k) xin[3 + k] = latent[row * L + k];
+        }
+        const long shape = zb1 ? (shape_index ? shape_index[p] : p / points_per_shape) : 0;
+        auto save = [&](int layer, const float* a) {
+            if (acts)
+                for (int o = 0; o < 256; ++o) acts[((long)layer * 256 + o) * ldn + p] = a[o];
+        };
+        dense(v.W1k, KU, xin, zb1 ? zb1 + shape * 256 : v.b, h, true, false);
+        save(0, h);
+        dense(v.W2, 256, h, v.b + 256, h2, true, false);
+        save(1, h2);
+        dense(v.W3, 256, h2, v.b + 512, h, true, false);
+        save(2, h);
+        dense(v.W4, 256, h, v.b + 768, h2, true, false);
+        save(3, h2);
+        dense(v.W5x, 256, h2, zb5 ? zb5 + shape * 256 : v.b + 1024, h, false, false);
+        dense(v.W5i, KU, xin, nullptr, h, true, true);
+        save(4, h);
+        dense(v.W6, 256, h, v.b + 1280, h2, true, false);
+        save(5, h2);
+        dense(v.W7, 256, h2, v.b + 1536, h, true, false);
+        save(6, h);
+        float s = v.b8[0];
+        for (int k = 0; k < 256; ++k) s += v.w8[k] * h[k];
+        out[p] = tanhf(s);
+    }
+    return SG_OK;
+}
+// dH_in[k] = sum_o W[o][k] dZ[o]
+static inline void dense_t(const float* W, int K, const float* dz, float* dh, bool accumulate) {
+    if (!accumulate)
+        for (int k = 0; k < K; ++k) dh[k] = 0.f;
+    for (int o = 0; o < 256; ++o) {
+        const float g = dz[o];
+        if (g == 0.f) continue;
+        const float* w = W + (long)o * K;
+        for (int k = 0; k < K; ++k) dh[k] += w[k] * g;
+    }
+}
+int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
+                      float* dx, long dx_ld, const float* packed, int kin_used, long ldn, long N, void*) {
+    CPU_CHECK(dout && out && acts && dz && dz8 && packed && N > 0 && kin_used >= 3 && kin_used <= 3 + 1024);
+    const CpuSdf v = sdf_view(packed, kin_used);
+    const float* Wt[7] = {nullptr, v.W2, v.W3, v.W4, v.W5x, v.W6, v.W7};   // W of layer l+1 maps H_l -> Z_{l+1}
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < N; ++p) {
+        float g[256], gn[256], dxa[3 + 1024];
+        const float o = out[p];
+        const float d8 = dout[p] * (1.f - o * o);
+        dz8[p] = d8;
+        auto masked_store = [&](int layer, float* gz) {
+            for (int r = 0; r < 256; ++r) {
+                gz[r] = acts[((long)layer * 256 + r) * ldn + p] > 0.f ? gz[r] : 0.f;
+                dz[((long)layer * 256 + r) * ldn + p] = gz[r];
+            }
+        };
+        for (int r = 0; r < 256; ++r) g[r] = v.w8[r] * d8;
+        masked_store(6, g);
+        for (int layer = 5; layer >= 0; --layer) {       // dH_layer = W_{layer+1}^T dZ_{layer+1}
+            dense_t(Wt[layer + 1], 256, g, gn, false);
+            if (dx && layer == 3) dense_t(v.W5i, kin_used, g, dxa, false);   // g is dZ5 here: the skip-connection input gradient
+            memcpy(g, gn, sizeof(g));
+            masked_store(layer, g);
+        }
+        if (dx) {
+            dense_t(v.W1k, kin_used, g, dxa, true);
+            for (int k = 0; k < kin_used; ++k) dx[p * dx_ld + k] = dxa[k];
+        }
+    }
+    if (bias_partials) {
+        const long nblk = (N + 63) / 64;   // == sg_sdfnet_bwd_blocks(N)
+#pragma omp parallel for schedule(static)
+        for (long r = 0; r < 7 * 256; ++r) {
+            double s = 0;
+            for (long p = 0; p < N; ++p) s += dz[r * ldn + p];
+            bias_partials[r * nblk] = (float)s;
+            for (long c = 1; c < nblk; ++c) bias_partials[r * nblk + c] = 0.f;
+        }
+    }
+    return SG_OK;
+}
+
+// ---- K8 - K11: elementwise, reductions, table rows, optimizers ---------------------------------------------------------------
+int sg_axpby_cpu(const float* x, const float* y, float* out, long n, float a, float b, void*) {
+    CPU_CHECK(x && out && n > 0);
+    for (long e = 0; e < n; ++e) out[e] = y ? a * x[e] + b * y[e] : a * x[e];
+    return SG_OK;
+}
+int sg_reduce_sum_cpu(const float* x, float* out, long n, float scale, void*, size_t, void*) {
+    CPU_CHECK(x && out && n > 0);
+    double s = 0;
+    for (long e = 0; e < n; ++e) s += x[e];
+    out[0] = (float)(s * (double)scale);
+    return SG_OK;
+}
+int sg_gather_rows_cpu(const float* table, const int64_t* idx, float* out, long n, int L, void*) {
+    CPU_CHECK(table && idx && out && n > 0 && L > 0);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) memcpy(out + i * L, table + idx[i] * L, sizeof(float) * L);
+    return SG_OK;
+}
+int sg_scatter_add_rows_cpu(const float* rows, long rows_ld, const int64_t* idx, float* table_grad, long n, int L, void*) {
+    CPU_CHECK(rows && idx && table_grad && n > 0 && L > 0 && rows_ld >= L);
+    for (long i = 0; i < n; ++i)
+        for (int k = 0; k < L; ++k) table_grad[idx[i] * L + k] += rows[i * rows_ld + k];
+    return SG_OK;
+}
+int sg_rmsprop_step_cpu(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale, float clip, void*) {
+    CPU_CHECK(p && g && sq && n > 0);
+    for (long e = 0; e < n; ++e) {
+        const float gg = g[e] * gscale;
+        const float s = alpha * sq[e] + (1.f - alpha) * gg * gg;
+        sq[e] = s;
+        float v = p[e] - lr * (gg / (sqrtf(s) + eps));
+        if (clip > 0.f) v = std::min(std::max(v, -clip), clip);
+        p[e] = v;
+    }
+    return SG_OK;
+}
+static void adam_update(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float bc1,
+                        float bc2_sqrt, float gscale) {
+    const float step = lr / bc1;
+    for (long e = 0; e < n; ++e) {
+        const float gg = g[e] * gscale;
+        const float mm = b1 * m[e] + (1.f - b1) * gg;
+        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+int sg_adam_step_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, long step,
+                     float gscale, void*) {
+    CPU_CHECK(p && g && m && v && n > 0 && step > 0);
+    adam_update(p, g, m, v, n, lr, b1, b2, eps, (float)(1.0 - pow((double)b1, (double)step)),
+                (float)sqrt(1.0 - pow((double)b2, (double)step)), gscale);
+    return SG_OK;
+}
+int sg_adam_step_dev_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                         long long* step_dev, float* corr_dev, float gscale, void*) {
+    CPU_CHECK(p && g && m && v && n > 0 && step_dev && corr_dev);
+    const long long t = ++*step_dev;
+    corr_dev[0] = (float)(1.0 - pow((double)b1, (double)t));
+    corr_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    adam_update(p, g, m, v, n, lr, b1, b2, eps, corr_dev[0], corr_dev[1], gscale);
+    return SG_OK;
+}
+int sg_clamp_cpu(float* p, long n, float lo, float hi, void*) {
+    CPU_CHECK(p && n > 0);
+    for (long e = 0; e < n; ++e) p[e] = std::min(std::max(p[e], lo), hi);
+    return SG_OK;
+}
+int sg_voxel_prepare_cpu(const float* x, float* out, long n, float c, float divisor, void*) {
+    CPU_CHECK(x && out && n > 0 && c >= 0.f);
+    for (long e = 0; e < n; ++e) {
+        float v = x[e];
+        v = v < -c ? -c : (v > c ? c : v);
+        out[e] = divisor > 0.f ? v / divisor : v;
+    }
+    return SG_OK;
+}
+
+// ---- losses / blends ----------------------------------------------------------------------------------------------------------
+int sg_loss_weighted_l1_fwd_cpu(const float* o, const float* t, long n, float negw, float* loss, void*, size_t, void*) {
+    CPU_CHECK(o && t && loss && n > 0);
+    double s = 0;
+    for (long e = 0; e < n; ++e) s += fabs((double)((o[e] - t[e]) * (t[e] < 0.f ? negw : 1.f)));
+    loss[0] = (float)(s / (double)n);
+    return SG_OK;
+}
+int sg_loss_weighted_l1_bwd_cpu(const float* o, const float* t, const float* gloss, float* d_o, long n, float negw, void*) {
+    CPU_CHECK(o && t && gloss && d_o && n > 0);
+    const float g = gloss[0] * (float)(1.0 / (double)n);
+    for (long e = 0; e < n; ++e) {
+        const float w = t[e] < 0.f ? negw : 1.f, d = (o[e] - t[e]) * w;
+        d_o[e] = g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+    }
+    return SG_OK;
+}
+int sg_loss_kld_fwd_cpu(const float* mu, const float* lv, long n, float* loss, void*, size_t, void*) {
+    CPU_CHECK(mu && lv && loss && n > 0);
+    double s = 0;
+    for (long e = 0; e < n; ++e) s += (double)(1.f + lv[e] - mu[e] * mu[e] - expf(lv[e]));
+    loss[0] = (float)(-0.5 * s / (double)n);
+    return SG_OK;
+}
+int sg_loss_kld_bwd_cpu(const float* mu, const float* lv, const float* gloss, float* dmu, float* dlv, long n, void*) {
+    CPU_CHECK(mu && lv && gloss && dmu && dlv && n > 0);
+    const float g = gloss[0] * (float)(1.0 / (double)n);
+    for (long e = 0; e < n; ++e) {
+        dmu[e] = g * mu[e];
+        dlv[e] = -0.5f * g * (1.f - expf(lv[e]));
+    }
+    return SG_OK;
+}
+int sg_loss_meansq_fwd_cpu(const float* x, const float* roww, long rows, int L, double denom, float* loss, void*, size_t, void*) {
+    CPU_CHECK(x && loss && rows > 0 && L > 0 && denom > 0);
+    double s = 0;
+    for (long e = 0; e < rows * L; ++e) s += (double)((roww ? roww[e / L] : 1.f) * x[e] * x[e]);
+    loss[0] = (float)(s / denom);
+    return SG_OK;
+}
+int sg_loss_meansq_bwd_cpu(const float* x, const float* roww, const float* gloss, float* dx, long rows, int L, double denom, void*) {
+    CPU_CHECK(x && gloss && dx && rows > 0 && L > 0 && denom > 0);
+    const float g = gloss[0] * (float)(2.0 / denom);
+    for (long e = 0; e < rows * L; ++e) dx[e] = (roww ? roww[e / L] : 1.f) * g * x[e];
+    return SG_OK;
+}
+int sg_gradient_penalty_fwd_cpu(const float* grad, long B, long M, float weight, float* norms, float* loss, void*) {
+    CPU_CHECK(grad && norms && loss && B > 0 && M > 0);
+    double acc = 0;
+    for (long b = 0; b < B; ++b) {
+        double s = 0;
+        for (long e = 0; e < M; ++e) s += (double)grad[b * M + e] * grad[b * M + e];
+        norms[b] = (float)sqrt(s);
+        acc += ((double)norms[b] - 1.0) * ((double)norms[b] - 1.0);
+    }
+    loss[0] = (float)(acc / (double)B * (double)weight);
+    return SG_OK;
+}
+int sg_gradient_penalty_bwd_cpu(const float* grad, const float* norms, const float* gloss, float* dgrad, long B, long M, float weight, void*) {
+    CPU_CHECK(grad && norms && gloss && dgrad && B > 0 && M > 0);
+    const float coef = (float)(2.0 * (double)weight / (double)B);
+    for (long b = 0; b < B; ++b) {
+        const float c = norms[b] > 0.f ? gloss[0] * coef * (norms[b] - 1.f) / norms[b] : 0.f;
+        for (long e = 0; e < M; ++e) dgrad[b * M + e] = c * grad[b * M + e];
+    }
+    return SG_OK;
+}
+int sg_lerp_rows_cpu(const float* a, const float* b, const float* alpha, float* out, long B, long M, void*) {
+    CPU_CHECK(a && b && alpha && out && B > 0 && M > 0);
+    for (long r = 0; r < B; ++r) {
+        const float al = alpha[r], be = 1.f - al;
+        for (long e = 0; e < M; ++e) {
+            const float t1 = al * a[r * M + e], t2 = be * b[r * M + e];
+            out[r * M + e] = t1 + t2;
+        }
+    }
+    return SG_OK;
+}
+int sg_fade_blend_cpu(const float* x, const float* half, float* out, long B, int C, long S, float fade, float hs, void*) {
+    CPU_CHECK(half && out && B > 0 && C > 0 && S > 0);
+    for (long b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (long e = 0; e < S; ++e) {
+                float v = x ? fade * x[(b * C + c) * S + e] : 0.f;
+                if (c == 0) v = v + hs * half[b * S + e];
+                out[(b * C + c) * S + e] = v;
+            }
+    return SG_OK;
+}
+int sg_channel0_cpu(const float* g, float* out, long B, int C, long S, float scale, void*) {
+    CPU_CHECK(g && out && B > 0 && C > 0 && S > 0);
+    for (long b = 0; b < B; ++b)
+        for (long e = 0; e < S; ++e) out[b * S + e] = scale * g[b * C * S + e];
+    return SG_OK;
+}
+int sg_subsample2_cpu(const float* x, float* out, long B, int R, void*) {
+    CPU_CHECK(x && out && B > 0 && R >= 2 && !(R & 1));
+    const int h = R / 2;
+    for (long b = 0; b < B; ++b)
+        for (int i = 0; i < h; ++i)
+            for (int j = 0; j < h; ++j)
+                for (int k = 0; k < h; ++k) out[((b * h + i) * h + j) * h + k] = x[((b * R + 2 * i) * R + 2 * j) * R + 2 * k];
+    return SG_OK;
+}
+int sg_subsample2_adjoint_cpu(const float* g, float* out, long B, int R, void*) {
+    CPU_CHECK(g && out && B > 0 && R >= 2 && !(R & 1));
+    const int h = R / 2;
+    memset(out, 0, sizeof(float) * B * R * R * R);
+    for (long b = 0; b < B; ++b)
+        for (int i = 0; i < h; ++i)
+            for (int j = 0; j < h; ++j)
+                for (int k = 0; k < h; ++k) out[((b * R + 2 * i) * R + 2 * j) * R + 2 * k] = g[((b * h + i) * h + j) * h + k];
+    return SG_OK;
+}
+
+// ---- PointNet family ------------------------------------------------------------------------------------------------------------
+int sg_layernorm_fwd_cpu(const float* x, long ldx, const float* rowbias, long rows_per_shape, const float* gamma,
+                         const float* beta, float* y, long ldy, float* mean, float* rstd, long R, int C, float eps, int act, void*) {
+    CPU_CHECK(x && gamma && beta && y && mean && rstd && R > 0 && C > 0 && (act == ACT_NONE || act == ACT_RELU));
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        const float* zb = rowbias ? rowbias + (r / rows_per_shape) * C : nullptr;
+        double s = 0, s2 = 0;
+        for (int c = 0; c < C; ++c) s += x[r * ldx + c] + (zb ? zb[c] : 0.f);
+        const double mu = s / C;
+        for (int c = 0; c < C; ++c) {
+            const double d = x[r * ldx + c] + (zb ? zb[c] : 0.f) - mu;
+            s2 += d * d;
+        }
+        const float rs = (float)(1.0 / sqrt(s2 / C + (double)eps));
+        mean[r] = (float)mu;
+        rstd[r] = rs;
+        for (int c = 0; c < C; ++c) {
+            const float v = gamma[c] * ((x[r * ldx + c] + (zb ? zb[c] : 0.f) - (float)mu) * rs) + beta[c];
+            y[r * ldy + c] = act == ACT_RELU ? (v > 0.f ? v : 0.f) : v;
+        }
+    }
+    return SG_OK;
+}
+int sg_layernorm_bwd_cpu(const float* x, long ldx, const float* rowbias, long rows_per_shape, const float* gamma, const float* y,
+                         long ldy, const float* dy, long lddy, const float* mean, const float* rstd, float* dz, long lddz,
+                         float* dgamma, float* dbeta, long R, int C, int act, void*, size_t, void*) {
+    CPU_CHECK(x && gamma && dy && mean && rstd && dz && dgamma && dbeta && R > 0 && C > 0);
+    std::vector<double> ag(C, 0.0), ab(C, 0.0);
+    for (long r = 0; r < R; ++r) {
+        const float* zb = rowbias ? rowbias + (r / rows_per_shape) * C : nullptr;
+        const float mu = mean[r], rs = rstd[r];
+        double s1 = 0, s2 = 0;
+        std::vector<float> xh(C), gh(C);
+        for (int c = 0; c < C; ++c) {
+            float g = dy[r * lddy + c];
+            if (act == ACT_RELU) g = y[r * ldy + c] > 0.f ? g : 0.f;
+            xh[c] = (x[r * ldx + c] + (zb ? zb[c] : 0.f) - mu) * rs;
+            gh[c] = g * gamma[c];
+            ag[c] += (double)g * xh[c];
+            ab[c] += g;
+            s1 += gh[c];
+            s2 += (double)gh[c] * xh[c];
+        }
+        const float m1 = (float)(s1 / C), m2 = (float)(s2 / C);
+        for (int c = 0; c < C; ++c) dz[r * lddz + c] = rs * (gh[c] - m1 - xh[c] * m2);
+    }
+    for (int c = 0; c < C; ++c) {
+        dgamma[c] = (float)ag[c];
+        dbeta[c] = (float)ab[c];
+    }
+    return SG_OK;
+}
+int sg_segmax_fwd_cpu(const float* x, float* out, int* idx, long B, long P, int C, void*) {
+    CPU_CHECK(x && out && idx && B > 0 && P > 0 && C > 0);
+    for (long b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float best = x[(b * P) * C + c];
+            int arg = 0;
+            for (long p = 1; p < P; ++p)
+                if (x[(b * P + p) * C + c] > best) {
+                    best = x[(b * P + p) * C + c];
+                    arg = (int)p;
+                }
+            out[b * C + c] = best;
+            idx[b * C + c] = arg;
+        }
+    return SG_OK;
+}
+int sg_segmax_scatter_cpu(const float* dy, const int* idx, float* dx, long B, long P, int C, void*) {
+    CPU_CHECK(dy && idx && dx && B > 0 && P > 0 && C > 0);
+    memset(dx, 0, sizeof(float) * B * P * C);
+    for (long b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) dx[(b * P + idx[b * C + c]) * C + c] = dy[b * C + c];
+    return SG_OK;
+}
+int sg_segmax_gather_cpu(const float* x, const int* idx, float* out, long B, long P, int C, void*) {
+    CPU_CHECK(x && idx && out && B > 0 && P > 0 && C > 0);
+    for (long b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) out[b * C + c] = x[(b * P + idx[b * C + c]) * C + c];
+    return SG_OK;
+}
+int sg_scatter_max_fwd_cpu(const float* x, const int64_t* batch, float* out, int* arg, long N, long B, int C, void*, size_t, void*) {
+    CPU_CHECK(x && batch && out && arg && N > 0 && B > 0 && C > 0);
+    for (long e = 0; e < B * C; ++e) {
+        arg[e] = -1;
+        out[e] = 0.f;
+    }
+    for (long i = 0; i < N; ++i) {
+        const long b = batch[i];
+        if (b < 0 || b >= B) continue;
+        for (int c = 0; c < C; ++c)
+            if (arg[b * C + c] < 0 || x[i * C + c] > out[b * C + c]) {
+                out[b * C + c] = x[i * C + c];
+                arg[b * C + c] = (int)i;
+            }
+    }
+    return SG_OK;
+}
+int sg_scatter_max_scatter_cpu(const float* dy, const int* arg, float* dx, long N, long B, int C, void*) {
+    CPU_CHECK(dy && arg && dx && N > 0 && B > 0 && C > 0);
+    memset(dx, 0, sizeof(float) * N * C);
+    for (long e = 0; e < B * C; ++e)
+        if (arg[e] >= 0) dx[(long)arg[e] * C + e % C] = dy[e];
+    return SG_OK;
+}
+int sg_scatter_max_gather_cpu(const float* x, const int* arg, float* out, long N, long B, int C, void*) {
+    CPU_CHECK(x && arg && out && N > 0 && B > 0 && C > 0);
+    for (long e = 0; e < B * C; ++e) out[e] = arg[e] >= 0 ? x[(long)arg[e] * C + e % C] : 0.f;
+    return SG_OK;
+}
+
+}  // extern "C"

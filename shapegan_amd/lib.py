@@ -1,7 +1,10 @@
-"""ctypes binding of libshapegan_hip.so — the only door from Python into the HIP kernels.
+"""ctypes binding of libshapegan_hip.so — the only door from Python into the HIP kernels — and of libshapegan_cpu.so, the
+plain-C++ twin of the same C ABI (`sg_<name>_cpu`, csrc_cpu/shapegan_cpu.cpp; SURVEY.md 8b, BASELINE configs[0] "on CPU").
 
-The product path has no CPU or eager-PyTorch fallback: if the shared library is missing (not built) or a call
-fails, this module raises.  Signatures mirror include/shapegan_hip.h one to one.
+Dispatch is by the DEVICE OF THE TENSORS of a call and nothing else: GPU tensors go to the HIP library, CPU tensors to the
+twin, a call that mixes them raises.  There is no fallback in either direction: a missing libshapegan_hip.so raises as soon
+as a GPU tensor (or any size query) needs it, a missing twin raises when a CPU tensor shows up; neither library ever stands
+in for the other, and no eager-PyTorch path exists.  Signatures mirror include/shapegan_hip.h one to one.
 """
 import ctypes
 import os
@@ -129,47 +132,122 @@ def check_comm(rc, what=""):
         raise RuntimeError("shapegan_comm %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
+# Entry points WITHOUT a twin: size queries and layout helpers are host code of libshapegan_hip.so (callable without a GPU; the
+# twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
+NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
+    "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks"}
+CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
+
+_hip = None
+_cpu = None
 _lib = None
 
 
+def _load_hip():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libshapegan_hip.so is missing at %s — build it with `python -m shapegan_amd.build` "
+                "(there is no CPU / eager fallback for the shapegan_amd hot path)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sg_abi_version() != 1:
+            raise RuntimeError("libshapegan_hip.so ABI version mismatch")
+        _hip = lib
+    return _hip
+
+
+def load_cpu():
+    """Loads libshapegan_cpu.so (once): `sg_<name>_cpu` for every entry point outside NO_TWIN, same argument lists."""
+    global _cpu
+    if _cpu is None:
+        if not os.path.exists(CPU_PATH):
+            raise RuntimeError("libshapegan_cpu.so is missing at %s — build it with `python -m shapegan_amd.build`; CPU tensors "
+                               "are computed by the C++ twin only, never by an eager-PyTorch path" % CPU_PATH)
+        lib = ctypes.CDLL(CPU_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if name not in NO_TWIN:
+                fn = getattr(lib, name + "_cpu")
+                fn.restype = res
+                fn.argtypes = args
+        lib.sg_cpu_last_error.restype = c_char_p
+        _cpu = lib
+    return _cpu
+
+
+class _DeviceOfCall(object):
+    """Which library the call being assembled belongs to: set by ptr() / note_device() while the arguments are evaluated,
+    consumed by the dispatcher when the call is made."""
+    kind = None
+
+
+def _note(is_cuda):
+    kind = "cuda" if is_cuda else "cpu"
+    if _DeviceOfCall.kind is not None and _DeviceOfCall.kind != kind:
+        _DeviceOfCall.kind = None
+        raise RuntimeError("shapegan_amd: one call received both GPU and CPU tensors")
+    _DeviceOfCall.kind = kind
+
+
+def note_device(t):
+    """For callers that pass `t.data_ptr()` arithmetic instead of ptr(t)."""
+    _note(t.is_cuda)
+
+
+class _Dispatch(object):
+    """`lib.sg_foo(...)`: the HIP entry for GPU tensors, `sg_foo_cpu` of the twin for CPU tensors."""
+
+    def __getattr__(self, name):
+        hip_fn = getattr(_load_hip(), name)
+        if name in NO_TWIN:
+            fn = hip_fn
+        else:
+            def fn(*args):
+                kind, _DeviceOfCall.kind = _DeviceOfCall.kind, None
+                if kind is None:
+                    raise RuntimeError("shapegan_amd: %s was called without a tensor argument that names its device" % name)
+                if kind == "cuda":
+                    return hip_fn(*args)
+                return getattr(load_cpu(), name + "_cpu")(*args)
+        setattr(self, name, fn)
+        return fn
+
+
 def load():
-    """Loads the shared library (once). Raises RuntimeError if it has not been built."""
+    """The dispatching view of the two libraries.  Raises RuntimeError if libshapegan_hip.so has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            "libshapegan_hip.so is missing at %s — build it with `python -m shapegan_amd.build` "
-            "(there is no CPU / eager fallback for the shapegan_amd hot path)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
-    if lib.sg_abi_version() != 1:
-        raise RuntimeError("libshapegan_hip.so ABI version mismatch")
-    _lib = lib
-    return lib
+    if _lib is None:
+        _load_hip()
+        _lib = _Dispatch()
+    return _lib
 
 
 def check(rc, what=""):
     if rc != 0:
-        msg = load().sg_last_error()
-        raise RuntimeError("shapegan_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        msgs = [_load_hip().sg_last_error()]
+        if _cpu is not None:
+            msgs.append(_cpu.sg_cpu_last_error())
+        raise RuntimeError("shapegan %s failed (%d): %s" % (what, rc, " | ".join(m.decode() for m in msgs if m)))
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    """Address of a contiguous fp32 / int tensor (None -> NULL); records the tensor's device for the dispatcher."""
     if t is None:
         return None
-    if not t.is_cuda:
-        raise RuntimeError("shapegan_amd kernels need tensors on the GPU (got %s); there is no CPU path" % t.device)
     if not t.is_contiguous():
         raise RuntimeError("shapegan_amd kernels need contiguous tensors")
+    _note(t.is_cuda)
     return t.data_ptr()
 
 
 def stream():
+    """The current HIP stream handle (None for a call on CPU tensors)."""
+    if _DeviceOfCall.kind == "cpu" or not torch.cuda.is_available():
+        return None
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -178,7 +256,10 @@ _workspaces = {}
 
 def workspace(name, nbytes, device):
     """Caller-owned scratch, cached per (device, stream, name) and grown on demand."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream(), name)
+    if device.type != "cuda":
+        key = ("cpu", 0, name)
+    else:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -125,6 +125,7 @@ class RMSprop(_Base):
         base_p, base_s = self.f.flat.data_ptr(), self.square_avg.data_ptr()
         for seg in self._segments():
             o, n, g = seg[0], seg[1], seg[2]
+            L.note_device(self.f.flat)
             check(lib.sg_rmsprop_step(base_p + 4 * o, g, base_s + 4 * o, n, self.lr, self.alpha, self.eps,
                                       self.grad_scale, self.clip, stream()), "rmsprop_step")
         L.bump_param_epoch()
@@ -155,11 +156,13 @@ class Adam(_Base):
         if self.capturable:
             if not f.coherent():
                 f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
+            L.note_device(f.flat)
             check(lib.sg_adam_step_dev(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                        self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
                                        self.grad_scale, stream()), "adam_step_dev")
         elif uniform:
             self.steps = [s + 1 for s in self.steps]
+            L.note_device(f.flat)
             check(lib.sg_adam_step(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                    self.betas[1], self.eps, self.steps[0], self.grad_scale, stream()), "adam_step")
         else:
@@ -168,6 +171,7 @@ class Adam(_Base):
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 self.steps[i] += 1
+                L.note_device(f.flat)
                 check(lib.sg_adam_step(base_p + 4 * o, g.data_ptr(), base_m + 4 * o, base_v + 4 * o, p.numel(), self.lr,
                                        self.betas[0], self.betas[1], self.eps, self.steps[i], self.grad_scale,
                                        stream()), "adam_step")

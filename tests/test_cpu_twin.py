@@ -1,0 +1,162 @@
+"""CPU tier: libshapegan_cpu.so, the plain-C++ twin of the C ABI (SURVEY.md 8b `*_cpu`, BASELINE configs[0] "on CPU").
+
+The twin is exercised through the SAME Python shells and the SAME parity checks as the HIP kernels: the bodies of the GPU-tier
+tests (tests/test_gpu_modules.py, tests/test_gpu_ops.py) are re-run here with `.cuda()` turned into a no-op, so every tensor
+stays on the CPU and shapegan_amd.lib dispatches each call to `sg_<name>_cpu`.  What is compared against is unchanged: the
+fixtures made from the real reference and the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import shapegan_amd.lib as L
+import test_gpu_modules as M
+import test_gpu_ops as OPS
+import test_gpu_losses as LOSS
+
+
+@pytest.fixture()
+def on_cpu(monkeypatch):
+    """Tensors / modules asked to move to the GPU stay where they are: the test body then runs on the CPU twin."""
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self.clone())   # a copy, like a device transfer
+    monkeypatch.setattr(nn.Module, "cuda", lambda self, *a, **k: self)
+    import shapegan_amd.util as U
+    monkeypatch.setattr(U, "device", torch.device("cpu"))
+    for mod in ("shapegan_amd.model.gan", "shapegan_amd.model.autoencoder"):
+        import importlib
+        monkeypatch.setattr(importlib.import_module(mod), "default_device", torch.device("cpu"))
+    for mod in (M, OPS, LOSS):
+        monkeypatch.setattr(mod, "DEV", "cpu")
+    twin = L.load_cpu()
+    yield twin
+
+
+def test_twin_exports_every_entry_point():
+    """`sg_<name>_cpu` exists for every entry point of the header except the size queries / forced-kernel test hooks."""
+    lib = ctypes.CDLL(L.CPU_PATH)
+    twins = [n for n in L.SIGNATURES if n not in L.NO_TWIN]
+    assert len(twins) >= 50
+    for n in twins:
+        assert hasattr(lib, n + "_cpu"), "missing twin: " + n
+    for n in L.NO_TWIN:
+        assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
+            "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks")
+
+
+def test_dispatch_is_by_tensor_device_only(on_cpu):
+    from shapegan_amd import ops
+    x = torch.randn(1, 2, 4, 4, 4)
+    w = torch.randn(3, 2, 4, 4, 4)
+    y = ops.conv_fwd_raw(x, w, None)
+    torch.testing.assert_close(y, torch.nn.functional.conv3d(x, w, None, stride=2, padding=1), rtol=1e-5, atol=1e-5)
+    # a size query has no tensor: it is host code of the HIP library and does not consume / need a device
+    assert L.load().sg_conv3d_k4s2p1_fwd_workspace_bytes(1, 2, 3, 2, 2, 2) >= 0
+    # a compute entry called without any tensor argument naming its device refuses to guess
+    with pytest.raises(RuntimeError, match="without a tensor argument"):
+        L.load().sg_clamp(0, 4, -1.0, 1.0, None)
+
+
+# ---- kernel families (bodies from tests/test_gpu_ops.py) ---------------------------------------------------------------------
+@pytest.mark.parametrize("N,Ci,Co,R", [(2, 3, 5, 8), (1, 1, 4, 6), (3, 8, 1, 4), (1, 2, 2, 2), (2, 24, 48, 8)])
+def test_conv3d(on_cpu, N, Ci, Co, R):
+    OPS.test_conv3d_fwd_dgrad_wgrad(N, Ci, Co, R)
+
+
+@pytest.mark.parametrize("N,Ci,Co,R", [(2, 16, 8, 4), (3, 8, 1, 8), (1, 5, 3, 3)])
+def test_conv_transpose3d(on_cpu, N, Ci, Co, R):
+    OPS.test_conv_transpose3d(N, Ci, Co, R)
+
+
+def test_from_sdf_zero_channels(on_cpu):
+    OPS.test_conv_from_sdf_zero_channels()
+
+
+@pytest.mark.parametrize("M_,N_,K_", [(64, 128, 256), (4, 128, 256), (5, 7, 3)])
+def test_linear(on_cpu, M_, N_, K_):
+    OPS.test_linear_fwd_bwd(M_, N_, K_)
+
+
+def test_gemm_double_backward(on_cpu):
+    OPS.test_gemm_double_backward()
+
+
+@pytest.mark.parametrize("N,C,S", [(4, 8, 64), (4, 256, 1), (3, 7, 27)])
+def test_batchnorm(on_cpu, N, C, S):
+    OPS.test_batchnorm_train_fwd_bwd(N, C, S)
+
+
+def test_activations_and_reductions(on_cpu):
+    OPS.test_activations()
+    OPS.test_mean_reduction()
+    OPS.test_gather_scatter_rows_bit_exact()
+
+
+def test_optimizers_match_torch(on_cpu):
+    OPS.test_rmsprop_adam_clamp_match_torch()
+
+
+@pytest.mark.parametrize("N,latent", [(1, 128), (63, 128), (777, 256), (130, 16)])
+def test_sdfnet_points(on_cpu, N, latent):
+    OPS.test_sdfnet_points_mode(N, latent)
+
+
+@pytest.mark.parametrize("S,pps", [(3, 512), (1, 37)])
+def test_sdfnet_shapes(on_cpu, S, pps):
+    OPS.test_sdfnet_shapes_mode(S, pps)
+
+
+@pytest.mark.parametrize("S,N", [(5, 700), (3, 64)])
+def test_sdfnet_segments(on_cpu, S, N):
+    OPS.test_sdfnet_segments_mode(S, N)
+
+
+def test_layernorm_segmax_colsum(on_cpu):
+    OPS.test_layernorm_act(300, 256, 100, True, 2)
+    OPS.test_layernorm_act(64, 64, 64, False, 0)
+    OPS.test_segmax_and_adjoints(3, 50, 64)
+    OPS.test_colsum_tall()
+
+
+def test_losses_and_blends(on_cpu):
+    LOSS.test_weighted_l1_matches_reconstruction_loss((3, 7, 5))
+    LOSS.test_kld_matches_reference()
+    LOSS.test_mean_sq_plain_and_row_weighted()
+    LOSS.test_lerp_rows_bit_exact()
+    LOSS.test_gradient_penalty_value_and_gradient(5, (7, 3))
+    LOSS.test_subsample2_bit_exact_and_adjoint()
+    LOSS.test_fade_blend_first_and_second_order(1, 0.3)
+    LOSS.test_scatter_max_ragged(1000, 7, 64, True)
+    LOSS.test_scatter_max_ragged(10, 12, 5, False)
+    LOSS.test_discriminator_clip_weights()
+
+
+# ---- modules and training steps (bodies from tests/test_gpu_modules.py: reference-made fixtures + CPU oracle) ----------------
+def test_generator_and_discriminator(on_cpu, golden_modules):
+    M.test_generator(golden_modules)
+    M.test_discriminator(golden_modules)
+
+
+def test_autoencoders(on_cpu, golden_modules, monkeypatch):
+    M.test_autoencoder_classic(golden_modules)
+    M.test_vae_forward(golden_modules, monkeypatch)
+
+
+@pytest.mark.parametrize("it,fade", [(0, 1.0), (1, 0.4), (2, 0.3)])
+def test_progressive_discriminator(on_cpu, golden_modules, it, fade):
+    M.test_progressive_discriminator(golden_modules, it, fade)
+
+
+def test_sdfnet_module_and_gradient_penalty(on_cpu, golden_modules):
+    M.test_sdfnet_module(golden_modules, 128)
+    M.test_gradient_penalty_double_backward(golden_modules)
+
+
+def test_training_trajectories(on_cpu, golden_steps):
+    """train_wgan.py, train_autoencoder.py (configs[0]'s loop body), train_sdf_autodecoder.py, train_hybrid_wgan.py steps
+    on the native optimizers and modules, all on the CPU twin, against the reference-made trajectories."""
+    M.test_wgan_trajectory(golden_steps)
+    M.test_autoencoder_trajectory(golden_steps)
+    M.test_sdf_autodecoder_trajectory(golden_steps)
+    M.test_hybrid_wgan_trajectory(golden_steps)

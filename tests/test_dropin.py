@@ -107,3 +107,30 @@ def test_reference_script_on_native_modules_gpu(name, tmp_path, monkeypatch):
         if key in ns:
             assert next(ns[key].parameters()).is_cuda
     compare(case, rec, _golden(case))
+
+
+@needs_reference
+@pytest.mark.parametrize("name", [c.name for c in cases.CASES if c.device == "any"])
+def test_reference_script_on_native_modules_cpu(name, tmp_path, monkeypatch):
+    """BASELINE configs[0] as written — `train_autoencoder.py classic`, batch 4, 16 synthetic shapes, on the CPU, no GPU — plus
+    train_wgan.py and train_sdf_autodecoder.py at CPU-sized constants: the reference's own script text on the native modules
+    with every tensor on the CPU, i.e. through libshapegan_cpu.so (the plain-C++ twin of the C ABI).  On a GPU box the
+    scripts' `device` is pinned to the CPU for this test; the HIP library is not asked to compute."""
+    import shapegan_amd.util as U
+    import shapegan_amd.model.gan as G
+    import shapegan_amd.model.autoencoder as A
+    import shapegan_amd.model.sdf_net as S
+    import shapegan_amd.lib as L
+    cpu = torch.device("cpu")
+    monkeypatch.setattr(U, "device", cpu)
+    monkeypatch.setattr(G, "default_device", cpu)
+    monkeypatch.setattr(A, "default_device", cpu)
+    if torch.cuda.is_available():
+        monkeypatch.setattr(S.SDFNet.__init__, "__defaults__", (128, "cpu"))
+    L.load_cpu()
+    case = cases.BY_NAME[name]
+    rec, ns = run_case(case, tmp_path, monkeypatch)
+    for key in ("generator", "critic", "autoencoder", "sdf_net"):
+        if key in ns:
+            assert not next(ns[key].parameters()).is_cuda
+    compare(case, rec, _golden(case))

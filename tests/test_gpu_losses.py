@@ -8,6 +8,7 @@ import torch.nn.functional as F
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"   # tests/test_cpu_twin.py re-runs these bodies on the CPU twin with DEV = "cpu"
 RTOL = 1e-4
 
 
@@ -226,10 +227,10 @@ def test_pointnet_ragged_batch_equals_dense():
     torch.manual_seed(11)
     net = PointNet(out_channels=1).cuda()
     B, P = 4, 256
-    pos, dist = torch.rand(B, P, 3, device="cuda") * 2 - 1, torch.randn(B, P, 1, device="cuda") * 0.1
+    pos, dist = torch.rand(B, P, 3, device=DEV) * 2 - 1, torch.randn(B, P, 1, device=DEV) * 0.1
     dense = net(pos, dist)
-    batch = torch.arange(B, device="cuda").view(-1, 1).repeat(1, P).view(-1)
-    perm = torch.randperm(B * P, device="cuda")
+    batch = torch.arange(B, device=DEV).view(-1, 1).repeat(1, P).view(-1)
+    perm = torch.randperm(B * P, device=DEV)
     ragged = net(pos.reshape(-1, 3)[perm], dist.reshape(-1, 1)[perm], batch[perm])
     close(ragged, dense.reshape(B, -1), rtol=1e-5)
 
@@ -396,16 +397,16 @@ def test_graph_replay_invalidates_weight_packs():
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     pc, shapes, L = 1000, 4, 128
     torch.manual_seed(19)
-    pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
-    sdf = torch.rand(shapes * pc, device="cuda") * 0.3 - 0.15
+    pts = torch.rand(shapes * pc, 3, device=DEV) * 2 - 1
+    sdf = torch.rand(shapes * pc, device=DEV) * 0.3 - 0.15
     net = SDFNet(latent_code_size=L)
-    tr = SDFAutoDecoderTrainer(net, torch.randn(shapes, L, device="cuda") * 1e-2, pts, sdf, pointcloud_size=pc, lr=1e-3,
+    tr = SDFAutoDecoderTrainer(net, torch.randn(shapes, L, device=DEV) * 1e-2, pts, sdf, pointcloud_size=pc, lr=1e-3,
                                capturable=True)
-    probe, z = pts[:512].contiguous(), torch.randn(1, L, device="cuda")
+    probe, z = pts[:512].contiguous(), torch.randn(1, L, device=DEV)
     with torch.no_grad():
         net.forward_shapes(probe, z, 512)                       # primes the pack cache with the initial weights
     for _ in range(6):
-        tr.step_graphed(torch.randint(0, shapes * pc, (2048,), device="cuda"))
+        tr.step_graphed(torch.randint(0, shapes * pc, (2048,), device=DEV))
     with torch.no_grad():
         after = net.forward_shapes(probe, z, 512)
     fresh = SDFNet(latent_code_size=L)
@@ -423,7 +424,7 @@ def test_native_allreduce_single_rank_stream_order():
     from shapegan_amd.parallel import NativeComm
     comm = NativeComm(rank=0, world=1)
     n = 1 << 24
-    x = torch.zeros(n, device="cuda")
+    x = torch.zeros(n, device=DEV)
     for it in range(3):
         x.add_(1.5)                    # producer on the compute stream
         comm.launch(x[: n // 2])       # two slices of the flat buffer, like the tail / head exchange

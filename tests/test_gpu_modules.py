@@ -8,6 +8,7 @@ from conftest import assert_summary_close
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"   # tests/test_cpu_twin.py re-runs these bodies on the CPU twin with DEV = "cpu"
 RTOL = 1e-4
 
 
@@ -516,7 +517,7 @@ def test_dp_shards_sum_to_full_batch_gradient():
     torch.manual_seed(3)
     d = Discriminator()
     d.use_sigmoid = False
-    x = torch.rand(8, 32, 32, 32, device="cuda") * 2 - 1
+    x = torch.rand(8, 32, 32, 32, device=DEV) * 2 - 1
     d(x).mean().backward()
     full = [p.grad.clone() for p in d.parameters()]
     d.zero_grad()
@@ -550,11 +551,11 @@ def test_full_size_hybrid_progressive_config():
         for s in (0, 7, 15):
             single = g.forward_shapes(grid, z[s:s + 1], R ** 3).reshape(R, R, R)
             assert torch.equal(single, full[s])
-        idx = torch.randint(0, B * R ** 3, (50000,), device="cuda")
+        idx = torch.randint(0, B * R ** 3, (50000,), device=DEV)
         pts = grid[idx % R ** 3]
         lat = z[idx // R ** 3]
         close(g(pts, lat), full.reshape(-1)[idx], atol=2e-6, what="per-point vs per-shape forward")
-        real = torch.rand(B, R, R, R, device="cuda") * 2 - 1
+        real = torch.rand(B, R, R, R, device=DEV) * 2 - 1
         whole = d(real)
         halves = torch.cat((d(real[:8]), d(real[8:])))
         close(whole, halves, rtol=1e-5, what="batch-split invariance")   # tile / split-K plans differ with the batch size
@@ -573,8 +574,8 @@ def test_wgan_step_odd_batches(B):
     g, d = Generator(), Discriminator()
     d.use_sigmoid = False
     g.eval()                                  # eval-mode BN: per-sample outputs are batch-independent
-    z = torch.randn(B, 128, device="cuda")
-    x = torch.rand(B, 32, 32, 32, device="cuda") * 2 - 1
+    z = torch.randn(B, 128, device=DEV)
+    x = torch.rand(B, 32, 32, 32, device=DEV) * 2 - 1
     with torch.no_grad():
         full_g, full_d = g(z), d(x).reshape(-1)
         for i in sorted({0, B // 2, B - 1}):
@@ -596,10 +597,10 @@ def test_sdf_autodecoder_graphed_step_equals_eager():
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     pc, shapes, L = 1000, 6, 128
     torch.manual_seed(7)
-    pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
-    sdf = torch.rand(shapes * pc, device="cuda") * 0.3 - 0.15
-    lat0 = torch.randn(shapes, L, device="cuda") * 1e-2
-    idxs = [torch.randint(0, shapes * pc, (2048,), device="cuda") for _ in range(6)]
+    pts = torch.rand(shapes * pc, 3, device=DEV) * 2 - 1
+    sdf = torch.rand(shapes * pc, device=DEV) * 0.3 - 0.15
+    lat0 = torch.randn(shapes, L, device=DEV) * 1e-2
+    idxs = [torch.randint(0, shapes * pc, (2048,), device=DEV) for _ in range(6)]
     runs = []
     for graphed in (False, True):
         torch.manual_seed(8)

@@ -9,6 +9,7 @@ from oracle import c_oracle
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"   # tests/test_cpu_twin.py re-runs these bodies on the CPU twin with DEV = "cpu"
 
 RTOL = 1e-4
 
@@ -123,7 +124,7 @@ def test_conv_linearity_and_adjoint_full_size():
     from shapegan_amd import ops
     torch.manual_seed(1)
     w = (torch.randn(128, 64, 4, 4, 4) / 64).cuda()
-    x1, x2 = torch.randn(64, 64, 16, 16, 16, device="cuda"), torch.randn(64, 64, 16, 16, 16, device="cuda")
+    x1, x2 = torch.randn(64, 64, 16, 16, 16, device=DEV), torch.randn(64, 64, 16, 16, 16, device=DEV)
     y1, y2 = ops.conv_fwd_raw(x1, w, None), ops.conv_fwd_raw(x2, w, None)
     y12 = ops.conv_fwd_raw(0.5 * x1 - 2.0 * x2, w, None)
     close(y12, 0.5 * y1 - 2.0 * y2, rtol=2e-4)
@@ -197,7 +198,7 @@ def test_batchnorm_train_fwd_bwd(N, C, S):
     dy = torch.randn_like(y_ref)
     y_ref.backward(dy)
     xg, gg, bg = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
-    rm_g, rv_g, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.long, device="cuda")
+    rm_g, rv_g, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.long, device=DEV)
     y = ops.BatchNormAct.apply(xg, gg, bg, rm_g, rv_g, nbt, True, 1e-5, 0.1, ACT_LEAKY, 0.2)
     close(y, y_ref, what="bn fwd")
     close(rm_g, rm_r, what="running_mean")
@@ -466,7 +467,7 @@ def test_voxel_prepare_bit_exact(golden_steps_f2):
     big = torch.rand(16, 64, 64, 64) * 0.5 - 0.25
     want = big.clone().clamp_(-0.1, 0.1)
     want /= 0.1
-    out = torch.empty_like(big, device="cuda")
+    out = torch.empty_like(big, device=DEV)
     ops.voxel_prepare(big.cuda(), 0.1, 0.1, out=out)
     assert torch.equal(out.cpu(), want)
 
@@ -544,14 +545,14 @@ def test_segmax_and_adjoints(B, P, C):
     if P > 4:
         first = (x == want_v.unsqueeze(1)).float().argmax(dim=1)     # first index attaining the max
         assert torch.equal(idx.cpu().long(), first)
-    w = torch.randn(B, C, device="cuda")
+    w = torch.randn(B, C, device=DEV)
     (out * w).sum().backward()
     ref = torch.zeros(B, P, C)
     ref.scatter_(1, idx.cpu().long().unsqueeze(1), w.cpu().unsqueeze(1))
     assert torch.equal(xs.grad.cpu(), ref)
     # adjointness <scatter(dy), u> == <dy, gather(u)> and double backward
-    u = torch.randn(B, P, C, device="cuda")
-    dy = torch.randn(B, C, device="cuda", requires_grad=True)
+    u = torch.randn(B, P, C, device=DEV)
+    dy = torch.randn(B, C, device=DEV, requires_grad=True)
     sc = ops.SegMaxScatter.apply(dy, idx, P)
     lhs = (sc * u).sum()
     rhs = (dy * ops.SegMaxGather.apply(u, idx)).sum()
@@ -563,10 +564,10 @@ def test_segmax_and_adjoints(B, P, C):
 def test_colsum_tall():
     from shapegan_amd import ops
     torch.manual_seed(5)
-    x = torch.randn(5, 3000, 70, device="cuda")
+    x = torch.randn(5, 3000, 70, device=DEV)
     got = ops.colsum_tall_raw(x, 5, 3000 * 70, 3000, 70, 70)
     np.testing.assert_allclose(got.cpu().numpy(), x.double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-4)
-    g = torch.randn(100000, 256, device="cuda", requires_grad=True)
+    g = torch.randn(100000, 256, device=DEV, requires_grad=True)
     s = ops.ColSum.apply(g)
     np.testing.assert_allclose(s.detach().cpu().numpy(), g.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
     s.sum().backward()
@@ -580,9 +581,9 @@ def test_gemm_nt_bigk(M, N, K, lda):
     4, leading dimensions with padding, row-strided output."""
     from shapegan_amd import ops
     torch.manual_seed(M + N + K)
-    a = torch.randn(M, lda, device="cuda")
-    b = torch.randn(N, lda, device="cuda")
-    out = torch.full((M, N + 5), 7.0, device="cuda")
+    a = torch.randn(M, lda, device=DEV)
+    b = torch.randn(N, lda, device=DEV)
+    out = torch.full((M, N + 5), 7.0, device=DEV)
     ops.gemm_nt_raw(a, b, out, M, N, K, lda, lda, N + 5)
     want = a[:, :K].double() @ b[:, :K].double().t()
     err = float((out[:, :N].double() - want).abs().max()) / float(want.abs().max())

@@ -36,20 +36,27 @@ def test_library_exports_every_declared_symbol():
 
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "_hip", None)
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libshapegan_hip.so")
     with pytest.raises(RuntimeError, match="libshapegan_hip.so is missing"):
         L.load()
 
 
-@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
-def test_no_cpu_fallback():
-    """The product path refuses CPU tensors instead of silently computing somewhere else."""
+def test_no_fallback_between_libraries(monkeypatch):
+    """Dispatch is by tensor device only and never falls back: CPU tensors need the C++ twin (a missing twin raises — no
+    eager-PyTorch path), the HIP library is required for every GPU tensor and size query, and one call may not mix devices."""
+    monkeypatch.setattr(L, "_cpu", None)
+    monkeypatch.setattr(L, "CPU_PATH", "/nonexistent/libshapegan_cpu.so")
     d = Discriminator()
-    with pytest.raises(RuntimeError, match="no CPU path"):
-        d(torch.zeros(2, 32, 32, 32))
-    s = SDFNet()
-    with pytest.raises(RuntimeError, match="no CPU path"):
-        s(torch.zeros(4, 3), torch.zeros(4, 128))
+    if not next(d.parameters()).is_cuda:
+        with pytest.raises(RuntimeError, match="libshapegan_cpu.so is missing"):
+            d(torch.zeros(2, 32, 32, 32))
+    monkeypatch.undo()
+    L._DeviceOfCall.kind = None
+    L._note(True)
+    with pytest.raises(RuntimeError, match="both GPU and CPU tensors"):
+        L.ptr(torch.zeros(4))          # a CPU tensor joining a call that already saw a GPU tensor
+    assert L._DeviceOfCall.kind is None
 
 
 def test_constants_and_filenames():
