@@ -30,32 +30,38 @@ def _free_port():
     return port
 
 
-def _setup(rank, world, port):
+def _setup(rank, world, port, device):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       SG_DIST_BACKEND="gloo")
     from shapegan_amd import parallel
-    r, w, _ = parallel.init_distributed()
+    r, w, _ = parallel.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
-    torch.cuda.set_device(0)
+    if device == "cuda":
+        torch.cuda.set_device(0)
+    else:   # the same trainers on CPU tensors (libshapegan_cpu.so): pin the modules' default device
+        import shapegan_amd.util as U
+        import shapegan_amd.model.gan as G
+        U.device = G.default_device = torch.device("cpu")
+        torch.set_num_threads(4)
     return parallel
 
 
-def _prog_worker(rank, world, port, out_dir):
-    parallel = _setup(rank, world, port)
+def _prog_worker(rank, world, port, out_dir, device="cuda"):
+    parallel = _setup(rank, world, port, device)
     from shapegan_amd.model.progressive_gan import Discriminator
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import HybridProgressiveGANTrainer
     from shapegan_amd.util import get_voxel_coordinates
     it, R, B = 1, 16, 4
-    grid = torch.tensor(get_voxel_coordinates(R)).cuda()
+    grid = torch.tensor(get_voxel_coordinates(R)).to(device)
     gen = torch.Generator().manual_seed(5)
-    real = (torch.rand(B, R, R, R, generator=gen) * 2 - 1).cuda()
-    z, alpha = torch.randn(B, 128, generator=gen).cuda(), torch.rand(B, 1, 1, 1, generator=gen).cuda()
+    real = (torch.rand(B, R, R, R, generator=gen) * 2 - 1).to(device)
+    z, alpha = torch.randn(B, 128, generator=gen).to(device), torch.rand(B, 1, 1, 1, generator=gen).to(device)
 
     def build():
         torch.manual_seed(21)                  # identical replicas by seed
-        g, d = SDFNet(), Discriminator().cuda()
+        g, d = SDFNet(device=device), Discriminator().to(device)
         d.set_iteration(it)
         d.fade_in_progress = 0.6               # the fade-in blend is on the gradient penalty's double-backward path too
         return g, d, HybridProgressiveGANTrainer(g, d, grid, R)
@@ -80,21 +86,21 @@ def _prog_worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def _sdf_worker(rank, world, port, out_dir):
-    parallel = _setup(rank, world, port)
+def _sdf_worker(rank, world, port, out_dir, device="cuda", n=131072):
+    parallel = _setup(rank, world, port, device)
     from shapegan_amd import ops
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
-    pc, shapes, L, n = 4000, 8, 128, 131072
+    pc, shapes, L = 4000, 8, 128
     gen = torch.Generator().manual_seed(6)
-    pts = (torch.rand(shapes * pc, 3, generator=gen) * 2 - 1).cuda()
-    sdf = (torch.rand(shapes * pc, generator=gen) * 0.3 - 0.15).cuda()
-    table = (torch.randn(shapes, L, generator=gen) * 1e-2).cuda()
-    idx = torch.randint(0, shapes * pc, (n,), generator=gen).cuda()
+    pts = (torch.rand(shapes * pc, 3, generator=gen) * 2 - 1).to(device)
+    sdf = (torch.rand(shapes * pc, generator=gen) * 0.3 - 0.15).to(device)
+    table = (torch.randn(shapes, L, generator=gen) * 1e-2).to(device)
+    idx = torch.randint(0, shapes * pc, (n,), generator=gen).to(device)
 
     def build():
         torch.manual_seed(22)
-        net = SDFNet(latent_code_size=L)
+        net = SDFNet(latent_code_size=L, device=device)
         return net, SDFAutoDecoderTrainer(net, table.clone(), pts, sdf, pointcloud_size=pc)
 
     net, tr = build()
@@ -134,8 +140,7 @@ def _mostly_close(a, b, rtol, max_bad=2e-3, what=""):
     assert bad.mean() <= max_bad, "%s: %.3f%% of entries differ (max err %.3e, scale %.3e)" % (what, 100 * bad.mean(), np.abs(a - b).max(), scale)
 
 
-def test_hybrid_progressive_discriminator_step_world2(tmp_path):
-    mp.spawn(_prog_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+def check_prog(tmp_path):
     full = np.load(tmp_path / "prog_full.npy")
     used = _used(tmp_path, "prog_slices.npy", full.size)
     g0, g1 = np.load(tmp_path / "prog_grad0.npy")[used], np.load(tmp_path / "prog_grad1.npy")[used]
@@ -144,8 +149,7 @@ def test_hybrid_progressive_discriminator_step_world2(tmp_path):
     np.testing.assert_array_equal(np.load(tmp_path / "prog_param0.npy"), np.load(tmp_path / "prog_param1.npy"))   # replicas stay identical
 
 
-def test_sdf_autodecoder_sorted_step_world2(tmp_path):
-    mp.spawn(_sdf_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+def check_sdf(tmp_path):
     full = np.load(tmp_path / "sdf_full.npy")
     used = _used(tmp_path, "sdf_slices.npy", full.size)
     g0, g1 = np.load(tmp_path / "sdf_grad0.npy")[used], np.load(tmp_path / "sdf_grad1.npy")[used]
@@ -155,3 +159,13 @@ def test_sdf_autodecoder_sorted_step_world2(tmp_path):
     np.testing.assert_array_equal(l0, l1)
     _mostly_close(l0, lf, 3e-4, what="dense latent-table gradient")
     np.testing.assert_array_equal(np.load(tmp_path / "sdf_table0.npy"), np.load(tmp_path / "sdf_table1.npy"))
+
+
+def test_hybrid_progressive_discriminator_step_world2(tmp_path):
+    mp.spawn(_prog_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    check_prog(tmp_path)
+
+
+def test_sdf_autodecoder_sorted_step_world2(tmp_path):
+    mp.spawn(_sdf_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    check_sdf(tmp_path)

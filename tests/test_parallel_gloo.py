@@ -79,3 +79,19 @@ def test_dp_gradient_equals_full_batch(tmp_path):
     a0, a1 = np.load(tmp_path / "again0.npy")[used], np.load(tmp_path / "again1.npy")[used]
     np.testing.assert_array_equal(a0, a1)
     np.testing.assert_allclose(a0, full, rtol=1e-4, atol=1e-7)  # also after module.zero_grad() dropped the flat views
+
+
+# ---- the trainers themselves with world size 2 on the CPU (gloo + libshapegan_cpu.so) --------------------------------------------
+# The same workers tests/test_gpu_dp.py runs on the GPU: BASELINE configs[3]'s discriminator update (WGAN-GP double backward,
+# fade-in blend, early tail-slice exchange from inside backward) and configs[2]'s shape-sorted auto-decoder step (dense
+# latent-table exchange), each on two half batches, must leave both ranks with the full batch's gradient and identical replicas.
+def test_hybrid_progressive_discriminator_step_world2_cpu(tmp_path):
+    import test_gpu_dp as DP
+    mp.spawn(DP._prog_worker, args=(2, _free_port(), str(tmp_path), "cpu"), nprocs=2, join=True)
+    DP.check_prog(tmp_path)
+
+
+def test_sdf_autodecoder_sorted_step_world2_cpu(tmp_path):
+    import test_gpu_dp as DP
+    mp.spawn(DP._sdf_worker, args=(2, _free_port(), str(tmp_path), "cpu", 4096), nprocs=2, join=True)
+    DP.check_sdf(tmp_path)
