@@ -613,3 +613,26 @@ def test_sdf_autodecoder_graphed_step_equals_eager():
     for k in runs[0][1]:
         torch.testing.assert_close(runs[0][1][k], runs[1][1][k], rtol=1e-6, atol=1e-9, msg=k)
     torch.testing.assert_close(runs[0][2], runs[1][2], rtol=1e-6, atol=1e-9)
+
+
+def test_autoencoder_graphed_step_equals_eager():
+    """AutoencoderTrainer.step_graphed (captured once, replayed) walks the same trajectory as the eager step at the script's
+    small batch: BatchNorm running statistics / counters, native losses and the device-side Adam step all live in the graph."""
+    from shapegan_amd.model.autoencoder import Autoencoder
+    from shapegan_amd.train_steps import AutoencoderTrainer
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.rand(4, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(6)]
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(9)
+        ae = Autoencoder(is_variational=False)
+        tr = AutoencoderTrainer(ae, capturable=graphed)
+        losses = [float((tr.step_graphed(b) if graphed else tr.step(b))[0].item()) for b in batches]
+        runs.append((losses, {k: v.detach().clone() for k, v in ae.state_dict().items()}))
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-5)
+    for k in runs[0][1]:
+        a, b = runs[0][1][k], runs[1][1][k]
+        if a.is_floating_point():
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-8, msg=k)
+        else:
+            assert torch.equal(a, b), k
