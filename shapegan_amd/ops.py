@@ -449,8 +449,12 @@ class LinearAct(Function):
             else:
                 gw = Gemm.apply(x, gz, True, False) if w_kn else Gemm.apply(gz, x, True, False)
         if has_b and ctx.needs_input_grad[2]:
-            if plain and not bias_shift:
-                gb = _colsum_raw(f32c(gz), L.grad_destination(b, b.shape))
+            if plain:
+                if bias_shift:   # one bias entry per group of 2^shift columns: column sums, then sums over each group
+                    cols = _colsum_raw(f32c(gz))
+                    gb = _colsum_raw(f32c(cols.reshape(-1, 1 << bias_shift).t()), L.grad_destination(b, b.shape))
+                else:
+                    gb = _colsum_raw(f32c(gz), L.grad_destination(b, b.shape))
             else:
                 gb = ColSum.apply(gz)
                 if bias_shift:
