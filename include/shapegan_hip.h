@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 1
+#define SG_ABI_VERSION 2
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 
@@ -107,7 +107,8 @@ int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
 /* rows [d*rows_per_dst, (d+1)*rows_per_dst) go to outs[d] (ndst <= 8 host-side pointers to device buffers): one launch for
  * bias gradients that live in separate slices of a flat gradient buffer */
-int sg_rowsum_multi(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, hipStream_t stream);
+int sg_rowsum_multi(const float* x, float* const* outs, const long* out_strides, int ndst, long rows_per_dst, long len, long ld,
+                    hipStream_t stream); /* out_strides (optional, host array): element stride of each destination, default 1 */
 /* out[r*nseg + s] = sum of x[r*ld + e] over e in [seg_off[s], seg_off[s+1])  (per-shape sums of SDFNet dZ columns) */
 int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, hipStream_t stream);
 
@@ -149,8 +150,14 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
                   long points_per_shape, const int* shape_index, float* out, float* acts, long ldn, long N,
                   hipStream_t stream);
 long sg_sdfnet_bwd_blocks(long N); /* workgroups of the backward kernel = columns of bias_partials */
+/* bias_partials (optional): [7*256][blocks] per-workgroup row sums of dZ1..dZ7 (sum each row: bias gradients).  With `points`
+ * (the xyz of the batch, as given to sg_sdfnet_fwd) it is [14*256][blocks]: rows 7*256.. = sum_p dz8[p] H7[row][p] (the
+ * layers2.6 weight gradient), rows (8+c)*256.. / (11+c)*256.. = sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns
+ * of the layers1.0 / layers2.0 weight gradients) — partial sums the kernel has the operands in registers for, instead of three
+ * more passes over the [256][N] images. */
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
-                  float* dx, long dx_ld, const float* packed, int kin_used, long ldn, long N, hipStream_t stream);
+                  const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
+                  long N, hipStream_t stream);
 
 /* ---- K8/K9/K10/K11: blends, reductions, latent-table rows, optimizers ------------------------------------------
  * reference: fade-in / GP lerp (model/progressive_gan.py:50, train_hybrid_progressive_gan.py:105), batch means

@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ x
 // an SDFNet backward land in seven separate slices of the optimizer's flat gradient buffer).
 struct RowsumDst {
     float* out[8];
+    long stride[8];
 };
 __global__ void __launch_bounds__(256) rowsum_multi_kernel(const float* __restrict__ x, RowsumDst dst, long rows_per_dst,
                                                            long len, long ld) {
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) rowsum_multi_kernel(const float* __restri
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dst.out[r / rows_per_dst][r % rows_per_dst] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) dst.out[r / rows_per_dst][(r % rows_per_dst) * dst.stride[r / rows_per_dst]] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // out[r*S + s] = sum_{e in [off[s], off[s+1])} x[r*ld + e]: one wave per (row, segment) pair
@@ -395,10 +396,14 @@ int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStrea
     return SG_OK;
 }
 
-int sg_rowsum_multi(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, hipStream_t stream) {
+int sg_rowsum_multi(const float* x, float* const* outs, const long* out_strides, int ndst, long rows_per_dst, long len, long ld,
+                    hipStream_t stream) {
     SG_CHECK_ARG(x && outs && ndst > 0 && ndst <= 8 && rows_per_dst > 0 && len > 0);
     RowsumDst d;
-    for (int i = 0; i < 8; ++i) d.out[i] = outs[i < ndst ? i : 0];
+    for (int i = 0; i < 8; ++i) {
+        d.out[i] = outs[i < ndst ? i : 0];
+        d.stride[i] = out_strides ? out_strides[i < ndst ? i : 0] : 1;
+    }
     for (int i = 0; i < ndst; ++i) SG_CHECK_ARG(outs[i] != nullptr);
     hipLaunchKernelGGL(rowsum_multi_kernel, dim3((unsigned)(rows_per_dst * ndst)), dim3(256), 0, stream, x, d, rows_per_dst,
                        len, ld);

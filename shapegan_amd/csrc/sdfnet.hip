@@ -343,7 +343,11 @@ struct SdfBwdArgs {
     const float* acts;   // [7][256][ldn]
     float* dz;           // [7][256][ldn]  dZ1..dZ7
     float* dz8;          // [N]
-    float* bsum;         // optional [7*256][nblk]: per-workgroup row sums of dZ1..dZ7 (bias-gradient partials)
+    float* bsum;         // optional [7*256][nblk]: per-workgroup row sums of dZ1..dZ7 (bias-gradient partials); with `points`
+                         // [14*256][nblk]: + rows 7*256.. : sum_p dz8[p] H7[row][p] (w8 gradient), rows (8+c)*256.. and
+                         // (11+c)*256.. : sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns of dW1 / dW5)
+    const float* points; // optional [*,3] (with bsum): the xyz of the points, for the extended partial sums
+    long points_period;
     float* dx;           // optional: input gradient, row-major [N][dx_ld] (first KU columns written)
     long dx_ld;
     const float* packed;
@@ -362,6 +366,7 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;            // [256][P]
     float* dz8s = Gs + kH * P;   // [P]
+    float* xs = dz8s + P;        // [3][P] xyz of the tile (only with a.points)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -379,6 +384,14 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
             a.dz8[gp] = v;
         }
         dz8s[tid] = v;
+    }
+    const bool ext = a.bsum && a.points;
+    if (ext && tid >= 64 && tid < 64 + 3 * P) {   // (P = 64: threads 64..255)
+        const int e = tid - 64, c = e / P, pp = e - c * P;
+        const long gp = p0 + pp;
+        float v = 0.f;
+        if (gp < a.N) v = a.points[(a.points_period > 0 ? gp % a.points_period : gp) * 3 + c];
+        xs[c * P + pp] = v;
     }
     __syncthreads();
 
@@ -416,7 +429,15 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
                 hf[q][t] = buf_load(hres, hload[t], (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4));
     };
     // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
-    auto mask_store = [&](int layer) __attribute__((always_inline)) {
+    // half-wave sum (the 32 lanes of a half-wave hold the P points of one row); lane r == 0 stores
+    auto row_partial = [&](float v, int prow) __attribute__((always_inline)) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (r == 0) a.bsum[(long)prow * gridDim.x + blockIdx.x] = v;
+    };
+    // XC: -1, or the block of extended partial rows (8: dW1 point columns, 11: dW5 point columns) this layer feeds
+    auto mask_store = [&](int layer, auto xtag) __attribute__((always_inline)) {
+        constexpr int XC = decltype(xtag)::value;
         const __amdgpu_buffer_rsrc_t zres = make_rsrc(a.dz + (long)layer * kH * a.ldn);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -431,10 +452,29 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
                                                           (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4 + t * 128), 0);
                 rs += g;
             }
-            if (a.bsum) {   // sum over the 32 lanes of the half-wave = the P points of this row
+            if (a.bsum) row_partial(rs, layer * kH + row);
+        }
+        if (XC >= 0 && ext) {
+            // point columns: a second, short pass over the rows this wave has just written to LDS (same wave, LDS operations
+            // are in order: no barrier), so that the products do not lengthen the register lifetimes of the loop above
+            float xv[3][NT];
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-                if (r == 0) a.bsum[((long)layer * kH + row) * gridDim.x + blockIdx.x] = rs;
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xv[c][t] = xs[c * P + t * 32 + r];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = wave * 32 + frag_row(q, kh);
+                float gq[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) gq[t] = Gs[row * P + t * 32 + r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v = fmaf(gq[t], xv[c][t], v);
+                    row_partial(v, (XC + c) * kH + row);
+                }
             }
         }
     };
@@ -448,24 +488,30 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
             const float wv = w8[wave * 32 + frag_row(q, kh)];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t][q] = wv * dz8s[t * 32 + r];
+            if (ext) {   // w8 gradient partial: sum_p dz8[p] * H7[row][p]  (H7 = relu output, already in registers)
+                float s8 = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) s8 = fmaf(pok[t] ? hf[q][t] : 0.f, dz8s[t * 32 + r], s8);
+                row_partial(s8, 7 * kH + wave * 32 + frag_row(q, kh));
+            }
         }
     }
-    mask_store(6);
+    mask_store(6, IntTag<-1>());
     __syncthreads();
-    auto back_step = [&](long toff, int layer) __attribute__((always_inline)) {  // dZ_layer+1 (LDS) -> dZ_layer (LDS, dz image)
+    auto back_step = [&](long toff, int layer, auto xtag) __attribute__((always_inline)) {  // dZ_layer+1 (LDS) -> dZ_layer
         load_h(layer);
         zero_acc();
         mlp_gemm<NT, 2>(acc, pk + (toff >> 2) + (long)wave * (kH / 8) * 64, kH / 8, Gs, P, lane);
         __syncthreads();   // every wave is done reading the tile
-        mask_store(layer);
+        mask_store(layer, xtag);
         __syncthreads();
     };
-    back_step(a.lay.T7, 5);    // dH6 -> dZ6
-    back_step(a.lay.T6, 4);    // dZ5
-    back_step(a.lay.T5x, 3);   // dZ4
-    back_step(a.lay.T4, 2);    // dZ3
-    back_step(a.lay.T3, 1);    // dZ2
-    back_step(a.lay.T2, 0);    // dZ1
+    back_step(a.lay.T7, 5, IntTag<-1>());    // dH6 -> dZ6
+    back_step(a.lay.T6, 4, IntTag<11>());    // dZ5 (+ point columns of dW5)
+    back_step(a.lay.T5x, 3, IntTag<-1>());   // dZ4
+    back_step(a.lay.T4, 2, IntTag<-1>());    // dZ3
+    back_step(a.lay.T3, 1, IntTag<-1>());    // dZ2
+    back_step(a.lay.T2, 0, IntTag<8>());     // dZ1 (+ point columns of dW1)
     // (element indexing of the dX part below)
     constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
     constexpr int RSTEP = 512 / P;
@@ -515,7 +561,7 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
 }
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
-static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + P) * sizeof(float); }
+static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
 
 template <class K>
 static int set_lds(K kern, size_t bytes) {
@@ -622,9 +668,12 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
 long sg_sdfnet_bwd_blocks(long N) { return (N + 63) / 64; }
 
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
-                  float* dx, long dx_ld, const float* packed, int kin_used, long ldn, long N, hipStream_t stream) {
+                  const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
+                  long N, hipStream_t stream) {
     SG_CHECK_ARG(dout && out && acts && dz && dz8 && packed && N > 0 && ldn >= N);
     SdfBwdArgs a;
+    a.points = points;
+    a.points_period = points_period;
     a.dout = dout;
     a.out = out;
     a.acts = acts;

@@ -250,12 +250,16 @@ int sg_rowsum_cpu(const float* x, float* out, long rows, long len, long ld, void
     }
     return SG_OK;
 }
-int sg_rowsum_multi_cpu(const float* x, float* const* outs, int ndst, long rows_per_dst, long len, long ld, void* st) {
-    CPU_CHECK(x && outs && ndst > 0 && ndst <= 8);
-    for (int d = 0; d < ndst; ++d) {
-        const int rc = sg_rowsum_cpu(x + (long)d * rows_per_dst * ld, outs[d], rows_per_dst, len, ld, st);
-        if (rc) return rc;
-    }
+int sg_rowsum_multi_cpu(const float* x, float* const* outs, const long* out_strides, int ndst, long rows_per_dst, long len,
+                        long ld, void*) {
+    CPU_CHECK(x && outs && ndst > 0 && ndst <= 8 && rows_per_dst > 0 && len > 0);
+    for (int d = 0; d < ndst; ++d)
+        for (long r = 0; r < rows_per_dst; ++r) {
+            double s = 0;
+            const float* p = x + ((long)d * rows_per_dst + r) * ld;
+            for (long e = 0; e < len; ++e) s += p[e];
+            outs[d][r * (out_strides ? out_strides[d] : 1)] = (float)s;
+        }
     return SG_OK;
 }
 int sg_segsum_cpu(const float* x, float* out, long rows, long ld, const int64_t* seg_off, long nseg, void*) {
@@ -503,7 +507,8 @@ static inline void dense_t(const float* W, int K, const float* dz, float* dh, bo
     }
 }
 int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
-                      float* dx, long dx_ld, const float* packed, int kin_used, long ldn, long N, void*) {
+                      const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used,
+                      long ldn, long N, void*) {
     CPU_CHECK(dout && out && acts && dz && dz8 && packed && N > 0 && kin_used >= 3 && kin_used <= 3 + 1024);
     const CpuSdf v = sdf_view(packed, kin_used);
     const float* Wt[7] = {nullptr, v.W2, v.W3, v.W4, v.W5x, v.W6, v.W7};   // W of layer l+1 maps H_l -> Z_{l+1}
@@ -534,12 +539,25 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
     }
     if (bias_partials) {
         const long nblk = (N + 63) / 64;   // == sg_sdfnet_bwd_blocks(N)
+        const long nrows = points ? 14 * 256 : 7 * 256;
 #pragma omp parallel for schedule(static)
-        for (long r = 0; r < 7 * 256; ++r) {
+        for (long r = 0; r < nrows; ++r) {
             double s = 0;
-            for (long p = 0; p < N; ++p) s += dz[r * ldn + p];
+            if (r < 7 * 256) {
+                for (long p = 0; p < N; ++p) s += dz[r * ldn + p];
+            } else if (r < 8 * 256) {                                   // w8 gradient: sum_p dz8[p] H7[row][p]
+                const long row = r - 7 * 256;
+                for (long p = 0; p < N; ++p) s += (double)dz8[p] * acts[(6L * 256 + row) * ldn + p];
+            } else {                                                    // point columns of dW1 (dZ1) / dW5 (dZ5)
+                const long q = r - 8 * 256, blk = q / (3 * 256), c = (q / 256) % 3, row = q % 256;
+                const long layer = blk == 0 ? 0 : 4;
+                for (long p = 0; p < N; ++p) {
+                    const long pi = points_period > 0 ? p % points_period : p;
+                    s += (double)dz[(layer * 256 + row) * ldn + p] * points[pi * 3 + c];
+                }
+            }
             bias_partials[r * nblk] = (float)s;
-            for (long c = 1; c < nblk; ++c) bias_partials[r * nblk + c] = 0.f;
+            for (long c2 = 1; c2 < nblk; ++c2) bias_partials[r * nblk + c2] = 0.f;
         }
     }
     return SG_OK;

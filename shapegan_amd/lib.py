@@ -40,7 +40,7 @@ SIGNATURES = {
     "sg_gemm": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_colsum": (c_int, [_P, _P, _I, _I, _L, _P]),
     "sg_rowsum": (c_int, [_P, _P, _L, _L, _L, _P]),
-    "sg_rowsum_multi": (c_int, [_P, _P, _I, _L, _L, _L, _P]),
+    "sg_rowsum_multi": (c_int, [_P, _P, _P, _I, _L, _L, _L, _P]),
     "sg_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P]),
     "sg_bn_workspace_bytes": (_Z, [_I]),
     "sg_bn_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
@@ -53,7 +53,7 @@ SIGNATURES = {
     "sg_sdfnet_pack": (c_int, [_P, _I, _I, _P, _P]),
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
-    "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _L, _L, _P]),
+    "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
     "sg_axpby": (c_int, [_P, _P, _P, _L, _F, _F, _P]),
     "sg_reduce_workspace_bytes": (_Z, []),
     "sg_reduce_sum": (c_int, [_P, _P, _L, _F, _P, _Z, _P]),
@@ -155,7 +155,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 1:
+        if lib.sg_abi_version() != 2:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip

@@ -556,13 +556,17 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
                  ldb=rows.shape[1], ldc=ldc, c_off=c_off)
 
     # bias gradients: [7*256][nblk] partial row sums from the fused backward -> one short reduction for all seven layers,
-    # each layer's 256 sums written where that parameter's gradient lives
+    # each layer's 256 sums written where that parameter's gradient lives.  With the extended partials ([14*256][nblk],
+    # sg_sdfnet_bwd given the points) the same launch also finishes the layers2.6 weight gradient.
     bias_idx = (1, 3, 5, 7, 9, 11, 13)                       # parameter index of the bias of dZ layer 0..6
     bouts = [_param_grad_out(ctx_params[pi], (_H,), dev) for pi in bias_idx]
+    extended = bsum is not None and bsum.shape[0] == 14 * _H
+    w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
     if bsum is not None:
         nblk = bsum.shape[1]
-        arr7 = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
-        check(lib.sg_rowsum_multi(ptr(bsum), arr7, 7, _H, nblk, nblk, stream()), "rowsum_multi")
+        dsts = bouts + ([w8] if extended else [])
+        arr = (ctypes.c_void_p * len(dsts))(*[ptr(t) for t in dsts])
+        check(lib.sg_rowsum_multi(ptr(bsum), arr, None, len(dsts), _H, nblk, nblk, stream()), "rowsum_multi")
     else:
         for layer_dz, out in enumerate(bouts):
             check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
@@ -574,7 +578,15 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
     # (every column of both is written: points / latent columns below or by the caller, the hidden block by the batch)
     w1 = _param_grad_out(ctx_params[0], (_H, kin_total), dev)
     w5 = _param_grad_out(ctx_params[8], (_H, _H + kin_total), dev)
+    if extended:
+        # the three point columns of both: column sums of the kernel's partials, written with the matrices' row strides
+        nblk = bsum.shape[1]
+        cols = (ctypes.c_void_p * 6)(*([ptr(w1) + 4 * c for c in range(3)] + [ptr(w5) + 4 * (_H + c) for c in range(3)]))
+        strides = (ctypes.c_long * 6)(*([kin_total] * 3 + [_H + kin_total] * 3))
+        check(lib.sg_rowsum_multi(ptr(bsum) + 4 * 8 * _H * nblk, cols, strides, 6, _H, nblk, nblk, stream()), "rowsum_multi")
     for rows, off, width in x_parts:
+        if extended and off == 0 and width == 3:
+            continue
         wgrad_from_rows(0, rows, width, w1, off, kin_total)
         wgrad_from_rows(4, rows, width, w5, _H + off, _H + kin_total)
     # the six 256 x 256 x N products dZ_l H_{l-1}^T in ONE launch (+ one finalize): layers2.0's hidden block, then layers
@@ -595,11 +607,12 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
     for i, (pi, (ldz, _)) in enumerate(zip((2, 4, 6, 10, 12), pairs[1:])):
         grads[pi] = hidden[i]
         grads[pi + 1] = bgrad(ldz)
-    # layers2.6: W8 [1,256], b8 [1]
-    w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
-    gemm_raw(dz8, False, acts, True, out=w8, b_off=6 * _H * ldn, M=1, N=_H, K=N, lda=N, ldb=ldn, ldc=_H)
+    # layers2.6: W8 [1,256] (from the partials when extended), b8 [1] (two-stage sum of dz8)
+    if not extended:
+        gemm_raw(dz8, False, acts, True, out=w8, b_off=6 * _H * ldn, M=1, N=_H, K=N, lda=N, ldb=ldn, ldc=_H)
     b8 = _param_grad_out(ctx_params[15], (1,), dev)
-    check(lib.sg_rowsum(ptr(dz8), ptr(b8), 1, N, N, stream()), "rowsum")
+    rws = workspace("reduce", lib.sg_reduce_workspace_bytes(), dev)
+    check(lib.sg_reduce_sum(ptr(dz8), ptr(b8), N, 1.0, ptr(rws), rws.numel(), stream()), "reduce_sum")
     grads[14], grads[15] = w8, b8
     return grads
 
@@ -638,9 +651,9 @@ class SDFNetPoints(Function):
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
         need_p = any(ctx.needs_input_grad[3:])
-        bsum = torch.empty((7 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
-        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(dx), kin, ptr(packed),
-                                kin, N, N, stream()), "sdfnet_bwd")
+        bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
+                                0, ptr(dx), kin, ptr(packed), kin, N, N, stream()), "sdfnet_bwd")
         grads = [None] * 16
         if need_p:
             grads = _sdf_param_grads(params, ctx.needs_input_grad[3:], dz, dz8, acts, N, N,
@@ -698,9 +711,9 @@ class SDFNetShapes(Function):
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         need_p = any(ctx.needs_input_grad[6:])
-        bsum = torch.empty((7 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
-        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(dx), 3, ptr(packed), 3,
-                                N, N, stream()), "sdfnet_bwd")
+        bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
+                                0, ptr(dx), 3, ptr(packed), 3, N, N, stream()), "sdfnet_bwd")
         need_z = ctx.needs_input_grad[2]
         grads = [None] * 16
         gz = None
