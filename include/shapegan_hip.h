@@ -149,8 +149,13 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
                   int latent_size, const float* packed, int kin_used, const float* zb1, const float* zb5,
                   long points_per_shape, const int* shape_index, float* out, float* acts, long ldn, long N,
                   hipStream_t stream);
-long sg_sdfnet_bwd_blocks(long N); /* workgroups of the backward kernel = columns of bias_partials */
-/* bias_partials (optional): [7*256][blocks] per-workgroup row sums of dZ1..dZ7 (sum each row: bias gradients).  With `points`
+/* Point tiles of the backward = columns of bias_partials: tile t covers the points [sg_sdfnet_bwd_tile_start(N, t),
+ * sg_sdfnet_bwd_tile_start(N, t + 1)).  With tiles = ceil(N / 64), full = tiles - tiles % 512, rem = tiles % 512: 64 points per
+ * tile, except that for full > 0 and 0 < 4 rem <= 3 * 512 the points from 64 * full on are cut into 32-point tiles (the last,
+ * partly filled round of workgroups finishes sooner).  A pure function of N: the layout does not depend on the device. */
+long sg_sdfnet_bwd_blocks(long N);
+long sg_sdfnet_bwd_tile_start(long N, long t);
+/* bias_partials (optional): [7*256][blocks] per-tile row sums of dZ1..dZ7 (sum each row: bias gradients).  With `points`
  * (the xyz of the batch, as given to sg_sdfnet_fwd) it is [14*256][blocks]: rows 7*256.. = sum_p dz8[p] H7[row][p] (the
  * layers2.6 weight gradient), rows (8+c)*256.. / (11+c)*256.. = sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns
  * of the layers1.0 / layers2.0 weight gradients) — partial sums the kernel has the operands in registers for, instead of three
@@ -158,6 +163,11 @@ long sg_sdfnet_bwd_blocks(long N); /* workgroups of the backward kernel = column
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
                   long N, hipStream_t stream);
+/* t1[256][nseg], t5[256][nseg]: sums of dZ1 / dZ5 over every segment [seg_off[s], seg_off[s+1]) of points (per-shape sums: the
+ * latent-table gradient and the latent columns of the layers1.0 / layers2.0 weight gradients of the shape-sorted auto-decoder
+ * step, train_sdf_autodecoder.py:80-91 backward), taken from `dz` and the `bias_partials` of the same sg_sdfnet_bwd call. */
+int sg_sdfnet_segsum(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
+                     float* t5, hipStream_t stream);
 
 /* ---- K8/K9/K10/K11: blends, reductions, latent-table rows, optimizers ------------------------------------------
  * reference: fade-in / GP lerp (model/progressive_gan.py:50, train_hybrid_progressive_gan.py:105), batch means
@@ -171,6 +181,17 @@ int sg_reduce_sum(const float* x, float* out, long n, float scale, void* workspa
 int sg_gather_rows(const float* table, const int64_t* idx, float* out, long n, int L, hipStream_t stream);
 int sg_scatter_add_rows(const float* rows, long rows_ld, const int64_t* idx, float* table_grad, long n, int L,
                         hipStream_t stream);
+/* Batch assembly of the auto-decoder step in shape-sorted order (train_sdf_autodecoder.py:78-85: model_indices =
+ * indices // POINTCLOUD_SIZE, points[indices], sdf[indices]) as ONE stable counting sort on the shape id: out_points[n,3] /
+ * out_sdf[n] / out_shape[n] hold the batch grouped by shape (entries of a shape keep their order in `indices`),
+ * seg_off[nshapes+1] bounds every shape's run, counts[nshapes] = run lengths as floats (weights of the latent regulariser).
+ * nshapes <= sg_sdf_batch_sort_max_shapes(); an index outside [0, nshapes*pointcloud_size) — an IndexError in the reference —
+ * sets *bad_index_flag (device int, sticky, caller-zeroed) and is clamped. */
+int sg_sdf_batch_sort_max_shapes(void);
+size_t sg_sdf_batch_sort_workspace_bytes(long n, long nshapes);
+int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points,
+                      const float* sdf, float* out_points, float* out_sdf, int* out_shape, int64_t* seg_off, float* counts,
+                      int* bad_index_flag, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float lr, float alpha, float eps,
                     float grad_scale, float clip, hipStream_t stream);
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,

@@ -190,10 +190,11 @@ struct SdfFwdArgs {
     float* acts;       // optional [7][256][ldn]
     long ldn;
     long N;
+    long nbig;         // workgroups [0, nbig): full tiles; the rest: kSmallTile points each
 };
 
 template <int P, bool SHAPE_BIAS>
-__global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
+__device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long p0) {
     constexpr int NT = P / 32;
     constexpr int LDX = P + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -203,7 +204,6 @@ __global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
-    const long p0 = (long)blockIdx.x * P;
     const int KU = a.lay.KU, KUp = a.lay.KUp;
 
     // ---- stage X = [xyz | latent] feature-major ----
@@ -337,6 +337,22 @@ __global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
     }
 }
 
+// Tile plan (see tile_plan below): workgroups [0, nbig) take P points each, the rest kSmallTile points each.  The small tiles
+// are the remainder of the last round of workgroups: a 200 000-point launch is 6.1 rounds of 128-point tiles on 256 CUs, and
+// the 27 tiles of the seventh round would keep the whole chip waiting for a full tile time; cut into 32-point tiles they
+// finish in about a third of it.  A point's arithmetic does not depend on the tile it is in (same k order), so the plan never
+// changes a result of the forward.
+constexpr int kSmallTile = 32;
+
+template <int P, bool SHAPE_BIAS>
+__global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
+    const long b = blockIdx.x;
+    if (b < a.nbig)
+        sdfnet_fwd_tile<P, SHAPE_BIAS>(a, b * P);
+    else
+        sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+}
+
 struct SdfBwdArgs {
     const float* dout;   // [N]
     const float* out;    // [N] forward output (tanh)
@@ -354,6 +370,7 @@ struct SdfBwdArgs {
     SdfPackLayout lay;
     long ldn;
     long N;
+    long nbig;           // workgroups [0, nbig): P-point tiles; the rest: kSmallTile points each (sg_sdfnet_bwd_tile_start)
 };
 
 // Backward-data chain for one tile of P points.  G[256][P] holds dH_l; the X-gradient tile DX[KUr][P+1]
@@ -361,7 +378,7 @@ struct SdfBwdArgs {
 // P = 64: 64.3 KB of LDS and <= 128 VGPRs, so two workgroups (16 waves) share a CU and one's mask / write-back phases
 // overlap the other's MFMA phases; P = 128 fills the LDS with one workgroup.
 template <int P>
-__global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfBwdArgs a) {
+__device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long p0) {
     constexpr int NT = P / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;            // [256][P]
@@ -370,7 +387,6 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
-    const long p0 = (long)blockIdx.x * P;
     const float4* pk = reinterpret_cast<const float4*>(a.packed);
     const int KUr = a.lay.KUr;
     const int nxt = KUr / 32;  // X row tiles
@@ -560,6 +576,64 @@ __global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfB
     }
 }
 
+template <int P>
+__global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfBwdArgs a) {
+    const long b = blockIdx.x;
+    if (b < a.nbig)
+        sdfnet_bwd_tile<P>(a, b * P);
+    else
+        sdfnet_bwd_tile<kSmallTile>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+}
+
+// t[which][row][s] = sum over the points of segment s of dZ_layer[row][.] (which 0: dZ1, 1: dZ5): the per-shape sums behind
+// the latent-table gradient and the latent columns of dW1 / dW5.  The fused backward has already reduced every row over every
+// tile (bias partials), so a segment costs its interior tiles' partials plus the points of the (at most two) tiles its ends cut:
+// 3 loads per lane instead of a pass over the two [256][N] images.  One wave per (row, segment).
+__global__ void __launch_bounds__(256) sdfnet_segsum_kernel(const float* __restrict__ dz, const float* __restrict__ bsum,
+                                                            long ldn, long nbig, long nblk, const int64_t* __restrict__ off,
+                                                            long S, float* __restrict__ t1, float* __restrict__ t5) {
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (long)kH * S) return;
+    const int layer = blockIdx.y ? 4 : 0;
+    const long row = pair / S, sg = pair - row * S;
+    const long beg = off[sg], end = off[sg + 1];
+    const int lane = threadIdx.x & 63;
+    const long edge = nbig * 64;   // first point of the small tiles
+    // first tile that starts at or after beg / last tile boundary at or before end
+    const long ta = beg <= edge ? (beg + 63) / 64 : nbig + (beg - edge + kSmallTile - 1) / kSmallTile;
+    const long tb = end <= edge ? end / 64 : nbig + (end - edge) / kSmallTile;
+    auto start = [&](long t) { return t <= nbig ? t * 64 : edge + (t - nbig) * kSmallTile; };
+    const float* p = dz + ((long)layer * kH + row) * ldn;
+    float acc = 0.f;
+    if (ta >= tb) {
+        for (long e = beg + lane; e < end; e += 64) acc += p[e];
+    } else {
+        const long head = start(ta), tail = start(tb);
+        for (long e = beg + lane; e < head; e += 64) acc += p[e];
+        const float* q = bsum + ((long)layer * kH + row) * nblk;
+        for (long t = ta + lane; t < tb; t += 64) acc += q[t];
+        for (long e = tail + lane; e < end; e += 64) acc += p[e];
+    }
+    acc = sg_wave_sum(acc);
+    if (lane == 0) (blockIdx.y ? t5 : t1)[pair] = acc;
+}
+
+// `nbig` tiles of P points followed by `nsmall` tiles of kSmallTile points: when the last round of `slots` concurrently resident
+// workgroups would be at most three quarters full, its points are cut into small tiles.  A pure function of N (the slot counts
+// are those of the full 256-CU device, not queried): the partial-sum layout of the backward, and with it the summation order of
+// everything derived from it, is the same on every device and partition mode.
+struct TilePlan {
+    long nbig, nsmall;
+};
+static TilePlan tile_plan(long N, int P, long slots) {
+    const long tiles = (N + P - 1) / P;
+    const long full = tiles / slots * slots, rem = tiles - full;
+    if (full == 0 || rem == 0 || 4 * rem > 3 * slots) return TilePlan{tiles, 0};
+    return TilePlan{full, (N - full * P + kSmallTile - 1) / kSmallTile};
+}
+constexpr long kFwdSlots = 256;   // one workgroup per CU (LDS)
+constexpr long kBwdSlots = 512;   // two per CU
+
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
 
@@ -650,13 +724,17 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
         SG_CHECK_ARG(shape_index || (points_per_shape > 0 && (points_per_shape % 128 == 0 || points_per_shape >= N)));
         const size_t lds = fwd_lds_bytes(128, a.lay.KUp);
         if (set_lds(sdfnet_fwd_kernel<128, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
-        hipLaunchKernelGGL((sdfnet_fwd_kernel<128, true>), dim3((unsigned)((N + 127) / 128)), dim3(512), lds, stream, a);
+        const TilePlan tp = tile_plan(N, 128, kFwdSlots);
+        a.nbig = tp.nbig;
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<128, true>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     } else {
         SG_CHECK_ARG(latent && kin_used == 3 + latent_size);
         const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
         if (lds > 160 * 1024) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_fwd: latent size %d needs %zu B LDS (> 160 KiB)", latent_size, lds);
         if (set_lds(sdfnet_fwd_kernel<64, false>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
-        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false>), dim3((unsigned)((N + 63) / 64)), dim3(512), lds, stream, a);
+        const TilePlan tp = tile_plan(N, 64, kFwdSlots);
+        a.nbig = tp.nbig;
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     }
     SG_CHECK_LAUNCH();
     return SG_OK;
@@ -665,7 +743,15 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
 // Backward-data.  Writes dz8[N], dz[7][256][ldn], (if bias_partials != NULL) the per-workgroup row sums of dZ1..dZ7
 // as [7*256][sg_sdfnet_bwd_blocks(N)] (sum each row for the bias gradients) and (if dx != NULL) the input gradient rows dx[N][dx_ld]
 // (kin_used columns: d/dpoints (3) then d/dlatent (L) in per-point mode, d/dpoints only in per-shape mode).
-long sg_sdfnet_bwd_blocks(long N) { return (N + 63) / 64; }
+long sg_sdfnet_bwd_blocks(long N) {
+    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    return tp.nbig + tp.nsmall;
+}
+long sg_sdfnet_bwd_tile_start(long N, long t) {
+    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    const long p = t <= tp.nbig ? t * 64 : tp.nbig * 64 + (t - tp.nbig) * kSmallTile;
+    return p < N ? p : N;
+}
 
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
@@ -692,8 +778,22 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
     {
         const size_t lds = bwd_lds_bytes(64, a.lay.KUr, dx != nullptr);
         if (set_lds(sdfnet_bwd_kernel<64>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_bwd: cannot reserve %zu B LDS", lds);
-        hipLaunchKernelGGL((sdfnet_bwd_kernel<64>), dim3((unsigned)((N + 63) / 64)), dim3(512), lds, stream, a);
+        const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+        a.nbig = tp.nbig;
+        hipLaunchKernelGGL((sdfnet_bwd_kernel<64>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Per-segment sums of dZ1 and dZ5 (t1, t5: [256][nseg]) from the images and the tile partials of the same sg_sdfnet_bwd call
+// (bias_partials as written there: rows [0, 7*256) x sg_sdfnet_bwd_blocks(N) columns).
+int sg_sdfnet_segsum(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
+                     float* t5, hipStream_t stream) {
+    SG_CHECK_ARG(dz && bias_partials && seg_off && t1 && t5 && N > 0 && ldn >= N && nseg > 0);
+    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    hipLaunchKernelGGL(sdfnet_segsum_kernel, dim3((unsigned)(((long)kH * nseg + 3) / 4), 2), dim3(256), 0, stream, dz,
+                       bias_partials, ldn, tp.nbig, tp.nbig + tp.nsmall, seg_off, nseg, t1, t5);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

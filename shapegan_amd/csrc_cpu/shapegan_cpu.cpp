@@ -506,6 +506,28 @@ static inline void dense_t(const float* W, int K, const float* dz, float* dh, bo
         for (int k = 0; k < K; ++k) dh[k] += w[k] * g;
     }
 }
+// the header's tile layout of the backward partials (sg_sdfnet_bwd_blocks / sg_sdfnet_bwd_tile_start)
+static void sdf_bwd_plan(long N, long& nbig, long& nsmall) {
+    const long tiles = (N + 63) / 64, rem = tiles % 512, full = tiles - rem;
+    if (full == 0 || rem == 0 || 4 * rem > 3 * 512) {
+        nbig = tiles;
+        nsmall = 0;
+    } else {
+        nbig = full;
+        nsmall = (N - full * 64 + 31) / 32;
+    }
+}
+static long sdf_bwd_tiles(long N) {
+    long nbig, nsmall;
+    sdf_bwd_plan(N, nbig, nsmall);
+    return nbig + nsmall;
+}
+static long sdf_bwd_tile_start(long N, long t) {
+    long nbig, nsmall;
+    sdf_bwd_plan(N, nbig, nsmall);
+    const long p = t <= nbig ? t * 64 : nbig * 64 + (t - nbig) * 32;
+    return p < N ? p : N;
+}
 int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                       const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used,
                       long ldn, long N, void*) {
@@ -538,27 +560,46 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
         }
     }
     if (bias_partials) {
-        const long nblk = (N + 63) / 64;   // == sg_sdfnet_bwd_blocks(N)
+        const long nblk = sdf_bwd_tiles(N);
         const long nrows = points ? 14 * 256 : 7 * 256;
 #pragma omp parallel for schedule(static)
         for (long r = 0; r < nrows; ++r) {
-            double s = 0;
-            if (r < 7 * 256) {
-                for (long p = 0; p < N; ++p) s += dz[r * ldn + p];
-            } else if (r < 8 * 256) {                                   // w8 gradient: sum_p dz8[p] H7[row][p]
-                const long row = r - 7 * 256;
-                for (long p = 0; p < N; ++p) s += (double)dz8[p] * acts[(6L * 256 + row) * ldn + p];
-            } else {                                                    // point columns of dW1 (dZ1) / dW5 (dZ5)
-                const long q = r - 8 * 256, blk = q / (3 * 256), c = (q / 256) % 3, row = q % 256;
-                const long layer = blk == 0 ? 0 : 4;
-                for (long p = 0; p < N; ++p) {
-                    const long pi = points_period > 0 ? p % points_period : p;
-                    s += (double)dz[(layer * 256 + row) * ldn + p] * points[pi * 3 + c];
+            for (long t = 0; t < nblk; ++t) {
+                const long p0 = sdf_bwd_tile_start(N, t), p1 = sdf_bwd_tile_start(N, t + 1);
+                double s = 0;
+                if (r < 7 * 256) {
+                    for (long p = p0; p < p1; ++p) s += dz[r * ldn + p];
+                } else if (r < 8 * 256) {                                   // w8 gradient: sum_p dz8[p] H7[row][p]
+                    const long row = r - 7 * 256;
+                    for (long p = p0; p < p1; ++p) s += (double)dz8[p] * acts[(6L * 256 + row) * ldn + p];
+                } else {                                                    // point columns of dW1 (dZ1) / dW5 (dZ5)
+                    const long q = r - 8 * 256, blk = q / (3 * 256), c = (q / 256) % 3, row = q % 256;
+                    const long layer = blk == 0 ? 0 : 4;
+                    for (long p = p0; p < p1; ++p) {
+                        const long pi = points_period > 0 ? p % points_period : p;
+                        s += (double)dz[(layer * 256 + row) * ldn + p] * points[pi * 3 + c];
+                    }
                 }
+                bias_partials[r * nblk + t] = (float)s;
             }
-            bias_partials[r * nblk] = (float)s;
-            for (long c2 = 1; c2 < nblk; ++c2) bias_partials[r * nblk + c2] = 0.f;
         }
+    }
+    return SG_OK;
+}
+// per-segment sums of dZ1 / dZ5 (header: sg_sdfnet_segsum), straight from the images
+int sg_sdfnet_segsum_cpu(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
+                         float* t5, void*) {
+    CPU_CHECK(dz && bias_partials && seg_off && t1 && t5 && N > 0 && ldn >= N && nseg > 0);
+#pragma omp parallel for schedule(static)
+    for (long pair = 0; pair < 256 * nseg; ++pair) {
+        const long row = pair / nseg, sgm = pair % nseg;
+        double a = 0, b = 0;
+        for (long e = seg_off[sgm]; e < seg_off[sgm + 1]; ++e) {
+            a += dz[row * ldn + e];
+            b += dz[(4L * 256 + row) * ldn + e];
+        }
+        t1[pair] = (float)a;
+        t5[pair] = (float)b;
     }
     return SG_OK;
 }
@@ -586,6 +627,35 @@ int sg_scatter_add_rows_cpu(const float* rows, long rows_ld, const int64_t* idx,
     CPU_CHECK(rows && idx && table_grad && n > 0 && L > 0 && rows_ld >= L);
     for (long i = 0; i < n; ++i)
         for (int k = 0; k < L; ++k) table_grad[idx[i] * L + k] += rows[i * rows_ld + k];
+    return SG_OK;
+}
+// stable counting sort of the batch on the shape id (header: sg_sdf_batch_sort)
+int sg_sdf_batch_sort_cpu(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points, const float* sdf,
+                          float* out_points, float* out_sdf, int* out_shape, int64_t* seg_off, float* counts, int* bad_index_flag,
+                          void*, size_t, void*) {
+    CPU_CHECK(indices && points && sdf && out_points && out_sdf && out_shape && seg_off && counts && bad_index_flag);
+    CPU_CHECK(n > 0 && pointcloud_size > 0 && nshapes > 0);
+    std::vector<int64_t> next(nshapes + 1, 0);
+    auto shape_of = [&](int64_t i) {
+        int64_t k = i >= 0 ? i / pointcloud_size : -1;
+        if (k < 0 || k >= nshapes) {
+            *bad_index_flag = 1;
+            k = k < 0 ? 0 : nshapes - 1;
+        }
+        return k;
+    };
+    for (long e = 0; e < n; ++e) next[shape_of(indices[e]) + 1] += 1;
+    for (long s = 0; s < nshapes; ++s) {
+        counts[s] = (float)next[s + 1];
+        next[s + 1] += next[s];
+    }
+    for (long s = 0; s <= nshapes; ++s) seg_off[s] = next[s];
+    for (long e = 0; e < n; ++e) {
+        const int64_t i = indices[e], k = shape_of(i), p = next[k]++;
+        memcpy(out_points + p * 3, points + i * 3, 3 * sizeof(float));
+        out_sdf[p] = sdf[i];
+        out_shape[p] = (int)k;
+    }
     return SG_OK;
 }
 int sg_rmsprop_step_cpu(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale, float clip, void*) {

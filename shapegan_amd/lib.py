@@ -53,12 +53,17 @@ SIGNATURES = {
     "sg_sdfnet_pack": (c_int, [_P, _I, _I, _P, _P]),
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
+    "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
+    "sg_sdfnet_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _P]),
     "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
     "sg_axpby": (c_int, [_P, _P, _P, _L, _F, _F, _P]),
     "sg_reduce_workspace_bytes": (_Z, []),
     "sg_reduce_sum": (c_int, [_P, _P, _L, _F, _P, _Z, _P]),
     "sg_gather_rows": (c_int, [_P, _P, _P, _L, _I, _P]),
     "sg_scatter_add_rows": (c_int, [_P, _L, _P, _P, _L, _I, _P]),
+    "sg_sdf_batch_sort_max_shapes": (c_int, []),
+    "sg_sdf_batch_sort_workspace_bytes": (_Z, [_L, _L]),
+    "sg_sdf_batch_sort": (c_int, [_P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "sg_rmsprop_step": (c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "sg_adam_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P]),
     "sg_adam_step_dev": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P]),
@@ -135,7 +140,7 @@ def check_comm(rc, what=""):
 # Entry points WITHOUT a twin: size queries and layout helpers are host code of libshapegan_hip.so (callable without a GPU; the
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
-    "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks"}
+    "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes"}
 CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
 
 _hip = None

@@ -724,6 +724,10 @@ class SDFNetShapes(Function):
             if ctx.seg_off is None:
                 check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
                 check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
+            elif bsum is not None:
+                # interior tiles of a segment come from the backward's own per-tile partials: no pass over the images
+                check(lib.sg_sdfnet_segsum(ptr(dz), ptr(bsum), N, N, ptr(ctx.seg_off), S, ptr(t1), ptr(t5), stream()),
+                      "sdfnet_segsum")
             else:
                 check(lib.sg_segsum(ptr(dz), ptr(t1), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
                 check(lib.sg_segsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
@@ -801,6 +805,51 @@ class GatherRows(Function):
 
 def gather_rows(table, idx):
     return GatherRows.apply(table, idx)
+
+
+_bad_index_flags = {}
+
+
+def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf):
+    """The auto-decoder batch grouped by shape in one stable counting sort (train_sdf_autodecoder.py:78-85): returns
+    points[indices] ([N,3]), sdf[indices] ([N]), the shape id of every entry (int32 [N]), the run bounds of every shape
+    (int64 [shapes+1]) and the run lengths (float32 [shapes]) — all in shape order; no host synchronisation.  An index
+    outside the tables raises at the next `check_batch_indices()` (the reference raises an IndexError)."""
+    lib = _lib()
+    if shapes > sdf_batch_sort_max_shapes():
+        raise RuntimeError("sdf_batch_sort: %d shapes (at most %d)" % (shapes, sdf_batch_sort_max_shapes()))
+    if indices.dtype != torch.int64 or not indices.is_contiguous():
+        indices = indices.to(torch.int64).contiguous()
+    points, sdf = f32c(points), f32c(sdf)
+    if points.shape[0] != sdf.shape[0] or points.shape[0] < shapes * pointcloud_size:
+        raise RuntimeError("sdf_batch_sort: tables hold %d / %d rows, need %d" % (points.shape[0], sdf.shape[0],
+                                                                                  shapes * pointcloud_size))
+    dev, n = points.device, indices.numel()
+    out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    out_shape = torch.empty(n, dtype=torch.int32, device=dev)
+    seg_off = torch.empty(shapes + 1, dtype=torch.int64, device=dev)
+    counts = torch.empty(shapes, dtype=torch.float32, device=dev)
+    flag = _bad_index_flags.get(dev)
+    if flag is None:
+        flag = _bad_index_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = workspace("sdf_batch_sort", lib.sg_sdf_batch_sort_workspace_bytes(n, shapes), dev)
+    check(lib.sg_sdf_batch_sort(ptr(indices), n, pointcloud_size, shapes, ptr(points), ptr(sdf), ptr(out_points), ptr(out_sdf),
+                                ptr(out_shape), ptr(seg_off), ptr(counts), ptr(flag), ptr(ws), ws.numel(), stream()),
+          "sdf_batch_sort")
+    return out_points, out_sdf, out_shape, seg_off, counts
+
+
+def sdf_batch_sort_max_shapes():
+    return L.load().sg_sdf_batch_sort_max_shapes()
+
+
+def check_batch_indices():
+    """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables."""
+    for dev, flag in _bad_index_flags.items():
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -199,27 +199,23 @@ class SDFAutoDecoderTrainer(object):
         and the latent-table gradient is assembled from per-shape sums, so `latent_codes[model_indices]` ([N,L]) and
         its scatter-add backward never exist.  The regulariser mean(z_batch^2) is evaluated through shape counts:
         sum_s count_s |z_s|^2 / (N L)."""
-        if indices.numel() < 65536:   # small batches: the sort / count bookkeeping costs more than it saves
+        # small batches: the per-shape bookkeeping costs more than it saves
+        if indices.numel() < 65536 or self.latent_codes.shape[0] > ops.sdf_batch_sort_max_shapes():
             return self.step_gathered(indices)
         return self.step_sorted(indices)
 
     def step_sorted(self, indices):
-        """The shape-sorted data flow described in `step`."""
-        model_indices = torch.div(indices, self.pointcloud_size, rounding_mode='floor')
-        order = torch.argsort(model_indices)
-        indices, model_indices = indices[order], model_indices[order]
+        """The shape-sorted data flow described in `step`: the batch is grouped by one native counting sort
+        (ops.sdf_batch_sort: keys, gathers of points / sdf, run bounds and counts; no host round trip)."""
         shapes = self.latent_codes.shape[0]
-        counts = torch.bincount(model_indices, minlength=shapes)
-        seg_off = torch.zeros(shapes + 1, dtype=torch.int64, device=indices.device)
-        seg_off[1:] = torch.cumsum(counts, 0)
+        batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
+            indices, self.pointcloud_size, shapes, self.points, self.sdf)
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
-        batch_points = ops.gather_rows(self.points, indices)
-        batch_sdf = ops.gather_rows(self.sdf.unsqueeze(1), indices).squeeze(1)
-        output = self.net.forward_segments(batch_points, self.latent_codes, model_indices.int(), seg_off)
+        output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
         n, width = indices.shape[0], self.latent_codes.shape[1]
         # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator
-        reg = ops.mean_sq(self.latent_codes, counts.to(torch.float32), n * width / self.sigma)
+        reg = ops.mean_sq(self.latent_codes, counts, n * width / self.sigma)
         loss = ops.weighted_l1(output, batch_sdf) + reg
         loss.backward()
         self.net_bucket.allreduce()

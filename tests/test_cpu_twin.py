@@ -42,7 +42,7 @@ def test_twin_exports_every_entry_point():
         assert hasattr(lib, n + "_cpu"), "missing twin: " + n
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
-            "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks")
+            "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes")
 
 
 def test_dispatch_is_by_tensor_device_only(on_cpu):
@@ -107,9 +107,14 @@ def test_sdfnet_shapes(on_cpu, S, pps):
     OPS.test_sdfnet_shapes_mode(S, pps)
 
 
-@pytest.mark.parametrize("S,N", [(5, 700), (3, 64)])
+@pytest.mark.parametrize("S,N", [(5, 700), (3, 64), (7, 33100)])   # 33100: 512 tiles of 64 + 11 of 32 in the partial-sum layout
 def test_sdfnet_segments(on_cpu, S, N):
     OPS.test_sdfnet_segments_mode(S, N)
+
+
+@pytest.mark.parametrize("S,pc,N", [(64, 200, 20000), (5, 40, 700), (300, 7, 1000), (4097, 3, 9000)])
+def test_sdf_batch_sort(on_cpu, S, pc, N):
+    OPS.test_sdf_batch_sort(S, pc, N)
 
 
 def test_layernorm_segmax_colsum(on_cpu):

@@ -298,7 +298,8 @@ def _sdf_state(seed, latent=128):
     return SDFNet(latent_code_size=latent)
 
 
-@pytest.mark.parametrize("N,latent", [(1, 128), (63, 128), (64, 128), (1000, 128), (20000, 128), (777, 256), (130, 16)])
+@pytest.mark.parametrize("N,latent", [(1, 128), (63, 128), (64, 128), (1000, 128), (20000, 128), (777, 256), (130, 16),
+                                      (33100, 32)])   # 33100: the backward's last round is cut into 32-point tiles
 def test_sdfnet_points_mode(N, latent):
     net = _sdf_state(8, latent)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -406,7 +407,7 @@ def test_conv_dgrad_halo_kernel(N, Ci, Co, O):
             close(got, ref, what="dgrad halo, %d parities per workgroup" % ppw)
 
 
-@pytest.mark.parametrize("S,N", [(5, 700), (64, 20000), (3, 129), (300, 1000)])
+@pytest.mark.parametrize("S,N", [(5, 700), (64, 20000), (3, 129), (300, 1000), (7, 33100)])
 def test_sdfnet_segments_mode(S, N):
     """Ragged per-shape latents (auto-decoder batches sorted by shape) == reference forward on gathered latents,
     including the dense latent-table gradient and shapes that receive no point at all."""
@@ -435,6 +436,36 @@ def test_sdfnet_segments_mode(S, N):
     close(tg.grad, tr.grad, rtol=2e-4, what="d latent table")
     for k, p in net.named_parameters():
         close(p.grad, P[k].grad, rtol=2e-4, what="grad " + k)
+
+
+@pytest.mark.parametrize("S,pc,N", [(64, 2000, 200000), (5, 40, 700), (3, 1000, 1), (300, 7, 1000), (1, 513, 1025),
+                                    (4097, 3, 9000)])
+def test_sdf_batch_sort(S, pc, N):
+    """The one-pass batch assembly == a stable sort of the batch on indices // pointcloud_size followed by the reference's
+    gathers (train_sdf_autodecoder.py:78-85); bit-exact, including shapes that receive no entry."""
+    from shapegan_amd import ops
+    torch.manual_seed(S + N)
+    points = torch.rand(S * pc, 3) * 2 - 1
+    sdf = torch.rand(S * pc) * 0.2 - 0.1
+    idx = torch.randint(0, S * pc, (N,))
+    if S == 300:
+        idx = (torch.randint(0, S // 2, (N,)) * 2) * pc + torch.randint(0, pc, (N,))      # odd shapes are absent
+    shape = torch.div(idx, pc, rounding_mode="floor")
+    order = torch.sort(shape, stable=True)[1]
+    bp, bs, sid, seg_off, counts = ops.sdf_batch_sort(dev(idx), pc, S, dev(points), dev(sdf))
+    assert torch.equal(bp.cpu(), points[idx[order]])
+    assert torch.equal(bs.cpu(), sdf[idx[order]])
+    assert sid.dtype == torch.int32 and torch.equal(sid.cpu().long(), shape[order])
+    cnt = torch.bincount(shape, minlength=S)
+    assert torch.equal(counts.cpu(), cnt.float())
+    assert seg_off.dtype == torch.int64 and torch.equal(seg_off.cpu()[1:], torch.cumsum(cnt, 0)) and int(seg_off[0]) == 0
+    ops.check_batch_indices()
+    bad = idx.clone()
+    bad[N // 2] = S * pc + 5
+    ops.sdf_batch_sort(dev(bad), pc, S, dev(points), dev(sdf))
+    with pytest.raises(IndexError):
+        ops.check_batch_indices()
+    ops.check_batch_indices()          # the flag was cleared
 
 
 @pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 3, 32, 8), (3, 16, 40, 8), (1, 8, 160, 16), (5, 2, 64, 8),

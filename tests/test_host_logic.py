@@ -268,3 +268,24 @@ def test_point_dataset_matches_reference(tmp_path):
     got = [ours[i] for i in (2, 0, 1)]
     for a, b in zip(want, got):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and b[0].shape == (64, 4)
+
+
+def test_sdfnet_backward_tile_layout_is_the_documented_function_of_n():
+    """include/shapegan_hip.h: 64-point tiles; when the last round of 512 tiles would be at most 3/4 full (and is not the
+    only round) its points are cut into 32-point tiles.  Host code of the library, callable without a GPU."""
+    lib = L.load()
+    for n in (1, 63, 64, 65, 20000, 32768, 32769, 33100, 200000, 57344, 57345, 65536, 262144, 1000003):
+        tiles = (n + 63) // 64
+        rem = tiles % 512
+        full = tiles - rem
+        if full == 0 or rem == 0 or 4 * rem > 3 * 512:
+            starts = [min(64 * t, n) for t in range(tiles + 1)]
+        else:
+            small = (n - 64 * full + 31) // 32
+            starts = [64 * t for t in range(full)] + [min(64 * full + 32 * t, n) for t in range(small + 1)]
+        blocks = lib.sg_sdfnet_bwd_blocks(n)
+        assert blocks == len(starts) - 1, n
+        probe = sorted(set(list(range(min(blocks + 1, 5))) + list(range(max(0, blocks - 40), blocks + 1)) + [blocks // 2]))
+        for t in probe:
+            assert lib.sg_sdfnet_bwd_tile_start(n, t) == starts[t], (n, t)
+        assert starts[-1] == n and all(b > a for a, b in zip(starts, starts[1:]))
