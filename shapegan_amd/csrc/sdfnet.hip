@@ -16,7 +16,7 @@
 // Two input modes:
 //   per-point latent (P=64):  X[3+L][P] is staged in LDS next to H; layers 1 and 5 run K over X as well
 //                             (reference semantics for arbitrary latent_codes[N,L], train_sdf_autodecoder.py:80-87)
-//   per-shape latent (P=128): every point of a shape shares z_s (hybrid GANs sample a fixed grid per shape,
+//   per-shape latent (P=64):  every point of a shape shares z_s (hybrid GANs sample a fixed grid per shape,
 //                             train_hybrid_wgan.py:67-72, train_hybrid_progressive_gan.py:90-96) - the latent
 //                             columns of layers 1 and 5 fold into per-shape bias vectors zb1/zb5 (a [S,L]x[L,256]
 //                             GEMM), the [N,L] tiling (2.15 GB at 64^3, B=16) is never materialised.
@@ -26,6 +26,14 @@
 // writes dZ1..dZ7 for the weight-gradient GEMMs (gemm.hip, split-K over points) and the input gradient.
 #include "common.h"
 #include "../../include/shapegan_hip.h"
+
+// tuning switches (scripts/ab_build.sh builds variants; the defaults are the product)
+#ifndef SG_BWD_RING
+#define SG_BWD_RING 4
+#endif
+#ifndef SG_BWD_TILE
+#define SG_BWD_TILE 64
+#endif
 
 namespace sg {
 
@@ -172,6 +180,64 @@ __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __rest
         if (sq + u < nsq) group(ar[u], sq + u);
 }
 
+// The same GEMM with the weight ring as caller-visible state, for the 256-wide layers that follow one another:
+//   * wring_start() issues the first RING weight loads of a layer.  The caller does that BEFORE the stores of the previous
+//     layer's epilogue: vmcnt retires in order, so a ring started after the 32 - 64 activation stores of an epilogue makes the
+//     first MFMA of the next layer wait for every one of those stores to be acknowledged by memory;
+//   * hook() runs once, right after the LAST weight load of the layer has been issued (RING groups before the end): loads the
+//     caller wants to have arrived by the end of the GEMM (the backward's ReLU-mask operand) go there — issued earlier they
+//     would sit in front of the remaining weight loads in the in-order return queue and stall the MFMAs for a full memory
+//     latency, issued later their latency is exposed in the epilogue.
+template <int RING>
+struct WRing {
+    __amdgpu_buffer_rsrc_t res;
+    float4 ar[RING];
+};
+template <int RING>
+__device__ __forceinline__ void wring_start(WRing<RING>& w, const float4* __restrict__ wp, int lane) {
+    const unsigned long long wq = (unsigned long long)wp;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wq), hi = __builtin_amdgcn_readfirstlane((unsigned)(wq >> 32));
+    w.res = make_rsrc((const void*)(((unsigned long long)hi << 32) | lo));
+#pragma unroll
+    for (int u = 0; u < RING; ++u) w.ar[u] = buf_load4(w.res, lane * 16u, (unsigned)u * 1024u);
+}
+template <int NT, int RING, int NSQ, class Hook>
+__device__ __forceinline__ void mlp_gemm_ring(f32x16 (&acc)[NT], WRing<RING>& w, const float* __restrict__ Bs, int ld, int lane,
+                                              Hook hook) {
+    static_assert(NSQ >= 2 * RING, "ring deeper than the GEMM");
+    const int r = lane & 31, kh = lane >> 5;
+    const unsigned wvoff = lane * 16;
+    const lds_float* bp = (const lds_float*)Bs + kh * ld + r;
+    float b[4][NT], bn[4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[j][t] = bp[j * 2 * ld + t * 32];
+#pragma unroll
+    for (int sq = 0; sq < NSQ; ++sq) {
+        const float4 a = w.ar[sq % RING];
+        if (sq + RING < NSQ) w.ar[sq % RING] = buf_load4(w.res, wvoff, (unsigned)(sq + RING) * 1024u);
+        if (sq + RING == NSQ) hook();
+        const lds_float* nb = bp + (sq + 1 < NSQ ? 8 * ld : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[j][t] = nb[j * 2 * ld + t * 32];
+        bp = nb;
+        __builtin_amdgcn_sched_barrier(0);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[j][t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[j][t] = bn[j][t];
+    }
+}
+
 __device__ __forceinline__ int frag_row(int q, int kh) { return (q & 3) + 8 * (q >> 2) + 4 * kh; }
 
 struct SdfFwdArgs {
@@ -266,8 +332,18 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
             for (int q = 0; q < 16; ++q) acc[t][q] = b[frag_row(q, kh)];
         }
     };
+    // training: H_l also goes to `acts` — buffer stores from a scalar base (this wave's row block at the tile's first point),
+    // lane offset = (4 kh) rows + point, fragment row in the scalar offset; lanes beyond N carry an out-of-range offset (dropped
+    // by the hardware), so the epilogue has neither 64-bit address arithmetic nor exec-mask branches
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 32;
+    unsigned astore[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        astore[t] = p0 + t * 32 + r < a.N ? (unsigned)((4L * kh * a.ldn + t * 32 + r) * 4) : kBufOutside;
     auto writeback = [&](int layer) {  // H <- relu(acc); optionally save
         __syncthreads();
+        const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.acts + ((long)layer * kH + wrow) * a.ldn + p0);
+        const bool save = a.acts != nullptr;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wave * 32 + frag_row(q, kh);
@@ -275,10 +351,9 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
             for (int t = 0; t < NT; ++t) {
                 const float v = fmaxf(acc[t][q], 0.f);
                 Hs[row * P + t * 32 + r] = v;
-                if (a.acts) {
-                    const long gp = p0 + t * 32 + r;
-                    if (gp < a.N) a.acts[((long)layer * kH + row) * a.ldn + gp] = v;
-                }
+                if (save)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ares, (int)astore[t],
+                                                          (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
             }
         }
         __syncthreads();
@@ -291,13 +366,23 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     else
         init_acc(SHAPE_BIAS ? a.zb1 + shape * kH : bias);
     mlp_gemm<NT>(acc, wtile(a.lay.F1, KUp / 8), KUp / 8, Xs, LDX, lane);
+    // the weight ring of the next 256-wide layer is started before each write-back (its stores would otherwise sit in front of
+    // the first weight loads in the in-order return queue, see WRing)
+    WRing<4> wr;
+    auto noop = []() {};
+    auto next_ring = [&](long off) __attribute__((always_inline)) {
+        wring_start(wr, wtile(off, kH / 8), lane);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    next_ring(a.lay.F2);
     writeback(0);
     // layers 2..4
-    const long Fm[3] = {a.lay.F2, a.lay.F3, a.lay.F4};
+    const long Fnext[3] = {a.lay.F3, a.lay.F4, a.lay.F5x};
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         init_acc(bias + (l + 1) * kH);
-        mlp_gemm<NT>(acc, wtile(Fm[l], kH / 8), kH / 8, Hs, P, lane);
+        mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+        next_ring(Fnext[l]);
         writeback(l + 1);
     }
     // layer 5: K over H (256) then X (skip connection, model/sdf_net.py:59)
@@ -305,17 +390,18 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
         init_acc_sid(a.zb5);
     else
         init_acc(SHAPE_BIAS ? a.zb5 + shape * kH : bias + 4 * kH);
-    mlp_gemm<NT>(acc, wtile(a.lay.F5x, kH / 8), kH / 8, Hs, P, lane);
+    mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     mlp_gemm<NT>(acc, wtile(a.lay.F5i, KUp / 8), KUp / 8, Xs, LDX, lane);
+    next_ring(a.lay.F6);
     writeback(4);
     // layers 6, 7
-    const long Fn[2] = {a.lay.F6, a.lay.F7};
-#pragma unroll 1
-    for (int l = 0; l < 2; ++l) {
-        init_acc(bias + (5 + l) * kH);
-        mlp_gemm<NT>(acc, wtile(Fn[l], kH / 8), kH / 8, Hs, P, lane);
-        writeback(5 + l);
-    }
+    init_acc(bias + 5 * kH);
+    mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+    next_ring(a.lay.F7);
+    writeback(5);
+    init_acc(bias + 6 * kH);
+    mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+    writeback(6);
     // layer 8: 256 -> 1, tanh.  512/P partial dot products per point, reduced through LDS.
     {
         constexpr int PARTS = 512 / P;
@@ -338,7 +424,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 }
 
 // Tile plan (see tile_plan below): workgroups [0, nbig) take P points each, the rest kSmallTile points each.  The small tiles
-// are the remainder of the last round of workgroups: a 200 000-point launch is 6.1 rounds of 128-point tiles on 256 CUs, and
+// are the remainder of the last round of workgroups: a 200 000-point launch is 6.1 rounds of 64-point tiles on 2 x 256 workgroup slots, and
 // the 27 tiles of the seventh round would keep the whole chip waiting for a full tile time; cut into 32-point tiles they
 // finish in about a third of it.  A point's arithmetic does not depend on the tile it is in (same k order), so the plan never
 // changes a result of the forward.
@@ -371,6 +457,7 @@ struct SdfBwdArgs {
     long ldn;
     long N;
     long nbig;           // workgroups [0, nbig): P-point tiles; the rest: kSmallTile points each (sg_sdfnet_bwd_tile_start)
+    long nblk;           // all workgroups = columns of bsum
 };
 
 // Backward-data chain for one tile of P points.  G[256][P] holds dH_l; the X-gradient tile DX[KUr][P+1]
@@ -422,39 +509,71 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     // t*32 + r).  The ReLU mask, the dZ_l write-back and the bias-gradient partial sums happen right there in the GEMM
     // epilogue: H_l is prefetched in the same layout while the GEMM runs (one lane offset + scalar offsets: buffer loads),
     // so there is no separate pass over the LDS tile and its HBM latency is off the critical path.
-    const long lane_el = ((long)wave * 32 + 4 * kh) * a.ldn + p0 + r;   // element of (q = 0, t = 0) inside a layer image
-    const bool big = lane_el * 4 + 31L * a.ldn * 4 + 128 >= (1L << 31);  // (never at the supported sizes; keeps offsets 32-bit)
-    const unsigned hvoff = big ? 0u : (unsigned)(lane_el * 4);
+    // Addressing: the resource base of a layer image is the wave's own row block at the tile's first point (a scalar), the lane
+    // adds (4 kh) rows + its point, the fragment row goes into the scalar offset: lane offset + scalar offset < 124 ldn + 256
+    // bytes, inside the 2 GiB window for up to 16 M points per call (checked by the host).
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 32;
     bool pok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) pok[t] = p0 + t * 32 + r < a.N;
+    const unsigned khoff = (unsigned)(4L * kh * a.ldn * 4);
     // Loads of H_l for points beyond N (the ragged last tile) are redirected to the tile's first point: their values are
     // masked out below, but the ADDRESS must stay inside the tensor — an image that ends at the end of a mapped segment put the
     // stray reads on an unmapped page, and the faulting wave then retried forever (seen as a hang that depended on where the
-    // caching allocator happened to place `acts`).
-    unsigned hload[NT];
+    // caching allocator happened to place `acts`).  Stores of such lanes get an out-of-range offset: the hardware drops them,
+    // so the epilogue has no exec-mask branches.
+    unsigned hload[NT], zstore[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) hload[t] = pok[t] ? hvoff + t * 128u : (unsigned)((((long)wave * 32 + 4 * kh) * a.ldn + p0) * 4);
+    for (int t = 0; t < NT; ++t) {
+        hload[t] = pok[t] ? khoff + (unsigned)(t * 32 + r) * 4u : khoff;
+        zstore[t] = pok[t] ? khoff + (unsigned)(t * 32 + r) * 4u : kBufOutside;
+    }
+    auto layer_rsrc = [&](const float* image, int layer) __attribute__((always_inline)) {
+        return make_rsrc(image + ((long)layer * kH + wrow) * a.ldn + p0);
+    };
     float hf[16][NT];
     auto load_h = [&](int layer) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t hres = make_rsrc(a.acts + (long)layer * kH * a.ldn);
+        const __amdgpu_buffer_rsrc_t hres = layer_rsrc(a.acts, layer);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
+#ifdef SG_ABL_NOLOAD
+                hf[q][t] = 1.f;
+#else
                 hf[q][t] = buf_load(hres, hload[t], (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4));
+#endif
+    };
+    // Row sums over the 32 points a half-wave holds, on the VALU's DPP path (quad swaps, half-row mirror, row mirror, then
+    // lane 15 of the even rows broadcast into the odd rows): no LDS traffic and no dependent ds_bpermute round trips, so the 16
+    // rows of an epilogue pipeline freely.  Lanes 16..31 / 48..63 end up with the totals of lanes 0..31 / 32..63; lanes 31 and 63
+    // store (every other lane carries an out-of-range offset).
+    auto dpp_add = [&](float v, auto ctrl, auto rowmask) __attribute__((always_inline)) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                         decltype(rowmask)::value, 0xf, false));
+    };
+    auto half_sum = [&](float v) __attribute__((always_inline)) {
+        v = dpp_add(v, IntTag<0xB1>(), IntTag<0xf>());    // quad_perm [1,0,3,2]
+        v = dpp_add(v, IntTag<0x4E>(), IntTag<0xf>());    // quad_perm [2,3,0,1]
+        v = dpp_add(v, IntTag<0x141>(), IntTag<0xf>());   // row_half_mirror
+        v = dpp_add(v, IntTag<0x140>(), IntTag<0xf>());   // row_mirror
+        return dpp_add(v, IntTag<0x142>(), IntTag<0xa>());   // row_bcast15 into rows 1 and 3
+    };
+    const unsigned bsoff = r == 31 ? (unsigned)((4L * kh * a.nblk + blockIdx.x) * 4) : kBufOutside;
+    // partial-sum block `blk` (0..6: dZ1..dZ7, 7: w8, 8..10 / 11..13: point columns): [256][nblk], this wave's rows from wrow
+    auto partial_rsrc = [&](int blk) __attribute__((always_inline)) {
+        return make_rsrc(a.bsum + ((long)blk * kH + wrow) * a.nblk);
+    };
+    auto row_partial = [&](float v, __amdgpu_buffer_rsrc_t res, int q) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(v)), res, (int)bsoff,
+                                              (int)(((q & 3) + 8 * (q >> 2)) * a.nblk * 4), 0);
     };
     // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
-    // half-wave sum (the 32 lanes of a half-wave hold the P points of one row); lane r == 0 stores
-    auto row_partial = [&](float v, int prow) __attribute__((always_inline)) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (r == 0) a.bsum[(long)prow * gridDim.x + blockIdx.x] = v;
-    };
     // XC: -1, or the block of extended partial rows (8: dW1 point columns, 11: dW5 point columns) this layer feeds
     auto mask_store = [&](int layer, auto xtag) __attribute__((always_inline)) {
         constexpr int XC = decltype(xtag)::value;
-        const __amdgpu_buffer_rsrc_t zres = make_rsrc(a.dz + (long)layer * kH * a.ldn);
+        const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, layer);
+        const __amdgpu_buffer_rsrc_t bres = partial_rsrc(a.bsum ? layer : 0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wave * 32 + frag_row(q, kh);
@@ -463,12 +582,13 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
             for (int t = 0; t < NT; ++t) {
                 const float g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
                 Gs[row * P + t * 32 + r] = g;
-                if (pok[t])
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)hvoff,
-                                                          (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4 + t * 128), 0);
+#ifndef SG_ABL_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[t],
+                                                      (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
+#endif
                 rs += g;
             }
-            if (a.bsum) row_partial(rs, layer * kH + row);
+            if (a.bsum) row_partial(rs, bres, q);
         }
         if (XC >= 0 && ext) {
             // point columns: a second, short pass over the rows this wave has just written to LDS (same wave, LDS operations
@@ -478,6 +598,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xv[c][t] = xs[c * P + t * 32 + r];
+            const __amdgpu_buffer_rsrc_t xres[3] = {partial_rsrc(XC), partial_rsrc(XC + 1), partial_rsrc(XC + 2)};
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = wave * 32 + frag_row(q, kh);
@@ -489,7 +610,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
                     float v = 0.f;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v = fmaf(gq[t], xv[c][t], v);
-                    row_partial(v, (XC + c) * kH + row);
+                    row_partial(v, xres[c], q);
                 }
             }
         }
@@ -499,6 +620,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     load_h(6);
     {
         const float* w8 = a.packed + a.lay.W8;
+        const __amdgpu_buffer_rsrc_t w8res = partial_rsrc(ext ? 7 : 0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float wv = w8[wave * 32 + frag_row(q, kh)];
@@ -508,26 +630,33 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
                 float s8 = 0.f;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) s8 = fmaf(pok[t] ? hf[q][t] : 0.f, dz8s[t * 32 + r], s8);
-                row_partial(s8, 7 * kH + wave * 32 + frag_row(q, kh));
+                row_partial(s8, w8res, q);
             }
         }
     }
+    // the weight ring of the next GEMM is started before the stores of each epilogue (see WRing)
+    WRing<SG_BWD_RING> wr;
+    auto wtile_t = [&](long toff) { return pk + (toff >> 2) + (long)wave * (kH / 8) * 64; };
+    wring_start(wr, wtile_t(a.lay.T7), lane);
+    __builtin_amdgcn_sched_barrier(0);
     mask_store(6, IntTag<-1>());
     __syncthreads();
-    auto back_step = [&](long toff, int layer, auto xtag) __attribute__((always_inline)) {  // dZ_layer+1 (LDS) -> dZ_layer
-        load_h(layer);
+    // dZ_layer+1 (LDS) -> dZ_layer; tnext: transposed pack of the following step (-1: none)
+    auto back_step = [&](int layer, long tnext, auto xtag) __attribute__((always_inline)) {
         zero_acc();
-        mlp_gemm<NT, 2>(acc, pk + (toff >> 2) + (long)wave * (kH / 8) * 64, kH / 8, Gs, P, lane);
+        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_h(layer); });
         __syncthreads();   // every wave is done reading the tile
+        if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
+        __builtin_amdgcn_sched_barrier(0);
         mask_store(layer, xtag);
         __syncthreads();
     };
-    back_step(a.lay.T7, 5, IntTag<-1>());    // dH6 -> dZ6
-    back_step(a.lay.T6, 4, IntTag<11>());    // dZ5 (+ point columns of dW5)
-    back_step(a.lay.T5x, 3, IntTag<-1>());   // dZ4
-    back_step(a.lay.T4, 2, IntTag<-1>());    // dZ3
-    back_step(a.lay.T3, 1, IntTag<-1>());    // dZ2
-    back_step(a.lay.T2, 0, IntTag<8>());     // dZ1 (+ point columns of dW1)
+    back_step(5, a.lay.T6, IntTag<-1>());    // dH6 -> dZ6
+    back_step(4, a.lay.T5x, IntTag<11>());   // dZ5 (+ point columns of dW5)
+    back_step(3, a.lay.T4, IntTag<-1>());    // dZ4
+    back_step(2, a.lay.T3, IntTag<-1>());    // dZ3
+    back_step(1, a.lay.T2, IntTag<-1>());    // dZ2
+    back_step(0, -1, IntTag<8>());           // dZ1 (+ point columns of dW1)
     // (element indexing of the dX part below)
     constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
     constexpr int RSTEP = 512 / P;
@@ -632,7 +761,7 @@ static TilePlan tile_plan(long N, int P, long slots) {
     return TilePlan{full, (N - full * P + kSmallTile - 1) / kSmallTile};
 }
 constexpr long kFwdSlots = 256;   // one workgroup per CU (LDS)
-constexpr long kBwdSlots = 512;   // two per CU
+constexpr long kBwdSlots = SG_BWD_TILE == 64 ? 512 : 256;   // two per CU
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
@@ -718,15 +847,19 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
     a.ldn = ldn;
     a.N = N;
     if (acts) SG_CHECK_ARG(ldn >= N);
+    if (acts && ldn > (1L << 24)) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_fwd: at most 16 777 216 points per training call (ldn = %ld)", ldn);
     const bool shape_bias = zb1 != nullptr;
     if (shape_bias) {
         SG_CHECK_ARG(zb5 && kin_used == 3);
-        SG_CHECK_ARG(shape_index || (points_per_shape > 0 && (points_per_shape % 128 == 0 || points_per_shape >= N)));
-        const size_t lds = fwd_lds_bytes(128, a.lay.KUp);
-        if (set_lds(sdfnet_fwd_kernel<128, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
-        const TilePlan tp = tile_plan(N, 128, kFwdSlots);
+        SG_CHECK_ARG(shape_index || (points_per_shape > 0 && (points_per_shape % 128 == 0 || points_per_shape >= N)));   // (tiles must not straddle shapes)
+        // 64-point tiles: 68 KB of LDS and < 128 VGPRs put two workgroups on a CU, so that one's barriers / write-back overlap
+        // the other's MFMA phases (measured against 128-point tiles, one workgroup per CU: 8 x 32^3 inference 1.687 -> 1.654 ms,
+        // 16 x 64^3 26.0 -> 25.0 ms, the training forward at 200 000 points 1.31 -> 1.24 ms)
+        const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
+        if (set_lds(sdfnet_fwd_kernel<64, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+        const TilePlan tp = tile_plan(N, 64, 2 * kFwdSlots);
         a.nbig = tp.nbig;
-        hipLaunchKernelGGL((sdfnet_fwd_kernel<128, true>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     } else {
         SG_CHECK_ARG(latent && kin_used == 3 + latent_size);
         const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
@@ -744,11 +877,11 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
 // as [7*256][sg_sdfnet_bwd_blocks(N)] (sum each row for the bias gradients) and (if dx != NULL) the input gradient rows dx[N][dx_ld]
 // (kin_used columns: d/dpoints (3) then d/dlatent (L) in per-point mode, d/dpoints only in per-shape mode).
 long sg_sdfnet_bwd_blocks(long N) {
-    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
     return tp.nbig + tp.nsmall;
 }
 long sg_sdfnet_bwd_tile_start(long N, long t) {
-    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
     const long p = t <= tp.nbig ? t * 64 : tp.nbig * 64 + (t - tp.nbig) * kSmallTile;
     return p < N ? p : N;
 }
@@ -773,14 +906,16 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
     a.ldn = ldn;
     a.N = N;
     if (dx) SG_CHECK_ARG(dx_ld >= kin_used);
+    if (ldn > (1L << 24)) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_bwd: at most 16 777 216 points per call (ldn = %ld)", ldn);
     // 64-point tiles for both input modes: 64.3 KB LDS / <= 128 VGPRs put two workgroups on a CU, whose phases
     // interleave (measured: 2.5 ms vs 3.1 ms for 128-point tiles on 200 000 points)
     {
-        const size_t lds = bwd_lds_bytes(64, a.lay.KUr, dx != nullptr);
-        if (set_lds(sdfnet_bwd_kernel<64>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_bwd: cannot reserve %zu B LDS", lds);
-        const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+        const size_t lds = bwd_lds_bytes(SG_BWD_TILE, a.lay.KUr, dx != nullptr);
+        if (set_lds(sdfnet_bwd_kernel<SG_BWD_TILE>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_bwd: cannot reserve %zu B LDS", lds);
+        const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
         a.nbig = tp.nbig;
-        hipLaunchKernelGGL((sdfnet_bwd_kernel<64>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
+        a.nblk = tp.nbig + tp.nsmall;
+        hipLaunchKernelGGL((sdfnet_bwd_kernel<SG_BWD_TILE>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     }
     SG_CHECK_LAUNCH();
     return SG_OK;
@@ -791,7 +926,7 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
 int sg_sdfnet_segsum(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
                      float* t5, hipStream_t stream) {
     SG_CHECK_ARG(dz && bias_partials && seg_off && t1 && t5 && N > 0 && ldn >= N && nseg > 0);
-    const TilePlan tp = tile_plan(N, 64, kBwdSlots);
+    const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
     hipLaunchKernelGGL(sdfnet_segsum_kernel, dim3((unsigned)(((long)kH * nseg + 3) / 4), 2), dim3(256), 0, stream, dz,
                        bias_partials, ldn, tp.nbig, tp.nbig + tp.nsmall, seg_off, nseg, t1, t5);
     SG_CHECK_LAUNCH();

@@ -150,3 +150,36 @@ def test_sdf_autodecoder_200k_L256_step_vs_oracle():
     for k, p in net.named_parameters():
         close_mostly(p.grad, orc.P[k].grad, rtol=3e-4, max_bad_frac=2e-3, what="net grad " + k)
     close_mostly(tr.latent_codes.grad, orc.latent_codes.grad, rtol=3e-4, max_bad_frac=2e-3, what="latent table grad")
+
+
+def test_sdfnet_backward_beyond_2m_points_equals_its_halves():
+    """configs[3]'s generator step evaluates 16 x 64^3 = 4.2 M points in one call: per-layer images of more than 2 GiB.  The
+    backward's addressing is 32-bit lane offset + scalar row offset from a per-wave base; this checks a 2.46 M-point call
+    (every image 2.5 GB) against the same work done as two 1.2 M-point calls (the size class the oracle tests cover), everything to 1e-4 / 2e-6 absolute on the outputs."""
+    from shapegan_amd.model.sdf_net import SDFNet
+    torch.manual_seed(5)
+    net = SDFNet(latent_code_size=32).cuda()
+    S, pps = 10, 245760
+    pts = (torch.rand(S * pps, 3, device="cuda") * 2 - 1)
+    z = torch.randn(S, 32, device="cuda") * 0.3
+    w = torch.randn(S * pps, device="cuda")
+
+    def run(lo, hi):
+        p = pts[lo * pps:hi * pps].clone().requires_grad_(True)
+        zz = z[lo:hi].clone().requires_grad_(True)
+        out = net.forward_shapes(p, zz, pps)
+        (out * w[lo * pps:hi * pps]).sum().backward()
+        grads = [q.grad.clone() for q in net.parameters()]
+        for q in net.parameters():
+            q.grad = None
+        return out.detach(), p.grad, zz.grad, grads
+
+    out, dp, dz, g = run(0, S)
+    out_a, dp_a, dz_a, g_a = run(0, S // 2)
+    out_b, dp_b, dz_b, g_b = run(S // 2, S)
+    # (not bit-equal: the [S,L] x [L,256] GEMM that folds the latents into per-shape biases splits K differently for 10 and 5 rows)
+    torch.testing.assert_close(out, torch.cat([out_a, out_b]), rtol=0, atol=2e-6)
+    close(dp, torch.cat([dp_a, dp_b]), what="d points")
+    close(dz, torch.cat([dz_a, dz_b]), what="d latent")
+    for (name, _), full, ha, hb in zip(net.named_parameters(), g, g_a, g_b):
+        close_mostly(full, ha + hb, what="grad " + name)      # sums over 2.46 M points: isolated entries differ at rounding level
