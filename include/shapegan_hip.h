@@ -220,6 +220,11 @@ int sg_loss_weighted_l1_fwd(const float* out, const float* target, long n, float
                             size_t workspace_bytes, hipStream_t stream);
 int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* gloss, float* dout, long n, float neg_weight,
                             hipStream_t stream);
+/* w_first * mean(x[0, n_first)) + w_rest * mean(x[n_first, n)) and its backward dx = gloss * (w / count) per part, one small
+ * launch each: the WGAN losses mean(fake) - mean(real) over the critic's concatenated batch (train_wgan.py:68,
+ * train_hybrid_wgan.py:89, train_hybrid_progressive_gan.py:147) and -mean(fake) (train_wgan.py:82; n_first = n, w_first = -1) */
+int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, hipStream_t stream);
+int sg_loss_mean_split_bwd(const float* gloss, float* dx, long n, long n_first, float w_first, float w_rest, hipStream_t stream);
 int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
                     hipStream_t stream);
 int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* gloss, float* dmean, float* dlog_variance,

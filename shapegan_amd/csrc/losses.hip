@@ -44,6 +44,42 @@ __global__ void __launch_bounds__(64) loss_final_kernel(const double* __restrict
     if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
+// ---- difference of two batch means (WGAN losses) ---------------------------------------------------------------------
+// loss = wa mean(x[0, na)) + wb mean(x[na, n)) in ONE single-workgroup launch (critic outputs: n = 2 x batch values), and its
+// backward dx[i] = g * (i < na ? wa / na : wb / (n - na)).  Replaces the two means, the subtraction and the slice / expand /
+// zero-fill / add nodes autograd would build for `mean(out[:na]) - mean(out[na:])`: 14 launches -> 2.
+__global__ void __launch_bounds__(256) mean_split_fwd_kernel(const float* __restrict__ x, long n, long na, float wa, float wb,
+                                                             float* __restrict__ loss) {
+    __shared__ double ra[4], rb[4];
+    double sa = 0, sb = 0;
+    for (long e = threadIdx.x; e < n; e += 256) {
+        const double v = (double)x[e];
+        if (e < na)
+            sa += v;
+        else
+            sb += v;
+    }
+    sa = sg_wave_sum_d(sa);
+    sb = sg_wave_sum_d(sb);
+    if ((threadIdx.x & 63) == 0) {
+        ra[threadIdx.x >> 6] = sa;
+        rb[threadIdx.x >> 6] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ta = (ra[0] + ra[1]) + (ra[2] + ra[3]), tb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+        double v = 0;
+        if (na > 0) v += (double)wa * ta / (double)na;
+        if (n > na) v += (double)wb * tb / (double)(n - na);
+        loss[0] = (float)v;
+    }
+}
+__global__ void __launch_bounds__(256) mean_split_bwd_kernel(const float* __restrict__ gloss, float* __restrict__ dx, long n,
+                                                             long na, float ca, float cb) {
+    const float g = gloss[0];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) dx[e] = g * (e < na ? ca : cb);
+}
+
 // ---- weighted L1 ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wl1_fwd_kernel(const float* __restrict__ o, const float* __restrict__ t, long n,
                                                       float negw, double* __restrict__ partial) {
@@ -312,6 +348,20 @@ int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* 
     SG_CHECK_ARG(out && target && gloss && dout && n > 0);
     hipLaunchKernelGGL(wl1_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, out, target, gloss, dout, n, neg_weight,
                        (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, hipStream_t stream) {
+    SG_CHECK_ARG(x && loss && n > 0 && n_first >= 0 && n_first <= n);
+    hipLaunchKernelGGL(mean_split_fwd_kernel, dim3(1), dim3(256), 0, stream, x, n, n_first, w_first, w_rest, loss);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_mean_split_bwd(const float* gloss, float* dx, long n, long n_first, float w_first, float w_rest, hipStream_t stream) {
+    SG_CHECK_ARG(gloss && dx && n > 0 && n_first >= 0 && n_first <= n);
+    const float ca = n_first > 0 ? (float)((double)w_first / (double)n_first) : 0.f;
+    const float cb = n > n_first ? (float)((double)w_rest / (double)(n - n_first)) : 0.f;
+    hipLaunchKernelGGL(mean_split_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, gloss, dx, n, n_first, ca, cb);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

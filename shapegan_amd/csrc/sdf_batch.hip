@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) sdf_sort_prefix_kernel(const int* __rest
 
 __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __restrict__ idx, const int* __restrict__ keys,
                                                               const int* __restrict__ base, const int* __restrict__ total,
-                                                              long n, int S, const float* __restrict__ points,
+                                                              long n, int S, long table_rows, const float* __restrict__ points,
                                                               const float* __restrict__ sdf, float* __restrict__ out_points,
                                                               float* __restrict__ out_sdf, int* __restrict__ out_shape,
                                                               int64_t* __restrict__ seg_off, float* __restrict__ counts) {
@@ -112,33 +112,51 @@ __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __r
     }
     if (chunk == 0 && lane == 63) seg_off[S] = n;
     __syncthreads();
-#pragma unroll 1
+    // three passes over the chunk's 8 rounds so that the memory latencies overlap instead of chaining per round: all keys and
+    // batch indices first, then the ranks (LDS only), then all table rows in flight together
+    int key[kSortRounds], p[kSortRounds];
+    long src[kSortRounds];
+#pragma unroll
     for (int it = 0; it < kSortRounds; ++it) {
         const long e = chunk * kSortChunk + it * 64 + lane;
         const bool ok = e < n;
-        const int key = ok ? keys[e] : -1 - lane;   // distinct negative keys: match nothing
+        key[it] = ok ? keys[e] : -1 - lane;   // distinct negative keys: match nothing
+        const long i = ok ? idx[e] : 0;
+        src[it] = i < 0 ? 0 : (i < table_rows ? i : table_rows - 1);   // (a bad index was flagged by the histogram pass)
+    }
+#pragma unroll
+    for (int it = 0; it < kSortRounds; ++it) {
+        const bool ok = key[it] >= 0;
         int rank = 0, later = 0;
 #pragma unroll
         for (int l = 0; l < 64; ++l) {
-            const int kl = __builtin_amdgcn_readlane(key, l);
-            rank += (kl == key && l < lane) ? 1 : 0;
-            later |= (kl == key && l > lane) ? 1 : 0;
+            const int kl = __builtin_amdgcn_readlane(key[it], l);
+            rank += (kl == key[it] && l < lane) ? 1 : 0;
+            later |= (kl == key[it] && l > lane) ? 1 : 0;
         }
-        int p = 0;
-        if (ok) p = pos[key] + rank;
+        p[it] = ok ? pos[key[it]] + rank : 0;
         __syncthreads();
-        if (ok && !later) pos[key] = p + 1;
+        if (ok && !later) pos[key[it]] = p[it] + 1;
         __syncthreads();
-        if (ok) {
-            const long i = idx[e];
-            const float* src = points + i * 3;
-            const float x = src[0], y = src[1], z = src[2];
-            float* dst = out_points + (long)p * 3;
-            dst[0] = x;
-            dst[1] = y;
-            dst[2] = z;
-            out_sdf[p] = sdf[i];
-            out_shape[p] = key;
+    }
+    float x[kSortRounds], y[kSortRounds], z[kSortRounds], d[kSortRounds];
+#pragma unroll
+    for (int it = 0; it < kSortRounds; ++it) {
+        const float* q = points + src[it] * 3;   // (row 0 for the lanes beyond n: in range, never stored)
+        x[it] = q[0];
+        y[it] = q[1];
+        z[it] = q[2];
+        d[it] = sdf[src[it]];
+    }
+#pragma unroll
+    for (int it = 0; it < kSortRounds; ++it) {
+        if (key[it] >= 0) {
+            float* dst = out_points + (long)p[it] * 3;
+            dst[0] = x[it];
+            dst[1] = y[it];
+            dst[2] = z[it];
+            out_sdf[p[it]] = d[it];
+            out_shape[p[it]] = key[it];
         }
     }
 }
@@ -183,7 +201,7 @@ int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long
                        hist, bad_index_flag);
     hipLaunchKernelGGL(sdf_sort_prefix_kernel, dim3((unsigned)((S + 63) / 64)), dim3(1024), 0, stream, hist, base, total, nc, S);
     hipLaunchKernelGGL(sdf_sort_scatter_kernel, dim3((unsigned)nc), dim3(64), lds, stream, indices, keys, base, total, n, S,
-                       points, sdf, out_points, out_sdf, out_shape, seg_off, counts);
+                       nshapes * pointcloud_size, points, sdf, out_points, out_sdf, out_shape, seg_off, counts);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -651,7 +651,8 @@ int sg_sdf_batch_sort_cpu(const int64_t* indices, long n, long pointcloud_size, 
     }
     for (long s = 0; s <= nshapes; ++s) seg_off[s] = next[s];
     for (long e = 0; e < n; ++e) {
-        const int64_t i = indices[e], k = shape_of(i), p = next[k]++;
+        const int64_t k = shape_of(indices[e]), p = next[k]++, rows = nshapes * pointcloud_size;
+        const int64_t i = indices[e] < 0 ? 0 : (indices[e] < rows ? indices[e] : rows - 1);   // (flagged above)
         memcpy(out_points + p * 3, points + i * 3, 3 * sizeof(float));
         out_sdf[p] = sdf[i];
         out_shape[p] = (int)k;
@@ -728,6 +729,23 @@ int sg_loss_weighted_l1_bwd_cpu(const float* o, const float* t, const float* glo
         const float w = t[e] < 0.f ? negw : 1.f, d = (o[e] - t[e]) * w;
         d_o[e] = g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
     }
+    return SG_OK;
+}
+int sg_loss_mean_split_fwd_cpu(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, void*) {
+    CPU_CHECK(x && loss && n > 0 && n_first >= 0 && n_first <= n);
+    double a = 0, b = 0;
+    for (long e = 0; e < n; ++e) (e < n_first ? a : b) += x[e];
+    double v = 0;
+    if (n_first > 0) v += (double)w_first * a / (double)n_first;
+    if (n > n_first) v += (double)w_rest * b / (double)(n - n_first);
+    loss[0] = (float)v;
+    return SG_OK;
+}
+int sg_loss_mean_split_bwd_cpu(const float* gloss, float* dx, long n, long n_first, float w_first, float w_rest, void*) {
+    CPU_CHECK(gloss && dx && n > 0 && n_first >= 0 && n_first <= n);
+    const float ca = n_first > 0 ? (float)((double)w_first / (double)n_first) : 0.f;
+    const float cb = n > n_first ? (float)((double)w_rest / (double)(n - n_first)) : 0.f;
+    for (long e = 0; e < n; ++e) dx[e] = gloss[0] * (e < n_first ? ca : cb);
     return SG_OK;
 }
 int sg_loss_kld_fwd_cpu(const float* mu, const float* lv, long n, float* loss, void*, size_t, void*) {

@@ -84,6 +84,8 @@ SIGNATURES = {
     "sg_loss_workspace_bytes": (_Z, []),
     "sg_loss_weighted_l1_fwd": (c_int, [_P, _P, _L, _F, _P, _P, _Z, _P]),
     "sg_loss_weighted_l1_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _P]),
+    "sg_loss_mean_split_fwd": (c_int, [_P, _L, _L, _F, _F, _P, _P]),
+    "sg_loss_mean_split_bwd": (c_int, [_P, _P, _L, _L, _F, _F, _P]),
     "sg_loss_kld_fwd": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),

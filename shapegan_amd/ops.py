@@ -772,6 +772,38 @@ def mean(x):
     return Mean.apply(x)
 
 
+class MeanSplit(Function):
+    """w_first * mean(x[:n_first]) + w_rest * mean(x[n_first:]) over the flattened x in one launch (and one for the backward):
+    the WGAN losses on the critic's concatenated fake+real batch (train_wgan.py:68,82)."""
+
+    @staticmethod
+    def forward(ctx, x, n_first, w_first, w_rest):
+        x = f32c(x)
+        ctx.shape, ctx.args = x.shape, (x.numel(), int(n_first), float(w_first), float(w_rest))
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        check(_lib().sg_loss_mean_split_fwd(ptr(x), x.numel(), int(n_first), float(w_first), float(w_rest), ptr(out), stream()),
+              "loss_mean_split_fwd")
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, n_first, w_first, w_rest = ctx.args
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(_lib().sg_loss_mean_split_bwd(ptr(f32c(g)), ptr(dx), n, n_first, w_first, w_rest, stream()), "loss_mean_split_bwd")
+        return dx, None, None, None
+
+
+def mean_difference(x, n_first):
+    """mean(x[:n_first]) - mean(x[n_first:])  (critic loss: scores of the fake half minus scores of the real half)."""
+    return MeanSplit.apply(x, n_first, 1.0, -1.0)
+
+
+def neg_mean(x):
+    """-mean(x)  (generator loss)."""
+    return MeanSplit.apply(x, x.numel(), -1.0, 0.0)
+
+
 class GatherRows(Function):
     """table[idx] for a 2-D table (latent_codes[model_indices], train_sdf_autodecoder.py:80); backward is the
     index_add scatter into a zero table-shaped gradient."""

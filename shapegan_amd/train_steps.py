@@ -46,7 +46,7 @@ class WGANTrainer(object):
         n_fake = fake.shape[0]
         out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
         out_fake, out_real = out[:n_fake], out[n_fake:]
-        loss = ops.mean(out_fake) - ops.mean(out_real)
+        loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
         self.c_bucket.arm()
         loss.backward()
         self.c_bucket.finish()
@@ -60,7 +60,7 @@ class WGANTrainer(object):
         fake = self.generator(z)
         with frozen(self.critic):
             out = self.critic(fake)
-        loss = -ops.mean(out)
+        loss = ops.neg_mean(out)
         self.g_bucket.arm()
         loss.backward()
         self.g_bucket.finish()
@@ -278,7 +278,7 @@ class HybridWGANTrainer(object):
         n_fake = fake.shape[0]
         out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
         out_fake, out_real = out[:n_fake], out[n_fake:]
-        loss = ops.mean(out_fake) - ops.mean(out_real)
+        loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
         self.c_bucket.arm()
         loss.backward()
         self.c_bucket.finish()
@@ -291,7 +291,7 @@ class HybridWGANTrainer(object):
         fake = self.generate(z)
         with frozen(self.critic):
             out = self.critic(fake)
-        loss = ops.mean(-out)
+        loss = ops.neg_mean(out)
         self.g_bucket.arm()
         loss.backward()
         self.g_bucket.finish()
@@ -337,7 +337,7 @@ class HybridProgressiveGANTrainer(object):
         fake = self.generate(z)
         with frozen(self.discriminator):
             out = self.discriminator(fake)
-        loss = -ops.mean(out)
+        loss = ops.neg_mean(out)
         self.g_bucket.arm()
         loss.backward()
         self.g_bucket.finish()
@@ -478,7 +478,7 @@ class PointGANTrainer(object):
         fake = self.generator(pos, z)
         with frozen(self.critic):
             out = self.critic(pos, fake)
-        loss = -ops.mean(out)
+        loss = ops.neg_mean(out)
         self.g_bucket.arm()
         loss.backward()
         self.g_bucket.finish()

@@ -129,6 +129,8 @@ def test_losses_and_blends(on_cpu):
     LOSS.test_kld_matches_reference()
     LOSS.test_mean_sq_plain_and_row_weighted()
     LOSS.test_lerp_rows_bit_exact()
+    LOSS.test_mean_difference_matches_torch(128, 64)
+    LOSS.test_mean_difference_matches_torch(7, 0)
     LOSS.test_gradient_penalty_value_and_gradient(5, (7, 3))
     LOSS.test_subsample2_bit_exact_and_adjoint()
     LOSS.test_fade_blend_first_and_second_order(1, 0.3)

@@ -104,6 +104,33 @@ def test_mean_sq_plain_and_row_weighted():
 
 
 # ---- gradient penalty pieces -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,n_first", [(128, 64), (8, 3), (1, 1), (5000, 1), (7, 7), (7, 0)])
+def test_mean_difference_matches_torch(n, n_first):
+    """train_wgan.py:68 / :82: mean(fake scores) - mean(real scores) on the concatenated critic batch, and -mean(scores), as
+    one launch each way; value and gradient against torch."""
+    from shapegan_amd import ops
+    torch.manual_seed(n + n_first)
+    x = torch.randn(n, 1) * 3 + 1
+    xr = x.clone().requires_grad_(True)
+    if 0 < n_first < n:
+        ref = torch.mean(xr[:n_first]) - torch.mean(xr[n_first:])
+    elif n_first == n:
+        ref = torch.mean(xr)
+    else:
+        ref = -torch.mean(xr)
+    (ref * 1.7).backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    got = ops.mean_difference(xg, n_first)
+    (got * 1.7).backward()
+    close(got, ref.detach(), rtol=1e-6, atol=1e-6, what="mean difference")
+    close(xg.grad, xr.grad, rtol=1e-6, atol=1e-9, what="d mean difference")
+    xg2 = x.clone().to(DEV).requires_grad_(True)
+    neg = ops.neg_mean(xg2)
+    neg.backward()
+    close(neg, -x.mean(), rtol=1e-6, atol=1e-6, what="neg mean")
+    close(xg2.grad, torch.full_like(x, -1.0 / n), rtol=1e-6, atol=1e-9, what="d neg mean")
+
+
 def test_lerp_rows_bit_exact():
     from shapegan_amd import ops
     torch.manual_seed(5)
