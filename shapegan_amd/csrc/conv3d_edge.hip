@@ -409,6 +409,166 @@ __global__ void __launch_bounds__(256) col2im_c1_kernel(const float* __restrict_
         }
 }
 
+// ---- input gradient, fused: tap groups in LDS ------------------------------------------------------------------------------
+// One workgroup per (sample, qd): its two output d-planes 2qd, 2qd+1 need exactly four (kd, source plane) tap groups —
+//   kd = 1, 2 of plane qd,  kd = 3 of plane qd-1,  kd = 0 of plane qd+1 — 16 (kh, kw) taps x OH*OW positions each (64 KB at
+// 16 x 16).  They are computed here (every tap-plane element is consumed by exactly one workgroup, so nothing is computed
+// twice), parked in LDS and gathered into the outputs: the 2 x 67 MB round trip of the tap planes through the Infinity Cache
+// and the second launch are gone; dy is read three times but by neighbouring workgroups of the same XCD (blockIdx -> (sample,
+// qd) keeps a sample's planes on one XCD's L2).
+//   plane qd   : rows = 32 positions, cols = [kd 1 | kd 2] taps, v_mfma_f32_32x32x2_f32, K = channel pairs
+//   planes qd-1 / qd+1 : only 16 columns are needed -> v_mfma_f32_16x16x4_f32 (rows = 16 positions, K = channel quads), so no
+//                half-empty 32-wide tiles: 512 instead of 768 MFMA-equivalents per workgroup (the kernel is MFMA-bound otherwise)
+struct ConvTFusedArgs {
+    const float* dy;     // [batch][Cy][OD][P2]
+    const float* w;      // [Cout][Cin_total][64], channel 0
+    const float* bias;   // optional [1]
+    float* dx;           // [batch][dx_sample], channel 0 written
+    int Cout, Cy, Cin_total;
+    int OD, OH, OW, P2;
+    long dx_sample;
+    int batch, act;
+    float slope;
+};
+constexpr int kFusedTapStride = 260;                    // floats per tap row in LDS (256 positions + 4: b128 writes of 16 taps hit 64 banks)
+constexpr int kFusedGroup = 16 * kFusedTapStride;       // one kd group
+
+template <bool ALLCH>   // ALLCH: Cout == 64 (no channel masks)
+__global__ void __launch_bounds__(512, (ALLCH ? 4 : 2)) convT_c1_fused_kernel(ConvTFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [kd][kh*4+kw][kFusedTapStride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh2 = lane >> 5;     // 32x32x2 fragments
+    const int i16 = lane & 15, kq = lane >> 4;    // 16x16x4 fragments
+    // XCD-aware decode: workgroup b runs on XCD b % 8; all planes of a sample stay on one XCD, neighbours in dispatch order
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int n = (j / a.OD) * 8 + xcd, qd = j % a.OD;
+    if (n >= a.batch) return;
+    const int P2 = a.P2, npt = (P2 + 31) >> 5;
+    const bool has_prev = qd > 0, has_next = qd + 1 < a.OD;
+
+    // weights as B fragments: wA[s] = W[co = 2s + kh2][tap 16 + r] (kd 1 | kd 2), wB3 / wB0[s] = W[co = 4s + kq][48 + i16] / [i16]
+    float wA[32], wB3[16], wB0[16];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int co = 2 * s + kh2, coc = co < a.Cout ? co : a.Cout - 1;
+        wA[s] = (ALLCH || co < a.Cout ? 1.f : 0.f) * a.w[(long)coc * a.Cin_total * 64 + 16 + r];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int co = 4 * s + kq, coc = co < a.Cout ? co : a.Cout - 1;
+        const float keep = ALLCH || co < a.Cout ? 1.f : 0.f;
+        wB3[s] = keep * a.w[(long)coc * a.Cin_total * 64 + 48 + i16];
+        wB0[s] = keep * a.w[(long)coc * a.Cin_total * 64 + i16];
+    }
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy + (long)n * a.Cy * a.OD * P2);
+    const unsigned chan = (unsigned)(a.OD * P2) * 4u;     // bytes between channels of a sample
+    lds_float* const Sl = (lds_float*)S;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+    for (int tp = wave; tp < npt; tp += 8) {   // 8 waves: one 32-position tile each at 16 x 16
+        // ---- all loads of this position tile first (96 in flight per lane) ----
+        const int pA = tp * 32 + r;
+        // channels beyond Cout (ALLCH == false): the lane reads channel Cout-1 instead — its weight fragment is zero — so that no
+        // per-load masks (32 + 64 SGPR pairs, spilled) are needed
+        const unsigned offA = pA < P2 ? (unsigned)((long)qd * P2 + pA) * 4u : kBufOutside;
+        float av[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            if (ALLCH)
+                av[s] = buf_load(dres, offA + (unsigned)kh2 * chan, (unsigned)(2 * s) * chan);
+            else
+                av[s] = buf_load(dres, offA + (unsigned)min(2 * s + kh2, a.Cout - 1) * chan, 0u);
+        }
+        float bv[2][2][16];   // [plane: prev / next][16-position half][k step]
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const bool have = pl == 0 ? has_prev : has_next;
+            const int plane = pl == 0 ? qd - 1 : qd + 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pB = tp * 32 + h * 16 + i16;
+                const unsigned offB = (have && pB < P2) ? (unsigned)((long)plane * P2 + pB) * 4u : kBufOutside;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (ALLCH)
+                        bv[pl][h][s] = buf_load(dres, offB + (unsigned)kq * chan, (unsigned)(4 * s) * chan);
+                    else
+                        bv[pl][h][s] = buf_load(dres, offB + (unsigned)min(4 * s + kq, a.Cout - 1) * chan, 0u);
+                }
+            }
+        }
+        // ---- plane qd: [32 positions] x [kd 1 | kd 2] ----
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wA[s], acc, 0, 0, 0);
+        {
+            // column r = tap: group kd = 1 + (r >> 4), tap row r & 15; rows of the fragment = positions 8c + 4 kh2 + (0..3)
+            lds_float* dst = Sl + (1 + (r >> 4)) * kFusedGroup + (r & 15) * kFusedTapStride + tp * 32 + 4 * kh2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4v v = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                *(__attribute__((address_space(3))) f32x4v*)(dst + 8 * c) = v;
+            }
+        }
+        // ---- planes qd-1 (kd 3) and qd+1 (kd 0): [16 positions] x [16 taps], K = 4 channels per step ----
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const bool have = pl == 0 ? has_prev : has_next;
+            if (!have) continue;     // (workgroup-uniform)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4v c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[pl][h][s], pl == 0 ? wB3[s] : wB0[s], c4, 0, 0, 0);
+                // column i16 = tap row, fragment rows 4 kq + (0..3) = positions
+                lds_float* dst = Sl + (pl == 0 ? 3 : 0) * kFusedGroup + i16 * kFusedTapStride + tp * 32 + h * 16 + 4 * kq;
+                *(__attribute__((address_space(3))) f32x4v*)dst = c4;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- gather: thread = (q position of the plane, output d-parity), its 2 x 2 outputs take 8 taps each ----
+    const int qi = tid & 255, pd = tid >> 8;
+    if (qi < P2) {
+        const int qh = qi / a.OW, qw = qi - qh * a.OW;
+        float o[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) (&o[0][0])[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // d-parity 0 takes kd 1 (plane qd) and kd 3 (plane qd-1), d-parity 1 takes kd 2 (plane qd) and kd 0 (plane qd+1)
+            const int kd = pd == 0 ? (t == 0 ? 1 : 3) : (t == 0 ? 2 : 0);
+            if ((kd == 0 && !has_next) || (kd == 3 && !has_prev)) continue;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int ph = (kh & 1) ? 0 : 1, dh = (kh == 0) ? 1 : (kh == 3 ? -1 : 0);
+                const int oh = qh + dh;
+                if ((unsigned)oh >= (unsigned)a.OH) continue;
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int pw = (kw & 1) ? 0 : 1, dw_ = (kw == 0) ? 1 : (kw == 3 ? -1 : 0);
+                    const int ow = qw + dw_;
+                    if ((unsigned)ow >= (unsigned)a.OW) continue;
+                    o[ph][pw] += Sl[kd * kFusedGroup + (kh * 4 + kw) * kFusedTapStride + oh * a.OW + ow];
+                }
+            }
+        }
+        const float b0 = a.bias ? a.bias[0] : 0.f;
+        const int IH = 2 * a.OH, IW = 2 * a.OW;
+        float* out = a.dx + (long)n * a.dx_sample;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float2 v;
+            v.x = sg_apply_act(o[ph][0] + b0, a.act, a.slope);
+            v.y = sg_apply_act(o[ph][1] + b0, a.act, a.slope);
+            *reinterpret_cast<float2*>(out + ((long)(2 * qd + pd) * IH + (2 * qh + ph)) * IW + 2 * qw) = v;
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 static size_t padded_floats(int batch, const ConvGeom& g) { return (size_t)batch * (g.ID + 2) * (g.IH + 2) * (g.IW + 2); }
 
@@ -520,7 +680,43 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force) {
     const long O3 = g.O3();
-    if (Cin != 1 || Cout > 64 || O3 % 32 != 0) return 0;
+    if (Cin != 1 || Cout > 64) return 0;
+    // fused kernel: a whole (OH x OW) plane of the four tap groups fits in LDS
+    static const bool fused_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 8);
+    if (!fused_off && g.OH * g.OW <= 256 && (size_t)g.Cy * O3 * 4 < (size_t)kBufRange && (force || (long)batch * O3 >= 512)) {
+        ConvTFusedArgs f;
+        f.dy = dy;
+        f.w = w;
+        f.bias = bias;
+        f.dx = dx;
+        f.Cout = Cout;
+        f.Cy = g.Cy;
+        f.Cin_total = Cin_total;
+        f.OD = g.OD;
+        f.OH = g.OH;
+        f.OW = g.OW;
+        f.P2 = g.OH * g.OW;
+        f.dx_sample = (long)g.Cx * g.I3();
+        f.batch = batch;
+        f.act = act;
+        f.slope = slope;
+        const size_t lds = (size_t)4 * kFusedGroup * sizeof(float);
+        static bool attr_set = false;   // > 48 KB of dynamic LDS needs the attribute once per process
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_fused_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_fused_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * g.OD);
+        if (Cout == 64)
+            hipLaunchKernelGGL((convT_c1_fused_kernel<true>), dim3(wgs), dim3(512), lds, stream, f);
+        else
+            hipLaunchKernelGGL((convT_c1_fused_kernel<false>), dim3(wgs), dim3(512), lds, stream, f);
+        return 1;
+    }
+    if (O3 % 32 != 0) return 0;
     if (!force && (long)batch * O3 < 65536) return 0;
     if (!workspace || workspace_bytes < edge_dgrad_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
     if ((size_t)batch * 64 * O3 * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;

@@ -72,7 +72,7 @@ def test_conv3d_fwd_dgrad_wgrad(N, Ci, Co, R):
 
 
 @pytest.mark.parametrize("N,Ci,Co,R", [(2, 256, 128, 4), (2, 128, 64, 8), (3, 64, 1, 16), (2, 96, 48, 4), (2, 24, 1, 16),
-                                       (1, 5, 3, 3)])
+                                       (1, 5, 3, 3), (9, 8, 1, 8), (10, 40, 1, 4), (70, 64, 1, 2), (2, 3, 1, 12)])
 def test_conv_transpose3d(N, Ci, Co, R):
     """nn.ConvTranspose3d(k4,s2,p1) with fused LeakyReLU / Tanh epilogues (model/gan.py:13-22)."""
     from shapegan_amd import ops
