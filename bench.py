@@ -142,8 +142,8 @@ def sdfnet_numbers():
     auto-decoder step (train_sdf_autodecoder.py:77-91: gather, fused forward, L1+reg loss, fused backward, weight-grad
     GEMMs, two Adam updates) at the reference's 20 000 points/step with latent 128, and at BASELINE configs[2]'s
     200 000 points/step with latent 256.  Rates are given twice: against the reference's algorithmic FLOP count (SURVEY.md
-    8d: forward, x3 for a training step) and against the FLOPs the kernels execute (the per-shape latent fold removes the
-    latent columns of two layers; the 20 000-point step keeps per-point latents and executes everything)."""
+    8d: forward, x3 for a training step) and against the FLOPs the kernels execute (both steps take the shape-sorted data
+    flow, whose per-shape latent fold removes the latent columns of two layers)."""
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     from shapegan_amd.util import get_voxel_coordinates
@@ -163,7 +163,7 @@ def sdfnet_numbers():
     pc, shapes = 200000, 64
     pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
     sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
-    for tag, npts, lat, folded in (("train_ref_20k_L128", 20000, 128, False), ("train_cfg_200k_L256", 200000, 256, True)):
+    for tag, npts, lat, folded in (("train_ref_20k_L128", 20000, 128, True), ("train_cfg_200k_L256", 200000, 256, True)):
         table = torch.randn(shapes, lat, device="cuda") * 1e-2
         tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
         idx = torch.randint(0, shapes * pc, (npts,), device="cuda")

@@ -163,6 +163,12 @@ long sg_sdfnet_bwd_tile_start(long N, long t);
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
                   long N, hipStream_t stream);
+/* Per-shape mode: backward of the latent fold zb1[s][o] = b1[o] + sum_k z[s][k] W1[o][3+k], zb5[s][o] = b5[o] + sum_k z[s][k] W5[o][259+k]
+ * (the latent columns of layers1.0 / layers2.0, model/sdf_net.py:27,41, enter sg_sdfnet_fwd as bias rows) from the per-shape sums
+ * t1 / t5 [256][nshapes] of dZ1 / dZ5, in one launch: the latent columns of dW1 [256][3+L] / dW5 [256][259+L] written in place
+ * (NULL, NULL to skip) and the latent gradient gz [nshapes][L] (NULL to skip); nshapes <= 6144. */
+int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
+                             const float* W5, float* dW1, float* dW5, float* gz, hipStream_t stream);
 /* t1[256][nseg], t5[256][nseg]: sums of dZ1 / dZ5 over every segment [seg_off[s], seg_off[s+1]) of points (per-shape sums: the
  * latent-table gradient and the latent columns of the layers1.0 / layers2.0 weight gradients of the shape-sorted auto-decoder
  * step, train_sdf_autodecoder.py:80-91 backward), taken from `dz` and the `bias_partials` of the same sg_sdfnet_bwd call. */

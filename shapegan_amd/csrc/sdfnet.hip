@@ -747,6 +747,53 @@ __global__ void __launch_bounds__(256) sdfnet_segsum_kernel(const float* __restr
     if (lane == 0) (blockIdx.y ? t5 : t1)[pair] = acc;
 }
 
+// ---- backward of the per-shape latent fold (the latent columns of layers1.0 / layers2.0 enter the forward as per-shape bias rows) ----
+// Backward of the fold from the per-shape sums t1 / t5 [256][S] of dZ1 / dZ5:
+//   blocks [0, 256):     row o of the latent columns  dW1[o][3 + k] = sum_s t1[o][s] z[s][k],  dW5[o][259 + k] = sum_s t5[o][s] z[s][k]
+//   blocks [256, 256+S): latent gradient row          gz[s][k] = sum_o t1[o][s] W1[o][3 + k] + t5[o][s] W5[o][259 + k]
+// thread = k (strided by 256 for L > 256); the broadcast operand (a t row / column) sits in LDS.
+__global__ void __launch_bounds__(256) shape_bias_bwd_kernel(const float* __restrict__ t1, const float* __restrict__ t5, int S,
+                                                             const float* __restrict__ z, int L, const float* __restrict__ W1,
+                                                             const float* __restrict__ W5, float* __restrict__ dW1,
+                                                             float* __restrict__ dW5, float* __restrict__ gz) {
+    extern __shared__ float sh[];   // rows: 2 x S, columns: 2 x 256
+    const int tid = threadIdx.x;
+    const int ld1 = 3 + L, ld5 = kH + 3 + L;
+    if (blockIdx.x < kH) {
+        if (!dW1) return;
+        const int o = blockIdx.x;
+        for (int s = tid; s < S; s += 256) {
+            sh[s] = t1[(long)o * S + s];
+            sh[S + s] = t5[(long)o * S + s];
+        }
+        __syncthreads();
+        for (int k = tid; k < L; k += 256) {
+            double a = 0, b = 0;    // few terms, ill-conditioned sums (per-shape sums of either sign): accumulate in double
+            for (int s = 0; s < S; ++s) {
+                const double zv = (double)z[(long)s * L + k];
+                a = fma((double)sh[s], zv, a);
+                b = fma((double)sh[S + s], zv, b);
+            }
+            dW1[(long)o * ld1 + 3 + k] = (float)a;
+            dW5[(long)o * ld5 + kH + 3 + k] = (float)b;
+        }
+    } else {
+        if (!gz) return;
+        const int s = blockIdx.x - kH;
+        sh[tid] = t1[(long)tid * S + s];
+        sh[kH + tid] = t5[(long)tid * S + s];
+        __syncthreads();
+        for (int k = tid; k < L; k += 256) {
+            double a = 0, b = 0;
+            for (int o = 0; o < kH; ++o) {
+                a = fma((double)sh[o], (double)W1[(long)o * ld1 + 3 + k], a);
+                b = fma((double)sh[kH + o], (double)W5[(long)o * ld5 + kH + 3 + k], b);
+            }
+            gz[(long)s * L + k] = (float)(a + b);
+        }
+    }
+}
+
 // `nbig` tiles of P points followed by `nsmall` tiles of kSmallTile points: when the last round of `slots` concurrently resident
 // workgroups would be at most three quarters full, its points are cut into small tiles.  A pure function of N (the slot counts
 // are those of the full 256-CU device, not queried): the partial-sum layout of the backward, and with it the summation order of
@@ -869,6 +916,20 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
         a.nbig = tp.nbig;
         hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
     }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Per-shape mode: the backward of the latent fold (zb1 = b1 + z W1[:, 3:]^T, zb5 = b5 + z W5[:, 259:]^T) from the per-shape sums
+// t1 / t5 [256][S] of dZ1 / dZ5 (sg_sdfnet_segsum or sg_rowsum): the latent columns of dW1 / dW5 (written in place, row strides of
+// the full matrices; pass NULL to skip) and the latent gradient gz [S][L] (NULL to skip).
+int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
+                             const float* W5, float* dW1, float* dW5, float* gz, hipStream_t stream) {
+    SG_CHECK_ARG(t1 && t5 && z && W1 && W5 && nshapes > 0 && latent > 0 && (dW1 == nullptr) == (dW5 == nullptr));
+    SG_CHECK_ARG(nshapes <= 6144);   // a t row of every shape in 48 KB of LDS
+    const size_t lds = (size_t)2 * (nshapes > kH ? nshapes : kH) * sizeof(float);
+    hipLaunchKernelGGL(shape_bias_bwd_kernel, dim3((unsigned)(kH + nshapes)), dim3(256), lds, stream, t1, t5, (int)nshapes, z,
+                       latent, W1, W5, dW1, dW5, gz);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -586,6 +586,36 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
     }
     return SG_OK;
 }
+// backward of the per-shape latent fold (header: sg_sdfnet_shape_bias_bwd)
+int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
+                                 const float* W5, float* dW1, float* dW5, float* gz, void*) {
+    CPU_CHECK(t1 && t5 && z && W1 && W5 && nshapes > 0 && latent > 0 && (dW1 == nullptr) == (dW5 == nullptr));
+    const long ld1 = 3 + latent, ld5 = 259 + latent;
+    if (dW1) {
+#pragma omp parallel for schedule(static)
+        for (int o = 0; o < 256; ++o)
+            for (int k = 0; k < latent; ++k) {
+                double a = 0, b = 0;
+                for (long s = 0; s < nshapes; ++s) {
+                    a += (double)t1[o * nshapes + s] * z[s * latent + k];
+                    b += (double)t5[o * nshapes + s] * z[s * latent + k];
+                }
+                dW1[o * ld1 + 3 + k] = (float)a;
+                dW5[o * ld5 + 259 + k] = (float)b;
+            }
+    }
+    if (gz) {
+#pragma omp parallel for schedule(static)
+        for (long s = 0; s < nshapes; ++s)
+            for (int k = 0; k < latent; ++k) {
+                double a = 0;
+                for (int o = 0; o < 256; ++o)
+                    a += (double)t1[o * nshapes + s] * W1[o * ld1 + 3 + k] + (double)t5[o * nshapes + s] * W5[o * ld5 + 259 + k];
+                gz[s * latent + k] = (float)a;
+            }
+    }
+    return SG_OK;
+}
 // per-segment sums of dZ1 / dZ5 (header: sg_sdfnet_segsum), straight from the images
 int sg_sdfnet_segsum_cpu(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
                          float* t5, void*) {

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
+    "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P]),
     "sg_sdfnet_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _P]),
     "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
     "sg_axpby": (c_int, [_P, _P, _P, _L, _F, _F, _P]),

@@ -663,6 +663,9 @@ class SDFNetPoints(Function):
         return (None, gp, gl) + tuple(grads)
 
 
+_FOLD_MAX_SHAPES = 1024   # the one-launch latent fold (sg_sdfnet_shape_bias_*) walks the shapes serially per thread
+
+
 class SDFNetShapes(Function):
     """Per-shape latents: out[s*pps + q] = SDFNet(points[s*pps + q], z[s]) without tiling z per point.
     The latent columns of layers1.0 / layers2.0 become per-shape biases (same products, summed in a different
@@ -683,6 +686,8 @@ class SDFNetShapes(Function):
         packed = cache.get(params, Lz, 3)
         w1, b1, w5, b5 = f32c(params[0]), params[1], f32c(params[8]), params[9]
         # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]
+        # (the [S,L] x [L,256] fold stays on sg_gemm: a dedicated one-launch kernel with double accumulation was exact to
+        # 1e-7 but saved only ~10 us, and any change of rounding here re-rolls which ReLU kinks flip in the trajectory tests)
         zb1 = gemm_raw(z, False, w1, True, bias_j=b1, b_off=3, M=S, N=_H, K=Lz, lda=Lz, ldb=kin_total)
         zb5 = gemm_raw(z, False, w5, True, bias_j=b5, b_off=_H + 3, M=S, N=_H, K=Lz, lda=Lz, ldb=_H + kin_total)
         need_grad = any(ctx.needs_input_grad[1:])
@@ -734,16 +739,26 @@ class SDFNetShapes(Function):
         if need_p:
             grads = _sdf_param_grads(params, ctx.needs_input_grad[6:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
                                      bsum)
-            # latent columns: dW1[:, 3:] = T1 @ z ; dW5[:, 259:] = T5 @ z
-            gemm_raw(t1, False, z, False, out=grads[0], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=kin_total, c_off=3)
-            gemm_raw(t5, False, z, False, out=grads[8], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=_H + kin_total,
-                     c_off=_H + 3)
-        if need_z:
+        if (need_p or need_z) and S <= _FOLD_MAX_SHAPES:
+            # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
+            # latent gradient gz = T1^T W1[:, 3:] + T5^T W5[:, 259:]
             w1, w5 = f32c(params[0]), f32c(params[8])
-            g1 = gemm_raw(t1, True, w1, False, b_off=3, M=S, N=Lz, K=_H, lda=S, ldb=kin_total)
-            g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
-            gz = _param_grad_out(z, g1.shape, dev)
-            check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
+            if need_z:
+                gz = _param_grad_out(z, (S, Lz), dev)
+            check(lib.sg_sdfnet_shape_bias_bwd(ptr(t1), ptr(t5), S, ptr(z), Lz, ptr(w1), ptr(w5),
+                                               ptr(grads[0]) if need_p else None, ptr(grads[8]) if need_p else None,
+                                               ptr(gz) if need_z else None, stream()), "sdfnet_shape_bias_bwd")
+        else:
+            if need_p:
+                gemm_raw(t1, False, z, False, out=grads[0], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=kin_total, c_off=3)
+                gemm_raw(t5, False, z, False, out=grads[8], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=_H + kin_total,
+                         c_off=_H + 3)
+            if need_z:
+                w1, w5 = f32c(params[0]), f32c(params[8])
+                g1 = gemm_raw(t1, True, w1, False, b_off=3, M=S, N=Lz, K=_H, lda=S, ldb=kin_total)
+                g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
+                gz = _param_grad_out(z, g1.shape, dev)
+                check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
         return (None, dx, gz, None, None, None) + tuple(grads)
 
 

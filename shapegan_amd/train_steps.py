@@ -199,8 +199,9 @@ class SDFAutoDecoderTrainer(object):
         and the latent-table gradient is assembled from per-shape sums, so `latent_codes[model_indices]` ([N,L]) and
         its scatter-add backward never exist.  The regulariser mean(z_batch^2) is evaluated through shape counts:
         sum_s count_s |z_s|^2 / (N L)."""
-        # small batches: the per-shape bookkeeping costs more than it saves
-        if indices.numel() < 65536 or self.latent_codes.shape[0] > ops.sdf_batch_sort_max_shapes():
+        # tiny batches: the per-shape bookkeeping costs more than it saves (measured: sorted 0.72 ms, gathered 0.80 ms at the
+        # reference's 20 000-point batch of 64 shapes)
+        if indices.numel() < 8192 or self.latent_codes.shape[0] > ops.sdf_batch_sort_max_shapes():
             return self.step_gathered(indices)
         return self.step_sorted(indices)
 
