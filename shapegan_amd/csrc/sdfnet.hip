@@ -769,6 +769,7 @@ __global__ void __launch_bounds__(256) shape_bias_bwd_kernel(const float* __rest
         __syncthreads();
         for (int k = tid; k < L; k += 256) {
             double a = 0, b = 0;    // few terms, ill-conditioned sums (per-shape sums of either sign): accumulate in double
+#pragma unroll 8
             for (int s = 0; s < S; ++s) {
                 const double zv = (double)z[(long)s * L + k];
                 a = fma((double)sh[s], zv, a);
@@ -785,6 +786,7 @@ __global__ void __launch_bounds__(256) shape_bias_bwd_kernel(const float* __rest
         __syncthreads();
         for (int k = tid; k < L; k += 256) {
             double a = 0, b = 0;
+#pragma unroll 8
             for (int o = 0; o < kH; ++o) {
                 a = fma((double)sh[o], (double)W1[(long)o * ld1 + 3 + k], a);
                 b = fma((double)sh[kH + o], (double)W5[(long)o * ld5 + kH + 3 + k], b);
