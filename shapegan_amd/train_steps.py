@@ -211,6 +211,9 @@ class SDFAutoDecoderTrainer(object):
         shapes = self.latent_codes.shape[0]
         batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
             indices, self.pointcloud_size, shapes, self.points, self.sdf)
+        self._sorted_calls = getattr(self, "_sorted_calls", 0) + 1
+        if self._sorted_calls % 256 == 1:       # the reference raises IndexError at once; here the sticky device flag is
+            ops.check_batch_indices()           # read on the first call and then every 256th (one host sync each)
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
         output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
