@@ -324,7 +324,7 @@ def test_sdfnet_points_mode(N, latent):
         close(p.grad, P[k].grad, rtol=2e-4, what="grad " + k)
 
 
-@pytest.mark.parametrize("S,pps", [(1, 128), (3, 512), (2, 4096), (1, 1000), (1, 37)])
+@pytest.mark.parametrize("S,pps", [(1, 128), (3, 512), (2, 4096), (1, 1000), (1, 37), (5, 6656)])   # 5 x 6656: 512 tiles + 16 small ones
 def test_sdfnet_shapes_mode(S, pps):
     """Per-shape latents (folded biases) == the reference's tiled-latent forward."""
     net = _sdf_state(9)
