@@ -71,6 +71,14 @@ int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int 
 int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
                            int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);
+/* Weight AND bias gradient of y = act(conv(x) + b) from dy = dLoss/dy in one pass: dz = dy * act'(y) is formed inside the
+ * weight-gradient kernel (act'(y) from the activated output, as sg_act_bwd), db[co] = sum of dz over batch and positions.  For a
+ * layer whose input needs no gradient (the critic's first layer, model/gan.py:49 under train_wgan.py:69) the activation backward
+ * then is no pass of its own.  Served shapes: sg_conv3d_k4s2p1_wgrad_act_eligible (one-channel layers, LeakyReLU / ReLU). */
+int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act);
+int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
+                               int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream);
 
 /* ---- K2: nn.ConvTranspose3d(kernel 4, stride 2, padding 1) -------------------------------------------------
  * reference: model/gan.py:13,17,21 (Generator), model/autoencoder.py:55,59,63 (decoder).

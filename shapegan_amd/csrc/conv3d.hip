@@ -728,6 +728,28 @@ int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int 
     return SG_OK;
 }
 
+// Weight + bias gradient of act(conv(x) + b) taken straight from the gradient w.r.t. the activated output: dz = dy * act'(y) is
+// formed inside the weight-gradient kernel (one-channel layers, LeakyReLU / ReLU), so the activation backward is not a pass of
+// its own.  sg_conv3d_k4s2p1_wgrad_act_eligible says whether a shape is served (host code, no GPU needed).
+int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act) {
+    return Cin == 1 && Cout <= 64 && OW % 16 == 0 && (long)batch * OD * OH * OW >= 65536 && (act == SG_ACT_LEAKY || act == SG_ACT_RELU) &&
+           edge_enabled(4);
+}
+int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
+                               int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(dy && y && x && dw && db && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
+    ConvGeom g;
+    if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_act: spatial dims must be even and >= 2");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad_act")) return SG_ERR_ARG;
+    if (!sg_conv3d_k4s2p1_wgrad_act_eligible(batch, Cin, Cout, g.OD, g.OH, g.OW, act) ||
+        edge_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace ? workspace_bytes : 0, stream, 0, y, act, slope,
+                       db) != 1)
+        SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_act: shape not served (see sg_conv3d_k4s2p1_wgrad_act_eligible) or workspace too small");
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
 int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
                            int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes,
                            hipStream_t stream) {

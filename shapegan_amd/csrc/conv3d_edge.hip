@@ -173,10 +173,13 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
+constexpr int kEdgePartial = 4096 + 64;   // floats per workgroup partial
 struct EdgeWgradArgs {
     const float* dy;    // [batch][Cy][O3]
+    const float* y;     // FUSE: the layer's activated output, same layout as dy: dz = dy * act'(y) is formed on the fly
+    float slope;
     const float* xp;    // padded grid
-    float* partial;     // [gridDim.x][64*64]
+    float* partial;     // [gridDim.x][kEdgePartial]: 64 x 64 weight-gradient tile (+ 64 bias-gradient sums with FUSE)
     int OD, OH, OW, Hp, Wp, Cout, Cy;
     long xp_sample;
     int passes_per_sample, total_passes;   // a pass = 32 consecutive positions of one sample
@@ -187,7 +190,11 @@ struct EdgeWgradArgs {
 // fragment loads would touch one 128-byte line per lane; instead the wave copies its [32 MT channels][32 positions] tile with
 // fully coalesced 16-byte loads (8 lanes per 128-byte row segment), stores it as [row][36] (conflict-free for the fragment
 // reads) and reads 16 consecutive positions per lane back as four ds_read_b128.
-template <int MT>
+// FUSE (0: off, SG_ACT_LEAKY, SG_ACT_RELU): the incoming gradient is taken through the layer's activation here — dz = dy * act'(y),
+// read from the sign of the activated output as sg_act_bwd does — and the bias gradient (channel sums of dz) comes out of the same
+// pass.  For the critic's first layer, whose input needs no gradient, dz then never exists in memory: the separate activation
+// backward (read dy + y, write dz: 402 MB at 128 x 64 x 16^3) and this kernel's read of dz become one read of dy + y.
+template <int MT, int FUSE>
 __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
     constexpr int kLd = 36;                       // floats per staged row
     constexpr int kStage = MT * 32 * kLd;         // floats per wave
@@ -195,9 +202,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh2 = lane >> 5;
     const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy);
+    const __amdgpu_buffer_rsrc_t yres = make_rsrc(FUSE ? a.y : a.dy);
     const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.xp);
     const unsigned O3 = (unsigned)(a.OD * a.OH * a.OW);
     float* stage = lds + wave * kStage;
+    __shared__ float bsh[4][64];   // FUSE: per-wave channel sums
     // copy lane -> (row within a group of 8, 16-byte column)
     const int crow = lane >> 3, ccol = (lane & 7) * 4;
     unsigned tapoff[2];
@@ -216,6 +225,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
 
     const int nwaves = gridDim.x * 4;
     f32x4 cv[MT * 4];     // this lane's pieces of the dy tile
+    f32x4 yv[FUSE ? MT * 4 : 1];
+    float rs[MT * 4];     // FUSE: running sums of dz over this lane's pieces (channel i*8 + crow)
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) rs[i] = 0.f;
     float bv[2][16];
     auto issue = [&](int ps) __attribute__((always_inline)) {
         uint32_t n, pp, seg, q1, od, oh;
@@ -225,6 +238,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
         for (int i = 0; i < MT * 4; ++i) {
             const int co = i * 8 + crow;
             cv[i] = buf_load4v(dres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
+            if (FUSE) yv[i] = buf_load4v(yres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
         }
         const uint32_t p0 = pp * 32 + 16 * kh2;   // this lane half's 16 positions: one row segment (od, oh, ow0 .. ow0+15)
         a.dOW16.divmod(p0 >> 4, q1, seg);
@@ -238,6 +252,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
     int ps = blockIdx.x * 4 + wave;
     if (ps < a.total_passes) issue(ps);
     for (; ps < a.total_passes; ps += nwaves) {
+        if (FUSE) {
+            const float neg = FUSE == SG_ACT_LEAKY ? a.slope : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv[i][j] = yv[i][j] > 0.f ? cv[i][j] : cv[i][j] * neg;
+                rs[i] += (cv[i][0] + cv[i][1]) + (cv[i][2] + cv[i][3]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(stage + (i * 8 + crow) * kLd + ccol) = cv[i];
         float bc[2][16];
@@ -272,16 +295,29 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
                 const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh2;
                 lds[wave * 4096 + row * 64 + nt * 32 + r] = acc[mt][nt][q];
             }
+    if (FUSE) {
+        // the 8 lanes that share `crow` hold the pieces of one 128-byte row segment: sum them (quad swaps + half-row mirror)
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            float v = rs[i];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+            if ((lane & 7) == 0) bsh[wave][i * 8 + crow] = v;
+        }
+    }
     __syncthreads();
-    float* out = a.partial + (long)blockIdx.x * 4096;
+    float* out = a.partial + (long)blockIdx.x * kEdgePartial;
     for (int e = threadIdx.x; e < MT * 32 * 64; e += 256)
         out[e] = (lds[e] + lds[4096 + e]) + (lds[2 * 4096 + e] + lds[3 * 4096 + e]);
+    if (FUSE && threadIdx.x < MT * 32) out[4096 + threadIdx.x] = (bsh[0][threadIdx.x] + bsh[1][threadIdx.x]) + (bsh[2][threadIdx.x] + bsh[3][threadIdx.x]);
 }
 
 // dw[co][0][tap] = sum over workgroup partials.  256 threads = 16 partial groups x 16 outputs; every thread keeps 8
 // independent loads in flight (a serial chain of 128 loads per thread took 32 us); fixed summation order.
+// (blocks beyond the 256 of the weight tile: the 64 bias-gradient sums of the fused form -> db)
 __global__ void __launch_bounds__(256) wgrad_c1_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                int nparts, int Cout, int Cin_total) {
+                                                                int nparts, int Cout, int Cin_total, float* __restrict__ db) {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + o;
@@ -292,7 +328,7 @@ __global__ void __launch_bounds__(256) wgrad_c1_finalize_kernel(const float* __r
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + 16 * u;
-            s[u] += p < nparts ? partial[(long)p * 4096 + e] : 0.f;
+            s[u] += p < nparts ? partial[(long)p * kEdgePartial + e] : 0.f;
         }
     }
     red[grp][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
@@ -302,7 +338,11 @@ __global__ void __launch_bounds__(256) wgrad_c1_finalize_kernel(const float* __r
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
         const int co = e >> 6, tap = e & 63;
-        if (co < Cout) dw[((long)co * Cin_total) * 64 + tap] = t;
+        if (e >= 4096) {
+            if (e - 4096 < Cout) db[e - 4096] = t;
+        } else if (co < Cout) {
+            dw[((long)co * Cin_total) * 64 + tap] = t;
+        }
     }
 }
 
@@ -576,7 +616,7 @@ size_t edge_fwd_workspace_bytes(int batch, int OD, int OH, int OW) {
     return (size_t)batch * (2 * OD + 2) * (2 * OH + 2) * (2 * OW + 2) * sizeof(float);
 }
 size_t edge_wgrad_workspace_bytes(int batch, int OD, int OH, int OW) {
-    return edge_fwd_workspace_bytes(batch, OD, OH, OW) + (size_t)512 * 4096 * sizeof(float);
+    return edge_fwd_workspace_bytes(batch, OD, OH, OW) + (size_t)512 * kEdgePartial * sizeof(float);
 }
 size_t edge_dgrad_workspace_bytes(int batch, int OD, int OH, int OW) { return (size_t)batch * 64 * OD * OH * OW * sizeof(float); }
 
@@ -638,10 +678,13 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
 }
 
 // Conv3d(1 -> Cout <= 64) weight gradient (channel 0 of dw; the caller zeroes the rest when Cin_total > 1).
+// y != NULL: fused activation backward (act = SG_ACT_LEAKY / SG_ACT_RELU), db receives the bias gradient
 int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force) {
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force, const float* y, int act, float slope,
+                   float* db) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64 || g.OW % 16 != 0) return 0;
+    if (y && ((act != SG_ACT_LEAKY && act != SG_ACT_RELU) || !db)) return 0;
     if (!force && (long)batch * O3 < 65536) return 0;
     if (!workspace || workspace_bytes < edge_wgrad_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
     if (padded_floats(batch, g) * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
@@ -650,6 +693,8 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     launch_pad(x, xp, batch, g, stream);
     EdgeWgradArgs a;
     a.dy = dy;
+    a.y = y;
+    a.slope = slope;
     a.xp = xp;
     a.partial = partial;
     a.OD = g.OD;
@@ -667,11 +712,20 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     a.dOH = FastDiv((uint32_t)g.OH);
     int wgs = (a.total_passes + 3) / 4;
     if (wgs > 512) wgs = 512;
-    if (Cout > 32)
-        hipLaunchKernelGGL((conv_wgrad_c1_kernel<2>), dim3(wgs), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv_wgrad_c1_kernel<1>), dim3(wgs), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(wgrad_c1_finalize_kernel, dim3(256), dim3(256), 0, stream, (const float*)partial, dw, wgs, Cout, Cin_total);
+    const int fuse = y ? act : 0;
+#define SG_LAUNCH_WGRAD_C1(MT, F) hipLaunchKernelGGL((conv_wgrad_c1_kernel<MT, F>), dim3(wgs), dim3(256), 0, stream, a)
+    if (Cout > 32) {
+        if (fuse == SG_ACT_LEAKY) SG_LAUNCH_WGRAD_C1(2, SG_ACT_LEAKY);
+        else if (fuse == SG_ACT_RELU) SG_LAUNCH_WGRAD_C1(2, SG_ACT_RELU);
+        else SG_LAUNCH_WGRAD_C1(2, 0);
+    } else {
+        if (fuse == SG_ACT_LEAKY) SG_LAUNCH_WGRAD_C1(1, SG_ACT_LEAKY);
+        else if (fuse == SG_ACT_RELU) SG_LAUNCH_WGRAD_C1(1, SG_ACT_RELU);
+        else SG_LAUNCH_WGRAD_C1(1, 0);
+    }
+#undef SG_LAUNCH_WGRAD_C1
+    hipLaunchKernelGGL(wgrad_c1_finalize_kernel, dim3(fuse ? 260 : 256), dim3(256), 0, stream, (const float*)partial, dw, wgs, Cout,
+                       Cin_total, db);
     return 1;
 }
 

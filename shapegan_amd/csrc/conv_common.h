@@ -82,7 +82,8 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
                  const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                  hipStream_t stream, int force = 0);
 int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0);
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0, const float* y = nullptr,
+                   int act = 0, float slope = 0.f, float* db = nullptr);
 int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force = 0);

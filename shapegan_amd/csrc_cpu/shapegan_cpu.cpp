@@ -394,6 +394,22 @@ int sg_act_bwd_rowsum_cpu(const float* y, const float* dy, float* dx, float* row
     }
     return SG_OK;
 }
+// weight + bias gradient through the activation (header: sg_conv3d_k4s2p1_wgrad_act): dz = dy * act'(y), then the plain forms
+int sg_conv3d_k4s2p1_wgrad_act_cpu(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
+                                   int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void*, size_t,
+                                   void*) {
+    CPU_CHECK(dy && y && x && dw && db && batch > 0 && Cout > 0 && !(ID & 1) && !(IH & 1) && !(IW & 1));
+    const long O3 = (long)(ID / 2) * (IH / 2) * (IW / 2), n = (long)batch * Cout * O3;
+    std::vector<float> dz((size_t)n);
+    for (long e = 0; e < n; ++e) dz[e] = act_grad_out(y[e], dy[e], act, slope);
+    for (int co = 0; co < Cout; ++co) {
+        double t = 0;
+        for (int b = 0; b < batch; ++b)
+            for (long e = 0; e < O3; ++e) t += dz[((long)b * Cout + co) * O3 + e];
+        db[co] = (float)t;
+    }
+    return sg_conv3d_k4s2p1_wgrad_cpu(dz.data(), x, dw, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, nullptr, 0, nullptr);
+}
 int sg_act_bwd_dy_cpu(const float* y, const float* dy, const float* ggx, float* out, long n, int act, void*) {
     CPU_CHECK(y && dy && ggx && out && n > 0 && (act == ACT_TANH || act == ACT_SIGMOID));
     for (long e = 0; e < n; ++e) out[e] = ggx[e] * dy[e] * (act == ACT_TANH ? -2.f * y[e] : 1.f - 2.f * y[e]);

@@ -113,6 +113,20 @@ def conv_wgrad_raw(dy, x, ct, out=None):
     return dw
 
 
+def conv_wgrad_act_raw(dy, y, x, act, slope, dw_out=None, db_out=None):
+    """(dw, db) of y = act(conv(x) + b) from dy = dLoss/dy in one pass (sg_conv3d_k4s2p1_wgrad_act)."""
+    N, Co, OD, OH, OW = dy.shape
+    Cx = x.shape[1]
+    dw = dw_out if dw_out is not None else torch.empty((Co, Cx, 4, 4, 4), dtype=torch.float32, device=dy.device)
+    db = db_out if db_out is not None else torch.empty(Co, dtype=torch.float32, device=dy.device)
+    lib = _lib()
+    nb = min(lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(N, Cx, Co, OD, OH, OW), _WGRAD_WS_CAP)
+    ws = workspace("splitk", nb, dy.device)
+    check(lib.sg_conv3d_k4s2p1_wgrad_act(ptr(dy), ptr(y), ptr(x), ptr(dw), ptr(db), N, Cx, Cx, Cx, Co, 2 * OD, 2 * OH, 2 * OW, act,
+                                         slope, ptr(ws), ws.numel(), stream()), "conv3d_wgrad_act")
+    return dw, db
+
+
 def conv_wgrad_halo_raw(dy, x, ct):
     """wgrad through the forced LDS-halo kernel — tests and tuning only."""
     N, Co, OD, OH, OW = dy.shape
@@ -283,6 +297,14 @@ class ConvFwd(Function):
         gb = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         plain = not torch.is_grad_enabled()      # no create_graph: raw kernels, parameter gradients straight into their slices
+        if (ctx.act != ACT_NONE and want_b and plain and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and w.shape[1] == x.shape[1] and _lib().sg_conv3d_k4s2p1_wgrad_act_eligible(
+                    x.shape[0], x.shape[1], w.shape[0], y.shape[2], y.shape[3], y.shape[4], ctx.act)):
+            # the input needs no gradient (first layer of the critic): the activation backward rides in the weight-gradient
+            # kernel, dz = dy * act'(y) is never written
+            gw, gb = conv_wgrad_act_raw(f32c(gy), y, x, ctx.act, ctx.slope, L.grad_destination(w, w.shape),
+                                        L.grad_destination(b, b.shape))
+            return None, gw, gb, None, None
         if ctx.act != ACT_NONE and want_b and plain and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
             # activation + bias sums in one pass
             gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope, L.grad_destination(b, b.shape))

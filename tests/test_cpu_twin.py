@@ -42,7 +42,8 @@ def test_twin_exports_every_entry_point():
         assert hasattr(lib, n + "_cpu"), "missing twin: " + n
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
-            "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes")
+            "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
+            "sg_conv3d_k4s2p1_wgrad_act_eligible")
 
 
 def test_dispatch_is_by_tensor_device_only(on_cpu):
@@ -67,6 +68,11 @@ def test_conv3d(on_cpu, N, Ci, Co, R):
 @pytest.mark.parametrize("N,Ci,Co,R", [(2, 16, 8, 4), (3, 8, 1, 8), (1, 5, 3, 3)])
 def test_conv_transpose3d(on_cpu, N, Ci, Co, R):
     OPS.test_conv_transpose3d(N, Ci, Co, R)
+
+
+def test_conv_wgrad_through_activation(on_cpu):
+    OPS.test_conv_wgrad_through_activation(2, 5, 4, 1)
+    OPS.test_conv_wgrad_through_activation(1, 3, 2, 2)
 
 
 def test_from_sdf_zero_channels(on_cpu):

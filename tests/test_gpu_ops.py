@@ -95,6 +95,33 @@ def test_conv_transpose3d(N, Ci, Co, R):
         close(bg.grad, br.grad, what="convT bias grad act%d" % act)
 
 
+@pytest.mark.parametrize("N,Co,O,act", [(16, 64, 16, 1), (17, 24, 16, 2), (128, 64, 16, 1)])
+def test_conv_wgrad_through_activation(N, Co, O, act):
+    """sg_conv3d_k4s2p1_wgrad_act: weight and bias gradient of act(conv(x) + b) for a one-channel input straight from dLoss/dy (the
+    activation backward rides in the weight-gradient kernel) == autograd of ATen conv3d + LeakyReLU / ReLU; and the module path
+    (ops.conv3d_k4s2p1 on an input that needs no gradient) takes it."""
+    from shapegan_amd import ops
+    torch.manual_seed(N + Co + O)
+    x = torch.rand(N, 1, 2 * O, 2 * O, 2 * O) * 2 - 1
+    w = (torch.randn(Co, 1, 4, 4, 4) * 0.2).requires_grad_(True)
+    b = (torch.randn(Co) * 0.1).requires_grad_(True)
+    fn = (lambda t: F.leaky_relu(t, 0.2)) if act == 1 else F.relu
+    pre = F.conv3d(x, w, b, stride=2, padding=1)
+    y_ref = fn(pre)
+    dy = torch.randn_like(y_ref)
+    dy[pre.detach().abs() < 1e-5] = 0      # a pre-activation within rounding of the kink may take either branch on the GPU
+    y_ref.backward(dy)
+    dw, db = ops.conv_wgrad_act_raw(dev(dy), dev(y_ref.detach()), dev(x), act, 0.2)
+    close(dw, w.grad, what="dw through activation")
+    close(db, b.grad, what="db through activation")
+    if DEV == "cuda":
+        wg, bg = dev(w.detach()).requires_grad_(True), dev(b.detach()).requires_grad_(True)
+        y = ops.conv3d_k4s2p1(dev(x), wg, bg, act, 0.2)
+        y.backward(dev(dy))
+        close(wg.grad, w.grad, what="module path dw")
+        close(bg.grad, b.grad, what="module path db")
+
+
 def test_conv_from_sdf_zero_channels():
     """First progressive stage: conv over [x, 0, ..., 0] == conv over channel 0 only; dW of the zero channels is 0."""
     from shapegan_amd import ops
