@@ -266,7 +266,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                // [256][P]
     float* Xs = Hs + kH * P;         // [KUp][LDX]
-    float* red = Xs + a.lay.KUp * LDX;  // [512]
+    float* red = Xs + a.lay.KUp * LDX;  // [16][P]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -402,21 +402,26 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     init_acc(bias + 6 * kH);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     writeback(6);
-    // layer 8: 256 -> 1, tanh.  512/P partial dot products per point, reduced through LDS.
+    // layer 8: 256 -> 1, tanh.  The dot product is cut into sixteen 16-row groups summed in a fixed order, whatever the tile
+    // size (a thread takes P / 32 groups of its point), so that a point's output does not depend on the tile it falls into.
     {
-        constexpr int PARTS = 512 / P;
-        constexpr int ROWS = kH / PARTS;
+        constexpr int PARTS = 512 / P;     // threads per point
+        constexpr int SUB = 16 / PARTS;    // row groups per thread
         const int p = tid % P, part = tid / P;
         const float* w8 = a.packed + a.lay.W8;
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = part * ROWS; k < (part + 1) * ROWS; ++k) s = fmaf(w8[k], Hs[k * P + p], s);
-        red[tid] = s;
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const int g = part * SUB + u;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 16 * g; k < 16 * g + 16; ++k) s = fmaf(w8[k], Hs[k * P + p], s);
+            red[g * P + p] = s;
+        }
         __syncthreads();
         if (tid < P) {
             float v = bias[7 * kH];
 #pragma unroll
-            for (int q = 0; q < PARTS; ++q) v += red[q * P + tid];
+            for (int q = 0; q < 16; ++q) v += red[q * P + tid];
             const long gp = p0 + tid;
             if (gp < a.N) a.out[gp] = tanhf(v);
         }
@@ -426,8 +431,8 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 // Tile plan (see tile_plan below): workgroups [0, nbig) take P points each, the rest kSmallTile points each.  The small tiles
 // are the remainder of the last round of workgroups: a 200 000-point launch is 6.1 rounds of 64-point tiles on 2 x 256 workgroup slots, and
 // the 27 tiles of the seventh round would keep the whole chip waiting for a full tile time; cut into 32-point tiles they
-// finish in about a third of it.  A point's arithmetic does not depend on the tile it is in (same k order), so the plan never
-// changes a result of the forward.
+// finish in about a third of it.  A point's arithmetic does not depend on the tile it is in (same k order in every layer, the
+// last layer's dot product in fixed 16-row groups), so the plan never changes a result of the forward.
 constexpr int kSmallTile = 32;
 
 template <int P, bool SHAPE_BIAS>
@@ -812,7 +817,7 @@ static TilePlan tile_plan(long N, int P, long slots) {
 constexpr long kFwdSlots = 256;   // one workgroup per CU (LDS)
 constexpr long kBwdSlots = SG_BWD_TILE == 64 ? 512 : 256;   // two per CU
 
-static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 512) * sizeof(float); }
+static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
 
 template <class K>

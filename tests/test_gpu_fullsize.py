@@ -183,3 +183,45 @@ def test_sdfnet_backward_beyond_2m_points_equals_its_halves():
     close(dz, torch.cat([dz_a, dz_b]), what="d latent")
     for (name, _), full, ha, hb in zip(net.named_parameters(), g, g_a, g_b):
         close_mostly(full, ha + hb, what="grad " + name)      # sums over 2.46 M points: isolated entries differ at rounding level
+
+
+def test_sdfnet_sorted_batches_at_random_sizes_equal_their_pieces():
+    """Fuzz of the SDFNet training kernels at ragged sizes (scripts/fuzz_sdf.py runs more of it): a shape-sorted batch evaluated in
+    one call against the same batch evaluated as two calls cut at a random point — other tile plans and partial-sum layouts, the
+    same per-point arithmetic, so no ReLU kink can flip between the two: outputs bit-equal, latent-table and parameter gradients
+    equal to summation-order rounding."""
+    import random
+    from shapegan_amd.model.sdf_net import SDFNet
+    random.seed(7)
+    torch.manual_seed(0)
+    nets = {L: SDFNet(latent_code_size=L).cuda() for L in (16, 128)}
+    for it in range(24):
+        L = random.choice((16, 128))
+        net = nets[L]
+        N = random.choice((1, 31, 33, 63, 64, 65, 127, 129)) if it % 4 == 0 else random.randint(2, random.choice((300, 5000, 40000, 70000)))
+        S = random.randint(1, min(40, N))
+        sid = torch.sort(torch.randint(0, S, (N,), device="cuda"))[0]
+        pts = torch.rand(N, 3, device="cuda") * 2 - 1
+        table = torch.randn(S, L, device="cuda") * 0.5
+        w = torch.randn(N, device="cuda")
+
+        def run(lo, hi):
+            t = table.clone().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            sg = torch.zeros(S + 1, dtype=torch.int64, device="cuda")
+            sg[1:] = torch.cumsum(torch.bincount(sid[lo:hi], minlength=S), 0)
+            out = net.forward_segments(pts[lo:hi].contiguous(), t, sid[lo:hi].int().contiguous(), sg)
+            (out * w[lo:hi]).sum().backward()
+            return out.detach(), t.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+        full = run(0, N)
+        if N == 1:
+            continue
+        cut = random.randint(1, N - 1)
+        a, b = run(0, cut), run(cut, N)
+        what = "N=%d cut=%d S=%d L=%d" % (N, cut, S, L)
+        assert torch.equal(full[0], torch.cat([a[0], b[0]])), what + ": outputs depend on the tiling"
+        close(full[1], a[1] + b[1], rtol=1e-3, what=what + " d latent table")
+        for (name, _), g, ga, gb in zip(net.named_parameters(), full[2], a[2], b[2]):
+            close(g, ga + gb, rtol=1e-3, what=what + " grad " + name)
