@@ -122,6 +122,24 @@ def test_conv_wgrad_through_activation(N, Co, O, act):
         close(bg.grad, b.grad, what="module path db")
 
 
+def test_conv_transpose3d_to_one_channel_random_shapes():
+    """ConvTranspose3d(C -> 1) through the fused tap-group kernel at random channel counts / odd plane sizes / batch sizes that
+    are no multiple of the XCD count (partial position tiles, clamped channel reads, idle workgroups) == ATen."""
+    import random
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_TANH
+    random.seed(5)
+    for it in range(14):
+        N, C, R = random.randint(1, 19), random.choice((1, 2, 7, 24, 33, 63, 64)), random.choice((1, 2, 3, 5, 6, 9, 12, 13, 16))
+        torch.manual_seed(it)
+        x = torch.randn(N, C, R, R, R)
+        w = torch.randn(C, 1, 4, 4, 4) / (C * 8) ** 0.5
+        b = torch.randn(1)
+        ref = torch.tanh(F.conv_transpose3d(x, w, b, stride=2, padding=1))
+        got = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0)
+        close(got, ref, what="convT C->1 N=%d C=%d R=%d" % (N, C, R))
+
+
 def test_conv_from_sdf_zero_channels():
     """First progressive stage: conv over [x, 0, ..., 0] == conv over channel 0 only; dW of the zero channels is 0."""
     from shapegan_amd import ops
