@@ -31,9 +31,7 @@
 #ifndef SG_BWD_RING
 #define SG_BWD_RING 4
 #endif
-#ifndef SG_BWD_TILE
-#define SG_BWD_TILE 64
-#endif
+#define SG_BWD_TILE 64   // (the tile layout of the partial sums is part of the ABI: include/shapegan_hip.h)
 
 namespace sg {
 
@@ -815,7 +813,7 @@ static TilePlan tile_plan(long N, int P, long slots) {
     return TilePlan{full, (N - full * P + kSmallTile - 1) / kSmallTile};
 }
 constexpr long kFwdSlots = 256;   // one workgroup per CU (LDS)
-constexpr long kBwdSlots = SG_BWD_TILE == 64 ? 512 : 256;   // two per CU
+constexpr long kBwdSlots = 512;   // two per CU
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
