@@ -165,6 +165,7 @@ class SDFAutoDecoderTrainer(object):
         self.net_bucket, self.lat_bucket = GradBucket(self.net_opt), GradBucket(self.lat_opt)
         self.capturable = capturable
         self._graph, self._graph_idx, self._graph_loss, self._graph_calls = None, None, None, 0
+        self._sorted_calls = 0
 
     def step_graphed(self, indices):
         """step_gathered as ONE captured graph launch (single process only).  The reference's 20 000-point batch is
@@ -211,7 +212,7 @@ class SDFAutoDecoderTrainer(object):
         shapes = self.latent_codes.shape[0]
         batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
             indices, self.pointcloud_size, shapes, self.points, self.sdf)
-        self._sorted_calls = getattr(self, "_sorted_calls", 0) + 1
+        self._sorted_calls += 1
         if self._sorted_calls % 256 == 1:       # the reference raises IndexError at once; here the sticky device flag is
             ops.check_batch_indices()           # read on the first call and then every 256th (one host sync each)
         self.net_opt.zero_grad()
