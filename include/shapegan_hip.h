@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 3
+#define SG_ABI_VERSION 4
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 
@@ -247,6 +247,11 @@ int sg_loss_meansq_fwd(const float* x, const float* row_weight, long rows, int L
                        size_t workspace_bytes, hipStream_t stream);
 int sg_loss_meansq_bwd(const float* x, const float* row_weight, const float* gloss, float* dx, long rows, int L, double denom,
                        hipStream_t stream);
+/* voxel_difference, train_autoencoder.py:50-52: count[0] = #{e : (a[e] * b[e]) < 0} with the product rounded to fp32 as the
+ * reference's `(input * target) < 0` does (a product that underflows to -0, or a NaN, does not count).  Integer arithmetic
+ * throughout: bit-exact.  The caller divides by n (`torch.sum(wrong_signs).item() / wrong_signs.nelement()`). */
+int sg_count_sign_mismatch(const float* a, const float* b, long n, long long* count, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream);
 int sg_gradient_penalty_fwd(const float* grad, long B, long M, float weight, float* norms, float* loss, hipStream_t stream);
 int sg_gradient_penalty_bwd(const float* grad, const float* norms, const float* gloss, float* dgrad, long B, long M,
                             float weight, hipStream_t stream);

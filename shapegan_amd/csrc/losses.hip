@@ -125,6 +125,41 @@ __global__ void __launch_bounds__(256) kld_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---- sign-mismatch count (voxel_difference, train_autoencoder.py:50-52) ----------------------------------------------
+// count of elements with (a * b) < 0 where a * b is the ROUNDED fp32 product, exactly as `(input * target) < 0` evaluates it:
+// a product that underflows to -0 does not count, a NaN operand does not count.  Integer partials, integer total: bit-exact and
+// independent of the launch geometry.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long other = ((unsigned long long)__shfl_xor(hi, off) << 32) | __shfl_xor(lo, off);
+        const unsigned long long sum = (((unsigned long long)hi << 32) | lo) + other;
+        lo = (unsigned)sum;
+        hi = (unsigned)(sum >> 32);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+__global__ void __launch_bounds__(256) sign_mismatch_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                            unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long red[4];
+    unsigned long long c = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float prod = a[e] * b[e];
+        c += prod < 0.f ? 1ull : 0ull;
+    }
+    c = wave_sum_u64(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(64) sign_mismatch_final_kernel(const unsigned long long* __restrict__ partial,
+                                                                 long long* __restrict__ count, int nb) {
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+    s = wave_sum_u64(s);
+    if (threadIdx.x == 0) count[0] = (long long)s;
+}
+
 // ---- (row-weighted) mean of squares ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ roww, long n,
                                                      int L, double* __restrict__ partial) {
@@ -380,6 +415,16 @@ int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* g
     SG_CHECK_ARG(mean && log_variance && gloss && dmean && dlog_variance && n > 0);
     hipLaunchKernelGGL(kld_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mean, log_variance, gloss, dmean,
                        dlog_variance, n, (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_count_sign_mismatch(const float* a, const float* b, long n, long long* count, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
+    SG_CHECK_ARG(a && b && count && n > 0);
+    SG_CHECK_WS();
+    const int nb = red_grid(n);
+    hipLaunchKernelGGL(sign_mismatch_kernel, dim3(nb), dim3(256), 0, stream, a, b, n, (unsigned long long*)workspace);
+    hipLaunchKernelGGL(sign_mismatch_final_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)workspace, count, nb);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -777,6 +777,16 @@ int sg_loss_weighted_l1_bwd_cpu(const float* o, const float* t, const float* glo
     }
     return SG_OK;
 }
+int sg_count_sign_mismatch_cpu(const float* a, const float* b, long n, long long* count, void*, size_t, void*) {
+    CPU_CHECK(a && b && count && n > 0);
+    long long c = 0;
+    for (long e = 0; e < n; ++e) {
+        volatile float prod = a[e] * b[e];     // the rounded fp32 product, as `(input * target) < 0` sees it
+        c += prod < 0.f ? 1 : 0;
+    }
+    count[0] = c;
+    return SG_OK;
+}
 int sg_loss_mean_split_fwd_cpu(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, void*) {
     CPU_CHECK(x && loss && n > 0 && n_first >= 0 && n_first <= n);
     double a = 0, b = 0;

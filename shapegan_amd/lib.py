@@ -93,6 +93,7 @@ SIGNATURES = {
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),
     "sg_loss_meansq_bwd": (c_int, [_P, _P, _P, _P, _L, _I, _D, _P]),
+    "sg_count_sign_mismatch": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_gradient_penalty_fwd": (c_int, [_P, _L, _L, _F, _P, _P, _P]),
     "sg_gradient_penalty_bwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
     "sg_lerp_rows": (c_int, [_P, _P, _P, _P, _L, _L, _P]),
@@ -166,7 +167,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 3:
+        if lib.sg_abi_version() != 4:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip

@@ -1079,6 +1079,18 @@ def weighted_l1(out, target, neg_weight=1.0):
     return WeightedL1.apply(out, target, float(neg_weight))
 
 
+def count_sign_mismatch(a, b):
+    """#{(a * b) < 0} as an int64 device scalar (voxel_difference, train_autoencoder.py:50-52): integer work, bit-exact."""
+    a, b = f32c(a.detach()), f32c(b.detach())
+    if a.numel() != b.numel():
+        raise RuntimeError("count_sign_mismatch: %d vs %d elements" % (a.numel(), b.numel()))
+    count = torch.empty((), dtype=torch.int64, device=a.device)
+    ws = _loss_ws(a.device)
+    check(_lib().sg_count_sign_mismatch(ptr(a), ptr(b), a.numel(), ptr(count), ptr(ws), ws.numel(), stream()),
+          "count_sign_mismatch")
+    return count
+
+
 class KLD(Function):
     """-0.5 * sum(1 + lv - mu^2 - exp(lv)) / numel (kld_loss, train_autoencoder.py:54-55)."""
 

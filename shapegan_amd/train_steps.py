@@ -89,8 +89,8 @@ def kld_loss(mean, log_variance):
 
 def voxel_difference(output, target):
     """train_autoencoder.py:50-52: fraction of sign mismatches (integer count, bit-exact)."""
-    wrong = (output * target) < 0
-    return torch.sum(wrong).item() / wrong.nelement()
+    target = target.reshape(output.shape) if target.numel() == output.numel() else target.expand_as(output).contiguous()
+    return ops.count_sign_mismatch(output, target).item() / output.numel()
 
 
 class AutoencoderTrainer(object):

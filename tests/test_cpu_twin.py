@@ -133,6 +133,8 @@ def test_layernorm_segmax_colsum(on_cpu):
 def test_losses_and_blends(on_cpu):
     LOSS.test_weighted_l1_matches_reconstruction_loss((3, 7, 5))
     LOSS.test_kld_matches_reference()
+    for shape in ((4, 32, 32, 32), (3, 7, 5), (1,), (2049,)):
+        LOSS.test_voxel_difference_bit_exact(shape)
     LOSS.test_mean_sq_plain_and_row_weighted()
     LOSS.test_lerp_rows_bit_exact()
     LOSS.test_mean_difference_matches_torch(128, 64)

@@ -31,6 +31,55 @@ def close_mostly(a, b, rtol=RTOL, max_bad_frac=1e-3, what=""):
         assert float((a - b).abs().max()) <= 0.5 * float(b.abs().max()), what + ": outlier larger than the tensor scale"
 
 
+# ---- voxel_difference: the integer, bit-exact loss of SURVEY.md 8 row a13 ----------------------------------------------------
+def _ref_voxel_difference(input, target):
+    """train_autoencoder.py:50-52, verbatim."""
+    wrong_signs = (input * target) < 0
+    return torch.sum(wrong_signs).item() / wrong_signs.nelement()
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 32, 32), (4, 32, 32, 32), (3, 7, 5), (1,), (2049,), (16, 64, 64, 64)])
+def test_voxel_difference_bit_exact(shape):
+    """sg_count_sign_mismatch against the reference expression on the CPU: the COUNT must be equal (integer work), hence the
+    returned fraction is the same double.  Edge values: +-0, NaN, +-inf, denormals, products that underflow to -0 (not
+    counted: the rounded fp32 product is what is compared with 0) and products that are denormal (counted)."""
+    from shapegan_amd import ops
+    from shapegan_amd.train_steps import voxel_difference
+    torch.manual_seed(len(shape) * 7 + shape[0])
+    a = torch.randn(shape)
+    b = torch.randn(shape)
+    fa, fb = a.view(-1), b.view(-1)
+    n = fa.numel()
+    special = [(0.0, -1.0), (-0.0, 1.0), (float("nan"), -1.0), (1.0, float("nan")), (float("inf"), -1.0),
+               (float("-inf"), float("-inf")), (float("inf"), -0.0), (1e-30, -1e-30), (1e-20, -1e-20), (-1e-45, 1.0),
+               (1e-45, -1e-45), (3.0, -2.0), (-3.0, -2.0)]
+    gen = torch.Generator().manual_seed(n)
+    for (x, y), pos in zip(special, torch.randperm(n, generator=gen)[:len(special)].tolist()):
+        fa[pos], fb[pos] = x, y
+    ref_count = int(torch.sum((a * b) < 0).item())
+    got = ops.count_sign_mismatch(a.to(DEV), b.to(DEV))
+    assert got.dtype == torch.int64 and int(got.item()) == ref_count
+    assert voxel_difference(a.to(DEV), b.to(DEV)) == _ref_voxel_difference(a, b)
+    # all-agree / all-disagree extremes
+    c = torch.rand(shape) + 1
+    assert voxel_difference(c.to(DEV), (c * 2).to(DEV)) == 0.0
+    assert voxel_difference(c.to(DEV), (-c).to(DEV)) == 1.0
+
+
+def test_voxel_difference_on_autoencoder_output(golden_modules):
+    """The call site: `voxel_difference(output, test_set)` in train_autoencoder.py:64-77 (eval-mode autoencoder output against
+    its input batch) — native module output, native count, against the reference expression on the same tensors."""
+    from shapegan_amd.model.autoencoder import Autoencoder
+    from shapegan_amd.train_steps import voxel_difference
+    torch.manual_seed(11)
+    ae = Autoencoder(is_variational=False).to(DEV)
+    ae.eval()
+    batch = (torch.rand(6, 32, 32, 32) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        out = ae(batch)
+    assert voxel_difference(out, batch) == _ref_voxel_difference(out.cpu(), batch.cpu())
+
+
 # ---- reconstruction / KLD / DeepSDF losses --------------------------------------------------------------------------
 def _ref_reconstruction_loss(output, target):
     """train_autoencoder.py:57-62, verbatim semantics (in-place masked scale)."""
