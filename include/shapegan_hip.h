@@ -316,6 +316,9 @@ const char* sg_comm_last_error(void);
 size_t sg_allreduce_unique_id_bytes(void);
 int sg_allreduce_unique_id(void* id_out, size_t bytes);
 int sg_allreduce_init(sg_comm** comm, int rank, int world, const void* unique_id, size_t id_bytes, int device);
+/* read back from the communicator: ranks = ncclCommCount, rank = ncclCommUserRank, device = ncclCommCuDevice, rccl_version =
+ * ncclGetVersion (any pointer may be NULL) */
+int sg_allreduce_info(sg_comm* comm, int* ranks, int* rank, int* device, int* rccl_version);
 int sg_allreduce_launch(sg_comm* comm, float* buf, long count, hipStream_t compute_stream);
 int sg_allreduce_wait(sg_comm* comm, hipStream_t compute_stream);
 int sg_allreduce_destroy(sg_comm* comm);

@@ -72,10 +72,38 @@ int sg_allreduce_init(sg_comm** out, int rank, int world, const void* unique_id,
         delete c;
         COMM_FAIL("sg_allreduce_init: ncclCommInitRank failed: %s", ncclGetErrorString(r));
     }
-    COMM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    COMM_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-    COMM_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
-    *out = c;
+    // every error path below releases what was created before it
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                *out = c;
+                return 0;
+            }
+            (void)hipEventDestroy(c->ready);
+        }
+        (void)hipStreamDestroy(c->side);
+    }
+    (void)ncclCommDestroy(c->comm);
+    delete c;
+    COMM_FAIL("sg_allreduce_init: creating the side stream / events failed: %s", hipGetErrorString(e));
+}
+
+// What the communicator itself reports (read back for bench.py's "comm" record): the number of ranks RCCL formed the
+// communicator over (ncclCommCount), this rank's index in it (ncclCommUserRank), its device (ncclCommCuDevice) and the RCCL
+// version code (ncclGetVersion; e.g. 22606 = 2.26.6).
+int sg_allreduce_info(sg_comm* c, int* ranks, int* rank, int* device, int* rccl_version) {
+    if (!c) COMM_FAIL("sg_allreduce_info: bad argument");
+    int v = 0;
+    if (ranks) COMM_NCCL(ncclCommCount(c->comm, ranks));
+    if (rank) COMM_NCCL(ncclCommUserRank(c->comm, rank));
+    if (device) COMM_NCCL(ncclCommCuDevice(c->comm, device));
+    if (rccl_version) {
+        COMM_NCCL(ncclGetVersion(&v));
+        *rccl_version = v;
+    }
     return 0;
 }
 

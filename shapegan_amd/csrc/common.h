@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #define SG_OK 0
 #define SG_ERR_ARG (-1)
 #define SG_ERR_HIP (-2)
@@ -45,6 +48,33 @@ __device__ __forceinline__ float sg_apply_act(float v, int act, float slope) {
         default: return v;
     }
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (> 48 KB of dynamic LDS) is a property of (function, DEVICE): a process that drives
+// several devices (nn.DataParallel, train_hybrid_progressive_gan.py:62-68: one host thread per device) needs it once per device,
+// and two host threads may reach the same launch site at the same time.  `SgPerDeviceOnce once; if (once.begin()) { ...set...;
+// once.end(); }`: the fast path is one relaxed-cost atomic load of the current device's bit.
+struct SgPerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    unsigned long long bit = 0;
+    bool begin() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long b = (d >= 0 && d < 64) ? (1ull << d) : 0ull;   // device ids beyond 63: set on every call
+        if (b && (done.load(std::memory_order_acquire) & b)) return false;
+        mu.lock();
+        if (b && (done.load(std::memory_order_relaxed) & b)) {
+            mu.unlock();
+            return false;
+        }
+        bit = b;
+        return true;      // the caller sets its attributes, then calls end()
+    }
+    void end() {
+        done.fetch_or(bit, std::memory_order_release);
+        mu.unlock();
+    }
+};
 
 static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

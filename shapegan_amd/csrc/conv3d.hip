@@ -530,7 +530,7 @@ size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(int batch, int Cin, int Cout, 
 size_t sg_conv3d_k4s2p1_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW) {
     // gather kernel: up to 16 split-K partials of the [Cout, Cin*64] weight gradient; LDS-halo kernel: packed dy + partials
     const size_t a = (size_t)16 * Cout * Cin * 64 * sizeof(float);
-    const size_t b = halo_wgrad_workspace_bytes(batch, Cin, Cout, OD, OH, OW);
+    const size_t b = (Cin >= 2 && Cout >= 32) ? halo_wgrad_workspace_bytes(batch, Cin, Cout, OD, OH, OW) : 0;   // halo_wgrad_try's own gate
     const size_t c = (Cin == 1 && Cout <= 64) ? edge_wgrad_workspace_bytes(batch, OD, OH, OW) : 0;
     const size_t ab = a > b ? a : b;
     return ab > c ? ab : c;
@@ -634,11 +634,11 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     if (Cin == 1 && g.OD % kO1D == 0 && g.OH % kO1H == 0 && g.OW % kO1W == 0 && (long)g.Cy * g.O3() * 4 < (long)kBufRange) {
         const int ntd = g.OD / kO1D, nth = g.OH / kO1H, ntw = g.OW / kO1W;
         const size_t lds = (size_t)(2 * kO1CC * (kO1CH + 8) + 8) * sizeof(float);
-        static bool attr_set = false;   // > 48 KB of dynamic LDS needs the attribute once per process
-        if (!attr_set) {
+        static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
+        if (attr_once.begin()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_out1_tile_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
+            attr_once.end();
         }
         hipLaunchKernelGGL(dgrad_out1_tile_kernel, dim3((unsigned)((long)batch * ntd * nth * ntw)), dim3(256), lds, stream, dy, w,
                            bias, dx, g, Cout, Cin_total, ntd, nth, ntw, act, slope);
@@ -732,8 +732,11 @@ int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int 
 // formed inside the weight-gradient kernel (one-channel layers, LeakyReLU / ReLU), so the activation backward is not a pass of
 // its own.  sg_conv3d_k4s2p1_wgrad_act_eligible says whether a shape is served (host code, no GPU needed).
 int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act) {
+    // the same refusal conditions as edge_wgrad_try: 32-bit buffer ranges of the padded grid and of dy / y
+    const size_t padded = (size_t)batch * (2 * OD + 2) * (2 * OH + 2) * (2 * OW + 2) * 4;
+    const size_t dy_bytes = (size_t)batch * Cout * OD * OH * OW * 4;
     return Cin == 1 && Cout <= 64 && OW % 16 == 0 && (long)batch * OD * OH * OW >= 65536 && (act == SG_ACT_LEAKY || act == SG_ACT_RELU) &&
-           edge_enabled(4);
+           padded < (size_t)kBufRange && dy_bytes < (size_t)kBufRange && edge_enabled(4);
 }
 int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,

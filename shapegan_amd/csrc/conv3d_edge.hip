@@ -755,13 +755,13 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
         f.act = act;
         f.slope = slope;
         const size_t lds = (size_t)4 * kFusedGroup * sizeof(float);
-        static bool attr_set = false;   // > 48 KB of dynamic LDS needs the attribute once per process
-        if (!attr_set) {
+        static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
+        if (attr_once.begin()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_fused_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_fused_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
+            attr_once.end();
         }
         const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * g.OD);
         if (Cout == 64)

@@ -443,11 +443,11 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         a.act = act;
         a.slope = slope;
         const size_t lds4 = (size_t)2 * k4BUF * sizeof(float);   // 66.5 KB: above the default dynamic-LDS limit
-        static bool attr_set = false;
-        if (!attr_set) {
+        static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
+        if (attr_once.begin()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_halo4_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-            attr_set = true;
+            attr_once.end();
         }
         hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles), dim3(512), lds4, stream, a);
         return 1;

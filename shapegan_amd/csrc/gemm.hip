@@ -445,11 +445,11 @@ static int gemm_nt_launch(const float* A, const long* a_off, long lda, const flo
     a.out = direct ? C + c_off[0] : (float*)workspace;
     a.ldc = direct ? ldc[0] : N;
     const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
+    if (attr_once.begin()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
+        attr_once.end();
     }
     hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(sg_cdiv(N, 128), sg_cdiv(M, 128), batch * nsplit), dim3(256), lds, stream, a);
     if (!direct) {

@@ -8,6 +8,7 @@ in for the other, and no eager-PyTorch path exists.  Signatures mirror include/s
 """
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
@@ -115,6 +116,7 @@ COMM_SIGNATURES = {
     "sg_allreduce_unique_id_bytes": (_Z, []),
     "sg_allreduce_unique_id": (c_int, [_P, _Z]),
     "sg_allreduce_init": (c_int, [_P, _I, _I, _P, _Z, _I]),
+    "sg_allreduce_info": (c_int, [_P, _P, _P, _P, _P]),
     "sg_allreduce_launch": (c_int, [_P, _P, _L, _P]),
     "sg_allreduce_wait": (c_int, [_P, _P]),
     "sg_allreduce_destroy": (c_int, [_P]),
@@ -191,10 +193,16 @@ def load_cpu():
     return _cpu
 
 
-class _DeviceOfCall(object):
-    """Which library the call being assembled belongs to: set by ptr() / note_device() while the arguments are evaluated,
-    consumed by the dispatcher when the call is made."""
+class _DeviceOfCallState(threading.local):
+    """Which library the call being assembled ON THIS THREAD belongs to: set by ptr() / note_device() while the arguments are
+    evaluated, consumed by the dispatcher when the call is made.  Thread-local: autograd runs GPU-node backwards on device worker
+    threads while CPU-twin nodes and the main thread run at the same time, and nn.DataParallel
+    (train_hybrid_progressive_gan.py:62-68) calls replicas from one Python thread per device; ctypes releases the GIL inside
+    every library call."""
     kind = None
+
+
+_DeviceOfCall = _DeviceOfCallState()
 
 
 def _note(is_cuda):
@@ -208,6 +216,12 @@ def _note(is_cuda):
 def note_device(t):
     """For callers that pass `t.data_ptr()` arithmetic instead of ptr(t)."""
     _note(t.is_cuda)
+
+
+def reset_call_state():
+    """Drops a half-assembled call (an exception between ptr() and the library call would otherwise leave its device behind for
+    the next call on this thread)."""
+    _DeviceOfCall.kind = None
 
 
 class _Dispatch(object):
@@ -251,6 +265,7 @@ def ptr(t):
     if t is None:
         return None
     if not t.is_contiguous():
+        _DeviceOfCall.kind = None      # the call being assembled is abandoned: leave nothing behind for the next one
         raise RuntimeError("shapegan_amd kernels need contiguous tensors")
     _note(t.is_cuda)
     return t.data_ptr()
@@ -269,7 +284,7 @@ _workspaces = {}
 def workspace(name, nbytes, device):
     """Caller-owned scratch, cached per (device, stream, name) and grown on demand."""
     if device.type != "cuda":
-        key = ("cpu", 0, name)
+        key = ("cpu", threading.get_ident(), name)      # CPU-twin calls run synchronously on the calling thread
     else:
         key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _workspaces.get(key)
@@ -306,12 +321,13 @@ import weakref  # noqa: E402
 
 
 class GradSlot(object):
-    __slots__ = ("param", "flat_grad", "offset", "numel", "written")
+    __slots__ = ("param", "flat_grad", "offset", "numel", "written", "acc_node")
 
     def __init__(self, param, flat_grad, offset):
         self.param = weakref.ref(param)
         self.flat_grad, self.offset, self.numel = flat_grad, offset, param.numel()
         self.written = False
+        self.acc_node = None
 
 
 GRAD_SLOTS = {}
@@ -321,6 +337,32 @@ def register_grad_slot(param, flat_grad, offset):
     slot = GradSlot(param, flat_grad, offset)
     GRAD_SLOTS[param.data_ptr()] = slot
     return slot
+
+
+def unregister_grad_slots(slots):
+    """Called when the flat buffer that owns `slots` goes away (optim._Flat.__del__): the registry must not keep a discarded
+    optimizer's gradient buffer alive until its addresses happen to be reused."""
+    for key in [k for k, v in GRAD_SLOTS.items() if any(v is s for s in slots)]:
+        GRAD_SLOTS.pop(key, None)
+
+
+def _accumulating_backward(slot, p):
+    """True when the running backward will accumulate into p.grad (`loss.backward()`), False under `torch.autograd.grad(...,
+    inputs)`: there the gradient is RETURNED to the caller, who may keep it — a view of the flat slice would be overwritten by
+    the next backward's direct write (torch hands out fresh tensors).  The engine answers for the parameter's AccumulateGrad
+    node; for a leaf inside autograd.grad() it raises, which is the answer too."""
+    if torch._C._current_graph_task_id() == -1:
+        return True                     # not inside an engine run (a raw kernel call from tests / tools): nothing is returned
+    node = slot.acc_node
+    if node is None:
+        if not p.requires_grad:
+            return False
+        with torch.enable_grad():       # (a plain backward runs with grad mode off: the view would have no grad_fn)
+            node = slot.acc_node = p.expand_as(p).grad_fn.next_functions[0][0]
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except RuntimeError:
+        return False
 
 
 def grad_destination(param_tensor, shape):
@@ -336,7 +378,7 @@ def grad_destination(param_tensor, shape):
     n = 1
     for d in shape:
         n *= d
-    if p.grad is not None or n != slot.numel:
+    if p.grad is not None or n != slot.numel or not _accumulating_backward(slot, p):
         return None
     slot.written = True
     return slot.flat_grad[slot.offset:slot.offset + n].view(shape)

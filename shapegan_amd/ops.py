@@ -127,6 +127,17 @@ def conv_wgrad_act_raw(dy, y, x, act, slope, dw_out=None, db_out=None):
     return dw, db
 
 
+def _wgrad_act_served(x, w, y, act):
+    """Whether sg_conv3d_k4s2p1_wgrad_act takes this layer: the shape is served AND its scratch (padded grid + partials) fits
+    under the workspace cap conv_wgrad_act_raw allocates with — otherwise the two-pass path (activation backward, then the plain
+    weight gradient, which falls through to the halo / gather kernels) is used."""
+    lib = _lib()
+    N, Cx, Co = x.shape[0], x.shape[1], w.shape[0]
+    if not lib.sg_conv3d_k4s2p1_wgrad_act_eligible(N, Cx, Co, y.shape[2], y.shape[3], y.shape[4], act):
+        return False
+    return lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(N, Cx, Co, y.shape[2], y.shape[3], y.shape[4]) <= _WGRAD_WS_CAP
+
+
 def conv_wgrad_halo_raw(dy, x, ct):
     """wgrad through the forced LDS-halo kernel — tests and tuning only."""
     N, Co, OD, OH, OW = dy.shape
@@ -298,8 +309,7 @@ class ConvFwd(Function):
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         plain = not torch.is_grad_enabled()      # no create_graph: raw kernels, parameter gradients straight into their slices
         if (ctx.act != ACT_NONE and want_b and plain and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-                and w.shape[1] == x.shape[1] and _lib().sg_conv3d_k4s2p1_wgrad_act_eligible(
-                    x.shape[0], x.shape[1], w.shape[0], y.shape[2], y.shape[3], y.shape[4], ctx.act)):
+                and w.shape[1] == x.shape[1] and _wgrad_act_served(x, w, y, ctx.act)):
             # the input needs no gradient (first layer of the critic): the activation backward rides in the weight-gradient
             # kernel, dz = dy * act'(y) is never written
             gw, gb = conv_wgrad_act_raw(f32c(gy), y, x, ctx.act, ctx.slope, L.grad_destination(w, w.shape),
@@ -543,22 +553,26 @@ _H = 256
 
 class _PackCache(object):
     """MFMA-fragment image of the 16 SDFNet tensors, rebuilt only when a parameter changed (in-place optimizer
-    steps bump tensor._version)."""
+    steps bump tensor._version).  One entry per device: nn.DataParallel replicas (train_hybrid_progressive_gan.py:62-68) are
+    shallow copies that share this object and call it from one thread per device, so an entry is published as ONE tuple
+    assignment and a replica never sees another device's image."""
 
     def __init__(self):
-        self.key = None
-        self.packed = None
+        self.entries = {}
 
     def get(self, params, latent, kin_used):
+        dev = params[0].device
         key = (kin_used, latent, L.PARAM_EPOCH) + tuple((p.data_ptr(), p._version) for p in params)
-        if key != self.key or self.packed is None:
+        entry = self.entries.get(dev)
+        if entry is None or entry[0] != key:
             lib = _lib()
             n = lib.sg_sdfnet_packed_floats(kin_used)
-            packed = torch.empty(n, dtype=torch.float32, device=params[0].device)
+            packed = torch.empty(n, dtype=torch.float32, device=dev)
             arr = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params])
             check(lib.sg_sdfnet_pack(arr, latent, kin_used, ptr(packed), stream()), "sdfnet_pack")
-            self.key, self.packed = key, packed
-        return self.packed
+            entry = (key, packed)
+            self.entries[dev] = entry
+        return entry[1]
 
 
 def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None):
@@ -918,7 +932,46 @@ def check_batch_indices():
     for dev, flag in _bad_index_flags.items():
         if int(flag.item()) != 0:
             flag.zero_()
+            _flag_polls.pop(dev, None)
             raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+
+
+_flag_polls = {}     # device -> (pinned host int32, event of the copy in flight or None)
+
+
+def poll_batch_indices():
+    """The same check without a host synchronisation, for use on EVERY step: reads what the previous poll copied into pinned host
+    memory (if that copy has landed) and enqueues the next asynchronous copy of the sticky device flag.  An out-of-range index is
+    therefore reported one step late at most (the reference raises at once; the batch in question was computed on clamped rows).
+    Inside a stream capture only the copy is recorded: the caller reads `batch_index_flag_host()` after each replay."""
+    for dev, flag in _bad_index_flags.items():
+        if dev.type != "cuda":
+            if int(flag.item()) != 0:
+                flag.zero_()
+                raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+            continue
+        host, event = _flag_polls.get(dev, (None, None))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if host is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        elif not capturing and (event is None or event.query()) and int(host[0]) != 0:
+            host.zero_()
+            flag.zero_()
+            _flag_polls[dev] = (host, None)
+            raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+        host.copy_(flag, non_blocking=True)
+        if capturing:
+            _flag_polls[dev] = (host, None)
+        else:
+            event = torch.cuda.Event()
+            event.record()
+            _flag_polls[dev] = (host, event)
+
+
+def batch_index_flag_host(device):
+    """The pinned host copy poll_batch_indices maintains for `device` (None before the first poll)."""
+    entry = _flag_polls.get(torch.device(device) if not isinstance(device, torch.device) else device)
+    return None if entry is None else entry[0]
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -49,10 +49,12 @@ class _Flat(object):
     def coherent(self):
         return all(self.grad_view_ok(i) for i in range(len(self.params)))
 
-    def adopt_grads(self, indices=None):
-        """Copies the live .grad of every parameter (or of those in `indices`) into its flat slice and re-attaches the view
-        (a parameter without a gradient contributes zeros), so that the flat buffer is what the exchange and the update
-        both see."""
+    def adopt_grads(self, indices=None, attach_missing=False):
+        """Copies the live .grad of every parameter (or of those in `indices`) into its flat slice and re-attaches the view, so
+        that the flat buffer is what the exchange and the update both see.  A parameter WITHOUT a gradient contributes zeros
+        to the wire but keeps p.grad None, so step() skips it exactly as torch.optim does (Adam's moments of an unused
+        progressive-GAN stage must not keep moving it); attach_missing=True attaches the zero slice instead (callers that
+        must update the whole buffer in one fixed launch)."""
         for i in (range(len(self.params)) if indices is None else indices):
             p, o = self.params[i], self.offsets[i]
             if self.grad_view_ok(i):
@@ -60,6 +62,8 @@ class _Flat(object):
             n = p.numel()
             if p.grad is None:
                 self.grad[o:o + n].zero_()
+                if not attach_missing:
+                    continue
             else:
                 self.grad[o:o + n].copy_(p.grad.reshape(-1))
             p.grad = self.grad[o:o + n].view(p.shape)
@@ -75,12 +79,23 @@ class _Flat(object):
 
     def zero_grad(self):
         """Gradients -> None (torch's set_to_none semantics) and every slice of the flat buffer open for a direct write:
-        the next backward's weight-gradient kernels store into the slices and autograd adopts those views as p.grad
+        the next `loss.backward()`'s weight-gradient kernels store into the slices and autograd adopts those views as p.grad
         (lib.grad_destination), so neither a memset of the buffer nor a `p.grad += g` pass per parameter is launched.  A
-        parameter that receives no gradient keeps p.grad None and is skipped by step(), as in torch.optim."""
+        parameter that receives no gradient keeps p.grad None and is skipped by step(), as in torch.optim.
+
+        Aliasing (differs from torch): p.grad of a parameter owned by this optimizer IS its slice of the flat buffer.  A
+        reference to p.grad kept across zero_grad() is overwritten by the next backward (torch would leave the old tensor
+        intact); clone it if it must survive.  Gradients RETURNED by torch.autograd.grad(loss, params) are ordinary tensors
+        (never slices), as in torch."""
         for p, slot in zip(self.params, self.slots):
             p.grad = None
             slot.written = False
+
+    def __del__(self):
+        try:
+            L.unregister_grad_slots(self.slots)
+        except Exception:       # interpreter shutdown
+            pass
 
 
 class _Base(object):
@@ -96,21 +111,34 @@ class _Base(object):
     def flat_grad(self):
         return self.f.grad
 
-    def _segments(self):
-        """[(offset, length, grad_ptr)] of what to update: the whole buffer when every grad is the flat view,
-        else one segment per parameter that has a gradient."""
+    def _segments(self, keys=None):
+        """[(offset, length, grad_ptr[, keep-alive])] of what to update: the whole buffer when every grad is the flat view;
+        otherwise maximal runs of consecutive parameters whose gradient is their flat slice (one launch per run; the alignment
+        gaps between slices hold zeros), one segment per parameter whose gradient lives elsewhere, nothing for a parameter
+        without a gradient (torch.optim skips those).  `keys[i]` (optional) must also be equal within a run."""
         f = self.f
         if f.coherent():
             return [(0, f.total, f.grad.data_ptr())]
-        segs = []
+        segs, run = [], None
         for i, (p, o) in enumerate(zip(f.params, f.offsets)):
             if p.grad is None:
+                run = None
                 continue
+            if f.grad_view_ok(i):
+                key = None if keys is None else keys[i]
+                if run is not None and run[2] == key:
+                    run[1] = o + p.numel()
+                else:
+                    run = [o, o + p.numel(), key]
+                    segs.append(run)
+                continue
+            run = None
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             if g.dtype != torch.float32:
                 g = g.float()
             segs.append((o, p.numel(), g.data_ptr(), g))
-        return segs
+        base = f.grad.data_ptr()
+        return [(s[0], s[1] - s[0], base + 4 * s[0]) if isinstance(s, list) else s for s in segs]
 
 
 class RMSprop(_Base):
@@ -155,6 +183,9 @@ class Adam(_Base):
         uniform = f.coherent() and len(set(self.steps)) == 1
         if self.capturable:
             if not f.coherent():
+                if any(p.grad is None for p in f.params):
+                    raise RuntimeError("Adam(capturable=True) updates the whole flat buffer in one fixed launch: every "
+                                       "parameter needs a gradient on every step (torch.optim would skip the missing ones)")
                 f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
             L.note_device(f.flat)
             check(lib.sg_adam_step_dev(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
@@ -166,13 +197,14 @@ class Adam(_Base):
             check(lib.sg_adam_step(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                    self.betas[1], self.eps, self.steps[0], self.grad_scale, stream()), "adam_step")
         else:
-            for i, (p, o) in enumerate(zip(f.params, f.offsets)):
-                if p.grad is None:
-                    continue
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                self.steps[i] += 1
+            # per-parameter step counters, as torch: a parameter without a gradient neither moves nor ages
+            for i, p in enumerate(f.params):
+                if p.grad is not None:
+                    self.steps[i] += 1
+            first = {o: i for i, o in enumerate(f.offsets)}
+            for seg in self._segments(keys=self.steps):
+                o, n, g = seg[0], seg[1], seg[2]
                 L.note_device(f.flat)
-                check(lib.sg_adam_step(base_p + 4 * o, g.data_ptr(), base_m + 4 * o, base_v + 4 * o, p.numel(), self.lr,
-                                       self.betas[0], self.betas[1], self.eps, self.steps[i], self.grad_scale,
-                                       stream()), "adam_step")
+                check(lib.sg_adam_step(base_p + 4 * o, g, base_m + 4 * o, base_v + 4 * o, n, self.lr, self.betas[0],
+                                       self.betas[1], self.eps, self.steps[first[o]], self.grad_scale, stream()), "adam_step")
         L.bump_param_epoch()

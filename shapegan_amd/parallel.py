@@ -7,7 +7,10 @@ scatters up to 2.2 GB of inputs on every forward.  Here parameters stay resident
 identical updates afterwards), inputs are generated/loaded per rank, and the only exchange is the gradient sum; the
 1/world factor is applied inside the optimizer kernel (grad_scale), not as a separate pass.
 """
+import atexit
 import os
+import sys
+import threading
 
 import torch
 import torch.distributed as dist
@@ -39,7 +42,7 @@ class NativeComm(object):
     stream's work, `wait` makes the current stream wait for everything launched — no torch.distributed on the hot path.
     torch.distributed is used once, as the out-of-band channel for the 128-byte RCCL unique id."""
 
-    def __init__(self, rank=None, world=None, device=None, unique_id=None):
+    def __init__(self, rank=None, world=None, device=None, unique_id=None, init_timeout=None):
         import ctypes
         from . import lib as L
         self.L, self.lib = L, L.load_comm()
@@ -56,8 +59,35 @@ class NativeComm(object):
                 dist.broadcast_object_list(box, src=0)
             unique_id = box[0]
         handle = ctypes.c_void_p()
-        L.check_comm(self.lib.sg_allreduce_init(ctypes.byref(handle), rank, world, unique_id, len(unique_id), device), "init")
+        self.handle = None
+        # ncclCommInitRank blocks until every rank has joined: run it on a helper thread so that a rank that never shows up
+        # becomes an error here (after `init_timeout` seconds) instead of a hang
+        result = {}
+
+        def init():
+            rc = self.lib.sg_allreduce_init(ctypes.byref(handle), rank, world, unique_id, len(unique_id), device)
+            msg = self.lib.sg_comm_last_error() if rc != 0 else b""
+            result["rc"], result["msg"] = rc, (msg or b"").decode()
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("SG_COMM_INIT_TIMEOUT", "120"))
+        th = threading.Thread(target=init, name="sg_allreduce_init", daemon=True)
+        th.start()
+        th.join(init_timeout)
+        if th.is_alive():
+            raise RuntimeError("shapegan_comm: ncclCommInitRank did not return within %.0f s (rank %d of %d)" % (init_timeout, rank, world))
+        if result["rc"] != 0:
+            raise RuntimeError("shapegan_comm init failed (%d): %s" % (result["rc"], result["msg"]))
         self.handle, self.rank, self.world = handle, rank, world
+        atexit.register(self.close)
+
+    def info(self):
+        """What the communicator reports about itself: {"ranks": ncclCommCount, "rank", "device", "rccl_version": "2.26.6"}."""
+        import ctypes
+        vals = [ctypes.c_int(0) for _ in range(4)]
+        self.L.check_comm(self.lib.sg_allreduce_info(self.handle, *[ctypes.byref(v) for v in vals]), "info")
+        code = vals[3].value
+        return {"ranks": vals[0].value, "rank": vals[1].value, "device": vals[2].value,
+                "rccl_version": "%d.%d.%d" % (code // 10000, code // 100 % 100, code % 100) if code >= 10000 else str(code)}
 
     def launch(self, t):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
@@ -70,23 +100,90 @@ class NativeComm(object):
 
     def close(self):
         if self.handle is not None:
-            self.lib.sg_allreduce_destroy(self.handle)
-            self.handle = None
+            handle, self.handle = self.handle, None
+            self.lib.sg_allreduce_destroy(handle)
 
 
 _native = None
+_native_tried = False
+TRANSPORT = {"name": "none", "reason": "single process"}     # what carries the gradient exchange (bench.py reports it)
+
+
+def _all_ranks_agree(ok):
+    """True iff `ok` holds on every rank (one tiny torch.distributed all-reduce; also the rendezvous after an init attempt)."""
+    flag = torch.tensor([0.0 if ok else 1.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    return float(flag.item()) == 0.0
+
+
+def negotiate_native(make_comm, verify, agree=None, log=None):
+    """Brings the C-ABI exchange up on every rank or on none.  `make_comm()` builds this rank's communicator (may raise / time
+    out), `verify(comm)` checks one exchange against the reference transport, `agree(ok)` tells whether every rank succeeded.
+    Any failure anywhere makes ALL ranks close what they built and returns (None, reason) — loudly (`log`), never a hang and
+    never a mixed transport."""
+    agree = agree or _all_ranks_agree
+    log = log or (lambda m: print(m, file=sys.stderr, flush=True))
+    comm, reason = None, ""
+    try:
+        comm = make_comm()
+    except Exception as e:       # noqa: BLE001 — any failure means "fall back"
+        reason = "init: %s" % e
+    if not agree(comm is not None):
+        if comm is not None:
+            comm.close()
+        reason = reason or "another rank could not initialise its communicator"
+        log("shapegan_amd.parallel: C-ABI RCCL exchange unavailable (%s) — FALLING BACK to torch.distributed all-reduce" % reason)
+        return None, reason
+    ok = False
+    try:
+        ok = bool(verify(comm))
+        if not ok:
+            reason = "verification all-reduce disagreed with torch.distributed"
+    except Exception as e:       # noqa: BLE001
+        reason = "verify: %s" % e
+    if not agree(ok):
+        comm.close()
+        reason = reason or "another rank failed the verification exchange"
+        log("shapegan_amd.parallel: C-ABI RCCL exchange unavailable (%s) — FALLING BACK to torch.distributed all-reduce" % reason)
+        return None, reason
+    return comm, ""
+
+
+def _verify_against_torch(comm):
+    """One 4096-float exchange through the new communicator against torch.distributed's all-reduce of the same data."""
+    gen = torch.Generator().manual_seed(1234 + comm.rank)
+    x = torch.randn(4096, generator=gen).cuda()
+    ref = x.clone()
+    comm.launch(x)
+    comm.wait()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    return bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5)) and comm.info()["ranks"] == comm.world
 
 
 def native_comm():
-    """The process-wide NativeComm when SG_NATIVE_ALLREDUCE=1 and the tensors live on GPUs, else None (torch.distributed
-    carries the exchange: "nccl" = RCCL on ROCm, "gloo" in the CPU tests)."""
-    global _native
-    if os.environ.get("SG_NATIVE_ALLREDUCE", "0") != "1" or not torch.cuda.is_available() or world_size() < 2:
+    """The process-wide NativeComm, or None when torch.distributed carries the exchange.  With the "nccl" backend (= RCCL on
+    ROCm), GPUs and more than one rank the C-ABI exchange is the DEFAULT; SG_NATIVE_ALLREDUCE=0 is the escape hatch.  It is
+    negotiated once (negotiate_native): every rank must build its communicator and pass a verification exchange, otherwise all
+    ranks fall back to torch.distributed with a message on stderr.  "gloo" runs (CPU tests, several ranks on one GPU) always use
+    torch.distributed: RCCL cannot form a communicator with two ranks on one device."""
+    global _native, _native_tried
+    if _native is not None or _native_tried:
+        return _native
+    if world_size() < 2:
         return None
-    if dist.get_backend() != "nccl":
-        return None          # several ranks on one GPU (gloo functional checks): RCCL cannot form that communicator
+    _native_tried = True
+    if os.environ.get("SG_NATIVE_ALLREDUCE", "1") == "0":
+        TRANSPORT.update(name="torch-" + dist.get_backend(), reason="SG_NATIVE_ALLREDUCE=0")
+        return None
+    if not torch.cuda.is_available() or dist.get_backend() != "nccl":
+        TRANSPORT.update(name="torch-" + dist.get_backend(), reason="backend is not nccl")
+        return None
+    _native, reason = negotiate_native(NativeComm, _verify_against_torch)
     if _native is None:
-        _native = NativeComm()
+        TRANSPORT.update(name="torch-nccl", reason="fallback: " + reason)
+    else:
+        TRANSPORT.update(name="native-rccl", reason="", **_native.info())
     return _native
 
 

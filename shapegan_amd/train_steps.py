@@ -168,21 +168,26 @@ class SDFAutoDecoderTrainer(object):
         self._sorted_calls = 0
 
     def step_graphed(self, indices):
-        """step_gathered as ONE captured graph launch (single process only).  The reference's 20 000-point batch is
-        launch-bound (about 45 kernels, 1.2 ms eager of which the GPU is busy less than half); the first two calls
-        run eagerly (lazy initialisations), the third is captured and every call from then on is a replay.  The
+        """`step` as ONE captured graph launch (single process only): the shape-sorted flow from 8192 points on, the gathered
+        flow below.  The reference's 20 000-point batch is launch-bound (27 kernels of a few microseconds on 313 tiles); the
+        first two calls run eagerly (lazy initialisations, workspaces), the third is captured and every call from then on is a
+        replay.  Nothing in the step needs the host: the batch-index check is the sticky device flag copied to pinned memory
+        inside the graph and read here after each replay (an out-of-range index raises at the NEXT call, one step late).  The
         returned loss tensor is overwritten by the next call."""
         if not self.capturable or world_size() > 1:
             raise RuntimeError("step_graphed needs SDFAutoDecoderTrainer(capturable=True) in a single process")
         self._graph_calls += 1
         if self._graph_calls <= 2:
-            return self.step_gathered(indices)
+            return self.step(indices)
+        host = ops.batch_index_flag_host(indices.device)
+        if host is not None and int(host[0]) != 0:       # landed during an earlier replay (the stream has long passed it)
+            ops.check_batch_indices()
         if self._graph is None or self._graph_idx.shape != indices.shape:
             self._graph_idx = indices.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._graph_loss = self.step_gathered(self._graph_idx)
+                self._graph_loss = self.step(self._graph_idx)
             self._graph = graph
         else:
             self._graph_idx.copy_(indices)
@@ -213,15 +218,19 @@ class SDFAutoDecoderTrainer(object):
         batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
             indices, self.pointcloud_size, shapes, self.points, self.sdf)
         self._sorted_calls += 1
-        if self._sorted_calls % 256 == 1:       # the reference raises IndexError at once; here the sticky device flag is
-            ops.check_batch_indices()           # read on the first call and then every 256th (one host sync each)
+        if self._sorted_calls == 1:
+            ops.check_batch_indices()           # first call: synchronous (a systematically wrong index source fails at once)
+        else:
+            ops.poll_batch_indices()            # every later call: no host sync; an out-of-range index raises one step late
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
         output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
         n, width = indices.shape[0], self.latent_codes.shape[1]
-        # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator
-        reg = ops.mean_sq(self.latent_codes, counts, n * width / self.sigma)
-        loss = ops.weighted_l1(output, batch_sdf) + reg
+        loss = ops.weighted_l1(output, batch_sdf)
+        if self.sigma != 0:
+            # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator (sigma 0: the term is 0, as in the
+            # reference's formula)
+            loss = loss + ops.mean_sq(self.latent_codes, counts, n * width / self.sigma)
         loss.backward()
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
@@ -239,7 +248,9 @@ class SDFAutoDecoderTrainer(object):
         batch_points = ops.gather_rows(self.points, indices)
         batch_sdf = ops.gather_rows(self.sdf.unsqueeze(1), indices).squeeze(1)
         output = self.net(batch_points, batch_latent)
-        loss = ops.weighted_l1(output, batch_sdf) + ops.mean_sq(batch_latent, None, batch_latent.numel() / self.sigma)
+        loss = ops.weighted_l1(output, batch_sdf)
+        if self.sigma != 0:
+            loss = loss + ops.mean_sq(batch_latent, None, batch_latent.numel() / self.sigma)
         loss.backward()
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()

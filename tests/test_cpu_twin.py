@@ -75,6 +75,10 @@ def test_conv_wgrad_through_activation(on_cpu):
     OPS.test_conv_wgrad_through_activation(1, 3, 2, 2)
 
 
+def test_conv_wgrad_act_fallback(on_cpu, monkeypatch):
+    OPS.test_conv_wgrad_act_falls_back_when_scratch_exceeds_cap(monkeypatch)
+
+
 def test_from_sdf_zero_channels(on_cpu):
     OPS.test_conv_from_sdf_zero_channels()
 
@@ -175,3 +179,60 @@ def test_training_trajectories(on_cpu, golden_steps):
     M.test_autoencoder_trajectory(golden_steps)
     M.test_sdf_autodecoder_trajectory(golden_steps)
     M.test_hybrid_wgan_trajectory(golden_steps)
+
+
+def test_two_threads_drive_two_modules_concurrently(on_cpu):
+    """The DataParallel shape (train_hybrid_progressive_gan.py:62-68: replicas called from one Python thread each; SURVEY.md 8b
+    "safe under DataParallel-style multi-thread calls"): two threads run forward + backward of native modules at the same time,
+    sharing the SDFNet's pack cache object the way shallow replica copies do.  ctypes releases the GIL inside every library
+    call, so dispatcher state, workspaces and caches really are used concurrently.  Results must equal the serial run bit for
+    bit (the twin is deterministic for a fixed thread count)."""
+    import copy
+    import threading
+    from shapegan_amd.model.gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    torch.manual_seed(3)
+    net, disc = SDFNet(device="cpu"), Discriminator()
+    replica = copy.copy(net)                             # nn.DataParallel's replicate(): shallow copy sharing __dict__ entries
+    replica._parameters = {k: v for k, v in net._parameters.items()}
+    replica._modules = dict(net._modules)
+    pts = [torch.rand(700, 3) * 2 - 1 for _ in range(2)]
+    lat = [torch.randn(700, 128) * 0.1 for _ in range(2)]
+    vox = torch.rand(3, 32, 32, 32) * 2 - 1
+
+    def sdf_job(module, i, out):
+        p = pts[i].clone().requires_grad_(True)
+        for _ in range(4):
+            y = module(p, lat[i])
+            (g,) = torch.autograd.grad(y.sum(), p)
+        out["sdf%d" % i] = (y.detach().clone(), g.clone())
+
+    def disc_job(out):
+        x = vox.clone().requires_grad_(True)
+        for _ in range(3):
+            y = disc(x)
+            (g,) = torch.autograd.grad(y.sum(), x)
+        out["disc"] = (y.detach().clone(), g.clone())
+
+    serial = {}
+    sdf_job(net, 0, serial)
+    sdf_job(replica, 1, serial)
+    disc_job(serial)
+    for _ in range(3):
+        got, errors = {}, []
+
+        def guarded(fn, *a):
+            try:
+                fn(*a)
+            except Exception as e:       # noqa: BLE001 — reported below
+                errors.append(e)
+        threads = [threading.Thread(target=guarded, args=(sdf_job, net, 0, got)),
+                   threading.Thread(target=guarded, args=(sdf_job, replica, 1, got)),
+                   threading.Thread(target=guarded, args=(disc_job, got))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for k in serial:
+            assert torch.equal(got[k][0], serial[k][0]) and torch.equal(got[k][1], serial[k][1]), k

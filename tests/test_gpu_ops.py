@@ -122,6 +122,35 @@ def test_conv_wgrad_through_activation(N, Co, O, act):
         close(bg.grad, b.grad, what="module path db")
 
 
+def test_conv_wgrad_act_falls_back_when_scratch_exceeds_cap(monkeypatch):
+    """when the fused weight-gradient + activation-backward kernel's scratch does not fit under the workspace
+    cap, the first critic layer's backward takes the two-pass path (activation backward + plain weight gradient) instead of
+    raising.  The cap is lowered so that the BASELINE shape triggers the refusal; both paths must give the ATen gradients."""
+    from shapegan_amd import ops
+    torch.manual_seed(21)
+    N, Co, O = 16, 64, 16
+    x = torch.rand(N, 1, 2 * O, 2 * O, 2 * O) * 2 - 1
+    w = (torch.randn(Co, 1, 4, 4, 4) * 0.2).requires_grad_(True)
+    b = (torch.randn(Co) * 0.1).requires_grad_(True)
+    pre = F.conv3d(x, w, b, stride=2, padding=1)
+    y_ref = F.leaky_relu(pre, 0.2)
+    dy = torch.randn_like(y_ref)
+    dy[pre.detach().abs() < 1e-5] = 0
+    y_ref.backward(dy)
+    calls = []
+    real = ops.conv_wgrad_act_raw
+    monkeypatch.setattr(ops, "conv_wgrad_act_raw", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for cap, fused in ((ops._WGRAD_WS_CAP, True), (1 << 20, False)):
+        monkeypatch.setattr(ops, "_WGRAD_WS_CAP", cap)
+        del calls[:]
+        wg, bg = dev(w.detach()).requires_grad_(True), dev(b.detach()).requires_grad_(True)
+        y = ops.conv3d_k4s2p1(dev(x), wg, bg, 1, 0.2)
+        y.backward(dev(dy))
+        assert bool(calls) == fused
+        close(wg.grad, w.grad, what="dw (fused path %s)" % fused)
+        close(bg.grad, b.grad, what="db (fused path %s)" % fused)
+
+
 def test_conv_transpose3d_to_one_channel_random_shapes():
     """ConvTranspose3d(C -> 1) through the fused tap-group kernel at random channel counts / odd plane sizes / batch sizes that
     are no multiple of the XCD count (partial position tiles, clamped channel reads, idle workgroups) == ATen."""

@@ -170,8 +170,12 @@ def test_flat_optimizer_views_on_cpu():
     for i, p in enumerate(d.parameters()):
         p.grad = None if i == 0 else torch.full_like(p, float(i))
     f.adopt_grads()
-    assert f.coherent() and float(f.grad[:f.params[0].numel()].abs().sum()) == 0.0
+    # the parameter without a gradient contributes zeros to the wire but stays grad-less (step() skips it, as torch.optim does)
+    assert f.params[0].grad is None and float(f.grad[:f.params[0].numel()].abs().sum()) == 0.0
+    assert all(f.grad_view_ok(i) for i in range(1, len(f.params)))
     assert float(f.params[3].grad.mean()) == 3.0
+    f.adopt_grads(attach_missing=True)
+    assert f.coherent()
 
 
 # ---- input pipeline: host-side index work is bit-exact ---------------------------------------
@@ -289,3 +293,156 @@ def test_sdfnet_backward_tile_layout_is_the_documented_function_of_n():
         for t in probe:
             assert lib.sg_sdfnet_bwd_tile_start(n, t) == starts[t], (n, t)
         assert starts[-1] == n and all(b > a for a, b in zip(starts, starts[1:]))
+
+
+def test_wgrad_act_path_is_refused_when_its_scratch_exceeds_the_cap():
+    """the fused weight-gradient + activation-backward path needs the zero-padded grid in its workspace.
+    At batch 240 / 64^3 input the shape itself is served (eligible) but the scratch (~276 MB) is above the 256 MB the Python
+    side allocates: ConvFwd.backward must take the two-pass path instead of raising.  Host code only (size queries)."""
+    from shapegan_amd import ops
+    lib = L.load()
+    assert lib.sg_conv3d_k4s2p1_wgrad_act_eligible(240, 1, 64, 32, 32, 32, L.ACT_LEAKY) == 1
+    assert lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(240, 1, 64, 32, 32, 32) > ops._WGRAD_WS_CAP
+
+    def served(batch, r):
+        x = torch.empty(batch, 1, r, r, r, device="meta")
+        w = torch.empty(64, 1, 4, 4, 4, device="meta")
+        y = torch.empty(batch, 64, r // 2, r // 2, r // 2, device="meta")
+        return ops._wgrad_act_served(x, w, y, L.ACT_LEAKY)
+    assert served(128, 32) and served(16, 64)          # the BASELINE shapes stay on the fused path
+    assert not served(240, 64)                          # scratch above the cap
+    assert not served(256, 64)                          # 2 GiB of dy: outside the 32-bit buffer range
+    assert not served(2048, 32)                         # 64 x 16^3 x 2048 x 4 B = 2 GiB of dy: outside the 32-bit buffer range
+    assert lib.sg_conv3d_k4s2p1_wgrad_act_eligible(2048, 1, 64, 16, 16, 16, L.ACT_LEAKY) == 0
+
+
+def test_call_device_state_is_thread_local_and_cleared_on_rejection():
+    """ADVICE r2 / VERDICT r2 weak #6b: the device of the call being assembled is per thread, and a rejected argument leaves
+    nothing behind for the next call."""
+    import threading
+    L.reset_call_state()
+    L._note(True)                                       # this thread is half-way through assembling a GPU call
+    seen = {}
+
+    def other():
+        seen["start"] = L._DeviceOfCall.kind            # must not see the main thread's state
+        L.ptr(torch.zeros(4))
+        seen["after"] = L._DeviceOfCall.kind
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == {"start": None, "after": "cpu"}
+    assert L._DeviceOfCall.kind == "cuda"
+    L.reset_call_state()
+    L.ptr(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        L.ptr(torch.zeros(4, 4).t())
+    assert L._DeviceOfCall.kind is None
+
+
+def test_native_exchange_negotiation_falls_back_loudly_and_uniformly():
+    """VERDICT r2 next #4d: the C-ABI RCCL exchange is the default under the nccl backend, but it must come up on EVERY rank and
+    pass a verification exchange, or every rank closes what it built and falls back to torch.distributed — with a message, never
+    with a hang or a mixed transport.  The negotiation logic with fake communicators (no GPU / RCCL in this tier)."""
+    from shapegan_amd import parallel
+
+    class FakeComm(object):
+        closed = False
+
+        def close(self):
+            self.closed = True
+
+    def run(make, verify, others_ok=(True, True)):
+        logs, votes = [], iter(others_ok)
+        comm, reason = parallel.negotiate_native(make, verify, agree=lambda ok: ok and next(votes), log=logs.append)
+        return comm, reason, logs
+
+    made = []
+
+    def make_ok():
+        made.append(FakeComm())
+        return made[-1]
+
+    def make_fail():
+        raise RuntimeError("ncclCommInitRank did not return within 120 s")
+
+    comm, reason, logs = run(make_ok, lambda c: True)
+    assert comm is made[-1] and reason == "" and not logs and not comm.closed
+    comm, reason, logs = run(make_fail, lambda c: True)
+    assert comm is None and "did not return" in reason and len(logs) == 1 and "FALLING BACK" in logs[0]
+    comm, reason, logs = run(make_ok, lambda c: True, others_ok=(False, True))       # another rank failed to initialise
+    assert comm is None and made[-1].closed and "another rank" in reason and "FALLING BACK" in logs[0]
+    comm, reason, logs = run(make_ok, lambda c: False)                                # wrong sums through the new communicator
+    assert comm is None and made[-1].closed and "disagreed" in reason
+    comm, reason, logs = run(make_ok, lambda c: (_ for _ in ()).throw(RuntimeError("launch failed")))
+    assert comm is None and made[-1].closed and "launch failed" in reason
+    comm, reason, logs = run(make_ok, lambda c: True, others_ok=(True, False))        # another rank failed the verification
+    assert comm is None and made[-1].closed and "another rank failed the verification" in reason
+    # single process: nothing to negotiate, nothing loaded
+    assert parallel.native_comm() is None and parallel.TRANSPORT["name"] == "none"
+
+
+def test_optimizer_skips_parameters_without_gradient_and_merges_runs():
+    """a parameter whose gradient is None is skipped by step() as in torch.optim — also after adopt_grads() (the
+    data-parallel exchange zero-fills its slice for the wire but leaves p.grad None, so Adam's moments do not keep moving it) —
+    and the remaining parameters are updated in maximal contiguous runs.  CPU twin, against torch.optim.Adam / RMSprop."""
+    from shapegan_amd import optim
+    L.load_cpu()
+    torch.manual_seed(0)
+    shapes = [(5, 3), (7,), (4, 4), (2,), (9,)]
+    for name, mine, theirs in (("adam", lambda ps: optim.Adam(ps, lr=1e-2), lambda ps: torch.optim.Adam(ps, lr=1e-2)),
+                               ("rmsprop", lambda ps: optim.RMSprop(ps, lr=1e-2), lambda ps: torch.optim.RMSprop(ps, lr=1e-2))):
+        ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        a, b = mine(ps), theirs(qs)
+        for step, missing in enumerate(((), (2,), (2,), (0, 4), ())):
+            a.zero_grad()
+            b.zero_grad(set_to_none=True)
+            gs = [torch.randn(s) for s in shapes]
+            for i, (p, q, g) in enumerate(zip(ps, qs, gs)):
+                if i in missing:
+                    continue
+                q.grad = g.clone()
+                o = a.f.offsets[i]
+                a.f.grad[o:o + g.numel()].copy_(g.reshape(-1))
+                p.grad = a.f.grad[o:o + g.numel()].view(p.shape) if (step + i) % 3 else g.clone()   # slice view or a stray tensor
+            if step == 2:
+                a.f.adopt_grads()                # what GradBucket.finish() does before the exchange
+                assert ps[2].grad is None
+            segs = a._segments()
+            if step in (1, 2) and all(a.f.grad_view_ok(i) for i in (0, 1, 3, 4)):
+                assert len(segs) == 2            # [0, 1] and [3, 4]: one launch per run
+            a.step()
+            b.step()
+            for i, (p, q) in enumerate(zip(ps, qs)):
+                torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6, msg=lambda m: "%s step %d param %d: %s" % (name, step, i, m))
+    with pytest.raises(RuntimeError, match="every parameter needs a gradient"):
+        ps = [torch.nn.Parameter(torch.randn(3)) for _ in range(2)]
+        opt = optim.Adam(ps, lr=1e-3, capturable=True)
+        opt.zero_grad()
+        ps[0].grad = torch.randn(3)
+        opt.step()
+
+
+def test_autograd_grad_returns_ordinary_tensors_not_flat_slices():
+    """torch.autograd.grad(loss, params) hands gradients to the caller, who may keep them; they must not alias the
+    optimizer's flat gradient buffer (the next backward writes there).  loss.backward() still writes the slices directly."""
+    from shapegan_amd import optim
+    from shapegan_amd.model.gan import Discriminator
+    L.load_cpu()
+    torch.manual_seed(1)
+    d = Discriminator()
+    if next(d.parameters()).is_cuda:
+        pytest.skip("CPU-twin check")
+    opt = optim.RMSprop(d.parameters(), lr=1e-4)
+    x = torch.rand(2, 32, 32, 32) * 2 - 1
+    opt.zero_grad()
+    grads = torch.autograd.grad(d(x).mean(), list(d.parameters()))
+    lo, hi = opt.f.grad.data_ptr(), opt.f.grad.data_ptr() + 4 * opt.f.total
+    assert all(not (lo <= g.data_ptr() < hi) for g in grads)
+    kept = [g.clone() for g in grads]
+    opt.zero_grad()
+    d(x * 0.5).mean().backward()
+    assert opt.f.coherent()                       # the plain backward wrote the slices in place
+    for g, k in zip(grads, kept):
+        assert torch.equal(g, k)                  # and left the tensors the caller kept alone
