@@ -163,11 +163,14 @@ def sdfnet_numbers():
     pc, shapes = 200000, 64
     pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
     sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
-    for tag, npts, lat, folded in (("train_ref_20k_L128", 20000, 128, True), ("train_cfg_200k_L256", 200000, 256, True)):
+    for tag, npts, lat, folded, graphed in (("train_ref_20k_L128", 20000, 128, True, False),
+                                            ("train_ref_20k_L128_graphed", 20000, 128, True, True),
+                                            ("train_cfg_200k_L256", 200000, 256, True, False)):
         table = torch.randn(shapes, lat, device="cuda") * 1e-2
-        tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
+        tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc, capturable=graphed)
         idx = torch.randint(0, shapes * pc, (npts,), device="cuda")
-        ms = event_time_ms(lambda: tr.step(idx), 10)
+        # graphed: the whole step (sort, fused forward / backward, weight gradients, two Adam updates) as one captured launch
+        ms = event_time_ms((lambda: tr.step_graphed(idx)) if graphed else (lambda: tr.step(idx)), 10)
         alg, exe = sdf_flops(lat)
         exe = exe if folded else alg
         out[tag] = {"mpoints_per_s": round(npts / ms / 1e3, 3), "ms_per_step": round(ms, 3),
@@ -177,16 +180,62 @@ def sdfnet_numbers():
     return out
 
 
+class _ReferenceWGAN(object):
+    """train_wgan.py:37-46,60-84 on the REFERENCE's OWN module classes (model.gan.Generator / Discriminator imported from the
+    reference checkout by oracle/ref_import.py), stock torch.optim.RMSprop, on the CPU — BASELINE.md section 2's baseline.  Only
+    possible where the checkout exists (the authoring container); the driver's GPU box has none."""
+
+    def __init__(self, ref, g_state, c_state, lr=0.00005, clip=0.01):
+        self.g, self.c = ref.Generator().cpu(), ref.Discriminator().cpu()
+        self.g.load_state_dict(g_state)
+        self.c.load_state_dict(c_state)
+        self.c.use_sigmoid = False
+        self.g_opt = torch.optim.RMSprop(self.g.parameters(), lr=lr)
+        self.c_opt = torch.optim.RMSprop(self.c.parameters(), lr=lr)
+        self.clip = clip
+
+    def critic_step(self, real, z):
+        self.g.zero_grad()
+        self.c.zero_grad()
+        fake = self.g(z).detach()
+        out_fake, out_real = self.c(fake), self.c(real)
+        loss = torch.mean(out_fake) - torch.mean(out_real)
+        loss.backward()
+        self.c_opt.step()
+        self.c.clip_weights(self.clip)
+        return loss.detach(), out_fake.detach(), out_real.detach()
+
+    def generator_step(self, z):
+        self.g.zero_grad()
+        self.c.zero_grad()
+        loss = -torch.mean(self.c(self.g(z)))
+        loss.backward()
+        self.g_opt.step()
+
+    def step(self, reals, zs, zg):
+        for i, (real, z) in enumerate(zip(reals, zs)):
+            self.critic_step(real, z)
+            if i == 0:
+                self.generator_step(zg)
+
+
 def cpu_baseline(reals, zs, zg, g_state, c_state):
-    """The CPU oracle (torch fp32 ops = the reference's own arithmetic engine, a PORT of the step body, not the reference's
-    module classes) on the same step, plus the agreement of the GPU path with it on the first critic update."""
+    """The same 5+1 step on the host cores, plus the agreement of the GPU path with it on the first critic update.  Where the
+    reference checkout is present the step runs on the reference's own modules (`kind: "reference"`); on a box without it — the
+    driver's GPU box: /root/reference does not travel — on oracle/torch_oracle.py, the CPU restatement of the same step on the
+    same torch fp32 ops (`kind: "port"`, `reference_present: false`)."""
+    from oracle import ref_import
     from oracle import torch_oracle as O
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
     # oneDNN's conv3d backward stops scaling past ~32 threads on the GPU box's 256-core host (measured: 0.49 s per
     # critic update at 16-32 threads, 1.6 s at 128, 15 s at 256): use the fastest setting and report it as `cores`
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    orc = O.WGANOracle(g_state, c_state)
+    have_ref = ref_import.available()
+    if have_ref:
+        orc, kind, who = _ReferenceWGAN(ref_import.load(), g_state, c_state), "reference", "the reference's model.gan modules (imported from the checkout)"
+    else:
+        orc, kind, who = O.WGANOracle(g_state, c_state), "port", "oracle/torch_oracle.py WGANOracle"
     reals = [r.cpu() for r in reals]
     zs = [z.cpu() for z in zs]
     zg = zg.cpu()
@@ -207,9 +256,12 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
     for _ in range(nsteps):
         orc.step(reals, zs, zg)
     dt = time.perf_counter() - t0
-    return {"value": round(nsteps / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full 5+1 WGAN step(s) at batch 64 after 1 warm-up critic update, oracle/torch_oracle.py "
-                      "WGANOracle on torch CPU fp32" % nsteps,
+    return {"value": round(nsteps / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": kind,
+            "reference_present": have_ref, "host_cores": os.cpu_count(),
+            "sample": "%d full 5+1 WGAN step(s) at batch 64 after 1 warm-up critic update, %s on torch CPU fp32"
+                      % (nsteps, who),
+            "why_port": None if have_ref else "the reference checkout (/root/reference) does not exist on this box, so its module "
+                        "classes cannot be imported; the port runs the same torch.nn.functional calls from the same state_dict",
             "gpu_vs_oracle": {"critic_scores_max_err_over_mean_abs": rel, "critic_loss_rel_err": loss_rel,
                               "what": "first critic update at batch 64 from the same initial state and inputs"}}
 
@@ -230,7 +282,8 @@ def make_wgan(rank):
     info = {"metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
             "unit": "steps/s", "units_per_step": 1.0,
             "workload": "train_wgan.py 32^3 voxel WGAN, fp32, batch=64 synthetic SDF grids (BASELINE configs[1])",
-            "batch": BATCH, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1}}
+            "batch": BATCH, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
+            "allreduce_bytes_per_step": 4 * (5 * trainer.c_opt.f.total + trainer.g_opt.f.total)}
     return (lambda: trainer.step(reals, zs, zg)), info, (reals, zs, zg, state)
 
 
@@ -257,7 +310,9 @@ def make_hybrid_progressive(rank):
             "unit": "steps/s", "units_per_step": 1.0,
             "workload": "train_hybrid_progressive_gan.py iteration=3 (64^3), SDFNet generator + progressive 3D-CNN discriminator, "
                         "WGAN-GP double backward, fp32, batch=16 (BASELINE configs[3])",
-            "batch": B, "extra": {"discriminator_updates_per_step": 5, "generator_updates_per_step": 1}}
+            "batch": B, "extra": {"discriminator_updates_per_step": 5, "generator_updates_per_step": 1},
+            "allreduce_bytes_per_step": 4 * (5 * tr.d_opt.f.total + tr.g_opt.f.total),
+            "sdfnet_points": {"forward": 6 * B * R ** 3, "backward": B * R ** 3, "latent": 128}}
     return step, info, None
 
 
@@ -281,7 +336,9 @@ def make_hybrid_wgan(rank):
     info = {"metric": "hybrid WGAN train steps/sec @32^3 (5 critic + 1 generator updates, batch 8/GPU)", "unit": "steps/s",
             "units_per_step": 1.0,
             "workload": "train_hybrid_wgan.py, SDFNet generator sampled to 32^3 + 3D-CNN critic, fp32, batch=8 (BASELINE configs[4])",
-            "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1}}
+            "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
+            "allreduce_bytes_per_step": 4 * (5 * tr.c_opt.f.total + tr.g_opt.f.total),
+            "sdfnet_points": {"forward": 6 * B * 32 ** 3, "backward": B * 32 ** 3, "latent": 128}}
     return step, info, None
 
 
@@ -299,8 +356,38 @@ def make_sdf(rank):
     info = {"metric": "SDFNet auto-decoder training Mpoints/sec (train_sdf_autodecoder.py, latent 256, 200 000 points/step/GPU)",
             "unit": "Mpoints/s", "units_per_step": npts / 1e6,
             "workload": "train_sdf_autodecoder.py DeepSDF, latent=256, 200k (xyz,sdf) points/step, fp32 (BASELINE configs[2])",
-            "batch": npts, "extra": {}}
+            "batch": npts, "extra": {},
+            "allreduce_bytes_per_step": 4 * (tr.net_opt.f.total + tr.lat_opt.f.total),
+            "sdfnet_points": {"forward": npts, "backward": npts, "latent": lat}}
     return (lambda: tr.step(idx)), info, None
+
+
+def other_configs(steps=3, warmup=2):
+    """The remaining BASELINE workloads (configs[2], [3], [4]) on this GPU, a few timed steps each, so that they appear in the
+    driver-run record next to the headline: `value` in the config's own unit, and the SDFNet share of the step (its generator
+    evaluations / its fused training kernels at the FLOPs they EXECUTE, against the fp32 MFMA peak)."""
+    out = {}
+    for name in ("sdf", "hybrid_progressive", "hybrid_wgan"):
+        torch.cuda.empty_cache()
+        step, info, _ = WORKLOADS[name](0)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        pts = info["sdfnet_points"]
+        _, exe = sdf_flops(pts["latent"])
+        flop = (pts["forward"] + 2 * pts["backward"]) * exe       # forward everywhere, + input & weight gradients where it trains
+        out[name] = {"workload": info["workload"], "metric": info["metric"], "unit": info["unit"], "steps": steps,
+                     "ms_per_step": round(ms, 3), "value": round(info["units_per_step"] / (ms * 1e-3), 4),
+                     "sdfnet_executed_tflop_per_step": round(flop / 1e12, 3),
+                     "sdfnet_executed_flop_over_step_time_frac_of_f32_mfma_peak": round(flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+        del step
+    torch.cuda.empty_cache()
+    return out
 
 
 WORKLOADS = {"wgan": make_wgan, "hybrid_progressive": make_hybrid_progressive, "hybrid_wgan": make_hybrid_wgan, "sdf": make_sdf}
@@ -353,11 +440,18 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config,
         }
+        if world > 1:
+            # what carried the gradient exchange, read back from the communicator itself (ncclCommCount / ncclGetVersion)
+            line["comm"] = dict(parallel.TRANSPORT, transport=parallel.TRANSPORT["name"], world=world,
+                                allreduce_bytes_per_step=info.get("allreduce_bytes_per_step"))
+            line["comm"].pop("name", None)
         if args.config == "wgan":
             line["critic_updates_per_s"] = round(world * args.steps * 5 / elapsed, 3)
             if not args.no_extras:
                 line["roofline"], line["kernels"] = roofline_and_kernels()
                 line["sdfnet"] = sdfnet_numbers()
+                if world == 1:
+                    line["other_configs"] = other_configs()
             if world == 1 and not args.no_cpu_baseline:
                 reals, zs, zg, (g_state, c_state) = wgan_data
                 line["cpu_baseline"] = cpu_baseline(reals, zs, zg, g_state, c_state)

@@ -49,10 +49,11 @@ def main(only=None):
             if not torch.cuda.is_available():
                 import model.sdf_net as ref_sdf_net                      # SDFNet(latent_code_size=128, device='cuda'):
                 ref_sdf_net.SDFNet.__init__.__defaults__ = (128, 'cpu')  # no GPU in the authoring container
-            cases.prepare(case)
-            ns = dropin.run_script(os.path.join(REFERENCE_ROOT, case.script), case.argv, epochs=case.epochs,
-                                   replace=case.replace, aliases=False)
-            return cases.collect(case, ns), ns
+            rec, ns = cases.run(case, REFERENCE_ROOT, aliases=False)
+            classes = {n: ns[n] for n in ("Generator", "Discriminator", "Autoencoder", "SDFNet") if n in ns}
+            if case.script == cases.PROG:
+                classes["ProgressiveDiscriminator"] = classes.pop("Discriminator")
+            return rec, cases.initial_states(case, classes)              # (in the run's directory: a continued run reads models/)
         finally:
             torch.set_num_threads(saved_threads)
             os.chdir(home)
@@ -60,14 +61,17 @@ def main(only=None):
     for case in cases.CASES:
         if only and case.name not in only:
             continue
-        rec, _ = run_reference(case, torch.get_num_threads())
+        for k in [k for k in out if k.startswith(case.name + "/")]:
+            del out[k]                                                   # regenerated: nothing of the old record survives
+        rec, init = run_reference(case, torch.get_num_threads())
         # the reference against itself: the same run on ONE thread (different fp32 summation order).  How far its updates
         # move is the noise floor the native run is allowed (tests/test_dropin.py::compare).
-        rec1, ns1 = run_reference(case, 1)
-        init = cases.initial_states(case, {n: ns1[n] for n in ("Generator", "Discriminator", "Autoencoder", "SDFNet")
-                                           if n in ns1})
-        for k, (frac, _) in cases.update_disagreement(rec1, rec, init).items():
+        rec1, init1 = run_reference(case, 1)
+        for k, (frac, _) in cases.update_disagreement(rec1, rec, init1, init_ref=init).items():
             rec[k + "#noise"] = np.array(frac)
+        if case.pre:
+            for k, v in init.items():
+                rec[k + "#init"] = v                                     # where the recorded run started from
         for k, v in rec.items():
             out["%s/%s" % (case.name, k)] = v
         print(case.name, "->", len(rec), "arrays; largest self-disagreement %.4f" %

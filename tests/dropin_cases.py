@@ -16,9 +16,13 @@ import torch
 STRIDE = 101          # large tensors are compared on every STRIDE-th element
 WHOLE_BELOW = 1 << 18  # floats; tensors below 1 MB are stored whole
 
-Case = collections.namedtuple("Case", "name script argv epochs replace data seed device")
+Case = collections.namedtuple("Case", "name script argv epochs replace data seed device pre", defaults=((),))
 
 SDF_FIX = {"model_indices = indices / POINTCLOUD_SIZE": "model_indices = indices // POINTCLOUD_SIZE"}
+# train_hybrid_progressive_gan.py:103 draws the gradient-penalty alpha with the DEVICE's generator; the recorded reference run
+# is a CPU run, so the draw is pinned to the CPU generator for both (identical on the CPU, makes a GPU run comparable)
+ALPHA_ON_CPU = {"torch.rand((real_sample.shape[0], 1, 1, 1), device=device)": "torch.rand((real_sample.shape[0], 1, 1, 1)).to(device)"}
+PROG = "train_hybrid_progressive_gan.py"
 
 CASES = [
     # BASELINE configs[0]: train_autoencoder.py classic, batch 4, 16 synthetic shapes (CPU plumbing; also run on the GPU)
@@ -32,6 +36,19 @@ CASES = [
     Case("wgan_b64", "train_wgan.py", ["nogui"], 1, None, ("voxels", 128), 3, "gpu"),
     Case("vae_b32", "train_autoencoder.py", ["nogui"], 1, None, ("voxels", 64), 4, "gpu"),
     Case("sdf_b20000", "train_sdf_autodecoder.py", ["nogui"], 1, SDF_FIX, ("sdf", 4, 200000), 5, "gpu"),
+    # BASELINE configs[4]: train_hybrid_wgan.py — SDFNet generator called per point with tiled latents (:67-72,84-86), gan
+    # critic with clipping; the critic update back-propagates through the generator too (the script does not detach)
+    Case("hybrid_wgan_b2", "train_hybrid_wgan.py", ["nogui"], 1, {"BATCH_SIZE = 8": "BATCH_SIZE = 2"}, ("voxels", 8), 6, "any"),
+    Case("hybrid_wgan_b8", "train_hybrid_wgan.py", ["nogui"], 1, None, ("voxels", 32), 7, "gpu"),
+    # BASELINE configs[3]: train_hybrid_progressive_gan.py — iteration 0 (8^3) from scratch; iteration 1 (16^3) started from the
+    # files iteration 0 left behind (generator.load / discriminator.load, :52-57), with the fade-in (:131-132) and the gradient
+    # penalty's double backward.  41 shapes: batches of 16, 16 and a short one of 9 (its own grid tiling, :127-128); 13 shapes at
+    # batch 4: 4, 4, 4 and a last batch of ONE shape, which the script skips (:122-123)
+    Case("prog_it0", PROG, ["nogui", "iteration=0", "epochs=1"], None, ALPHA_ON_CPU, ("split", 41, (8,)), 8, "any"),
+    Case("prog_it1_b4", PROG, ["nogui", "iteration=1", "epochs=1"], None, dict(ALPHA_ON_CPU, **{"BATCH_SIZE = 16": "BATCH_SIZE = 4"}),
+         ("split", 13, (8, 16)), 9, "any", (["nogui", "iteration=0", "epochs=1"],)),
+    Case("prog_it1", PROG, ["nogui", "iteration=1", "epochs=1"], None, ALPHA_ON_CPU, ("split", 41, (8, 16)), 10, "gpu",
+         (["nogui", "iteration=0", "epochs=1"],)),
 ]
 BY_NAME = {c.name: c for c in CASES}
 
@@ -45,6 +62,18 @@ def prepare(case):
             # blobby signed fields in [-0.2, 0.2]: the dataset clamps to +-0.1 and rescales (datasets.py:19-22)
             grid = (rng.rand(32, 32, 32).astype(np.float32) * 0.4 - 0.2)
             np.save("data/chairs/voxels_32/shape%03d.npy" % i, grid)
+    elif case.data[0] == "split":
+        # VoxelDataset.from_split (datasets.py:34-40): data/chairs/train.txt names the ids, one voxels_<R>/ directory per
+        # resolution; one id of the split has no file (from_split skips it)
+        count, resolutions = case.data[1], case.data[2]
+        os.makedirs("data/chairs", exist_ok=True)
+        ids = ["shape%03d" % i for i in range(count)]
+        with open("data/chairs/train.txt", "w") as fh:
+            fh.write("\n".join(ids + ["missing_shape"]) + "\n")
+        for r in resolutions:
+            os.makedirs("data/chairs/voxels_%d" % r, exist_ok=True)
+            for name in ids:
+                np.save("data/chairs/voxels_%d/%s.npy" % (r, name), rng.rand(r, r, r).astype(np.float32) * 0.4 - 0.2)
     else:
         shapes, pc = case.data[1], case.data[2]
         os.makedirs("data", exist_ok=True)
@@ -57,17 +86,29 @@ def prepare(case):
     torch.manual_seed(case.seed)
 
 
-def sample(t):
+def iteration_of(case):
+    return int([a for a in case.argv if a.startswith("iteration=")][0].split("=")[1])
+
+
+def whole_below(case):
+    """Tensors with fewer floats than this are stored whole.  The hybrid-script cases (added in round 3: two networks, a
+    continued run that also records its starting point) sample everything above 16 K floats to keep the fixture small."""
+    return (1 << 14) if case.script in ("train_hybrid_wgan.py", PROG) else WHOLE_BELOW
+
+
+def sample(t, below=WHOLE_BELOW):
     """What is stored / compared for one tensor: (values, sum, abs-sum)."""
     a = t.detach().double().cpu().reshape(-1)
-    vals = a if a.numel() < WHOLE_BELOW else a[::STRIDE]
+    vals = a if a.numel() < below else a[::STRIDE]
     return vals.float().numpy(), np.array([a.sum().item(), a.abs().sum().item()])
 
 
-def _record_module(rec, prefix, module):
+def _record_module(rec, prefix, module, below=WHOLE_BELOW):
     for k, v in module.state_dict().items():
+        if k.startswith("optional_layer_"):
+            continue        # progressive_gan.py:36-37 registers every stage twice; the `optional_layers.i` entries are the same tensors
         if v.is_floating_point():
-            vals, sums = sample(v)
+            vals, sums = sample(v, below)
             rec["%s/%s" % (prefix, k)] = vals
             rec["%s/%s#sums" % (prefix, k)] = sums
         else:
@@ -91,6 +132,24 @@ def collect(case, ns):
         files = ["models/" + ae.filename, "models/checkpoints/" + ae.filename.replace(".to", "-epoch-00000.to")]
         rec["reconstruction_loss"] = np.array(list(ns["reconstruction_error_history"]), dtype=np.float64)
         rec["kld_loss"] = np.array(list(ns["kld_error_history"]), dtype=np.float64)
+    elif case.script == "train_hybrid_wgan.py":
+        _record_module(rec, "generator", ns["generator"], whole_below(case))
+        _record_module(rec, "critic", ns["critic"], whole_below(case))
+        files = ["models/hybrid_wgan_generator.to", "models/hybrid_wgan_critic.to",
+                 "models/checkpoints/hybrid_wgan_generator-epoch-00000.to", "models/checkpoints/hybrid_wgan_critic-epoch-00000.to",
+                 "plots/hybrid_wgan_training.csv"]
+        log = open("plots/hybrid_wgan_training.csv").read().split()
+        rec["log"] = np.array([float(log[2]), float(log[3])])           # mean critic value on fakes / reals (4 decimals)
+    elif case.script == PROG:
+        it = iteration_of(case)
+        _record_module(rec, "generator", ns["generator"], whole_below(case))
+        _record_module(rec, "discriminator", ns["discriminator"], whole_below(case))
+        stems = ["hybrid_progressive_gan_generator_%d" % it, "hybrid_progressive_gan_discriminator_%d" % it]
+        files = ["models/%s.to" % n for n in stems] + ["models/checkpoints/%s-epoch-00000.to" % n for n in stems] + [
+            "plots/hybrid_gan_training_%d.csv" % it]
+        log = open(files[-1]).read().split()
+        rec["log"] = np.array([float(log[2]), float(log[3]), float(log[4])])   # D(fake), D(real), gradient penalty (4 decimals)
+        rec["fade_in_progress"] = np.array(float(ns["discriminator"].fade_in_progress))
     else:
         _record_module(rec, "sdf_net", ns["sdf_net"])
         rec["latent_codes"] = ns["latent_codes"].detach().cpu().numpy()
@@ -111,9 +170,25 @@ def initial_states(case, classes):
     the names the script imports (Generator, Discriminator, Autoencoder, SDFNet) to the implementation under test: the
     reference's and the native ones initialise bit-identically (tests/test_host_logic.py::test_state_dict_contract)."""
     out = {}
+    if case.pre:
+        # started from what the preceding run of the same script left in models/ (generator.load(), discriminator.load()):
+        # read in the run's working directory
+        it = iteration_of(case) - 1
+        for prefix, name in (("generator", "hybrid_progressive_gan_generator_%d.to" % it),
+                             ("discriminator", "hybrid_progressive_gan_discriminator_%d.to" % it)):
+            for k, v in torch.load(os.path.join("models", name), map_location="cpu").items():
+                if v.is_floating_point() and not k.startswith("optional_layer_"):
+                    out["%s/%s" % (prefix, k)] = sample(v, whole_below(case))[0]
+        return out
     if case.script == "train_wgan.py":
         torch.manual_seed(case.seed)
         mods = {"generator": classes["Generator"](), "critic": classes["Discriminator"]()}
+    elif case.script == "train_hybrid_wgan.py":
+        torch.manual_seed(case.seed)
+        mods = {"generator": classes["SDFNet"](), "critic": classes["Discriminator"]()}          # construction order: :34-37
+    elif case.script == PROG:
+        torch.manual_seed(case.seed)
+        mods = {"generator": classes["SDFNet"](device="cpu"), "discriminator": classes["ProgressiveDiscriminator"]()}   # :48-49
     elif case.script == "train_autoencoder.py":
         torch.manual_seed(0)                                      # the script seeds itself (train_autoencoder.py:10-11)
         mods = {"autoencoder": classes["Autoencoder"](is_variational="classic" not in case.argv)}
@@ -124,7 +199,7 @@ def initial_states(case, classes):
     for prefix, m in mods.items():
         for k, v in m.state_dict().items():
             if v.is_floating_point():
-                out["%s/%s" % (prefix, k)] = sample(v)[0]
+                out["%s/%s" % (prefix, k)] = sample(v, whole_below(case))[0]
     return out
 
 
@@ -142,19 +217,33 @@ def gradient_free(key):
     return False
 
 
-META = ("saved_keys", "log", "reconstruction_loss", "kld_loss")
+META = ("saved_keys", "log", "reconstruction_loss", "kld_loss", "fade_in_progress")
 
 
-def update_disagreement(rec, ref, init, rel=0.1):
+def update_disagreement(rec, ref, init, rel=0.1, init_ref=None):
     """Per trained tensor: (fraction of entries whose UPDATE u = final - initial differs between the two runs by more than
-    rel * mean|u_ref|, mean|u_ref|).  Skips buffers, integer state, gradient-free biases and untouched tensors."""
+    rel * mean|u_ref|, mean|u_ref|).  Skips buffers, integer state, gradient-free biases and untouched tensors.  `init_ref`:
+    the initial state of the reference run when it is not the same as the run's own (a run continued from saved files)."""
     out = {}
+    init_ref = init if init_ref is None else init_ref
     for k, r in ref.items():
         if "#" in k or k in META or not np.issubdtype(r.dtype, np.floating) or "running_" in k or gradient_free(k):
             continue
-        u_ref, u_got = r.astype(np.float64) - init[k], rec[k].astype(np.float64) - init[k]
+        u_ref, u_got = r.astype(np.float64) - init_ref[k], rec[k].astype(np.float64) - init[k]
         scale = float(np.abs(u_ref).mean())
         if scale == 0.0:
             continue
         out[k] = (float((np.abs(u_got - u_ref) > rel * scale).mean()), scale)
     return out
+
+
+def run(case, script_dir, aliases):
+    """prepare + the preceding runs (`case.pre`) + the recorded run, in the CWD.  Returns (record, namespace, initial states);
+    `aliases` as in shapegan_amd.dropin.run_script (True: the names the script imports resolve to shapegan_amd)."""
+    from shapegan_amd import dropin
+    prepare(case)
+    path = os.path.join(script_dir, case.script)
+    for argv in case.pre:
+        dropin.run_script(path, argv, epochs=case.epochs, replace=case.replace, aliases=aliases)
+    ns = dropin.run_script(path, case.argv, epochs=case.epochs, replace=case.replace, aliases=aliases)
+    return collect(case, ns), ns

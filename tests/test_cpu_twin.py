@@ -15,6 +15,7 @@ import shapegan_amd.lib as L
 import test_gpu_modules as M
 import test_gpu_ops as OPS
 import test_gpu_losses as LOSS
+import test_gpu_fullsize as FULL
 
 
 @pytest.fixture()
@@ -236,3 +237,10 @@ def test_two_threads_drive_two_modules_concurrently(on_cpu):
         assert not errors, errors
         for k in serial:
             assert torch.equal(got[k][0], serial[k][0]) and torch.equal(got[k][1], serial[k][1]), k
+
+
+def test_config3_and_config4_step_checks_at_cpu_size(on_cpu):
+    """The bodies of the BASELINE-size configs[3] / configs[4] oracle checks (tests/test_gpu_fullsize.py) at sizes the twin
+    finishes in seconds: iteration 1 (16^3) with fade-in, batch 3; hybrid WGAN at batch 1."""
+    FULL.hybrid_progressive_case(1, 3, 0.5, 2000)
+    FULL.hybrid_wgan_case(1)

@@ -131,7 +131,10 @@ def test_wgan_batch64_update_vs_oracle():
 
 def test_sdf_autodecoder_200k_L256_step_vs_oracle():
     """BASELINE configs[2]: one auto-decoder step (train_sdf_autodecoder.py:77-91) at 200 000 points, latent 256, through the
-    shape-sorted data flow, against SDFAutoDecoderOracle: loss, network gradients, dense latent-table gradient."""
+    shape-sorted data flow, against SDFAutoDecoderOracle in fp32 AND fp64: loss, network gradients, dense latent-table gradient,
+    by the same criterion as the WGAN update above (1e-4 of the tensor's scale around the fp64 truth plus 4x the fp32 oracle's
+    own error; sums over 200 000 points through 7 ReLU layers: up to 0.2 % kink outliers)."""
+    from test_gpu_modules import check_against_oracles
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     torch.manual_seed(2)
@@ -142,14 +145,154 @@ def test_sdf_autodecoder_200k_L256_step_vs_oracle():
     table = torch.randn(shapes, L) * 1e-2
     idx = torch.randint(0, shapes * pc, (n,))
     net = SDFNet(latent_code_size=L)
-    orc = O.SDFAutoDecoderOracle(_state(net), table, pts, sdf, pointcloud_size=pc)
+    o32 = O.SDFAutoDecoderOracle(_state(net), table, pts, sdf, pointcloud_size=pc)
+    o64 = O.SDFAutoDecoderOracle(_state64(net), table.double(), pts.double(), sdf.double(), pointcloud_size=pc)
     tr = SDFAutoDecoderTrainer(net, table.clone().cuda(), pts.cuda(), sdf.cuda(), pointcloud_size=pc)
     loss = tr.step(idx.cuda())
-    loss_ref = orc.step(idx)
-    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=RTOL)
+    l32, l64 = o32.step(idx), o64.step(idx)
+    np.testing.assert_allclose(loss.item(), l64.item(), rtol=RTOL)
+    gscale = max(float(v.grad.abs().mean()) for v in o64.P.values() if v.requires_grad)
     for k, p in net.named_parameters():
-        close_mostly(p.grad, orc.P[k].grad, rtol=3e-4, max_bad_frac=2e-3, what="net grad " + k)
-    close_mostly(tr.latent_codes.grad, orc.latent_codes.grad, rtol=3e-4, max_bad_frac=2e-3, what="latent table grad")
+        check_against_oracles(p.grad, o32.P[k].grad, o64.P[k].grad, "net grad " + k, gscale=gscale, max_frac=2e-3)
+    check_against_oracles(tr.latent_codes.grad, o32.latent_codes.grad, o64.latent_codes.grad, "latent table grad", max_frac=2e-3)
+
+
+def _inject_fake(oracle, fake_cpu, dtype):
+    """The oracle's generator replaced by a given batch of generated grids: at 16 x 64^3 = 4.2 M points the SDFNet generator
+    (3.9 TFLOP forward) is out of the CPU's reach, so the discriminator side of configs[3] is checked on the grids the native
+    generator produced (its own parity at this size: test_gpu_modules.py::test_full_size_hybrid_progressive_config and the
+    masked-subset check below)."""
+    oracle.generate = lambda z, f=fake_cpu.to(dtype): f
+
+
+@pytest.mark.parametrize("fade", [1.0, 0.5])
+def test_hybrid_progressive_it3_b16_steps_vs_oracle(fade):
+    hybrid_progressive_case(3, 16, fade, 50000)
+
+
+def hybrid_progressive_case(iteration, B, fade, subset):
+    """BASELINE configs[3] at its benchmarked size — train_hybrid_progressive_gan.py iteration=3 (64^3), batch 16 — against
+    HybridProgressiveGANOracle in fp32 and fp64 (train_hybrid_progressive_gan.py:102-111,134-166):
+      (1) one discriminator update with gradient penalty (D(fake), D(real), lerp, double backward): loss, penalty and every
+          parameter gradient, both sides fed the same generated grids;
+      (2) the generator update's discriminator half: loss -mean D(G(z)) and dLoss/dfake [16,64,64,64];
+      (3) its SDFNet half: the 4.2 M-point backward with the upstream gradient restricted to a 50 000-point subset (every other
+          entry zero), against the oracle evaluated on exactly those points (reference semantics: tiled latents, cat + Linear)."""
+    from test_gpu_modules import check_against_oracles
+    from shapegan_amd.model.progressive_gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import HybridProgressiveGANTrainer, frozen
+    from shapegan_amd.util import get_voxel_coordinates
+    from shapegan_amd import ops
+    torch.manual_seed(31)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    R = (8, 16, 32, 64)[iteration]
+    g, d = SDFNet(), Discriminator().cuda()
+    d.set_iteration(iteration)
+    d.fade_in_progress = fade
+    grid = torch.tensor(get_voxel_coordinates(R))
+    o32 = O.HybridProgressiveGANOracle(_state(g), _state(d), grid, iteration, fade)
+    o64 = O.HybridProgressiveGANOracle(_state64(g), _state64(d), grid.double(), iteration, fade)
+    tr = HybridProgressiveGANTrainer(g, d, grid.cuda(), R)
+    gen = torch.Generator().manual_seed(3100)
+    real = torch.rand(B, R, R, R, generator=gen) * 2 - 1
+    z1, z2 = torch.randn(B, 128, generator=gen), torch.randn(B, 128, generator=gen)
+    alpha = torch.rand(B, 1, 1, 1, generator=gen)
+
+    # (2) + (3) first: the generator update sees the initial discriminator on both sides
+    fake = tr.generate(z1.cuda())                       # [16,64,64,64] with its autograd graph (4.2 M points)
+    fake.retain_grad()
+    with frozen(d):
+        loss_g = ops.neg_mean(d(fake))
+    loss_g.backward()
+    g_fake = fake.grad.detach().clone()
+    refs = []
+    for o, dt in ((o32, torch.float32), (o64, torch.float64)):
+        f = fake.detach().cpu().to(dt).requires_grad_(True)
+        lo = -o.disc(f).mean()
+        refs.append((lo.detach(), torch.autograd.grad(lo, f)[0]))
+    np.testing.assert_allclose(loss_g.item(), refs[1][0].item(), rtol=RTOL, atol=1e-7)
+    check_against_oracles(g_fake, refs[0][1], refs[1][1], "dLoss/dfake through the 64^3 discriminator", max_frac=3e-3)
+
+    sel = torch.randperm(B * R ** 3, generator=gen)[:subset]
+    pts_s, lat_s = grid[sel % R ** 3], z1[sel // R ** 3]
+    fragile = O.sdfnet_min_preactivation(o64.G, pts_s.double(), lat_s.double()) < 1e-6     # points on a ReLU kink (oracle docstring): zero upstream gradient
+    assert float(fragile.float().mean()) < 0.05
+    up = refs[1][1].reshape(-1)[sel].float() * (~fragile).float()
+    u = torch.zeros(B * R ** 3)
+    u[sel] = up
+    for p in g.parameters():
+        p.grad = None
+    fake2 = tr.generate(z1.cuda())
+    fake2.backward(u.reshape(B, R, R, R).cuda())
+    sub = []
+    for o, dt in ((o32, torch.float32), (o64, torch.float64)):
+        out = O.sdfnet_forward(o.G, pts_s.to(dt), lat_s.to(dt))
+        out.backward(up.to(dt))
+        sub.append(out.detach())
+    check_against_oracles(fake2.detach().reshape(-1).cpu()[sel], sub[0], sub[1], "generated sdf at the subset")
+    gscale = max(float(v.grad.abs().mean()) for v in o64.G.values() if v.requires_grad)
+    for k, p in g.named_parameters():
+        check_against_oracles(p.grad, o32.G[k].grad, o64.G[k].grad, "generator grad (subset upstream) " + k, gscale=gscale,
+                              max_frac=2e-3)
+
+    # (1) the discriminator update
+    with torch.no_grad():
+        fake_d = tr.generate(z2.cuda()).cpu()
+    _inject_fake(o32, fake_d, torch.float32)
+    _inject_fake(o64, fake_d, torch.float64)
+    dl, gp = tr.discriminator_step(real.cuda(), z2.cuda(), alpha.cuda())
+    r32 = o32.discriminator_step(real, z2, alpha)
+    r64 = o64.discriminator_step(real.double(), z2.double(), alpha.double())
+    np.testing.assert_allclose([dl.item(), gp.item()], [r64[0].item(), r64[1].item()], rtol=RTOL, atol=1e-6)
+    named = dict(d.named_parameters())
+    used = [k for k in named if o64.D[k].grad is not None]
+    assert sorted(k for k in named if named[k].grad is not None) == sorted(used)     # the head and the stages up to `iteration`
+    gscale = max(float(o64.D[k].grad.abs().mean()) for k in used)
+    for k in used:
+        check_against_oracles(named[k].grad, o32.D[k].grad, o64.D[k].grad, "discriminator grad " + k, gscale=gscale, max_frac=3e-3)
+
+
+def test_hybrid_wgan_32_b8_steps_vs_oracle():
+    hybrid_wgan_case(8)
+
+
+def hybrid_wgan_case(B):
+    """BASELINE configs[4] at its benchmarked size — train_hybrid_wgan.py, SDFNet generator sampled to 32^3, batch 8 (262 144
+    points per generator evaluation), critic with weight clipping — one critic update and one generator update against
+    HybridWGANOracle in fp32 and fp64 (train_hybrid_wgan.py:83-115), the generator on the CPU at full size: losses, the 8 scores
+    of each side, every gradient of both networks."""
+    from test_gpu_modules import check_against_oracles
+    from shapegan_amd.model.gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import HybridWGANTrainer
+    from shapegan_amd.util import get_voxel_coordinates
+    torch.manual_seed(41)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    g, c = SDFNet(), Discriminator()
+    grid = torch.tensor(get_voxel_coordinates(32))
+    o32 = O.HybridWGANOracle(_state(g), _state(c), grid)
+    o64 = O.HybridWGANOracle(_state64(g), _state64(c), grid.double())
+    tr = HybridWGANTrainer(g, c, grid.cuda())
+    gen = torch.Generator().manual_seed(4100)
+    real = torch.rand(B, 32, 32, 32, generator=gen) * 0.2 - 0.1          # rescale_sdf = False (train_hybrid_wgan.py:31)
+    z1, z2 = torch.randn(B, 128, generator=gen), torch.randn(B, 128, generator=gen)
+    loss, out_fake, out_real = tr.critic_step(real.cuda(), z1.cuda())
+    c_grads = {k: p.grad.detach().clone() for k, p in c.named_parameters()}
+    r32, r64 = o32.critic_step(real, z1), o64.critic_step(real.double(), z1.double())
+    np.testing.assert_allclose(loss.item(), r64[0].item(), rtol=RTOL, atol=1e-7)
+    check_against_oracles(out_fake, r32[1], r64[1], "critic(fake)")
+    check_against_oracles(out_real, r32[2], r64[2], "critic(real)")
+    gscale = max(float(o64.C[k].grad.abs().mean()) for k in c_grads)
+    for k in c_grads:
+        check_against_oracles(c_grads[k], o32.C[k].grad, o64.C[k].grad, "critic grad " + k, gscale=gscale, max_frac=3e-3)
+    gl, out = tr.generator_step(z2.cuda())
+    g32, g64 = o32.generator_step(z2), o64.generator_step(z2.double())
+    np.testing.assert_allclose(gl.item(), g64[0].item(), rtol=RTOL, atol=1e-7)
+    check_against_oracles(out, g32[1], g64[1], "critic(generator(grid, z))")
+    gscale = max(float(v.grad.abs().mean()) for v in o64.G.values() if v.requires_grad)
+    for k, p in g.named_parameters():
+        check_against_oracles(p.grad, o32.G[k].grad, o64.G[k].grad, "generator grad " + k, gscale=gscale, max_frac=3e-3)
 
 
 def test_sdfnet_backward_beyond_2m_points_equals_its_halves():
