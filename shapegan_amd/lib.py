@@ -321,13 +321,12 @@ import weakref  # noqa: E402
 
 
 class GradSlot(object):
-    __slots__ = ("param", "flat_grad", "offset", "numel", "written", "acc_node")
+    __slots__ = ("param", "flat_grad", "offset", "numel", "written")
 
     def __init__(self, param, flat_grad, offset):
         self.param = weakref.ref(param)
         self.flat_grad, self.offset, self.numel = flat_grad, offset, param.numel()
         self.written = False
-        self.acc_node = None
 
 
 GRAD_SLOTS = {}
@@ -346,28 +345,29 @@ def unregister_grad_slots(slots):
         GRAD_SLOTS.pop(key, None)
 
 
-def _accumulating_backward(slot, p):
-    """True when the running backward will accumulate into p.grad (`loss.backward()`), False under `torch.autograd.grad(...,
-    inputs)`: there the gradient is RETURNED to the caller, who may keep it — a view of the flat slice would be overwritten by
-    the next backward's direct write (torch hands out fresh tensors).  The engine answers for the parameter's AccumulateGrad
-    node; for a leaf inside autograd.grad() it raises, which is the answer too."""
-    if torch._C._current_graph_task_id() == -1:
-        return True                     # not inside an engine run (a raw kernel call from tests / tools): nothing is returned
-    node = slot.acc_node
-    if node is None:
-        if not p.requires_grad:
-            return False
-        with torch.enable_grad():       # (a plain backward runs with grad mode off: the view would have no grad_fn)
-            node = slot.acc_node = p.expand_as(p).grad_fn.next_functions[0][0]
+_direct_write_depth = 0      # > 0 while a backward started through `backward()` below is running (process-wide: the engine
+                             # runs GPU nodes on its own worker threads, so this cannot be thread-local)
+
+
+def backward(loss, **kwargs):
+    """`loss.backward(**kwargs)` with direct gradient writes enabled: inside it, weight-gradient kernels may store straight into
+    the flat-gradient slices registered by shapegan_amd.optim and autograd adopts those views as p.grad.  The trainers call
+    this.  A backward started any other way — a plain `loss.backward()`, and in particular `torch.autograd.grad(loss, params)`,
+    which RETURNS gradients to a caller who may keep them — always receives ordinary tensors, as in torch (a
+    returned view of the flat slice would be overwritten by the next backward)."""
+    global _direct_write_depth
+    _direct_write_depth += 1
     try:
-        return bool(torch._C._will_engine_execute_node(node))
-    except RuntimeError:
-        return False
+        loss.backward(**kwargs)
+    finally:
+        _direct_write_depth -= 1
 
 
 def grad_destination(param_tensor, shape):
     """A view (of `shape`) of the flat-gradient slice of the parameter whose storage `param_tensor` is, if this backward
     may write its gradient there directly; else None."""
+    if _direct_write_depth == 0:
+        return None
     slot = GRAD_SLOTS.get(param_tensor.data_ptr())
     if slot is None or slot.written or torch.is_grad_enabled():
         return None
@@ -378,7 +378,7 @@ def grad_destination(param_tensor, shape):
     n = 1
     for d in shape:
         n *= d
-    if p.grad is not None or n != slot.numel or not _accumulating_backward(slot, p):
+    if p.grad is not None or n != slot.numel:
         return None
     slot.written = True
     return slot.flat_grad[slot.offset:slot.offset + n].view(shape)

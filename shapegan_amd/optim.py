@@ -79,14 +79,15 @@ class _Flat(object):
 
     def zero_grad(self):
         """Gradients -> None (torch's set_to_none semantics) and every slice of the flat buffer open for a direct write:
-        the next `loss.backward()`'s weight-gradient kernels store into the slices and autograd adopts those views as p.grad
+        the next `lib.backward(loss)`'s weight-gradient kernels store into the slices and autograd adopts those views as p.grad
         (lib.grad_destination), so neither a memset of the buffer nor a `p.grad += g` pass per parameter is launched.  A
         parameter that receives no gradient keeps p.grad None and is skipped by step(), as in torch.optim.
 
         Aliasing (differs from torch): p.grad of a parameter owned by this optimizer IS its slice of the flat buffer.  A
         reference to p.grad kept across zero_grad() is overwritten by the next backward (torch would leave the old tensor
-        intact); clone it if it must survive.  Gradients RETURNED by torch.autograd.grad(loss, params) are ordinary tensors
-        (never slices), as in torch."""
+        intact); clone it if it must survive.  Direct writes happen only inside `shapegan_amd.lib.backward(loss)` (what the
+        trainers call): gradients RETURNED by torch.autograd.grad(loss, params), and those of a plain `loss.backward()`, are
+        ordinary tensors (never slices), as in torch; step() / the exchange copy them in on demand."""
         for p, slot in zip(self.params, self.slots):
             p.grad = None
             slot.written = False

@@ -48,7 +48,7 @@ class WGANTrainer(object):
         out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
         self.c_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.c_bucket.finish()
         self.c_opt.step()
         return loss.detach(), out_fake.detach(), out_real.detach()
@@ -62,7 +62,7 @@ class WGANTrainer(object):
             out = self.critic(fake)
         loss = ops.neg_mean(out)
         self.g_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach(), out.detach()
@@ -143,7 +143,7 @@ class AutoencoderTrainer(object):
         rec = reconstruction_loss(output, batch)
         loss = rec + kld
         self.bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.bucket.finish()
         self.opt.step()
         return rec.detach(), output.detach()
@@ -231,7 +231,7 @@ class SDFAutoDecoderTrainer(object):
             # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator (sigma 0: the term is 0, as in the
             # reference's formula)
             loss = loss + ops.mean_sq(self.latent_codes, counts, n * width / self.sigma)
-        loss.backward()
+        lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
         self.net_opt.step()
@@ -251,7 +251,7 @@ class SDFAutoDecoderTrainer(object):
         loss = ops.weighted_l1(output, batch_sdf)
         if self.sigma != 0:
             loss = loss + ops.mean_sq(batch_latent, None, batch_latent.numel() / self.sigma)
-        loss.backward()
+        lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
         self.net_opt.step()
@@ -296,7 +296,7 @@ class HybridWGANTrainer(object):
         out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
         self.c_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.c_bucket.finish()
         self.c_opt.step()
         return loss.detach(), out_fake.detach(), out_real.detach()
@@ -309,7 +309,7 @@ class HybridWGANTrainer(object):
             out = self.critic(fake)
         loss = ops.neg_mean(out)
         self.g_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach(), out.detach()
@@ -355,7 +355,7 @@ class HybridProgressiveGANTrainer(object):
             out = self.discriminator(fake)
         loss = ops.neg_mean(out)
         self.g_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach()
@@ -371,7 +371,7 @@ class HybridProgressiveGANTrainer(object):
         gp = self.gradient_penalty(real.detach(), fake.detach(), alpha)
         loss = ops.mean_difference(out, fake.shape[0]) + gp          # mean(out_fake) - mean(out_real) + penalty
         self.d_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.d_bucket.finish()
         self.d_opt.step()
         return loss.detach(), gp.detach()
@@ -400,7 +400,7 @@ class ClassicGANTrainer(object):
             out = self.discriminator(fake)
         loss = -torch.mean(torch.log(out))
         self.g_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach()
@@ -410,7 +410,7 @@ class ClassicGANTrainer(object):
         out = self.discriminator(sample)
         loss = torch.nn.functional.binary_cross_entropy(out, torch.full_like(out, target_value))
         self.d_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.d_bucket.finish()
         self.d_opt.step()
         return loss.detach(), out.detach()
@@ -483,7 +483,7 @@ class PointGANTrainer(object):
         gp = self.gradient_penalty(pos, dist, fake, alpha)
         loss = d_loss + gp
         self.d_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.d_bucket.finish()
         self.d_opt.step()
         return d_loss.detach(), gp.detach()
@@ -497,7 +497,7 @@ class PointGANTrainer(object):
             out = self.critic(pos, fake)
         loss = ops.neg_mean(out)
         self.g_bucket.arm()
-        loss.backward()
+        lib.backward(loss)
         self.g_bucket.finish()
         self.g_opt.step()
         return loss.detach()

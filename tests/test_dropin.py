@@ -83,7 +83,12 @@ def compare(case, rec, gold, report=None):
             k, 100 * frac, 100 * noise)
     if "log" in gold:
         atol = {"train_wgan.py": 0.011, "train_hybrid_wgan.py": 1.1e-4, cases.PROG: 1.1e-4}.get(case.script, 2e-6)   # printed decimals
-        np.testing.assert_allclose(rec["log"], gold["log"], rtol=2e-4, atol=atol)
+        # the hybrid scripts log means of discriminator outputs taken AFTER 1-6 RMSprop updates whose first steps are
+        # 10 * lr * sign(g) = 1e-3 per weight (lr 1e-4): weights whose gradient is at rounding level step the other way in two
+        # correct fp32 runs and the later outputs inherit that (measured on the MI355X: 4e-4 / 1.2e-3 relative after the
+        # continued 16^3 run, 6e-5 after the first three updates)
+        rtol = 3e-3 if case.script in ("train_hybrid_wgan.py", cases.PROG) else 2e-4
+        np.testing.assert_allclose(rec["log"], gold["log"], rtol=rtol, atol=atol)
     if "fade_in_progress" in gold:
         assert float(rec["fade_in_progress"]) == float(gold["fade_in_progress"])
     if "reconstruction_loss" in gold:

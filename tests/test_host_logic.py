@@ -160,12 +160,17 @@ def test_flat_optimizer_views_on_cpu():
     w = d.head[1].weight
     wi = [i for i, p in enumerate(f.params) if p is w][0]
     with torch.no_grad():                              # a plain backward runs with grad mode off
-        dst = L.grad_destination(w, w.shape)           # what a weight-gradient kernel asks for
-        assert dst is not None and dst.data_ptr() == f.grad.data_ptr() + 4 * f.offsets[wi]
-        assert L.grad_destination(w, w.shape) is None  # a second contribution in the same cycle must not clobber the first
-    f.zero_grad()
-    with torch.enable_grad():
-        assert L.grad_destination(w, w.shape) is None  # create_graph backward: gradients must stay ordinary tensors
+        assert L.grad_destination(w, w.shape) is None  # not inside lib.backward(): gradients stay ordinary tensors
+        L._direct_write_depth += 1                     # what lib.backward(loss) does around loss.backward()
+        try:
+            dst = L.grad_destination(w, w.shape)           # what a weight-gradient kernel asks for
+            assert dst is not None and dst.data_ptr() == f.grad.data_ptr() + 4 * f.offsets[wi]
+            assert L.grad_destination(w, w.shape) is None  # a second contribution in the same cycle must not clobber the first
+            f.zero_grad()
+            with torch.enable_grad():
+                assert L.grad_destination(w, w.shape) is None  # create_graph backward: gradients must stay ordinary tensors
+        finally:
+            L._direct_write_depth -= 1
     # gradients that arrived as ordinary tensors (stock autograd, or None) are pulled into the flat buffer on demand
     for i, p in enumerate(d.parameters()):
         p.grad = None if i == 0 else torch.full_like(p, float(i))
@@ -426,7 +431,7 @@ def test_optimizer_skips_parameters_without_gradient_and_merges_runs():
 
 def test_autograd_grad_returns_ordinary_tensors_not_flat_slices():
     """torch.autograd.grad(loss, params) hands gradients to the caller, who may keep them; they must not alias the
-    optimizer's flat gradient buffer (the next backward writes there).  loss.backward() still writes the slices directly."""
+    optimizer's flat gradient buffer (the next backward writes there).  Direct slice writes happen only inside lib.backward()."""
     from shapegan_amd import optim
     from shapegan_amd.model.gan import Discriminator
     L.load_cpu()
@@ -442,7 +447,11 @@ def test_autograd_grad_returns_ordinary_tensors_not_flat_slices():
     assert all(not (lo <= g.data_ptr() < hi) for g in grads)
     kept = [g.clone() for g in grads]
     opt.zero_grad()
-    d(x * 0.5).mean().backward()
-    assert opt.f.coherent()                       # the plain backward wrote the slices in place
+    L.backward(d(x * 0.5).mean())
+    assert opt.f.coherent()                       # the trainers' backward wrote the slices in place
     for g, k in zip(grads, kept):
         assert torch.equal(g, k)                  # and left the tensors the caller kept alone
+    opt.zero_grad()
+    d(x * 0.25).mean().backward()                 # a plain backward: ordinary tensors, copied in on demand by step() / the exchange
+    assert all(not (lo <= p.grad.data_ptr() < hi) for p in d.parameters())
+    opt.step()
