@@ -152,6 +152,11 @@ int sg_act_bwd_rowsum(const float* y, const float* dy, float* dx, float* rowsum,
  * semantics) or 3 (per-shape latents folded into zb1/zb5 biases; replaces the [B*R^3, L] tiling of
  * train_hybrid_wgan.py:67-70 / train_hybrid_progressive_gan.py:90-93). */
 size_t sg_sdfnet_packed_floats(int kin_used);
+/* floats of the activation buffer `acts` of a training call (sg_sdfnet_fwd writes it, sg_sdfnet_bwd and the weight-gradient
+ * GEMMs read it): the fp32 images H1..H7 [7][256][ldn], followed by their SIGN MASKS, unsigned short [7][16][ldn] — bit q of
+ * mask[l][2 w + h][p] is (H_{l+1}[32 w + (q & 3) + 8 (q >> 2) + 4 h][p] > 0), one 16-bit word per point and group of 16 rows.
+ * The backward takes ReLU' of H1..H6 from the masks (1/32 of the bytes) instead of re-reading the images. */
+size_t sg_sdfnet_acts_floats(long ldn);
 int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream);
 int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, const int64_t* latent_idx,
                   int latent_size, const float* packed, int kin_used, const float* zb1, const float* zb5,

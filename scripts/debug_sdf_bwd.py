@@ -26,7 +26,7 @@ kin = 3 + Lz
 packed = net._pack_points.get(list(net.parameters()), Lz, kin) if hasattr(net, "_pack_points") else None
 if packed is None:
     cache = ops._PackCache(); packed = cache.get(list(net.parameters()), Lz, kin)
-out = torch.empty(N, device="cuda"); acts = torch.full((7, 256, N), 7.0, device="cuda")
+out = torch.empty(N, device="cuda"); acts = torch.full((lib.sg_sdfnet_acts_floats(N),), 7.0, device="cuda")
 check(lib.sg_sdfnet_fwd(ptr(pts.detach()), 0, ptr(lat.detach()), None, Lz, ptr(packed), kin, None, None, 0, None, ptr(out), ptr(acts), N, N, stream()), "fwd")
 print("out err", float((out - out_ref).abs().max()))
 for l in range(7):

@@ -6,7 +6,8 @@
 //
 // x is [N, C, S] (S = D*H*W, 1 for BatchNorm1d).  Statistics are HBM-bound reductions: each (channel, split)
 // workgroup streams its slice with float4 loads, reduces per wave with shuffles (DPP), then across the 4 waves
-// through LDS; partials are combined in double by a finalize kernel that also updates the running statistics.
+// through LDS; the partials are combined in double at the head of the second pass (finalize + apply in one launch), whose
+// (channel, 0) workgroup also updates the running statistics.
 // Sums are shifted by the channel's first element so E[x^2]-E[x]^2 does not cancel when |mean| >> std.
 #include "common.h"
 #include "../../include/shapegan_hip.h"
@@ -56,33 +57,6 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ partial,
-                                                          float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* running_mean, float* running_var,
-                                                          long long* num_batches_tracked, int N, int C, long S,
-                                                          int nsplit, float eps, float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int i = 0; i < nsplit; ++i) {
-        s1 += partial[((long)c * nsplit + i) * 2];
-        s2 += partial[((long)c * nsplit + i) * 2 + 1];
-    }
-    const double n = (double)N * (double)S;
-    const double K = (double)x[(long)c * S];
-    const double m = s1 / n;
-    double var = s2 / n - m * m;
-    if (var < 0) var = 0;
-    mean[c] = (float)(K + m);
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)(K + m);
-        const double unbiased = n > 1 ? var * n / (n - 1) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-}
-
 __global__ void __launch_bounds__(256) bn_eval_stats_kernel(const float* __restrict__ running_mean,
                                                             const float* __restrict__ running_var,
                                                             float* __restrict__ mean, float* __restrict__ invstd, int C,
@@ -114,6 +88,69 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
             const int c = (int)((e / S) % C);
             const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
             y[e] = sg_apply_act(fmaf(x[e], sc, sh), act, slope);
+        }
+    }
+}
+
+// Training forward, second pass: FINALIZE + APPLY in one launch.  Grid (C, nsplit) like the statistics pass: every workgroup of
+// channel c first combines the channel's `nparts` double partials (threads < nparts load one pair each, wave butterflies in
+// double: a fixed order, so all workgroups of a channel — and every run — get bit-identical statistics), then streams its slice
+// of the channel.  Workgroup (c, 0) publishes mean / invstd and updates the running statistics; (0, 0) bumps the batch counter.
+// (One launch less per BatchNorm and no per-element `e / S % C`.)
+__global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                const double* __restrict__ partial,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ mean, float* __restrict__ invstd,
+                                                                float* running_mean, float* running_var,
+                                                                long long* num_batches_tracked, int N, int C, long S, int nparts,
+                                                                int nsplit, float eps, float momentum, int act, float slope) {
+    const int c = blockIdx.x, sp = blockIdx.y;
+    __shared__ float stat[2];
+    if (threadIdx.x < 64) {      // nparts <= 64: one wave
+        double s1 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2] : 0.0;
+        double s2 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2 + 1] : 0.0;
+        s1 = sg_wave_sum_d(s1);
+        s2 = sg_wave_sum_d(s2);
+        if (threadIdx.x == 0) {
+            const double n = (double)N * (double)S;
+            const double K = (double)x[(long)c * S];
+            const double m = s1 / n;
+            double var = s2 / n - m * m;
+            if (var < 0) var = 0;
+            const float mu = (float)(K + m), is = (float)(1.0 / sqrt(var + (double)eps));
+            stat[0] = mu;
+            stat[1] = is;
+            if (sp == 0) {
+                mean[c] = mu;
+                invstd[c] = is;
+                if (running_mean) {
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+                    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+                }
+                if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+            }
+        }
+    }
+    __syncthreads();
+    const float sc = gamma[c] * stat[1], sh = beta[c] - stat[0] * sc;
+    const long total = (long)N * S;
+    const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
+    const long beg = sp * chunk, end = min(total, beg + chunk);
+    if ((S & 3) == 0) {
+        for (long e = beg + (long)threadIdx.x * 4; e < end; e += 1024) {
+            const long ad = chan_addr(e, c, C, S);
+            float4 v = *reinterpret_cast<const float4*>(x + ad);
+            v.x = sg_apply_act(fmaf(v.x, sc, sh), act, slope);
+            v.y = sg_apply_act(fmaf(v.y, sc, sh), act, slope);
+            v.z = sg_apply_act(fmaf(v.z, sc, sh), act, slope);
+            v.w = sg_apply_act(fmaf(v.w, sc, sh), act, slope);
+            *reinterpret_cast<float4*>(y + ad) = v;
+        }
+    } else {
+        for (long e = beg + threadIdx.x; e < end; e += 256) {
+            const long ad = chan_addr(e, c, C, S);
+            y[ad] = sg_apply_act(fmaf(x[ad], sc, sh), act, slope);
         }
     }
 }
@@ -165,37 +202,45 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restri
     }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int C, int nsplit) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int i = 0; i < nsplit; ++i) {
-        s1 += partial[((long)c * nsplit + i) * 2];
-        s2 += partial[((long)c * nsplit + i) * 2 + 1];
+// Backward, second pass: FINALIZE + APPLY (same scheme as bn_finalize_apply_kernel): every workgroup of channel c combines the
+// channel's partial sums in a fixed order, workgroup (c, 0) writes dgamma / dbeta.
+__global__ void __launch_bounds__(256) bn_bwd_finalize_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    float* __restrict__ dx, const double* __restrict__ partial,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                                    int C, long S, int nparts, int nsplit, int train, int act,
+                                                                    float slope) {
+    const int c = blockIdx.x, sp = blockIdx.y;
+    __shared__ float sums[2];
+    if (threadIdx.x < 64) {
+        double s1 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2] : 0.0;
+        double s2 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2 + 1] : 0.0;
+        s1 = sg_wave_sum_d(s1);
+        s2 = sg_wave_sum_d(s2);
+        if (threadIdx.x == 0) {
+            sums[0] = (float)s1;
+            sums[1] = (float)s2;
+            if (sp == 0) {
+                dbeta[c] = (float)s1;
+                dgamma[c] = (float)s2;
+            }
+        }
     }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-}
-
-// train: dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n);  eval (stats constant): dx = gamma*invstd*g
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           float* __restrict__ dx, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
-                                                           const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, int C, long S, long total,
-                                                           float inv_n, int train, int act, float slope) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c = (int)((e / S) % C);
-        const float is = invstd[c], g = gamma[c];
-        const float xh = (x[e] - mean[c]) * is;
-        const float gg = bn_act_grad(xh, g, beta[c], dy[e], act, slope);
+    __syncthreads();
+    const float inv_n = 1.f / ((float)N * (float)S);
+    const float is = invstd[c], g = gamma[c], b = beta[c], mu = mean[c];
+    const float db = sums[0] * inv_n, dg = sums[1] * inv_n;
+    const long total = (long)N * S;
+    const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
+    const long beg = sp * chunk, end = min(total, beg + chunk);
+    for (long e = beg + threadIdx.x; e < end; e += 256) {
+        const long ad = chan_addr(e, c, C, S);
+        const float xh = (x[ad] - mu) * is;
+        const float gg = bn_act_grad(xh, g, b, dy[ad], act, slope);
         float v = gg;
-        if (train) v = gg - dbeta[c] * inv_n - xh * dgamma[c] * inv_n;
-        dx[e] = g * is * v;
+        if (train) v = gg - db - xh * dg;
+        dx[ad] = g * is * v;
     }
 }
 
@@ -207,6 +252,17 @@ static int bn_nsplit(int N, int C, long S) {
     if (maxs < 1) maxs = 1;
     long s = want < maxs ? want : maxs;
     if (s > 64) s = 64;
+    return (int)s;
+}
+// slices per channel of the apply passes: enough workgroups to fill the chip (~8 per CU), each at least 4096 elements
+static int bn_apply_split(int N, int C, long S) {
+    const long per = (long)N * S;
+    long want = (2048 + C - 1) / (C > 0 ? C : 1);
+    long maxs = per / 4096;
+    if (maxs < 1) maxs = 1;
+    long s = want < maxs ? want : maxs;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
     return (int)s;
 }
 static int ew_blocks(long total, int per_thread) {
@@ -233,11 +289,11 @@ int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float
     const int ns = bn_nsplit(N, C, S);
     double* part = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, stream, x, part, N, C, S, ns);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sg_cdiv(C, 256)), dim3(256), 0, stream, x, (const double*)part, save_mean,
-                       save_invstd, running_mean, running_var, num_batches_tracked, N, C, S, ns, eps, momentum);
-    const long total = (long)N * C * S;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total, 4)), dim3(256), 0, stream, x, y, gamma, beta,
-                       (const float*)save_mean, (const float*)save_invstd, C, S, total, act, slope);
+    // finalize + apply in one launch; the apply pass may use more slices per channel than the statistics pass
+    const int na = bn_apply_split(N, C, S);
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, na), dim3(256), 0, stream, x, y, (const double*)part, gamma, beta,
+                       save_mean, save_invstd, running_mean, running_var, num_batches_tracked, N, C, S, ns, na, eps, momentum, act,
+                       slope);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -264,12 +320,9 @@ int sg_bn_bwd(const float* dy, const float* x, const float* gamma, const float* 
     double* part = (double*)workspace;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, ns), dim3(256), 0, stream, dy, x, gamma, beta, save_mean, save_invstd,
                        part, N, C, S, ns, act, slope);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sg_cdiv(C, 256)), dim3(256), 0, stream, (const double*)part, dgamma,
-                       dbeta, C, ns);
-    const long total = (long)N * C * S;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total, 1)), dim3(256), 0, stream, dy, x, dx, gamma, beta,
-                       save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, C, S, total,
-                       1.f / ((float)N * (float)S), train, act, slope);
+    const int na = bn_apply_split(N, C, S);
+    hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, dim3(C, na), dim3(256), 0, stream, dy, x, dx, (const double*)part, gamma,
+                       beta, save_mean, save_invstd, dgamma, dbeta, N, C, S, ns, na, train, act, slope);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

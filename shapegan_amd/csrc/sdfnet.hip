@@ -238,6 +238,12 @@ __device__ __forceinline__ void mlp_gemm_ring(f32x16 (&acc)[NT], WRing<RING>& w,
 
 __device__ __forceinline__ int frag_row(int q, int kh) { return (q & 3) + 8 * (q >> 2) + 4 * kh; }
 
+// The activation buffer of a training call: [7][256][ldn] fp32 images H1..H7 followed by the sign masks, unsigned short
+// [7][16][ldn]: bit q of masks[l][2 w + kh][p] = (H_{l+1}[32 w + frag_row(q, kh)][p] > 0)  (sg_sdfnet_acts_floats in the header).
+__host__ __device__ __forceinline__ const unsigned short* sdf_mask_base(const float* acts, long ldn) {
+    return reinterpret_cast<const unsigned short*>(acts + 7L * kH * ldn);
+}
+
 struct SdfFwdArgs {
     const float* points;    // [*,3]
     long points_period;     // >0: point index = p % period (shared voxel grid); 0: p
@@ -338,10 +344,20 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         astore[t] = p0 + t * 32 + r < a.N ? (unsigned)((4L * kh * a.ldn + t * 32 + r) * 4) : kBufOutside;
+    // ... and the SIGN MASK of H_l, 1 bit per element: a lane holds 16 rows (q) of one point per column tile, so it packs them
+    // into one 16-bit word at masks[layer][16-row group = 2 wave + kh][point] (sg_sdfnet_mask_* in the header): 1/32 of the H
+    // traffic.  The backward reads ReLU'(.) from these words instead of re-reading the fp32 images.
+    unsigned mstore[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        mstore[t] = p0 + t * 32 + r < a.N ? (unsigned)(((long)kh * a.ldn + t * 32 + r) * 2) : kBufOutside;
     auto writeback = [&](int layer) {  // H <- relu(acc); optionally save
         __syncthreads();
         const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.acts + ((long)layer * kH + wrow) * a.ldn + p0);
         const bool save = a.acts != nullptr;
+        unsigned mk[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mk[t] = 0u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wave * 32 + frag_row(q, kh);
@@ -349,10 +365,17 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
             for (int t = 0; t < NT; ++t) {
                 const float v = fmaxf(acc[t][q], 0.f);
                 Hs[row * P + t * 32 + r] = v;
+                mk[t] |= v > 0.f ? (1u << q) : 0u;
                 if (save)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ares, (int)astore[t],
                                                           (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
             }
+        }
+        if (save) {
+            const __amdgpu_buffer_rsrc_t mres =
+                make_rsrc(sdf_mask_base(a.acts, a.ldn) + ((long)layer * 16 + (wrow >> 4)) * a.ldn + p0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mk[t], mres, (int)mstore[t], 0, 0);
         }
         __syncthreads();
     };
@@ -534,6 +557,26 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     auto layer_rsrc = [&](const float* image, int layer) __attribute__((always_inline)) {
         return make_rsrc(image + ((long)layer * kH + wrow) * a.ldn + p0);
     };
+    // ReLU'(H_l) for the layers below the last one comes from the forward's 16-bit sign words (one 2-byte load per column tile
+    // instead of 16 dword loads): bit q of mk[t] <-> row frag_row(q, kh), point t*32 + r
+    unsigned mk[NT];
+    // this wave's mask row of the layer about to be processed (walks down one layer = 16 rows per step: a running scalar, so
+    // that the six bases are not all computed — and kept in SGPRs — up front)
+    const unsigned short* mkrow = sdf_mask_base(a.acts, a.ldn) + ((long)5 * 16 + (wrow >> 4)) * a.ldn + p0;
+    auto load_mask = [&](int layer) __attribute__((always_inline)) {
+        // the resource starts at this wave's (layer, group 2 wave + kh) row and the tile's first point: the lane offset is just
+        // its point (lanes beyond N read the tile's first point; their bits are masked by pok)
+        const __amdgpu_buffer_rsrc_t mres = make_rsrc(mkrow);
+        mkrow -= 16 * a.ldn;
+        asm volatile("" : "+s"(mkrow));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#ifdef SG_ABL_NOLOAD
+            mk[t] = 0xffffu;
+#else
+            mk[t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(mres, (int)(((hload[t] - khoff) >> 1) + (khoff >> 3)), 0, 0);
+#endif
+    };
     float hf[16][NT];
     auto load_h = [&](int layer) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t hres = layer_rsrc(a.acts, layer);
@@ -573,8 +616,9 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     };
     // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
     // XC: -1, or the block of extended partial rows (8: dW1 point columns, 11: dW5 point columns) this layer feeds
-    auto mask_store = [&](int layer, auto xtag) __attribute__((always_inline)) {
+    auto mask_store = [&](int layer, auto xtag, auto bits_tag) __attribute__((always_inline)) {
         constexpr int XC = decltype(xtag)::value;
+        constexpr bool BITS = decltype(bits_tag)::value != 0;    // ReLU' from the sign words (mk) instead of the fp32 image (hf)
         const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, layer);
         const __amdgpu_buffer_rsrc_t bres = partial_rsrc(a.bsum ? layer : 0);
 #pragma unroll
@@ -583,7 +627,15 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
             float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
+                float g;
+                if (BITS) {
+                    // bit q of the sign word, sign-extended to 0 / ~0 and ANDed onto the value: two VALU instructions and no
+                    // SGPR-pair compare masks (32 of them in flight spilled SGPRs); lanes beyond N had their word cleared
+                    const int keep = (int)(mk[t] << (31 - q)) >> 31;
+                    g = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[t][q]) & keep);
+                } else {
+                    g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
+                }
                 Gs[row * P + t * 32 + r] = g;
 #ifndef SG_ABL_NOSTORE
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[t],
@@ -642,16 +694,18 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     auto wtile_t = [&](long toff) { return pk + (toff >> 2) + (long)wave * (kH / 8) * 64; };
     wring_start(wr, wtile_t(a.lay.T7), lane);
     __builtin_amdgcn_sched_barrier(0);
-    mask_store(6, IntTag<-1>());
+    mask_store(6, IntTag<-1>(), IntTag<0>());      // (H7 itself is in registers: the w8 gradient above needs its values)
     __syncthreads();
     // dZ_layer+1 (LDS) -> dZ_layer; tnext: transposed pack of the following step (-1: none)
     auto back_step = [&](int layer, long tnext, auto xtag) __attribute__((always_inline)) {
         zero_acc();
-        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_h(layer); });
+        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_mask(layer); });
         __syncthreads();   // every wave is done reading the tile
         if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
         __builtin_amdgcn_sched_barrier(0);
-        mask_store(layer, xtag);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mk[t] = pok[t] ? mk[t] : 0u;
+        mask_store(layer, xtag, IntTag<1>());
         __syncthreads();
     };
     back_step(5, a.lay.T6, IntTag<-1>());    // dH6 -> dZ6
@@ -835,6 +889,10 @@ using namespace sg;
 extern "C" {
 
 size_t sg_sdfnet_packed_floats(int kin_used) { return (size_t)make_layout(kin_used).total; }
+
+// floats of the activation buffer of a training call with leading dimension ldn: the seven fp32 images [7][256][ldn] plus the
+// sign masks (unsigned short [7][16][ldn] = 56 ldn floats)
+size_t sg_sdfnet_acts_floats(long ldn) { return (size_t)7 * kH * ldn + (size_t)56 * ldn; }
 
 // params: host array of 16 device pointers in state_dict order
 //   layers1.{0,2,4,6}.{weight,bias}, layers2.{0,2,4,6}.{weight,bias}   (model/sdf_net.py:26-53)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sg_act_bwd": (c_int, [_P, _P, _P, _L, _I, _F, _P]),
     "sg_act_bwd_rowsum": (c_int, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
     "sg_sdfnet_packed_floats": (_Z, [_I]),
+    "sg_sdfnet_acts_floats": (_Z, [_L]),
     "sg_sdfnet_pack": (c_int, [_P, _I, _I, _P, _P]),
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
@@ -148,7 +149,7 @@ def check_comm(rc, what=""):
 # Entry points WITHOUT a twin: size queries and layout helpers are host code of libshapegan_hip.so (callable without a GPU; the
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
-    "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
+    "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
     "sg_conv3d_k4s2p1_wgrad_act_eligible"}
 CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
 
@@ -345,6 +346,7 @@ def unregister_grad_slots(slots):
         GRAD_SLOTS.pop(key, None)
 
 
+_ONES = {}
 _direct_write_depth = 0      # > 0 while a backward started through `backward()` below is running (process-wide: the engine
                              # runs GPU nodes on its own worker threads, so this cannot be thread-local)
 
@@ -356,6 +358,13 @@ def backward(loss, **kwargs):
     which RETURNS gradients to a caller who may keep them — always receives ordinary tensors, as in torch (a
     returned view of the flat slice would be overwritten by the next backward)."""
     global _direct_write_depth
+    if "gradient" not in kwargs and loss.dim() == 0:
+        # the engine would create the implicit d loss / d loss = 1 with a fill launch on every call: keep one per device / dtype
+        key = (loss.device, loss.dtype)
+        one = _ONES.get(key)
+        if one is None:
+            one = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+        kwargs["gradient"] = one
     _direct_write_depth += 1
     try:
         loss.backward(**kwargs)

@@ -665,7 +665,7 @@ class SDFNetPoints(Function):
         packed = cache.get(params, Lz, kin)
         need_grad = any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
-        acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
+        acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
         check(lib.sg_sdfnet_fwd(ptr(points), 0, ptr(latent), None, Lz, ptr(packed), kin, None, None, 0, None, ptr(out),
                                 ptr(acts), N, N, stream()), "sdfnet_fwd")
         ctx.cache, ctx.Lz = cache, Lz
@@ -728,7 +728,7 @@ class SDFNetShapes(Function):
         zb5 = gemm_raw(z, False, w5, True, bias_j=b5, b_off=_H + 3, M=S, N=_H, K=Lz, lda=Lz, ldb=_H + kin_total)
         need_grad = any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
-        acts = torch.empty((7, _H, N), dtype=torch.float32, device=points.device) if need_grad else None
+        acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
         check(lib.sg_sdfnet_fwd(ptr(points), 0, None, None, Lz, ptr(packed), 3, ptr(zb1), ptr(zb5), pps, ptr(sid),
                                 ptr(out), ptr(acts), N, N, stream()), "sdfnet_fwd")
         ctx.pps = pps
