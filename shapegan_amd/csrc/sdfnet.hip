@@ -629,10 +629,11 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
             for (int t = 0; t < NT; ++t) {
                 float g;
                 if (BITS) {
-                    // bit q of the sign word, sign-extended to 0 / ~0 and ANDed onto the value: two VALU instructions and no
-                    // SGPR-pair compare masks (32 of them in flight spilled SGPRs); lanes beyond N had their word cleared
-                    const int keep = (int)(mk[t] << (31 - q)) >> 31;
-                    g = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[t][q]) & keep);
+                    // bit q of the sign word; lanes beyond N had their word cleared
+                    // (toolchain note, hipcc ROCm 7.2: forming the result as `bit_cast<int>(acc[t][q]) & -(bit q)` — two VALU
+                    // instructions, no compare — compiled to ANDs that all read element 0 of the accumulator vector; caught
+                    // by the parity tests, kept as a select)
+                    g = ((mk[t] >> q) & 1u) ? acc[t][q] : 0.f;
                 } else {
                     g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
                 }
