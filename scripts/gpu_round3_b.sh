@@ -1,7 +1,8 @@
 set -x
+export SHAPEGAN_REFERENCE_DIR=$PWD/.refscratch
 mkdir -p gpurun_out/r03
-timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > gpurun_out/r03/pytest_b.log
-tail -5 gpurun_out/r03/pytest_b.log
+timeout 1200 python -m pytest tests -m gpu -q --tb=line 2>&1 | tail -30 > gpurun_out/r03/pytest_b.log
+tail -8 gpurun_out/r03/pytest_b.log
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r03/bench_b.json 2> gpurun_out/r03/bench_b.err
 tail -3 gpurun_out/r03/bench_b.err
 bash scripts/timeline_run.sh > gpurun_out/r03/timeline_b.log 2>&1

@@ -1,7 +1,6 @@
 mkdir -p gpurun_out/r03
-for v in 0 1 2 3; do
-  echo "=== variant $v" >> gpurun_out/r03/debug_var.log
-  if [ $v = 0 ]; then unset SHAPEGAN_HIP_LIB; else export SHAPEGAN_HIP_LIB=$PWD/scripts/_abl/lib_v$v.so; fi
-  timeout 300 python scripts/debug_sdf_mask.py 2>&1 | grep -v "H==0" | head -12 >> gpurun_out/r03/debug_var.log
-done
-cat gpurun_out/r03/debug_var.log
+L=gpurun_out/r03/c.log; rm -f $L
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_modules.py -q --tb=short -x -k "conv or discriminator or wgan or autoencoder or progressive" 2>&1 | tail -8 >> $L
+python scripts/edge_ab.py >> $L 2>&1
+SG_EDGE_DEBUG=1 python scripts/edge_ab.py >> $L 2>&1
+cat $L | grep -v amdgpu.ids

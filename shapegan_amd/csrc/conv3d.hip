@@ -732,11 +732,12 @@ int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int 
 // formed inside the weight-gradient kernel (one-channel layers, LeakyReLU / ReLU), so the activation backward is not a pass of
 // its own.  sg_conv3d_k4s2p1_wgrad_act_eligible says whether a shape is served (host code, no GPU needed).
 int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act) {
-    // the same refusal conditions as edge_wgrad_try: 32-bit buffer ranges of the padded grid and of dy / y
-    const size_t padded = (size_t)batch * (2 * OD + 2) * (2 * OH + 2) * (2 * OW + 2) * 4;
+    // the same refusal conditions as edge_wgrad_try: 32-bit buffer ranges of the one-channel grid (read in place; the
+    // resource starts (IH + 1) rows + 1 element before it) and of dy / y
+    const size_t x_bytes = ((size_t)batch * 8 * OD * OH * OW + (size_t)(2 * OH + 1) * 2 * OW + 4) * 4;
     const size_t dy_bytes = (size_t)batch * Cout * OD * OH * OW * 4;
     return Cin == 1 && Cout <= 64 && OW % 16 == 0 && (long)batch * OD * OH * OW >= 65536 && (act == SG_ACT_LEAKY || act == SG_ACT_RELU) &&
-           padded < (size_t)kBufRange && dy_bytes < (size_t)kBufRange && edge_enabled(4);
+           x_bytes < (size_t)kBufRange && dy_bytes < (size_t)kBufRange && edge_enabled(4);
 }
 int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,

@@ -7,17 +7,17 @@
 // These layers move 64x more activation bytes than grid bytes and are HBM-bound (28 flop/B): SURVEY.md 8d asks for HBM GB/s
 // here.  Each output/operand is touched once; the small 1-channel grid is re-read from L1/L2.
 //
-//   forward  (conv_fwd_c1_kernel)    GEMM rows = positions, cols = Cout (<= 64), K = 64 taps.  The grid is zero-padded once into the
-//            workspace (one small pass), so a lane's patch values are plain 8-byte loads at lane_base + (kd, kh) scalar offset:
-//            no masks, no LDS, no VALU in the loop.  The 64 x 64 weight matrix lives in registers as MFMA B fragments for the
-//            whole kernel; a wave walks position tiles of 32, the patch loads of the next tile are issued before the MFMAs of
-//            the current one.  K is ordered (kd, kh, kw-pair) so that lane half h owns taps kw = 2h, 2h+1 (one b64 load).
-//            Positions are the ROWS of the product so that 4 accumulator registers are 4 consecutive positions of one channel:
-//            16-byte stores (row-per-lane dword stores were store-issue bound).
+//   forward  (conv_fwd_c1_kernel)    GEMM rows = positions, cols = Cout (<= 64), K = 64 taps.  The grid is read IN PLACE: a lane's tap
+//            values are dword buffer loads at lane offset + (kd, kh) scalar offset, and a tap that falls into the zero padding
+//            carries an out-of-range offset (the hardware returns 0): no padded copy, no masks, no LDS, no VALU on the operands.
+//            The 64 x 64 weight matrix lives in registers as MFMA B fragments for the whole kernel (filled through LDS); a wave
+//            walks a contiguous run of position tiles of 32, the patch loads of the next tile are issued before the MFMAs of
+//            the current one.  Positions are the ROWS of the product so that 4 accumulator registers are 4 consecutive
+//            positions of one channel: 16-byte stores (row-per-lane dword stores were store-issue bound).
 //   wgrad    (conv_wgrad_c1_kernel)  GEMM M = Cout, N = 64 taps, K = positions (split over all waves, deterministic two-level
 //            reduction).  The dy tile of a pass ([Cout][32 positions]) is copied with fully coalesced 16-byte loads, transposed
-//            through a wave-private LDS tile and read back as fragments; the patch operand comes from the same padded grid
-//            (lane = tap, stride-2 gather served by L1).
+//            through a wave-private LDS tile and read back as fragments; the patch operand comes from x in place (lane = tap,
+//            stride-2 gather served by L1, padding by out-of-range offsets).
 //   dgrad    (tapplane_gemm_kernel + col2im_c1_kernel)  out[2q+p] = sum_co sum_t dy[co][q+d] w[co][k]: first the 64 tap planes
 //            S[k][q] = sum_co w[co][k] dy[co][q] (a dense GEMM rows = positions, cols = 64 taps, K = Cout; a 1-row GEMM per
 //            parity would waste 31/32 of every MFMA), then each output gathers its 8 taps from the planes (every plane element
@@ -29,36 +29,14 @@
 
 namespace sg {
 
-// ---- zero-padded copy of channel 0: xp[n][d+1][h+1][w+1] = x[n][0][d][h][w] ------------------------------------------------------
-// one workgroup per padded (sample, d) plane: 32-bit index math, rows written contiguously
-__global__ void __launch_bounds__(256) pad1_kernel(const float* __restrict__ x, float* __restrict__ xp, int D, int H, int W,
-                                                   long sample_stride) {
-    const int Wp = W + 2, Hp = H + 2, Dp = D + 2;
-    const int n = blockIdx.x / Dp, d = blockIdx.x - n * Dp;
-    float* dst = xp + (long)blockIdx.x * Hp * Wp;
-    const bool din = d >= 1 && d <= D;
-    const float* src = x + (long)n * sample_stride + (long)(d - 1) * H * W;
-    const int plane = Hp * Wp;
-    for (int e = threadIdx.x; e < plane; e += 256) {
-        const int h = e / Wp, w = e - h * Wp;
-        const bool in = din && w >= 1 && w <= W && h >= 1 && h <= H;
-        dst[e] = in ? src[(h - 1) * W + (w - 1)] : 0.f;
-    }
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
-}
-
 // ---- forward ---------------------------------------------------------------------------------------------------------
 struct EdgeFwdArgs {
-    const float* xp;    // [batch][Dp][Hp][Wp]
+    const float* x;     // [batch][Cx][ID][IH][IW], channel 0 is read — straight from the tensor, no padded copy
     const float* w;     // [Cout][Cin_total][64], channel 0 used
     const float* bias;  // [Cout] or null
     float* y;           // [batch][Cy][O3]
-    int OD, OH, OW, Hp, Wp, Cout, Cy, Cin_total;
-    long xp_sample;     // floats per padded sample
+    int OD, OH, OW, IH, IW, Cout, Cy, Cin_total;
+    long x_sample;      // floats between samples of x (Cx * I3)
     int tiles_per_sample, total_tiles;
     FastDiv dtps, dOW, dOH;
     int act;
@@ -86,58 +64,150 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // D[row = position][col = channel]: the patch values are the A operand, the weights the B operand, so that a lane ends up
 // with 4 consecutive positions of ONE channel per 4 accumulator registers -> 16-byte stores (4x fewer store instructions than
 // channel-major rows, which were store-issue bound).
+//
+// Round 3 (measured on the MI355X: 67 -> see DESIGN.md 3.2):
+//  * no padded copy of the grid.  K is ordered (kd, kh, kw') with lane half 0 owning the taps kw = 1, 2 (w = 2 ow, 2 ow + 1: always
+//    inside the row) and lane half 1 the taps kw = 3, 0 (w = 2 ow + 2, 2 ow - 1: outside the row at the right / left border).  Every
+//    tap value is one dword buffer load at lane offset + (kd, kh) scalar offset; a lane whose tap falls into the zero padding
+//    (left / right by its own ow, top / bottom / front / back by its (od, oh) and the (kd, kh) of the load) carries an
+//    out-of-range offset instead and the hardware returns 0 — exact padding semantics, no masks on the values, no stray reads
+//    outside the tensor, and the 14 us pad pass per call is gone;
+//  * the 64 x 64 weight tile reaches the B fragments through LDS (one coalesced copy per workgroup, conflict-free fragment
+//    reads) instead of 64 uncoalesced dword loads per lane (32 cache lines per instruction: ~8 us per CU before the first MFMA);
+//  * every wave walks a contiguous run of tiles (consecutive 128-byte lines of each channel row, the patch rows of the next
+//    tile already in L1);
+//  * bias + LeakyReLU as max(t, slope t) on 2-wide packed adds / multiplies.
 template <int NT, int ACT>   // NT: column tiles of 32 output channels (1 or 2); ACT: 0 none, 1 LeakyReLU, 2 any (sg_apply_act)
 __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
+    constexpr int kWL = 65;   // LDS row stride of the weight tile: lane = channel row -> 32 distinct banks per fragment read
+    constexpr int kTL = 36;   // LDS row stride of the output staging tile [channel][32 positions + 4]: 16-byte aligned rows
+    __shared__ float wl[NT * 32 * kWL];
+    __shared__ __attribute__((aligned(16))) float tl[4][NT * 32 * kTL];   // one staging tile per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh2 = lane >> 5;
-    // B fragments: wfr[nt][kd*4+kh][j] = W[32 nt + r][0][kd][kh][2*kh2 + j]
+    {
+        // all loads of the copy are issued before the first LDS write (a load / wait / write loop serialises NT * 8 memory
+        // latencies: measured 10+ us of every launch); rows beyond Cout become zero columns
+        const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.w);
+        f32x4 wv[NT * 2];
+#pragma unroll
+        for (int i = 0; i < NT * 2; ++i) {
+            const int e4 = threadIdx.x + 256 * i, co = e4 >> 4, t4 = e4 & 15;     // 16 float4 per weight row
+            wv[i] = buf_load4v(wres, co < a.Cout ? (unsigned)(((long)co * a.Cin_total * 64 + t4 * 4) * 4) : kBufOutside, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 2; ++i) {
+            const int e4 = threadIdx.x + 256 * i, co = e4 >> 4, t4 = e4 & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wl[co * kWL + t4 * 4 + j] = wv[i][j];
+        }
+    }
+    __syncthreads();
+    // B fragments: wfr[nt][kd*4+kh][j] = W[32 nt + r][kd][kh][kw], kw = 1, 2 (lane half 0) / 3, 0 (lane half 1) for j = 0, 1
     float wfr[NT][16][2], bl[NT];
+    const int kw0 = kh2 ? 3 : 1, kw1 = kh2 ? 0 : 2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 32 + r, coc = co < a.Cout ? co : a.Cout - 1;   // clamped row, masked by a multiply: no branches
-        const float keep = co < a.Cout ? 1.f : 0.f;
-        bl[nt] = a.bias ? keep * a.bias[coc] : 0.f;
+        const int co = nt * 32 + r;
+        bl[nt] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) wfr[nt][g][j] = keep * a.w[(long)coc * a.Cin_total * 64 + g * 4 + 2 * kh2 + j];
+        for (int g = 0; g < 16; ++g) {
+            wfr[nt][g][0] = wl[co * kWL + g * 4 + kw0];
+            wfr[nt][g][1] = wl[co * kWL + g * 4 + kw1];
+        }
     }
-    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.xp);
+    // x is addressed from (IH + 1) rows before its start, so that the (kd, kh) = (0, 0) scalar offset is 0 and lane offsets are
+    // non-negative; nothing below x is ever dereferenced (those lanes carry the out-of-range offset)
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x - ((long)a.IH * a.IW + a.IW));
     const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.y);
     const unsigned O3 = (unsigned)(a.OD * a.OH * a.OW);
     unsigned soff[16];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) soff[g] = (unsigned)(((g >> 2) * a.Hp + (g & 3)) * a.Wp) * 4u;
+    for (int g = 0; g < 16; ++g) soff[g] = (unsigned)(((g >> 2) * a.IH + (g & 3)) * a.IW) * 4u;
 
+    // every wave takes a contiguous run of tiles
     const int nwaves = gridDim.x * 4;
-    int t = blockIdx.x * 4 + wave;
-    // xoff: this lane's patch origin (position tile*32 + r); yoff[nt]: this lane's channel row at the tile's first position
-    auto lane_offsets = [&](int tile, unsigned& xoff, unsigned (&yoff)[NT]) __attribute__((always_inline)) {
+    const int per_wave = (a.total_tiles + nwaves - 1) / nwaves;
+    int t = (blockIdx.x * 4 + wave) * per_wave;
+    const int t_end = min(a.total_tiles, t + per_wave);
+    if (t >= t_end) return;
+
+    // per tile and lane: o0 / o1 = offsets of the lane's two taps in the (kd, kh) = (0, 0) row (or out of range at the left /
+    // right border), edge[4] = the lane's position touches the front / back / top / bottom face, yoff = its output rows
+    struct TileLane {
+        unsigned o0, o1;
+        bool d0, d3, h0, h3;
+    };
+    auto lane_offsets = [&](int tile, TileLane& L, unsigned (&yoff)[1]) __attribute__((always_inline)) {
         uint32_t n, tp, q1, ow, oh, od;
         a.dtps.divmod((uint32_t)tile, n, tp);
         const uint32_t p = tp * 32 + r;
         a.dOW.divmod(p, q1, ow);
         a.dOH.divmod(q1, od, oh);
-        xoff = (unsigned)((long)n * a.xp_sample + ((long)(2 * od) * a.Hp + 2 * oh) * a.Wp + 2 * ow + 2 * kh2) * 4u;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            yoff[nt] = nt * 32 + r < a.Cout ? (unsigned)(((long)n * a.Cy + nt * 32 + r) * O3 + tp * 32 + 4 * kh2) * 4u : kBufOutside;
+        const unsigned base = (unsigned)((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * oh) * a.IW + 2 * ow) * 4u;   // w = 2 ow
+        const bool left = ow == 0, right = (int)ow == a.OW - 1;
+        L.o0 = kh2 ? (right ? kBufOutside : base + 8u) : base;          // kw 3: w = 2 ow + 2   | kw 1: w = 2 ow
+        L.o1 = kh2 ? (left ? kBufOutside : base - 4u) : base + 4u;      // kw 0: w = 2 ow - 1   | kw 2: w = 2 ow + 1
+        L.d0 = od == 0;
+        L.d3 = (int)od == a.OD - 1;
+        L.h0 = oh == 0;
+        L.h3 = (int)oh == a.OH - 1;
+        // output: this lane stores 16 bytes of channel row (lane >> 3) + 8 i at positions 4 (lane & 7) .. + 3 of the tile
+        yoff[0] = (unsigned)(((long)n * a.Cy + (lane >> 3)) * O3 + tp * 32 + 4 * (lane & 7)) * 4u;
     };
-    if (t >= a.total_tiles) return;
-    unsigned xoff, yoff[NT];
-    lane_offsets(t, xoff, yoff);
-    f32x2 bcur[16], bnext[16];
+    auto load_patch = [&](const TileLane& L, float (&b0)[16], float (&b1)[16]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) bcur[g] = buf_load2(xres, xoff, soff[g]);
-    for (; t < a.total_tiles; t += nwaves) {
-        const int tn = t + nwaves;
-        unsigned xoff_n = xoff, yoff_n[NT];
+        for (int g = 0; g < 16; ++g) {
+            const int kd = g >> 2, kh = g & 3;
+            bool out = false;   // (compile-time structure: the interior (kd, kh) need no test at all)
+            if (kd == 0) out = out || L.d0;
+            if (kd == 3) out = out || L.d3;
+            if (kh == 0) out = out || L.h0;
+            if (kh == 3) out = out || L.h3;
+            b0[g] = buf_load(xres, out ? kBufOutside : L.o0, soff[g]);
+            b1[g] = buf_load(xres, out ? kBufOutside : L.o1, soff[g]);
+        }
+    };
+    TileLane L;
+    unsigned yoff[1];
+    lane_offsets(t, L, yoff);
+    float* const tw = tl[wave];
+    float c0[16], c1[16], n0[16], n1[16];
+    load_patch(L, c0, c1);
+
+    // Software pipeline: the epilogue of tile t-1 (bias + activation, the trip through the LDS staging tile, the stores) is cut
+    // into 16 slices that are issued BETWEEN the 16 MFMA groups of tile t — a 32x32x2 MFMA occupies the matrix pipe for 64
+    // cycles during which the wave is free to issue its VALU / LDS / VMEM work, so the pipe no longer idles through an
+    // epilogue (two waves per SIMD with identical phase structure run in lockstep and do not hide each other's epilogues:
+    // the matrix pipe was 39 % busy by the counters).  pv holds the finished accumulators of the previous tile.
+    // Output path: registers 4c .. 4c+3 of D are 4 consecutive positions of channel r; written as they are, a store instruction
+    // would put 32 bytes into each of 32 channel rows — partial cache lines, which the HBM write path handles worst (1.8 TB/s
+    // once the output outgrows the Infinity Cache).  The tile goes through a wave-private LDS tile [channel][32 positions] (16-byte
+    // writes and reads, conflict-free with the 36-float row stride) and leaves as whole 128-byte lines: 8 lanes per channel
+    // row, 8 rows per store instruction.
+    float pv[NT][16];
+    unsigned yprev = kBufOutside;
+    auto epilogue_slice = [&](int sl) __attribute__((always_inline)) {
+        if (sl < NT * 4) {            // slices 0 .. 4 NT - 1: one (column tile, 4-position group) each -> LDS
+            const int nt = sl >> 2, c = sl & 3;
+            f32x4 v = {pv[nt][4 * c], pv[nt][4 * c + 1], pv[nt][4 * c + 2], pv[nt][4 * c + 3]};
+            v = v + bl[nt];
+            if (ACT == 1) {
+                const f32x4 sv = v * a.slope;           // LeakyReLU with 0 <= slope <= 1: max(t, slope t)
+                v = __builtin_elementwise_max(v, sv);
+            } else if (ACT == 2) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) yoff_n[nt] = yoff[nt];
-        if (tn < a.total_tiles) lane_offsets(tn, xoff_n, yoff_n);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) bnext[g] = buf_load2(xres, xoff_n, soff[g]);   // the last tile re-reads itself (unused)
-        __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 4; ++i) v[i] = sg_apply_act(v[i], a.act, a.slope);
+            }
+            *reinterpret_cast<f32x4*>(tw + (nt * 32 + r) * kTL + 8 * c + 4 * kh2) = v;
+        } else if (sl >= 8 && sl < 8 + NT * 4) {   // slices 8 ..: 8 channel rows each -> memory
+            const int i = sl - 8;
+            const int row = 8 * i + (lane >> 3);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * kTL + 4 * (lane & 7));
+            buf_store4(yres, row < a.Cout ? yprev : kBufOutside, (unsigned)(8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto tile_mfma = [&](auto with_epilogue) __attribute__((always_inline)) {
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -146,30 +216,54 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[g].x, wfr[nt][g][0], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[g], wfr[nt][g][0], acc[nt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[g].y, wfr[nt][g][1], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[g], wfr[nt][g][1], acc[nt], 0, 0, 0);
+            if (decltype(with_epilogue)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue_slice(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // rows of D = positions (q & 3) + 8 (q >> 2) + 4 kh2: registers 4c .. 4c+3 are 4 consecutive positions.  The
-        // activation is a template parameter: one straight-line epilogue per kernel.
-        auto fn = [&](float v) __attribute__((always_inline)) {
-            if (ACT == 0) return v;
-            if (ACT == 1) return fmaxf(v, 0.f) + a.slope * fminf(v, 0.f);
-            return sg_apply_act(v, a.act, a.slope);
-        };
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                buf_store4(yres, yoff[nt], 32u * c, fn(acc[nt][4 * c] + bl[nt]), fn(acc[nt][4 * c + 1] + bl[nt]),
-                           fn(acc[nt][4 * c + 2] + bl[nt]), fn(acc[nt][4 * c + 3] + bl[nt]));
+            for (int q = 0; q < 16; ++q) pv[nt][q] = acc[nt][q];
+    };
+    auto advance = [&](int tcur) __attribute__((always_inline)) {   // issue the patch loads of tile tcur + 1 (or re-read tcur: unused)
+        TileLane Ln = L;
+        unsigned yn[1] = {yoff[0]};
+        if (tcur + 1 < t_end) lane_offsets(tcur + 1, Ln, yn);
+        load_patch(Ln, n0, n1);
+        yprev = yoff[0];       // where tile tcur's output goes (its epilogue runs during tile tcur + 1)
+        L = Ln;
+        yoff[0] = yn[0];
+    };
+    auto rotate = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) bcur[g] = bnext[g];
-        xoff = xoff_n;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) yoff[nt] = yoff_n[nt];
+        for (int g = 0; g < 16; ++g) {
+            c0[g] = n0[g];
+            c1[g] = n1[g];
+        }
+    };
+    // first tile: nothing to drain yet
+    advance(t);
+    __builtin_amdgcn_sched_barrier(0);
+    tile_mfma(IntTag<0>());
+    rotate();
+    for (++t; t < t_end; ++t) {
+        const unsigned ydone = yprev;     // output offsets of tile t - 1, whose epilogue runs inside this tile's MFMA groups
+        advance(t);
+        const unsigned ynext = yprev;
+        yprev = ydone;
+        __builtin_amdgcn_sched_barrier(0);
+        tile_mfma(IntTag<1>());
+        yprev = ynext;
+        rotate();
     }
+    // drain: the epilogue of the last tile
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) epilogue_slice(sl);
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
@@ -178,10 +272,10 @@ struct EdgeWgradArgs {
     const float* dy;    // [batch][Cy][O3]
     const float* y;     // FUSE: the layer's activated output, same layout as dy: dz = dy * act'(y) is formed on the fly
     float slope;
-    const float* xp;    // padded grid
+    const float* x;     // [batch][Cx][ID][IH][IW], channel 0 is read in place (no padded copy)
     float* partial;     // [gridDim.x][kEdgePartial]: 64 x 64 weight-gradient tile (+ 64 bias-gradient sums with FUSE)
-    int OD, OH, OW, Hp, Wp, Cout, Cy;
-    long xp_sample;
+    int OD, OH, OW, IH, IW, Cout, Cy;
+    long x_sample;      // floats between samples of x (Cx * I3)
     int passes_per_sample, total_passes;   // a pass = 32 consecutive positions of one sample
     FastDiv dpps, dOW16, dOH;               // dOW16: OW / 16 row segments per row
 };
@@ -203,7 +297,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
     const int r = lane & 31, kh2 = lane >> 5;
     const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy);
     const __amdgpu_buffer_rsrc_t yres = make_rsrc(FUSE ? a.y : a.dy);
-    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.xp);
+    // the patch operand comes straight from x: the resource starts (IH + 1) rows + 1 element before it, so that tap (0, 0, 0) is
+    // offset 0; a lane (= tap) whose row falls into the zero padding for this pass's (od, oh), or whose column does at the
+    // first / last position of a row, carries the out-of-range offset and receives 0 (nothing outside x is dereferenced)
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x - ((long)a.IH * a.IW + a.IW + 1));
     const unsigned O3 = (unsigned)(a.OD * a.OH * a.OW);
     float* stage = lds + wave * kStage;
     __shared__ float bsh[4][64];   // FUSE: per-wave channel sums
@@ -213,8 +310,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int tap = nt * 32 + r, kd = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
-        tapoff[nt] = (unsigned)((kd * a.Hp + kh) * a.Wp + kw) * 4u;
+        tapoff[nt] = (unsigned)((kd * a.IH + kh) * a.IW + kw) * 4u;
     }
+    // this lane's taps: nt 0 -> kd in {0, 1}, nt 1 -> kd in {2, 3}; (kh, kw) are the same for both
+    const int lkh = (r >> 2) & 3, lkw = r & 3, lkd0 = r >> 4;
+    const int nseg = a.OW >> 4;
     f32x16 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -243,11 +343,21 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
         const uint32_t p0 = pp * 32 + 16 * kh2;   // this lane half's 16 positions: one row segment (od, oh, ow0 .. ow0+15)
         a.dOW16.divmod(p0 >> 4, q1, seg);
         a.dOH.divmod(q1, od, oh);
-        const unsigned xbase = (unsigned)((long)n * a.xp_sample + ((long)(2 * od) * a.Hp + 2 * oh) * a.Wp + 32 * seg) * 4u;
+        const unsigned xbase = (unsigned)((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * oh) * a.IW + 32 * seg) * 4u;
+        const bool hout = (lkh == 0 && oh == 0) || (lkh == 3 && (int)oh == a.OH - 1);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int kd = 2 * nt + lkd0;
+            const bool out = hout || (kd == 0 && od == 0) || (kd == 3 && (int)od == a.OD - 1);
+            const unsigned off = out ? kBufOutside : xbase + tapoff[nt];
+            // w = 2 (16 seg + j) + kw - 1: left of the row for (kw 0, first position), right of it for (kw 3, last position)
+            const unsigned offl = (lkw == 0 && seg == 0) ? kBufOutside : off;
+            const unsigned offr = (lkw == 3 && (int)seg == nseg - 1) ? kBufOutside : off;
+            bv[nt][0] = buf_load(xres, offl, 0u);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) bv[nt][j] = buf_load(xres, xbase + tapoff[nt], 8u * j);
+            for (int j = 1; j < 15; ++j) bv[nt][j] = buf_load(xres, off, 8u * j);
+            bv[nt][15] = buf_load(xres, offr, 8u * 15);
+        }
     };
     int ps = blockIdx.x * 4 + wave;
     if (ps < a.total_passes) issue(ps);
@@ -610,46 +720,39 @@ __global__ void __launch_bounds__(512, (ALLCH ? 4 : 2)) convT_c1_fused_kernel(Co
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-static size_t padded_floats(int batch, const ConvGeom& g) { return (size_t)batch * (g.ID + 2) * (g.IH + 2) * (g.IW + 2); }
-
-size_t edge_fwd_workspace_bytes(int batch, int OD, int OH, int OW) {
-    return (size_t)batch * (2 * OD + 2) * (2 * OH + 2) * (2 * OW + 2) * sizeof(float);
-}
-size_t edge_wgrad_workspace_bytes(int batch, int OD, int OH, int OW) {
-    return edge_fwd_workspace_bytes(batch, OD, OH, OW) + (size_t)512 * kEdgePartial * sizeof(float);
-}
+size_t edge_fwd_workspace_bytes(int, int, int, int) { return 0; }   // the forward reads the grid in place
+size_t edge_wgrad_workspace_bytes(int, int, int, int) { return (size_t)512 * kEdgePartial * sizeof(float); }   // partial tiles
 size_t edge_dgrad_workspace_bytes(int batch, int OD, int OH, int OW) { return (size_t)batch * 64 * OD * OH * OW * sizeof(float); }
 
-static void launch_pad(const float* x, float* xp, int batch, const ConvGeom& g, hipStream_t stream) {
-    hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)(batch * (g.ID + 2))), dim3(256), 0, stream, x, xp, g.ID, g.IH, g.IW,
-                       (long)g.Cx * g.I3());
-}
-
-// Conv3d(1 -> Cout <= 64) forward.  Returns 1 if handled, 0 if not eligible.
+// Conv3d(1 -> Cout <= 64) forward.  Returns 1 if handled, 0 if not eligible.  Needs no workspace (the grid is read in place).
 int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                  const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                  hipStream_t stream, int force) {
+    (void)workspace;
+    (void)workspace_bytes;
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64 || O3 % 32 != 0) return 0;
     if (!force && (long)batch * O3 < 65536) return 0;   // small problems: the generic kernel's launch is as good
-    if (!workspace || workspace_bytes < edge_fwd_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
-    if (padded_floats(batch, g) * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
-    float* xp = (float*)workspace;
-    launch_pad(x, xp, batch, g, stream);
+    // 32-bit buffer offsets: x (plus the (IH + 1) rows the resource starts before it) and y inside the 2 GiB window
+    if (((size_t)batch * g.Cx * g.I3() + (size_t)(g.IH + 1) * g.IW + 4) * 4 >= (size_t)kBufRange ||
+        (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange)
+        return 0;
+    // LeakyReLU runs as max(t, slope t): only for slopes in [0, 1]; anything else takes the generic epilogue
+    const int actk = act == SG_ACT_NONE ? 0 : ((act == SG_ACT_LEAKY && slope >= 0.f && slope <= 1.f) ? 1 : 2);
     EdgeFwdArgs a;
-    a.xp = xp;
+    a.x = x;
     a.w = w;
     a.bias = bias;
     a.y = y;
     a.OD = g.OD;
     a.OH = g.OH;
     a.OW = g.OW;
-    a.Hp = g.IH + 2;
-    a.Wp = g.IW + 2;
+    a.IH = g.IH;
+    a.IW = g.IW;
     a.Cout = Cout;
     a.Cy = g.Cy;
     a.Cin_total = Cin_total;
-    a.xp_sample = (long)(g.ID + 2) * (g.IH + 2) * (g.IW + 2);
+    a.x_sample = (long)g.Cx * g.I3();
     a.tiles_per_sample = (int)(O3 / 32);
     a.total_tiles = batch * a.tiles_per_sample;
     a.dtps = FastDiv((uint32_t)a.tiles_per_sample);
@@ -665,8 +768,8 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         if (d & 1) wgs = wgs > 256 ? 256 : wgs;
         if (d & 2) (void)hipStreamSynchronize(stream);
         if (d & 4) wgs = wgs > 128 ? 128 : wgs;
+        if ((d & 8) && (a.total_tiles + 3) / 4 >= 768) wgs = 768;
     }
-    const int actk = act == SG_ACT_NONE ? 0 : (act == SG_ACT_LEAKY ? 1 : 2);
 #define SG_FWD_C1(NT_, ACT_) hipLaunchKernelGGL((conv_fwd_c1_kernel<NT_, ACT_>), dim3(wgs), dim3(256), 0, stream, a)
     if (Cout > 32) {
         if (actk == 0) SG_FWD_C1(2, 0); else if (actk == 1) SG_FWD_C1(2, 1); else SG_FWD_C1(2, 2);
@@ -687,24 +790,24 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     if (y && ((act != SG_ACT_LEAKY && act != SG_ACT_RELU) || !db)) return 0;
     if (!force && (long)batch * O3 < 65536) return 0;
     if (!workspace || workspace_bytes < edge_wgrad_workspace_bytes(batch, g.OD, g.OH, g.OW)) return 0;
-    if (padded_floats(batch, g) * 4 >= (size_t)kBufRange || (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
-    float* xp = (float*)workspace;
-    float* partial = xp + padded_floats(batch, g);
-    launch_pad(x, xp, batch, g, stream);
+    if (((size_t)batch * g.Cx * g.I3() + (size_t)(g.IH + 1) * g.IW + 4) * 4 >= (size_t)kBufRange ||
+        (size_t)batch * g.Cy * O3 * 4 >= (size_t)kBufRange)
+        return 0;
+    float* partial = (float*)workspace;
     EdgeWgradArgs a;
     a.dy = dy;
     a.y = y;
     a.slope = slope;
-    a.xp = xp;
+    a.x = x;
     a.partial = partial;
     a.OD = g.OD;
     a.OH = g.OH;
     a.OW = g.OW;
-    a.Hp = g.IH + 2;
-    a.Wp = g.IW + 2;
+    a.IH = g.IH;
+    a.IW = g.IW;
     a.Cout = Cout;
     a.Cy = g.Cy;
-    a.xp_sample = (long)(g.ID + 2) * (g.IH + 2) * (g.IW + 2);
+    a.x_sample = (long)g.Cx * g.I3();
     a.passes_per_sample = (int)(O3 / 32);
     a.total_passes = batch * a.passes_per_sample;
     a.dpps = FastDiv((uint32_t)a.passes_per_sample);
@@ -712,6 +815,10 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     a.dOH = FastDiv((uint32_t)g.OH);
     int wgs = (a.total_passes + 3) / 4;
     if (wgs > 512) wgs = 512;
+    {
+        const char* dbg = getenv("SG_EDGE_DEBUG");   // tuning: bit 16 -> at most 256 workgroups (half the partial tiles)
+        if (dbg && (atoi(dbg) & 16) && wgs > 256) wgs = 256;
+    }
     const int fuse = y ? act : 0;
 #define SG_LAUNCH_WGRAD_C1(MT, F) hipLaunchKernelGGL((conv_wgrad_c1_kernel<MT, F>), dim3(wgs), dim3(256), 0, stream, a)
     if (Cout > 32) {

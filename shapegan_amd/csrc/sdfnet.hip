@@ -263,7 +263,7 @@ struct SdfFwdArgs {
     long nbig;         // workgroups [0, nbig): full tiles; the rest: kSmallTile points each
 };
 
-template <int P, bool SHAPE_BIAS>
+template <int P, bool SHAPE_BIAS, bool TRAIN>   // TRAIN: `acts` is given (H images + sign masks are written)
 __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long p0) {
     constexpr int NT = P / 32;
     constexpr int LDX = P + 1;
@@ -351,6 +351,8 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         mstore[t] = p0 + t * 32 + r < a.N ? (unsigned)(((long)kh * a.ldn + t * 32 + r) * 2) : kBufOutside;
+    // (`save` stays a run-time condition even in the TRAIN instantiation: as a compile-time constant the stores lose their place
+    // in the schedule, the write-back's live ranges grow and the kernel no longer fits the 128 VGPRs of two workgroups per CU)
     auto writeback = [&](int layer) {  // H <- relu(acc); optionally save
         __syncthreads();
         const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.acts + ((long)layer * kH + wrow) * a.ldn + p0);
@@ -365,17 +367,27 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
             for (int t = 0; t < NT; ++t) {
                 const float v = fmaxf(acc[t][q], 0.f);
                 Hs[row * P + t * 32 + r] = v;
-                mk[t] |= v > 0.f ? (1u << q) : 0u;
                 if (save)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ares, (int)astore[t],
                                                           (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
             }
         }
-        if (save) {
-            const __amdgpu_buffer_rsrc_t mres =
-                make_rsrc(sdf_mask_base(a.acts, a.ldn) + ((long)layer * 16 + (wrow >> 4)) * a.ldn + p0);
+        if constexpr (TRAIN) {
+            if (save) {
+                // sign word: mk = 2 mk + (acc > 0), rows 15 .. 0, so that bit q ends up belonging to row q — compare into vcc and
+                // add-with-carry, two VALU instructions per element (the C form `mk |= v > 0 ? 1 << q : 0` took three and kept
+                // 16 more values live).  The accumulators were all read by the loop above: no MFMA result hazard is left.
 #pragma unroll
-            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mk[t], mres, (int)mstore[t], 0, 0);
+                for (int q = 15; q >= 0; --q)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk[t]) : "v"(acc[t][q]) : "vcc");
+                const __amdgpu_buffer_rsrc_t mres =
+                    make_rsrc(sdf_mask_base(a.acts, a.ldn) + ((long)layer * 16 + (wrow >> 4)) * a.ldn + p0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mk[t], mres, (int)mstore[t], 0, 0);
+            }
         }
         __syncthreads();
     };
@@ -456,13 +468,15 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 // last layer's dot product in fixed 16-row groups), so the plan never changes a result of the forward.
 constexpr int kSmallTile = 32;
 
-template <int P, bool SHAPE_BIAS>
-__global__ void __launch_bounds__(512) sdfnet_fwd_kernel(SdfFwdArgs a) {
+// (512 threads, 4 waves per SIMD = two workgroups per CU: the register budget is 128 VGPRs, stated explicitly — the kernel sat
+// just below it by luck before, and one more live value silently halves the occupancy)
+template <int P, bool SHAPE_BIAS, bool TRAIN>
+__global__ void __launch_bounds__(512, 4) sdfnet_fwd_kernel(SdfFwdArgs a) {
     const long b = blockIdx.x;
     if (b < a.nbig)
-        sdfnet_fwd_tile<P, SHAPE_BIAS>(a, b * P);
+        sdfnet_fwd_tile<P, SHAPE_BIAS, TRAIN>(a, b * P);
     else
-        sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+        sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS, TRAIN>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
 }
 
 struct SdfBwdArgs {
@@ -967,18 +981,30 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
         // the other's MFMA phases (measured against 128-point tiles, one workgroup per CU: 8 x 32^3 inference 1.687 -> 1.654 ms,
         // 16 x 64^3 26.0 -> 25.0 ms, the training forward at 200 000 points 1.31 -> 1.24 ms)
         const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
-        if (set_lds(sdfnet_fwd_kernel<64, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
         const TilePlan tp = tile_plan(N, 64, 2 * kFwdSlots);
         a.nbig = tp.nbig;
-        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
+        const dim3 grid((unsigned)(tp.nbig + tp.nsmall));
+        if (acts) {
+            if (set_lds(sdfnet_fwd_kernel<64, true, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+            hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true, true>), grid, dim3(512), lds, stream, a);
+        } else {
+            if (set_lds(sdfnet_fwd_kernel<64, true, false>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+            hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true, false>), grid, dim3(512), lds, stream, a);
+        }
     } else {
         SG_CHECK_ARG(latent && kin_used == 3 + latent_size);
         const size_t lds = fwd_lds_bytes(64, a.lay.KUp);
         if (lds > 160 * 1024) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_fwd: latent size %d needs %zu B LDS (> 160 KiB)", latent_size, lds);
-        if (set_lds(sdfnet_fwd_kernel<64, false>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
         const TilePlan tp = tile_plan(N, 64, kFwdSlots);
         a.nbig = tp.nbig;
-        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false>), dim3((unsigned)(tp.nbig + tp.nsmall)), dim3(512), lds, stream, a);
+        const dim3 grid((unsigned)(tp.nbig + tp.nsmall));
+        if (acts) {
+            if (set_lds(sdfnet_fwd_kernel<64, false, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+            hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false, true>), grid, dim3(512), lds, stream, a);
+        } else {
+            if (set_lds(sdfnet_fwd_kernel<64, false, false>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
+            hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false, false>), grid, dim3(512), lds, stream, a);
+        }
     }
     SG_CHECK_LAUNCH();
     return SG_OK;

@@ -300,25 +300,27 @@ def test_sdfnet_backward_tile_layout_is_the_documented_function_of_n():
         assert starts[-1] == n and all(b > a for a, b in zip(starts, starts[1:]))
 
 
-def test_wgrad_act_path_is_refused_when_its_scratch_exceeds_the_cap():
-    """the fused weight-gradient + activation-backward path needs the zero-padded grid in its workspace.
-    At batch 240 / 64^3 input the shape itself is served (eligible) but the scratch (~276 MB) is above the 256 MB the Python
-    side allocates: ConvFwd.backward must take the two-pass path instead of raising.  Host code only (size queries)."""
+def test_wgrad_act_path_is_refused_outside_its_limits(monkeypatch):
+    """ConvFwd.backward takes the fused weight-gradient + activation-backward kernel only when
+    sg_conv3d_k4s2p1_wgrad_act will really serve the call — the shape is eligible (incl. the 32-bit buffer ranges the kernel
+    itself checks) AND its scratch fits under the workspace cap — and the two-pass path otherwise, instead of raising.  (Since
+    round 3 the kernel reads the grid in place: the scratch is the 8.5 MB of partial tiles, whatever the batch.)  Host code only."""
     from shapegan_amd import ops
     lib = L.load()
-    assert lib.sg_conv3d_k4s2p1_wgrad_act_eligible(240, 1, 64, 32, 32, 32, L.ACT_LEAKY) == 1
-    assert lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(240, 1, 64, 32, 32, 32) > ops._WGRAD_WS_CAP
 
     def served(batch, r):
         x = torch.empty(batch, 1, r, r, r, device="meta")
         w = torch.empty(64, 1, 4, 4, 4, device="meta")
         y = torch.empty(batch, 64, r // 2, r // 2, r // 2, device="meta")
         return ops._wgrad_act_served(x, w, y, L.ACT_LEAKY)
-    assert served(128, 32) and served(16, 64)          # the BASELINE shapes stay on the fused path
-    assert not served(240, 64)                          # scratch above the cap
-    assert not served(256, 64)                          # 2 GiB of dy: outside the 32-bit buffer range
-    assert not served(2048, 32)                         # 64 x 16^3 x 2048 x 4 B = 2 GiB of dy: outside the 32-bit buffer range
+    assert served(128, 32) and served(16, 64) and served(240, 64)      # BASELINE shapes and the large batch ADVICE r2 named
+    assert lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(240, 1, 64, 32, 32, 32) <= 16 << 20
+    assert not served(256, 64)                          # 256 x 64 x 32^3 x 4 B = 2 GiB of dy: outside the 32-bit buffer range
+    assert not served(2048, 32)
     assert lib.sg_conv3d_k4s2p1_wgrad_act_eligible(2048, 1, 64, 16, 16, 16, L.ACT_LEAKY) == 0
+    assert not served(4, 32)                            # too small: the generic path is as good
+    monkeypatch.setattr(ops, "_WGRAD_WS_CAP", 1 << 20)  # a cap below the scratch: refused, not attempted
+    assert not served(128, 32)
 
 
 def test_call_device_state_is_thread_local_and_cleared_on_rejection():
