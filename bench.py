@@ -22,7 +22,11 @@ Rank 0 prints ONE JSON line (schema in the task contract).  At N=1 with the defa
                   step (MFMA-bound ones against the fp32 MFMA peak, Cin=1 / Cout=1 edge layers against HBM),
   `sdfnet`        the SDFNet half of the metric (fused forward, both auto-decoder training configs) with algorithmic AND
                   executed FLOP rates,
-  `cpu_baseline`  the CPU oracle's time for the same step on the host cores and the GPU-vs-oracle loss agreement.
+  `other_configs` BASELINE configs[2] / [3] / [4] on the same GPU (a few timed steps each: value, ms per step, the SDFNet share),
+  `cpu_baseline`  the same step on the host cores — the reference's own modules where the checkout exists (`kind: "reference"`),
+                  else the CPU restatement (`kind: "port"`, `reference_present: false`) — and the GPU-vs-oracle loss agreement.
+With N > 1 the line carries `comm`: what exchanged the gradients (`native-rccl`: the C-ABI exchange, ranks / RCCL version read
+back from the communicator; `torch-nccl`: torch.distributed, with the reason) and the all-reduced bytes per step.
 """
 import argparse
 import json
@@ -108,6 +112,10 @@ def conv_kernel_table():
         lambda: ops.conv_fwd_raw(x32, w1, b1, 1, 0.2))
     hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv1 wgrad", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
         lambda: ops.conv_wgrad_raw(y16, x32, 1))
+    ya = torch.randn(nb, 64, 16, 16, 16, device="cuda")
+    hbm("Conv3d 1->64 weight + bias gradient through LeakyReLU (the critic's first layer: reads dy and y), 128 samples",
+        "conv_wgrad_c1_kernel<2,LEAKY>", 4.0 * (x32.numel() + 2 * y16.numel() + w1.numel()), f1,
+        lambda: ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2))
     y16g = y16[:BATCH].contiguous()
     hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "dgrad_out1", 4.0 * (y16g.numel() + BATCH * 32768 + w1.numel()),
         f1 / 2, lambda: ops.conv_dgrad_raw(y16g, w1, None, 1))
@@ -118,11 +126,13 @@ def roofline_and_kernels():
     rows = conv_kernel_table()
     dom = rows[0]   # conv_dgrad_halo_kernel<0>: the largest share of the step's kernel time (profiles/r02_wgan_step_kernel_stats.csv)
     traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (cannot be read in-process)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_hbm.json")) as fh:
-            traffic = float(json.load(fh)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
+    for tag in ("r03", "r02"):     # the newest committed counter pass (scripts/profile_round.sh + collect_profiles.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_dominant_kernel_hbm.json")) as fh:
+                traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+            break
+        except (OSError, KeyError, ValueError):
+            pass
     roof = {"bound": "mfma", "kernel": dom["kernel"] + " (" + dom["name"] + "; the largest share of the step's kernel time)",
             "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
             "launch_ms": round(dom["us"] / 1e3, 4), "flop_per_launch": dom["flop"]}
@@ -362,7 +372,7 @@ def make_sdf(rank):
     return (lambda: tr.step(idx)), info, None
 
 
-def other_configs(steps=3, warmup=2):
+def other_configs(steps=4, warmup=3):
     """The remaining BASELINE workloads (configs[2], [3], [4]) on this GPU, a few timed steps each, so that they appear in the
     driver-run record next to the headline: `value` in the config's own unit, and the SDFNet share of the step (its generator
     evaluations / its fused training kernels at the FLOPs they EXECUTE, against the fp32 MFMA peak)."""
@@ -377,7 +387,7 @@ def other_configs(steps=3, warmup=2):
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        ms = (time.perf_counter() - t0) / steps * 1e3      # wall clock around synchronised steps, as the headline is timed
         pts = info["sdfnet_points"]
         _, exe = sdf_flops(pts["latent"])
         flop = (pts["forward"] + 2 * pts["backward"]) * exe       # forward everywhere, + input & weight gradients where it trains

@@ -1,8 +1,10 @@
 """Workloads for the rocprofv3 counter passes of a round (run one mode per pass; see scripts/profile_round.sh).
 
-    mfma : SDFNet fused forward / training steps (sdfnet_fwd, sdfnet_bwd, gemm_nt_bigk batched) and the three halo conv forms
-           at the critic's 128-sample pass -> SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE
-    hbm  : two WGAN 5+1 steps (covers the Cin=1 / Cout=1 edge kernels) + calibration streams of a known byte count
+    mfma : SDFNet fused forward / training steps (sdfnet_fwd, sdfnet_bwd, gemm_nt_bigk batched), the three halo conv forms and the
+           one-channel layers at the critic's 128-sample pass, one 5+1 unit of configs[3] and [4]
+           -> SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE
+    hbm  : two WGAN 5+1 steps (covers the Cin=1 / Cout=1 edge kernels), configs[2] / [3] / [4] + calibration streams of a known
+           byte count
            (1 GiB read + 1 GiB write through b32 loads (sg_axpby) and through b128 loads (sg_act_fwd)) -> FETCH_SIZE / WRITE_SIZE
 """
 import os
@@ -42,6 +44,26 @@ if mode == "mfma":
         y = ops.conv_fwd_raw(x, w, b, 1, 0.2)
         ops.conv_dgrad_raw(y, w, None, 64)
         ops.conv_wgrad_raw(y, x, 64)
+    # the one-channel layers at the critic's shapes (28 flop/B: their matrix-pipe share is what bounds them next to HBM)
+    x32 = torch.randn(128, 1, 32, 32, 32, device="cuda")
+    w1 = torch.randn(64, 1, 4, 4, 4, device="cuda") * 0.1
+    b1 = torch.zeros(64, device="cuda")
+    y16, ya = torch.randn(128, 64, 16, 16, 16, device="cuda"), torch.randn(128, 64, 16, 16, 16, device="cuda")
+    for _ in range(4):
+        ops.conv_fwd_raw(x32, w1, b1, 1, 0.2)
+        ops.conv_wgrad_raw(y16, x32, 1)
+        ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2)
+        ops.conv_dgrad_raw(y16[:64].contiguous(), w1, None, 1)
+    # BASELINE configs[3] / [4]: one 5+1 unit each (16 x 64^3 SDFNet evaluations, the progressive discriminator with the
+    # gradient penalty's double backward, the batch-8 critic)
+    sys.argv = [sys.argv[0]]
+    import bench
+    for cfg in ("hybrid_progressive", "hybrid_wgan"):
+        step, _, _ = bench.WORKLOADS[cfg](0)
+        for _ in range(2):
+            step()
+        del step
+        torch.cuda.empty_cache()
 elif mode == "hbm":
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
@@ -51,6 +73,15 @@ elif mode == "hbm":
     zg = torch.randn(64, 128).cuda()
     for _ in range(2):
         tr.step(reals, zs, zg)
+    # BASELINE configs[2] / [3] / [4]: one step / 5+1 unit each
+    sys.argv = [sys.argv[0]]
+    import bench
+    for cfg in ("sdf", "hybrid_progressive", "hybrid_wgan"):
+        step, _, _ = bench.WORKLOADS[cfg](0)
+        for _ in range(2):
+            step()
+        del step
+        torch.cuda.empty_cache()
     n = 1 << 28                                                   # 1 GiB of floats: past the 256 MiB Infinity Cache
     a, o = torch.randn(n, device="cuda"), torch.empty(n, device="cuda")
     lib = ops.L.load()

@@ -19,9 +19,18 @@ run_pmc() {  # name, counters, command...
 run_stats bench python $repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline
 run_stats wgan_step python $repo/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extras
 run_stats sdf_train python $repo/scripts/sdf_train_bench.py
+run_stats hybrid_progressive python $repo/bench.py --config hybrid_progressive --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+run_stats hybrid_wgan python $repo/bench.py --config hybrid_wgan --steps 4 --warmup 1 --no-cpu-baseline --no-extras
 run_pmc mfma_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python $repo/scripts/prof_targets.py mfma
 run_pmc hbm_fetch "FETCH_SIZE" python $repo/scripts/prof_targets.py hbm
 run_pmc hbm_write "WRITE_SIZE" python $repo/scripts/prof_targets.py hbm
 python $repo/scripts/pmc_table.py $out/${tag}_mfma_counters.csv $out/mfma_sq_counters.csv
 python $repo/scripts/pmc_table.py $out/${tag}_hbm_counters.csv $out/hbm_fetch_counters.csv $out/hbm_write_counters.csv
-ls -la $out | head -40
+# what this box streams (the edge-layer argument of DESIGN.md 3.2 rests on it) and how the one-channel kernels scale with the batch
+cd $repo
+python scripts/stream_calibration.py > $out/${tag}_stream_calibration.json 2> $out/stream.err
+python scripts/edge_ab.py > $out/${tag}_edge_kernels_by_batch.json 2> $out/edge_ab.err
+# ordered launch lists of one steady-state step
+bash scripts/timeline_run.sh > $out/timeline.log 2>&1
+for n in wgan sdf200k sdf20k; do cp gpurun_out/timeline/$n.txt $out/${tag}_${n}_step_timeline.txt; done
+ls -la $out | head -60

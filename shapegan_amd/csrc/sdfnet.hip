@@ -714,6 +714,13 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     // dZ_layer+1 (LDS) -> dZ_layer; tnext: transposed pack of the following step (-1: none)
     auto back_step = [&](int layer, long tnext, auto xtag) __attribute__((always_inline)) {
         zero_acc();
+#ifdef SG_SDF_NO_MASK   // A/B build (scripts/ab_build.sh): ReLU' from the fp32 images, as before round 3
+        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_h(layer); });
+        __syncthreads();
+        if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mask_store(layer, xtag, IntTag<0>());
+#else
         mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_mask(layer); });
         __syncthreads();   // every wave is done reading the tile
         if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
@@ -721,6 +728,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
 #pragma unroll
         for (int t = 0; t < NT; ++t) mk[t] = pok[t] ? mk[t] : 0u;
         mask_store(layer, xtag, IntTag<1>());
+#endif
         __syncthreads();
     };
     back_step(5, a.lay.T6, IntTag<-1>());    // dH6 -> dZ6
@@ -984,7 +992,11 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
         const TilePlan tp = tile_plan(N, 64, 2 * kFwdSlots);
         a.nbig = tp.nbig;
         const dim3 grid((unsigned)(tp.nbig + tp.nsmall));
+#ifdef SG_SDF_NO_MASK
+        if (false) {
+#else
         if (acts) {
+#endif
             if (set_lds(sdfnet_fwd_kernel<64, true, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
             hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true, true>), grid, dim3(512), lds, stream, a);
         } else {
@@ -998,7 +1010,11 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
         const TilePlan tp = tile_plan(N, 64, kFwdSlots);
         a.nbig = tp.nbig;
         const dim3 grid((unsigned)(tp.nbig + tp.nsmall));
+#ifdef SG_SDF_NO_MASK
+        if (false) {
+#else
         if (acts) {
+#endif
             if (set_lds(sdfnet_fwd_kernel<64, false, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfnet_fwd: cannot reserve %zu B LDS", lds);
             hipLaunchKernelGGL((sdfnet_fwd_kernel<64, false, true>), grid, dim3(512), lds, stream, a);
         } else {
