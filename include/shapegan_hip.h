@@ -205,7 +205,9 @@ int sg_scatter_add_rows(const float* rows, long rows_ld, const int64_t* idx, flo
  * out_sdf[n] / out_shape[n] hold the batch grouped by shape (entries of a shape keep their order in `indices`),
  * seg_off[nshapes+1] bounds every shape's run, counts[nshapes] = run lengths as floats (weights of the latent regulariser).
  * nshapes <= sg_sdf_batch_sort_max_shapes(); an index outside [0, nshapes*pointcloud_size) — an IndexError in the reference —
- * sets *bad_index_flag (device int, sticky, caller-zeroed) and is clamped. */
+ * sets *bad_index_flag and is clamped.  The flag is an int the kernel can write — device memory, or pinned host memory (what the
+ * Python shell passes: the host then polls it with a plain load, no copy / launch / synchronisation per step); sticky, caller-zeroed,
+ * written only when an index is bad. */
 int sg_sdf_batch_sort_max_shapes(void);
 size_t sg_sdf_batch_sort_workspace_bytes(long n, long nshapes);
 int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points,

@@ -915,10 +915,16 @@ def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf):
     counts = torch.empty(shapes, dtype=torch.float32, device=dev)
     flag = _bad_index_flags.get(dev)
     if flag is None:
-        flag = _bad_index_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the sticky "bad index" word lives in PINNED HOST memory (device-accessible under unified addressing): the kernel
+        # touches it only when an index is out of range, and the host reads it with a plain load — no copy, no launch, no
+        # synchronisation per step, nothing to capture
+        flag = torch.zeros(1, dtype=torch.int32)
+        if dev.type == "cuda":
+            flag = flag.pin_memory()
+        _bad_index_flags[dev] = flag
     ws = workspace("sdf_batch_sort", lib.sg_sdf_batch_sort_workspace_bytes(n, shapes), dev)
     check(lib.sg_sdf_batch_sort(ptr(indices), n, pointcloud_size, shapes, ptr(points), ptr(sdf), ptr(out_points), ptr(out_sdf),
-                                ptr(out_shape), ptr(seg_off), ptr(counts), ptr(flag), ptr(ws), ws.numel(), stream()),
+                                ptr(out_shape), ptr(seg_off), ptr(counts), flag.data_ptr(), ptr(ws), ws.numel(), stream()),
           "sdf_batch_sort")
     return out_points, out_sdf, out_shape, seg_off, counts
 
@@ -930,48 +936,24 @@ def sdf_batch_sort_max_shapes():
 def check_batch_indices():
     """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables."""
     for dev, flag in _bad_index_flags.items():
-        if int(flag.item()) != 0:
-            flag.zero_()
-            _flag_polls.pop(dev, None)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        if int(flag[0]) != 0:
+            flag[0] = 0
             raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
-
-
-_flag_polls = {}     # device -> (pinned host int32, event of the copy in flight or None)
 
 
 def poll_batch_indices():
-    """The same check without a host synchronisation, for use on EVERY step: reads what the previous poll copied into pinned host
-    memory (if that copy has landed) and enqueues the next asynchronous copy of the sticky device flag.  An out-of-range index is
-    therefore reported one step late at most (the reference raises at once; the batch in question was computed on clamped rows).
-    Inside a stream capture only the copy is recorded: the caller reads `batch_index_flag_host()` after each replay."""
+    """The same check without a synchronisation, for use on EVERY step: a plain read of the pinned host word the sort kernels set.
+    An out-of-range index is reported as soon as the kernel that saw it has run — in practice at the next step (the reference
+    raises at once; the batch in question was computed on clamped rows).  Costs nothing on the device and is safe inside a stream
+    capture (there is nothing to record)."""
     for dev, flag in _bad_index_flags.items():
-        if dev.type != "cuda":
-            if int(flag.item()) != 0:
-                flag.zero_()
-                raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
-            continue
-        host, event = _flag_polls.get(dev, (None, None))
-        capturing = torch.cuda.is_current_stream_capturing()
-        if host is None:
-            host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        elif not capturing and (event is None or event.query()) and int(host[0]) != 0:
-            host.zero_()
-            flag.zero_()
-            _flag_polls[dev] = (host, None)
+        if int(flag[0]) != 0:
+            if dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(dev)
+            flag[0] = 0
             raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
-        host.copy_(flag, non_blocking=True)
-        if capturing:
-            _flag_polls[dev] = (host, None)
-        else:
-            event = torch.cuda.Event()
-            event.record()
-            _flag_polls[dev] = (host, event)
-
-
-def batch_index_flag_host(device):
-    """The pinned host copy poll_batch_indices maintains for `device` (None before the first poll)."""
-    entry = _flag_polls.get(torch.device(device) if not isinstance(device, torch.device) else device)
-    return None if entry is None else entry[0]
 
 
 # --------------------------------------------------------------------------------------------------------------

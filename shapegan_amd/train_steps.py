@@ -171,17 +171,15 @@ class SDFAutoDecoderTrainer(object):
         """`step` as ONE captured graph launch (single process only): the shape-sorted flow from 8192 points on, the gathered
         flow below.  The reference's 20 000-point batch is launch-bound (27 kernels of a few microseconds on 313 tiles); the
         first two calls run eagerly (lazy initialisations, workspaces), the third is captured and every call from then on is a
-        replay.  Nothing in the step needs the host: the batch-index check is the sticky device flag copied to pinned memory
-        inside the graph and read here after each replay (an out-of-range index raises at the NEXT call, one step late).  The
+        replay.  Nothing in the step needs the host: the batch-index check is a word in pinned host memory that the sort kernel
+        sets and this method reads before each replay (an out-of-range index raises at the NEXT call, one step late).  The
         returned loss tensor is overwritten by the next call."""
         if not self.capturable or world_size() > 1:
             raise RuntimeError("step_graphed needs SDFAutoDecoderTrainer(capturable=True) in a single process")
         self._graph_calls += 1
         if self._graph_calls <= 2:
             return self.step(indices)
-        host = ops.batch_index_flag_host(indices.device)
-        if host is not None and int(host[0]) != 0:       # landed during an earlier replay (the stream has long passed it)
-            ops.check_batch_indices()
+        ops.poll_batch_indices()       # the pinned host word an earlier replay's sort kernel may have set
         if self._graph is None or self._graph_idx.shape != indices.shape:
             self._graph_idx = indices.clone()
             torch.cuda.synchronize()
