@@ -16,11 +16,7 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
     f = os.path.join(src, "%s_%s_kernel_stats.csv" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
-for name in ("mfma", "hbm"):
-    f = os.path.join(src, "%s_%s_counters.csv" % (tag, name))
-    if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
-for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
+for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
              "sdf20k_step_timeline.txt"):
     f = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(f):
@@ -34,26 +30,47 @@ def table(path):
     return by
 
 
-mf = table(os.path.join(src, tag + "_mfma_counters.csv"))
-out = []
-for k, v in mf.items():
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v["SQ_VALU_MFMA_BUSY_CYCLES"][0] > 1e6:
-        busy, gui = v["SQ_VALU_MFMA_BUSY_CYCLES"][0], v["GRBM_GUI_ACTIVE"][0]
-        ns = v["GRBM_GUI_ACTIVE"][1]
-        out.append({"kernel": k, "launches": v["GRBM_GUI_ACTIVE"][2], "dispatch_us": round(ns / 1e3, 1),
-                    "mfma_busy_cycles": busy, "gui_active_cycles_all_xcd": gui,
-                    "mfma_util": round(busy / (gui / 8.0 * 1024.0), 4), "clock_ghz_while_profiled": round(gui / 8.0 / ns, 3)})
-out.sort(key=lambda r: -r["mfma_busy_cycles"])
+def mfma_table(name):
+    path = os.path.join(src, "%s_%s_counters.csv" % (tag, name))
+    if not os.path.exists(path):
+        return []
+    shutil.copy(path, os.path.join(dst, os.path.basename(path)))
+    out = []
+    for k, v in table(path).items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v["SQ_VALU_MFMA_BUSY_CYCLES"][0] > 1e6:
+            busy, gui = v["SQ_VALU_MFMA_BUSY_CYCLES"][0], v["GRBM_GUI_ACTIVE"][0]
+            ns = v["GRBM_GUI_ACTIVE"][1]
+            out.append({"kernel": k, "launches": v["GRBM_GUI_ACTIVE"][2], "dispatch_us": round(ns / 1e3, 1),
+                        "mfma_busy_cycles": busy, "gui_active_cycles_all_xcd": gui,
+                        "mfma_util": round(busy / (gui / 8.0 * 1024.0), 4), "clock_ghz_while_profiled": round(gui / 8.0 / ns, 3)})
+    out.sort(key=lambda r: -r["mfma_busy_cycles"])
+    return out
+
+
+def hbm_table(name):
+    path = os.path.join(src, "%s_%s_counters.csv" % (tag, name))
+    if not os.path.exists(path):
+        return []
+    shutil.copy(path, os.path.join(dst, os.path.basename(path)))
+    rows = []
+    for k, v in table(path).items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and (v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) > 1000:
+            fetch, write, ns = v["FETCH_SIZE"][0] * 1024 * 2, v["WRITE_SIZE"][0] * 1024, v["FETCH_SIZE"][1]
+            rows.append({"kernel": k, "launches": v["FETCH_SIZE"][2], "dispatch_us": round(ns / 1e3, 1), "hbm_read_bytes": fetch,
+                         "hbm_write_bytes": write, "hbm_gb_per_s": round((fetch + write) / ns, 1)})
+    rows.sort(key=lambda r: -(r["hbm_read_bytes"] + r["hbm_write_bytes"]))
+    return rows
+
+
+out = mfma_table("mfma")
 json.dump(out, open(os.path.join(dst, tag + "_mfma_utilisation.json"), "w"), indent=1)
-hb = table(os.path.join(src, tag + "_hbm_counters.csv"))
-rows = []
-for k, v in hb.items():
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v and (v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) > 1000:
-        fetch, write, ns = v["FETCH_SIZE"][0] * 1024 * 2, v["WRITE_SIZE"][0] * 1024, v["FETCH_SIZE"][1]
-        rows.append({"kernel": k, "launches": v["FETCH_SIZE"][2], "dispatch_us": round(ns / 1e3, 1), "hbm_read_bytes": fetch,
-                     "hbm_write_bytes": write, "hbm_gb_per_s": round((fetch + write) / ns, 1)})
-rows.sort(key=lambda r: -(r["hbm_read_bytes"] + r["hbm_write_bytes"]))
+rows = hbm_table("hbm")
 json.dump(rows, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+cfg_m, cfg_h = mfma_table("configs_mfma"), hbm_table("configs_hbm")
+if cfg_m:
+    json.dump(cfg_m, open(os.path.join(dst, tag + "_configs_mfma_utilisation.json"), "w"), indent=1)
+if cfg_h:
+    json.dump(cfg_h, open(os.path.join(dst, tag + "_configs_hbm_traffic.json"), "w"), indent=1)
 dom = [r for r in rows if "conv_dgrad_halo_kernel<0>" in r["kernel"]]
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_read_bytes"] + dom[0]["hbm_write_bytes"],

@@ -21,5 +21,11 @@ for P, B in ((1024, 32), (4096, 32), (16384, 12), (32768, 6)):
     z, a = torch.randn(B, 128, device="cuda"), torch.rand(B, 1, 1, device="cuda")
     tc = timeit(lambda: tr.critic_step(u, z, a))
     tg = timeit(lambda: tr.generator_step(u, z))
-    # critic: G fwd (0.92 MF/pt) + 3 D passes fwd (0.34 MF/pt) + bwd/double-bwd ~ 2x + 3x; generator: 3x(G + D)
-    print("P=%5d B=%2d  critic+GP %.2f ms  generator %.2f ms  (%.2f Mpoints/s per critic update)" % (P, B, tc, tg, B * P / tc / 1e3), flush=True)
+    # FLOP per point, forward: SDFGenerator 2 (3 256 + 3 256^2 + 259 256 + 2 256^2 + 256) = 0.790 M, PointNet 2 (4 64 + 64 128
+    # + 128 256 + 256 512) = 0.345 M.  Critic update: G forward + D(real) + D(fake) + D(interpolated) forward, their weight /
+    # input gradients (2x a forward each) and the penalty's double backward through D (another 2x of one pass):
+    # 0.790 + 0.345 (3 + 6 + 2) = 4.58 MFLOP / point.  Generator update: 3 x (G + D) = 3.40 MFLOP / point.
+    fc, fg = 4.58e6 * B * P, 3.40e6 * B * P
+    print("P=%5d B=%2d  critic+GP %.2f ms (%.1f TFLOP/s = %.3f of the f32 MFMA peak)  generator %.2f ms (%.1f TFLOP/s = %.3f)  "
+          "%.2f Mpoints/s per critic update" % (P, B, tc, fc / tc / 1e9, fc / tc / 1e9 / 157.3, tg, fg / tg / 1e9,
+                                                 fg / tg / 1e9 / 157.3, B * P / tc / 1e3), flush=True)

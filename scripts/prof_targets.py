@@ -1,10 +1,11 @@
 """Workloads for the rocprofv3 counter passes of a round (run one mode per pass; see scripts/profile_round.sh).
 
-    mfma : SDFNet fused forward / training steps (sdfnet_fwd, sdfnet_bwd, gemm_nt_bigk batched), the three halo conv forms and the
-           one-channel layers at the critic's 128-sample pass, one 5+1 unit of configs[3] and [4]
-           -> SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE
-    hbm  : two WGAN 5+1 steps (covers the Cin=1 / Cout=1 edge kernels), configs[2] / [3] / [4] + calibration streams of a known
-           byte count
+    mfma    : SDFNet fused forward / training steps (sdfnet_fwd, sdfnet_bwd, gemm_nt_bigk batched), the three halo conv forms and
+              the one-channel layers at the critic's 128-sample pass
+              -> SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE
+    hbm     : two WGAN 5+1 steps (covers the Cin=1 / Cout=1 edge kernels) + calibration streams of a known byte count
+    configs : BASELINE configs[2] / [3] / [4] (their kernels run at other shapes than the WGAN's: kept out of the two passes
+              above so that those stay per-shape medians), used with both counter groups
            (1 GiB read + 1 GiB write through b32 loads (sg_axpby) and through b128 loads (sg_act_fwd)) -> FETCH_SIZE / WRITE_SIZE
 """
 import os
@@ -54,16 +55,6 @@ if mode == "mfma":
         ops.conv_wgrad_raw(y16, x32, 1)
         ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2)
         ops.conv_dgrad_raw(y16[:64].contiguous(), w1, None, 1)
-    # BASELINE configs[3] / [4]: one 5+1 unit each (16 x 64^3 SDFNet evaluations, the progressive discriminator with the
-    # gradient penalty's double backward, the batch-8 critic)
-    sys.argv = [sys.argv[0]]
-    import bench
-    for cfg in ("hybrid_progressive", "hybrid_wgan"):
-        step, _, _ = bench.WORKLOADS[cfg](0)
-        for _ in range(2):
-            step()
-        del step
-        torch.cuda.empty_cache()
 elif mode == "hbm":
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
@@ -73,7 +64,15 @@ elif mode == "hbm":
     zg = torch.randn(64, 128).cuda()
     for _ in range(2):
         tr.step(reals, zs, zg)
-    # BASELINE configs[2] / [3] / [4]: one step / 5+1 unit each
+    n = 1 << 28                                                   # 1 GiB of floats: past the 256 MiB Infinity Cache
+    a, o = torch.randn(n, device="cuda"), torch.empty(n, device="cuda")
+    lib = ops.L.load()
+    for _ in range(3):
+        check(lib.sg_axpby(ptr(a), None, ptr(o), n, 2.0, 0.0, stream()), "axpby")      # b32 loads / stores
+        check(lib.sg_act_fwd(ptr(a), ptr(o), n, 1, 0.2, stream()), "act_fwd")          # b128 loads / stores
+elif mode == "configs":
+    # BASELINE configs[2] / [3] / [4]: two steps / 5+1 units each (the auto-decoder step at 200 000 points, 16 x 64^3 SDFNet
+    # evaluations + the progressive discriminator with the gradient penalty's double backward, the batch-8 hybrid WGAN)
     sys.argv = [sys.argv[0]]
     import bench
     for cfg in ("sdf", "hybrid_progressive", "hybrid_wgan"):
@@ -82,10 +81,4 @@ elif mode == "hbm":
             step()
         del step
         torch.cuda.empty_cache()
-    n = 1 << 28                                                   # 1 GiB of floats: past the 256 MiB Infinity Cache
-    a, o = torch.randn(n, device="cuda"), torch.empty(n, device="cuda")
-    lib = ops.L.load()
-    for _ in range(3):
-        check(lib.sg_axpby(ptr(a), None, ptr(o), n, 2.0, 0.0, stream()), "axpby")      # b32 loads / stores
-        check(lib.sg_act_fwd(ptr(a), ptr(o), n, 1, 0.2, stream()), "act_fwd")          # b128 loads / stores
 torch.cuda.synchronize()

@@ -24,12 +24,18 @@ run_stats hybrid_wgan python $repo/bench.py --config hybrid_wgan --steps 4 --war
 run_pmc mfma_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python $repo/scripts/prof_targets.py mfma
 run_pmc hbm_fetch "FETCH_SIZE" python $repo/scripts/prof_targets.py hbm
 run_pmc hbm_write "WRITE_SIZE" python $repo/scripts/prof_targets.py hbm
+run_pmc cfg_mfma_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python $repo/scripts/prof_targets.py configs
+run_pmc cfg_hbm_fetch "FETCH_SIZE" python $repo/scripts/prof_targets.py configs
+run_pmc cfg_hbm_write "WRITE_SIZE" python $repo/scripts/prof_targets.py configs
 python $repo/scripts/pmc_table.py $out/${tag}_mfma_counters.csv $out/mfma_sq_counters.csv
 python $repo/scripts/pmc_table.py $out/${tag}_hbm_counters.csv $out/hbm_fetch_counters.csv $out/hbm_write_counters.csv
+python $repo/scripts/pmc_table.py $out/${tag}_configs_mfma_counters.csv $out/cfg_mfma_sq_counters.csv
+python $repo/scripts/pmc_table.py $out/${tag}_configs_hbm_counters.csv $out/cfg_hbm_fetch_counters.csv $out/cfg_hbm_write_counters.csv
 # what this box streams (the edge-layer argument of DESIGN.md 3.2 rests on it) and how the one-channel kernels scale with the batch
 cd $repo
 python scripts/stream_calibration.py > $out/${tag}_stream_calibration.json 2> $out/stream.err
 python scripts/edge_ab.py > $out/${tag}_edge_kernels_by_batch.json 2> $out/edge_ab.err
+python scripts/point_gan_bench.py > $out/${tag}_point_gan_bench.txt 2> $out/point_gan.err
 # ordered launch lists of one steady-state step
 bash scripts/timeline_run.sh > $out/timeline.log 2>&1
 for n in wgan sdf200k sdf20k; do cp gpurun_out/timeline/$n.txt $out/${tag}_${n}_step_timeline.txt; done
