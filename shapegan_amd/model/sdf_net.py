@@ -61,13 +61,13 @@ class SDFNet(SavableModule):
 
     def forward(self, points, latent_codes):
         """points [N,3], latent_codes [N,L] -> sdf [N]   (model/sdf_net.py:56-61)."""
-        return ops.SDFNetPoints.apply(self._pack_points, points, latent_codes, *self._params()).squeeze()
+        return ops.SDFNetPoints.apply(self._pack_points, points, latent_codes, torch.is_grad_enabled(), *self._params()).squeeze()
 
     def forward_shapes(self, points, latent_codes, points_per_shape):
         """points [S*pps,3], latent_codes [S,L] -> sdf [S*pps]: row s*pps+q uses latent s.  Same function as
         forward(points, latent.repeat_interleave(pps)) without materialising the tiled latents."""
         return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_codes, int(points_per_shape), None, None,
-                                      *self._params())
+                                      torch.is_grad_enabled(), *self._params())
 
     def forward_segments(self, points, latent_table, shape_index, segment_offsets):
         """points [N,3] grouped by shape, latent_table [S,L], shape_index [N] (int32), segment_offsets [S+1] (int64):
@@ -75,7 +75,7 @@ class SDFNet(SavableModule):
         gather (train_sdf_autodecoder.py:80) without the [N,L] tensor: latent columns fold into per-shape biases and
         the latent-table gradient comes out dense, [S,L], from per-shape sums."""
         return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_table, 0, shape_index, segment_offsets,
-                                      *self._params())
+                                      torch.is_grad_enabled(), *self._params())
 
     # ---- inference helpers (reference signatures) ----
     def evaluate_in_batches(self, points, latent_code, batch_size=100000, return_cpu_tensor=True):

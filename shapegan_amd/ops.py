@@ -657,13 +657,17 @@ class SDFNetPoints(Function):
     """SDFNet.forward(points[N,3], latent_codes[N,L]) with reference semantics (model/sdf_net.py:56-61)."""
 
     @staticmethod
-    def forward(ctx, cache, points, latent, *params):
+    def forward(ctx, cache, points, latent, grad_mode, *params):
+        """grad_mode: torch.is_grad_enabled() of the CALLER.  Inside a Function's forward grad mode is always off and
+        ctx.needs_input_grad is True for every parameter even under torch.no_grad(), so without it every no_grad evaluation (the
+        discriminator updates of the hybrid GANs: 5 of 6 generator evaluations) would write the seven activation images
+        (30 GB at 16 x 64^3 points) for a backward that never comes."""
         points, latent = f32c(points), f32c(latent)
         N, Lz = latent.shape
         kin = 3 + Lz
         lib = _lib()
         packed = cache.get(params, Lz, kin)
-        need_grad = any(ctx.needs_input_grad[1:])
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
         check(lib.sg_sdfnet_fwd(ptr(points), 0, ptr(latent), None, Lz, ptr(packed), kin, None, None, 0, None, ptr(out),
@@ -677,6 +681,8 @@ class SDFNetPoints(Function):
     def backward(ctx, gout):
         points, latent, out, acts, packed = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
+        if acts is None:
+            raise RuntimeError("SDFNet: backward through a forward that ran without grad mode")
         N, Lz = latent.shape
         kin = 3 + Lz
         gout = f32c(gout)
@@ -686,17 +692,17 @@ class SDFNetPoints(Function):
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
-        need_p = any(ctx.needs_input_grad[3:])
+        need_p = any(ctx.needs_input_grad[4:])
         bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
         check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
                                 0, ptr(dx), kin, ptr(packed), kin, N, N, stream()), "sdfnet_bwd")
         grads = [None] * 16
         if need_p:
-            grads = _sdf_param_grads(params, ctx.needs_input_grad[3:], dz, dz8, acts, N, N,
+            grads = _sdf_param_grads(params, ctx.needs_input_grad[4:], dz, dz8, acts, N, N,
                                      [(points, 0, 3), (latent, 3, Lz)], kin, bsum)
         gp = dx[:, :3] if ctx.needs_input_grad[1] else None
         gl = dx[:, 3:] if ctx.needs_input_grad[2] else None
-        return (None, gp, gl) + tuple(grads)
+        return (None, gp, gl, None) + tuple(grads)
 
 
 _FOLD_MAX_SHAPES = 1024   # the one-launch latent fold (sg_sdfnet_shape_bias_*) walks the shapes serially per thread
@@ -709,8 +715,8 @@ class SDFNetShapes(Function):
     train_hybrid_progressive_gan.py:90-96,138-139."""
 
     @staticmethod
-    def forward(ctx, cache, points, z, pps, sid, seg_off, *params):
-        """Uniform segments: sid is None, row s*pps+q uses z[s].  Ragged segments: sid[N] (int32) names each point's
+    def forward(ctx, cache, points, z, pps, sid, seg_off, grad_mode, *params):
+        """(grad_mode: the caller's torch.is_grad_enabled(), see SDFNetPoints.forward.)  Uniform segments: sid is None, row s*pps+q uses z[s].  Ragged segments: sid[N] (int32) names each point's
         latent row and seg_off[S+1] (int64) bounds the contiguous run of every shape (points sorted by shape)."""
         points, z = f32c(points), f32c(z)
         S, Lz = z.shape
@@ -726,7 +732,7 @@ class SDFNetShapes(Function):
         # 1e-7 but saved only ~10 us, and any change of rounding here re-rolls which ReLU kinks flip in the trajectory tests)
         zb1 = gemm_raw(z, False, w1, True, bias_j=b1, b_off=3, M=S, N=_H, K=Lz, lda=Lz, ldb=kin_total)
         zb5 = gemm_raw(z, False, w5, True, bias_j=b5, b_off=_H + 3, M=S, N=_H, K=Lz, lda=Lz, ldb=_H + kin_total)
-        need_grad = any(ctx.needs_input_grad[1:])
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
         check(lib.sg_sdfnet_fwd(ptr(points), 0, None, None, Lz, ptr(packed), 3, ptr(zb1), ptr(zb5), pps, ptr(sid),
@@ -741,6 +747,8 @@ class SDFNetShapes(Function):
     def backward(ctx, gout):
         points, z, out, acts, packed = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
+        if acts is None:
+            raise RuntimeError("SDFNet: backward through a forward that ran without grad mode")
         S, Lz = z.shape
         pps = ctx.pps
         N = out.shape[0]
@@ -751,7 +759,7 @@ class SDFNetShapes(Function):
         dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        need_p = any(ctx.needs_input_grad[6:])
+        need_p = any(ctx.needs_input_grad[7:])
         bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
         check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
                                 0, ptr(dx), 3, ptr(packed), 3, N, N, stream()), "sdfnet_bwd")
@@ -773,7 +781,7 @@ class SDFNetShapes(Function):
                 check(lib.sg_segsum(ptr(dz), ptr(t1), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
                 check(lib.sg_segsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
         if need_p:
-            grads = _sdf_param_grads(params, ctx.needs_input_grad[6:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
+            grads = _sdf_param_grads(params, ctx.needs_input_grad[7:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
                                      bsum)
         if (need_p or need_z) and S <= _FOLD_MAX_SHAPES:
             # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
@@ -795,7 +803,7 @@ class SDFNetShapes(Function):
                 g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
                 gz = _param_grad_out(z, g1.shape, dev)
                 check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
-        return (None, dx, gz, None, None, None) + tuple(grads)
+        return (None, dx, gz, None, None, None, None) + tuple(grads)
 
 
 # --------------------------------------------------------------------------------------------------------------
