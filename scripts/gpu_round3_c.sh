@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r03
 L=gpurun_out/r03/c.log; rm -f $L
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_modules.py tests/test_gpu_losses.py -q --tb=short -x -k "sdf or autodecoder or sort or graph" 2>&1 | tail -6 >> $L
-python scripts/sdf_train_bench.py >> $L 2>&1
-cat $L | grep -v amdgpu.ids
+export HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3
+timeout 420 python -X faulthandler -m pytest tests/test_gpu_fullsize.py -q --tb=short -x -v --timeout=100 2>&1 | grep -v "PASSED" | head -150 >> $L
+cat $L | grep -v amdgpu.ids | cut -c1-200 | grep -v "site-packages\|dist-packages" | head -80

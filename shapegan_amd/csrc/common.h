@@ -98,6 +98,13 @@ constexpr unsigned kBufOutside = 0x80000000u;   // byte offset that is out of ra
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)kBufRange, 0x00020000);
 }
+// the same with an exact extent: every dword at or beyond `bytes` reads as 0 WITHOUT touching memory (range checking of raw
+// buffers is per dword on gfx950, also inside a 16-byte load: measured).  For operands whose vector loads may overshoot their
+// last element.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_bytes(const void* base, long bytes) {
+    const unsigned n = bytes <= 0 ? 0u : (bytes < (long)kBufRange ? (unsigned)bytes : kBufRange);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
+}
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }

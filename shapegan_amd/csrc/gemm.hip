@@ -185,8 +185,14 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
 
     // copy: thread -> (row inside a 32-row pass, 16-byte piece kq of the 128-byte segment)
     const int rowl = tid >> 3, kq = tid & 7;
-    const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.A + a.a_off[bz] + (long)i0 * a.lda + kbeg);
-    const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.B + a.b_off[bz] + (long)j0 * a.ldb + kbeg);
+    // The 16-byte pieces of the last stage overshoot K (their tail is zeroed in registers, mask_tail): inside the matrix that lands
+    // in the next row, but behind the LAST row of an operand it is behind the operand — and behind the allocation when the operand
+    // ends it (dZ7 ends `dz`).  An unmapped page there hangs the wave (seen once the caching allocator placed `dz` at the end of a
+    // segment), so the resources end exactly at the operand's last element (extents below 2 GiB; larger ones keep the window).
+    const __amdgpu_buffer_rsrc_t ares = make_rsrc_bytes(a.A + a.a_off[bz] + (long)i0 * a.lda + kbeg,
+                                                        ((long)(a.M - 1 - i0) * a.lda + (a.K - kbeg)) * 4);
+    const __amdgpu_buffer_rsrc_t bres = make_rsrc_bytes(a.B + a.b_off[bz] + (long)j0 * a.ldb + kbeg,
+                                                        ((long)(a.N - 1 - j0) * a.ldb + (a.K - kbeg)) * 4);
     unsigned avoff[4], bvoff[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

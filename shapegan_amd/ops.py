@@ -688,7 +688,7 @@ class SDFNetPoints(Function):
         gout = f32c(gout)
         lib = _lib()
         dev = out.device
-        dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
+        dz = torch.empty(7 * _H * N + 32, dtype=torch.float32, device=dev)[:7 * _H * N].view(7, _H, N)   # (+128 B: vector loads of the last row's tail)
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
@@ -756,7 +756,7 @@ class SDFNetShapes(Function):
         gout = f32c(gout)
         lib = _lib()
         dev = out.device
-        dz = torch.empty((7, _H, N), dtype=torch.float32, device=dev)
+        dz = torch.empty(7 * _H * N + 32, dtype=torch.float32, device=dev)[:7 * _H * N].view(7, _H, N)   # (+128 B: vector loads of the last row's tail)
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         need_p = any(ctx.needs_input_grad[7:])
