@@ -163,9 +163,11 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
                   long points_per_shape, const int* shape_index, float* out, float* acts, long ldn, long N,
                   hipStream_t stream);
 /* Point tiles of the backward = columns of bias_partials: tile t covers the points [sg_sdfnet_bwd_tile_start(N, t),
- * sg_sdfnet_bwd_tile_start(N, t + 1)).  With tiles = ceil(N / 64), full = tiles - tiles % 512, rem = tiles % 512: 64 points per
- * tile, except that for full > 0 and 0 < 4 rem <= 3 * 512 the points from 64 * full on are cut into 32-point tiles (the last,
- * partly filled round of workgroups finishes sooner).  A pure function of N: the layout does not depend on the device. */
+ * sg_sdfnet_bwd_tile_start(N, t + 1)).  With tiles = ceil(N / 64), rem = tiles % 512, full = tiles - rem: 64 points per tile,
+ * except for the last, partly filled round of workgroups (512 = two per CU):
+ *   256 < rem <= 384: 64-point tiles up to full + 256 (one more per CU), the points after them in 32-point tiles;
+ *   full > 0 and 0 < rem <= 256: the points from 64 * full on in 32-point tiles.
+ * A pure function of N: the layout does not depend on the device. */
 long sg_sdfnet_bwd_blocks(long N);
 long sg_sdfnet_bwd_tile_start(long N, long t);
 /* bias_partials (optional): [7*256][blocks] per-tile row sums of dZ1..dZ7 (sum each row: bias gradients).  With `points`

@@ -467,6 +467,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 // finish in about a third of it.  A point's arithmetic does not depend on the tile it is in (same k order in every layer, the
 // last layer's dot product in fixed 16-row groups), so the plan never changes a result of the forward.
 constexpr int kSmallTile = 32;
+constexpr long kCUs = 256;
 
 // (512 threads, 4 waves per SIMD = two workgroups per CU: the register budget is 128 VGPRs, stated explicitly — the kernel sat
 // just below it by luck before, and one more live value silently halves the occupancy)
@@ -902,14 +903,23 @@ __global__ void __launch_bounds__(256) shape_bias_bwd_kernel(const float* __rest
 struct TilePlan {
     long nbig, nsmall;
 };
+// `per_cu` workgroups share a CU (slots = per_cu x 256).  The last, partly filled round of `rem` tiles:
+//   * per_cu == 2 and slots/2 < rem <= 3 slots/4: rem big tiles would leave some CUs with two of them (128 points) next to CUs
+//     with one; slots/2 big tiles (one per CU — the dispatcher places workgroups breadth-first) + the rest of the points as
+//     small tiles gives every CU at most 64 + 32 points.  This is the reference's own 20 000-point batch (313 tiles);
+//   * otherwise, when it is not the only round and at most 3/4 full: all of it as small tiles.
 static TilePlan tile_plan(long N, int P, long slots) {
     const long tiles = (N + P - 1) / P;
     const long full = tiles / slots * slots, rem = tiles - full;
+    if (slots == 2 * kCUs && 2 * rem > slots && 4 * rem <= 3 * slots) {
+        const long nbig = full + slots / 2;
+        return TilePlan{nbig, (N - nbig * P + kSmallTile - 1) / kSmallTile};
+    }
     if (full == 0 || rem == 0 || 4 * rem > 3 * slots) return TilePlan{tiles, 0};
     return TilePlan{full, (N - full * P + kSmallTile - 1) / kSmallTile};
 }
-constexpr long kFwdSlots = 256;   // one workgroup per CU (LDS)
-constexpr long kBwdSlots = 512;   // two per CU
+constexpr long kFwdSlots = kCUs;       // one workgroup per CU (LDS)
+constexpr long kBwdSlots = 2 * kCUs;   // two per CU
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }

@@ -525,7 +525,10 @@ static inline void dense_t(const float* W, int K, const float* dz, float* dh, bo
 // the header's tile layout of the backward partials (sg_sdfnet_bwd_blocks / sg_sdfnet_bwd_tile_start)
 static void sdf_bwd_plan(long N, long& nbig, long& nsmall) {
     const long tiles = (N + 63) / 64, rem = tiles % 512, full = tiles - rem;
-    if (full == 0 || rem == 0 || 4 * rem > 3 * 512) {
+    if (rem > 256 && rem <= 384) {
+        nbig = full + 256;
+        nsmall = (N - nbig * 64 + 31) / 32;
+    } else if (full == 0 || rem == 0 || rem > 384) {
         nbig = tiles;
         nsmall = 0;
     } else {

@@ -280,14 +280,20 @@ def test_point_dataset_matches_reference(tmp_path):
 
 
 def test_sdfnet_backward_tile_layout_is_the_documented_function_of_n():
-    """include/shapegan_hip.h: 64-point tiles; when the last round of 512 tiles would be at most 3/4 full (and is not the
-    only round) its points are cut into 32-point tiles.  Host code of the library, callable without a GPU."""
+    """include/shapegan_hip.h: 64-point tiles; the last round of 512 tiles is cut differently when it is between 1/2 and 3/4
+    full (256 more 64-point tiles, the rest 32-point tiles) or at most half full and not the only round (all 32-point tiles).
+    Host code of the library, callable without a GPU."""
     lib = L.load()
-    for n in (1, 63, 64, 65, 20000, 32768, 32769, 33100, 200000, 57344, 57345, 65536, 262144, 1000003):
+    for n in (1, 63, 64, 65, 16384, 16385, 16416, 20000, 24576, 24577, 32768, 32769, 33100, 200000, 49152, 49153, 50000, 57344,
+              57345, 65536, 262144, 1000003):
         tiles = (n + 63) // 64
         rem = tiles % 512
         full = tiles - rem
-        if full == 0 or rem == 0 or 4 * rem > 3 * 512:
+        if 256 < rem <= 384:
+            big = full + 256
+            small = (n - 64 * big + 31) // 32
+            starts = [64 * t for t in range(big)] + [min(64 * big + 32 * t, n) for t in range(small + 1)]
+        elif full == 0 or rem == 0 or rem > 384:
             starts = [min(64 * t, n) for t in range(tiles + 1)]
         else:
             small = (n - 64 * full + 31) // 32
