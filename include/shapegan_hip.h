@@ -256,6 +256,13 @@ int sg_loss_meansq_fwd(const float* x, const float* row_weight, long rows, int L
                        size_t workspace_bytes, hipStream_t stream);
 int sg_loss_meansq_bwd(const float* x, const float* row_weight, const float* gloss, float* dx, long rows, int L, double denom,
                        hipStream_t stream);
+/* The whole DeepSDF loss of train_sdf_autodecoder.py:88, loss = mean|out - target| + sum_r w_r |z_r|^2 / denom, as ONE pass over
+ * both operands + the finishing wave, and its backward (dout[n], dz[rows][L]) as one launch: the arithmetic and its order are
+ * those of sg_loss_weighted_l1 with neg_weight 1, sg_loss_meansq and an fp32 add of the two rounded terms, bit for bit. */
+int sg_loss_deepsdf_fwd(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                        double denom, float* loss, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int sg_loss_deepsdf_bwd(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                        double denom, const float* gloss, float* dout, float* dz, hipStream_t stream);
 /* voxel_difference, train_autoencoder.py:50-52: count[0] = #{e : (a[e] * b[e]) < 0} with the product rounded to fp32 as the
  * reference's `(input * target) < 0` does (a product that underflows to -0, or a NaN, does not count).  Integer arithmetic
  * throughout: bit-exact.  The caller divides by n (`torch.sum(wrong_signs).item() / wrong_signs.nelement()`). */

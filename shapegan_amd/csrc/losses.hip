@@ -178,6 +178,59 @@ __global__ void __launch_bounds__(256) sq_bwd_kernel(const float* __restrict__ x
         dx[e] = (roww ? roww[e / L] : 1.f) * g * x[e];
 }
 
+// ---- the whole DeepSDF loss (train_sdf_autodecoder.py:88) in one pass ---------------------------------------------------
+// loss = mean|out - sdf| + sum_r w_r |z_r|^2 / denom: workgroups [0, nb1) take the data term, the rest the regulariser; the
+// finishing wave rounds each term to fp32 and adds them in fp32, and the backward is one launch over both operands — the same
+// arithmetic, in the same order, as sg_loss_weighted_l1 (neg_weight 1) + sg_loss_meansq + the fp32 add (7 launches -> 3).
+__global__ void __launch_bounds__(256) deepsdf_fwd_kernel(const float* __restrict__ o, const float* __restrict__ t, long n,
+                                                          int nb1, const float* __restrict__ x, const float* __restrict__ roww,
+                                                          long m, int L, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0;
+    const int b = blockIdx.x;
+    if (b < nb1) {
+        for (long e = (long)b * 256 + threadIdx.x; e < n; e += (long)nb1 * 256) s += (double)fabsf(o[e] - t[e]);
+    } else {
+        const long nb2 = gridDim.x - nb1;
+        for (long e = (long)(b - nb1) * 256 + threadIdx.x; e < m; e += nb2 * 256) {
+            const float v = x[e];
+            s += (double)(roww ? roww[e / L] * v * v : v * v);
+        }
+    }
+    s = sg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[b < nb1 ? b : kRedBlocks + (b - nb1)] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(64) deepsdf_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int nb1,
+                                                           int nb2, double scale1, double scale2) {
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < nb1; i += 64) s1 += partial[i];
+    for (int i = threadIdx.x; i < nb2; i += 64) s2 += partial[kRedBlocks + i];
+    s1 = sg_wave_sum_d(s1);
+    s2 = sg_wave_sum_d(s2);
+    if (threadIdx.x == 0) out[0] = (float)(s1 * scale1) + (float)(s2 * scale2);
+}
+__global__ void __launch_bounds__(256) deepsdf_bwd_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                          const float* __restrict__ gloss, float* __restrict__ d_o, long n,
+                                                          float inv_n, int nb1, const float* __restrict__ x,
+                                                          const float* __restrict__ roww, float* __restrict__ dx, long m, int L,
+                                                          float scale2) {
+    const int b = blockIdx.x;
+    if (b < nb1) {
+        const float g = gloss[0] * inv_n;
+        for (long e = (long)b * 256 + threadIdx.x; e < n; e += (long)nb1 * 256) {
+            const float d = o[e] - t[e];
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            d_o[e] = g * sgn;
+        }
+    } else {
+        const long nb2 = gridDim.x - nb1;
+        const float g = gloss[0] * scale2;
+        for (long e = (long)(b - nb1) * 256 + threadIdx.x; e < m; e += nb2 * 256) dx[e] = (roww ? roww[e / L] : 1.f) * g * x[e];
+    }
+}
+
 // ---- gradient penalty ----------------------------------------------------------------------------------------------
 // one workgroup per sample row: norm_b = ||g_b||_2
 __global__ void __launch_bounds__(256) row_norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long M) {
@@ -362,7 +415,7 @@ using namespace sg;
 
 extern "C" {
 
-size_t sg_loss_workspace_bytes(void) { return kRedBlocks * sizeof(double); }
+size_t sg_loss_workspace_bytes(void) { return 2 * kRedBlocks * sizeof(double); }   // (two partial arrays: sg_loss_deepsdf)
 
 #define SG_CHECK_WS()                                                             \
     if (!workspace || workspace_bytes < sg_loss_workspace_bytes())                \
@@ -445,6 +498,29 @@ int sg_loss_meansq_bwd(const float* x, const float* row_weight, const float* glo
     const long n = rows * L;
     hipLaunchKernelGGL(sq_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, row_weight, gloss, dx, n, L,
                        (float)(2.0 / denom));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_deepsdf_fwd(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                        double denom, float* loss, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(out && target && z && loss && n > 0 && rows > 0 && L > 0 && denom > 0);
+    SG_CHECK_WS();
+    const long m = rows * L;
+    const int nb1 = red_grid(n), nb2 = red_grid(m);
+    hipLaunchKernelGGL(deepsdf_fwd_kernel, dim3(nb1 + nb2), dim3(256), 0, stream, out, target, n, nb1, z, row_weight, m, L,
+                       (double*)workspace);
+    hipLaunchKernelGGL(deepsdf_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, loss, nb1, nb2,
+                       1.0 / (double)n, 1.0 / denom);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_deepsdf_bwd(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                        double denom, const float* gloss, float* dout, float* dz, hipStream_t stream) {
+    SG_CHECK_ARG(out && target && z && gloss && dout && dz && n > 0 && rows > 0 && L > 0 && denom > 0);
+    const long m = rows * L;
+    const int nb1 = ew_blocks(n), nb2 = ew_blocks(m);
+    hipLaunchKernelGGL(deepsdf_bwd_kernel, dim3(nb1 + nb2), dim3(256), 0, stream, out, target, gloss, dout, n,
+                       (float)(1.0 / (double)n), nb1, z, row_weight, dz, m, L, (float)(2.0 / denom));
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -836,6 +836,26 @@ int sg_loss_meansq_bwd_cpu(const float* x, const float* roww, const float* gloss
     for (long e = 0; e < rows * L; ++e) dx[e] = (roww ? roww[e / L] : 1.f) * g * x[e];
     return SG_OK;
 }
+int sg_loss_deepsdf_fwd_cpu(const float* o, const float* t, long n, const float* z, const float* roww, long rows, int L, double denom,
+                            float* loss, void*, size_t, void*) {
+    CPU_CHECK(o && t && z && loss && n > 0 && rows > 0 && L > 0 && denom > 0);
+    double s1 = 0, s2 = 0;
+    for (long e = 0; e < n; ++e) s1 += fabs((double)(o[e] - t[e]));
+    for (long e = 0; e < rows * L; ++e) s2 += (double)((roww ? roww[e / L] : 1.f) * z[e] * z[e]);
+    loss[0] = (float)(s1 / (double)n) + (float)(s2 / denom);
+    return SG_OK;
+}
+int sg_loss_deepsdf_bwd_cpu(const float* o, const float* t, long n, const float* z, const float* roww, long rows, int L, double denom,
+                            const float* gloss, float* d_o, float* dz, void*) {
+    CPU_CHECK(o && t && z && gloss && d_o && dz && n > 0 && rows > 0 && L > 0 && denom > 0);
+    const float g1 = gloss[0] * (float)(1.0 / (double)n), g2 = gloss[0] * (float)(2.0 / denom);
+    for (long e = 0; e < n; ++e) {
+        const float d = o[e] - t[e];
+        d_o[e] = g1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    for (long e = 0; e < rows * L; ++e) dz[e] = (roww ? roww[e / L] : 1.f) * g2 * z[e];
+    return SG_OK;
+}
 int sg_gradient_penalty_fwd_cpu(const float* grad, long B, long M, float weight, float* norms, float* loss, void*) {
     CPU_CHECK(grad && norms && loss && B > 0 && M > 0);
     double acc = 0;

@@ -95,6 +95,8 @@ SIGNATURES = {
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),
     "sg_loss_meansq_bwd": (c_int, [_P, _P, _P, _P, _L, _I, _D, _P]),
+    "sg_loss_deepsdf_fwd": (c_int, [_P, _P, _L, _P, _P, _L, _I, _D, _P, _P, _Z, _P]),
+    "sg_loss_deepsdf_bwd": (c_int, [_P, _P, _L, _P, _P, _L, _I, _D, _P, _P, _P, _P]),
     "sg_count_sign_mismatch": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_gradient_penalty_fwd": (c_int, [_P, _L, _L, _F, _P, _P, _P]),
     "sg_gradient_penalty_bwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),

@@ -1194,6 +1194,40 @@ def mean_sq(x, row_weight=None, denom=None):
     return MeanSq.apply(x2, row_weight, float(x.numel() if denom is None else denom))
 
 
+class DeepSDFLoss(Function):
+    """mean|out - sdf| + sum_r w_r |z_r|^2 / denom, the loss of train_sdf_autodecoder.py:88 as one op: one pass + the finishing
+    wave forward, one launch backward (weighted_l1 + mean_sq + their fp32 add, bit for bit, in 3 launches instead of 7)."""
+
+    @staticmethod
+    def forward(ctx, out, target, z, row_weight, denom):
+        out, target, z = f32c(out), f32c(target.detach()), f32c(z)
+        if out.shape != target.shape:
+            raise RuntimeError("deepsdf_loss: shape mismatch %s vs %s" % (tuple(out.shape), tuple(target.shape)))
+        rows, width = z.shape
+        rw = None if row_weight is None else f32c(row_weight)
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        ws = _loss_ws(out.device)
+        check(_lib().sg_loss_deepsdf_fwd(ptr(out), ptr(target), out.numel(), ptr(z), ptr(rw), rows, width, float(denom),
+                                         ptr(loss), ptr(ws), ws.numel(), stream()), "loss_deepsdf_fwd")
+        ctx.denom = float(denom)
+        ctx.save_for_backward(out, target, z, rw)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        out, target, z, rw = ctx.saved_tensors
+        d, dz = torch.empty_like(out), torch.empty_like(z)
+        check(_lib().sg_loss_deepsdf_bwd(ptr(out), ptr(target), out.numel(), ptr(z), ptr(rw), z.shape[0], z.shape[1],
+                                         ctx.denom, ptr(f32c(g)), ptr(d), ptr(dz), stream()), "loss_deepsdf_bwd")
+        return d, None, dz, None, None
+
+
+def deepsdf_loss(out, target, z, row_weight=None, denom=None):
+    z2 = z.reshape(z.shape[0], -1) if z.dim() != 2 else z
+    return DeepSDFLoss.apply(out, target, z2, row_weight, float(z.numel() if denom is None else denom))
+
+
 class GradientPenalty(Function):
     """((||g_b||_2 - 1)^2).mean() * weight over the per-sample rows of `gradients`
     (train_hybrid_progressive_gan.py:110-111, train_point_gan.py:68-70)."""

@@ -224,11 +224,12 @@ class SDFAutoDecoderTrainer(object):
         self.lat_opt.zero_grad()
         output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
         n, width = indices.shape[0], self.latent_codes.shape[1]
-        loss = ops.weighted_l1(output, batch_sdf)
         if self.sigma != 0:
-            # sigma * mean(z_batch^2) through shape counts; sigma rides in the denominator (sigma 0: the term is 0, as in the
-            # reference's formula)
-            loss = loss + ops.mean_sq(self.latent_codes, counts, n * width / self.sigma)
+            # data term + sigma * mean(z_batch^2) through shape counts in one op; sigma rides in the denominator (sigma 0: the
+            # term is 0, as in the reference's formula)
+            loss = ops.deepsdf_loss(output, batch_sdf, self.latent_codes, counts, n * width / self.sigma)
+        else:
+            loss = ops.weighted_l1(output, batch_sdf)
         lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
@@ -246,9 +247,10 @@ class SDFAutoDecoderTrainer(object):
         batch_points = ops.gather_rows(self.points, indices)
         batch_sdf = ops.gather_rows(self.sdf.unsqueeze(1), indices).squeeze(1)
         output = self.net(batch_points, batch_latent)
-        loss = ops.weighted_l1(output, batch_sdf)
         if self.sigma != 0:
-            loss = loss + ops.mean_sq(batch_latent, None, batch_latent.numel() / self.sigma)
+            loss = ops.deepsdf_loss(output, batch_sdf, batch_latent, None, batch_latent.numel() / self.sigma)
+        else:
+            loss = ops.weighted_l1(output, batch_sdf)
         lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()

@@ -141,6 +141,9 @@ def test_losses_and_blends(on_cpu):
     for shape in ((4, 32, 32, 32), (3, 7, 5), (1,), (2049,)):
         LOSS.test_voxel_difference_bit_exact(shape)
     LOSS.test_mean_sq_plain_and_row_weighted()
+    LOSS.test_deepsdf_loss_is_the_sum_of_its_two_ops_bit_for_bit(20000, 64, 128, True)
+    LOSS.test_deepsdf_loss_is_the_sum_of_its_two_ops_bit_for_bit(5000, 5000, 16, False)
+    LOSS.test_deepsdf_loss_is_the_sum_of_its_two_ops_bit_for_bit(1, 1, 1, True)
     LOSS.test_lerp_rows_bit_exact()
     LOSS.test_mean_difference_matches_torch(128, 64)
     LOSS.test_mean_difference_matches_torch(7, 0)

@@ -152,6 +152,43 @@ def test_mean_sq_plain_and_row_weighted():
     close(t.grad, t_ref.grad, rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,shapes,width,counted", [(20000, 64, 128, True), (200000, 64, 256, True), (5000, 5000, 16, False),
+                                                    (1, 1, 1, True), (777, 3, 5, True)])
+def test_deepsdf_loss_is_the_sum_of_its_two_ops_bit_for_bit(n, shapes, width, counted):
+    """train_sdf_autodecoder.py:88 `l1(out, sdf) + SIGMA * mean(z_batch^2)`: the one-op form against the reference expression in
+    torch (value, both gradients) and, bit for bit, against weighted_l1 + mean_sq + the fp32 add it replaces."""
+    from shapegan_amd import ops
+    g = torch.Generator().manual_seed(n + width)
+    out = (torch.rand(n, generator=g) * 0.4 - 0.2)
+    sdf = (torch.rand(n, generator=g) * 0.2 - 0.1)
+    out[::7] = sdf[::7]                                           # exact zeros of the difference: sign(0) = 0
+    table = torch.randn(shapes, width, generator=g) * 0.01
+    sigma = 0.01
+    if counted:
+        model_indices = torch.randint(0, shapes, (n,), generator=g)
+        counts = torch.bincount(model_indices, minlength=shapes).float()
+        z, rw, denom = table, counts, n * width / sigma
+        o_ref, t_ref = out.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        ref = torch.nn.functional.l1_loss(o_ref, sdf) + sigma * torch.mean(torch.pow(t_ref[model_indices, :], 2))
+    else:
+        z, rw, denom = table, None, table.numel() / sigma
+        o_ref, t_ref = out.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        ref = torch.nn.functional.l1_loss(o_ref, sdf) + sigma * torch.mean(torch.pow(t_ref, 2))
+    (ref * 1.3).backward()
+    o1, z1 = out.clone().to(DEV).requires_grad_(True), z.clone().to(DEV).requires_grad_(True)
+    rwd = None if rw is None else rw.to(DEV)
+    fused = ops.deepsdf_loss(o1, sdf.to(DEV), z1, rwd, denom)
+    (fused * 1.3).backward()
+    o2, z2 = out.clone().to(DEV).requires_grad_(True), z.clone().to(DEV).requires_grad_(True)
+    split = ops.weighted_l1(o2, sdf.to(DEV)) + ops.mean_sq(z2, rwd, denom)
+    (split * 1.3).backward()
+    assert torch.equal(fused.detach(), split.detach())
+    assert torch.equal(o1.grad, o2.grad) and torch.equal(z1.grad, z2.grad)
+    np.testing.assert_allclose(fused.item(), ref.item(), rtol=2e-6)
+    close(o1.grad, o_ref.grad, rtol=1e-6, atol=0.0 if n > 1 else 1e-12, what="d loss / d out")
+    close(z1.grad, t_ref.grad, rtol=1e-5, what="d loss / d latent codes")
+
+
 # ---- gradient penalty pieces -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,n_first", [(128, 64), (8, 3), (1, 1), (5000, 1), (7, 7), (7, 0)])
 def test_mean_difference_matches_torch(n, n_first):
