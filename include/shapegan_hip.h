@@ -60,6 +60,14 @@ size_t sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(int batch, int Cin, int Cout, 
 int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                            int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                            void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* sg_conv3d_k4s2p1_dgrad with the packed weight image KEPT between calls — the forward of a ConvTranspose3d whose weights
+ * did not change since its last call (model/gan.py:29-35: the WGAN generator is evaluated six times per 5+1 training unit of
+ * train_wgan.py:60-84 and updated once).  `workspace` is a buffer the caller dedicates to this weight tensor (size as for
+ * sg_conv3d_k4s2p1_dgrad); weights_unchanged != 0 promises that the previous call on it had the same weight values and the same
+ * shapes and that nothing else wrote to it: the packing launch is then skipped.  Results are those of sg_conv3d_k4s2p1_dgrad. */
+int sg_conv3d_k4s2p1_dgrad_keep(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                                void* workspace, size_t workspace_bytes, int weights_unchanged, hipStream_t stream);
 int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                                 int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
                                 void* workspace, size_t workspace_bytes, int impl, hipStream_t stream); /* tests */
@@ -246,7 +254,8 @@ int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* 
 /* w_first * mean(x[0, n_first)) + w_rest * mean(x[n_first, n)) and its backward dx = gloss * (w / count) per part, one small
  * launch each: the WGAN losses mean(fake) - mean(real) over the critic's concatenated batch (train_wgan.py:68,
  * train_hybrid_wgan.py:89, train_hybrid_progressive_gan.py:147) and -mean(fake) (train_wgan.py:82; n_first = n, w_first = -1) */
-int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, hipStream_t stream);
+int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, float* dx_unit,
+                           hipStream_t stream);   /* dx_unit (optional, [n]): the backward for gloss == 1, from the same launch */
 int sg_loss_mean_split_bwd(const float* gloss, float* dx, long n, long n_first, float w_first, float w_rest, hipStream_t stream);
 int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
                     hipStream_t stream);

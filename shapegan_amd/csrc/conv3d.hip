@@ -618,9 +618,13 @@ int sg_conv3d_k4s2p1_fwd_impl(const float* x, const float* w, const float* bias,
     return SG_OK;
 }
 
-int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
-                           int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
-                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
+}  // extern "C"
+
+// `packed_already`: the weight image a kernel of this call would build in the workspace is still there (same weights, same
+// shapes, workspace untouched since): the packing launch is skipped.  Which kernel serves a call depends on the shapes only.
+static int dgrad_call(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total, int Cx,
+                      int Cout, int ID, int IH, int IW, int act, float slope, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream, bool packed_already) {
     SG_CHECK_ARG(dy && w && dx && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_dgrad: spatial dims must be even and >= 2");
@@ -654,7 +658,7 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     }
     {
         const int rc = halo_dgrad_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, workspace,
-                                      workspace_bytes, stream, 0);
+                                      workspace_bytes, stream, 0, packed_already);
         if (rc < 0) return rc;
         if (rc == 1) {
             SG_CHECK_LAUNCH();
@@ -665,7 +669,7 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
     if (!workspace || workspace_bytes < need)
         SG_FAIL(SG_ERR_WORKSPACE, "sg_conv3d_k4s2p1_dgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     float* wt = (float*)workspace;
-    {
+    if (!packed_already) {
         const long total = 8L * Cout * 8 * Cin;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
@@ -696,6 +700,25 @@ int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, f
 #undef SG_DGRAD_LAUNCH
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+
+extern "C" {
+
+int sg_conv3d_k4s2p1_dgrad(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                           int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return dgrad_call(dy, w, bias, dx, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, workspace, workspace_bytes, stream,
+                      false);
+}
+// The same with the packed weight image KEPT between calls (a ConvTranspose3d forward whose weights did not change since the
+// last call: the WGAN generator is evaluated six times per training unit and updated once): `workspace` is a buffer the
+// caller dedicates to this weight tensor; weights_unchanged != 0 promises that the previous call on it had the same weight
+// values and the same shapes and that nothing else wrote to it.
+int sg_conv3d_k4s2p1_dgrad_keep(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,
+                                void* workspace, size_t workspace_bytes, int weights_unchanged, hipStream_t stream) {
+    return dgrad_call(dy, w, bias, dx, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, workspace, workspace_bytes, stream,
+                      weights_unchanged != 0);
 }
 
 // testing / tuning: impl 1 forces the LDS-halo dgrad kernel (SG_ERR_ARG if the shape is not eligible)

@@ -807,7 +807,7 @@ size_t halo_dgrad_workspace_bytes(int Cin, int Cout) { return (size_t)8 * ((Cin 
 
 int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream, int force) {
+                   hipStream_t stream, int force, bool packed_already) {
     const bool mode1 = g.OD == 4 && g.OH == 4 && g.OW == 4;
     if (!mode1 && (g.OW % 8 != 0 || g.OH % 8 != 0 || g.OD % 2 != 0)) return 0;
     if (Cout % 16 != 0 || Cin < 32 || Cin % 8 != 0) return 0;
@@ -821,7 +821,7 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     if (!force && tiles * mtiles * 8 < 512) return 0;
     if (tiles >= (1L << 31) || mtiles > 65535) return 0;
     float4* wp = (float4*)workspace;
-    {
+    if (!packed_already) {
         const long total = 8L * mtiles * 2 * Cout * 64;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

@@ -66,9 +66,10 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
                  hipStream_t stream, int force = 0, int debug = 0);
 
 size_t halo_dgrad_workspace_bytes(int Cin, int Cout);
+// (packed_already: the workspace still holds this weight's fragment image from an earlier call — sg_conv3d_k4s2p1_dgrad_keep)
 int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream, int force = 0);
+                   hipStream_t stream, int force = 0, bool packed_already = false);
 
 size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,

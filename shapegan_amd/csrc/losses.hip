@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(64) loss_final_kernel(const double* __restrict
 // backward dx[i] = g * (i < na ? wa / na : wb / (n - na)).  Replaces the two means, the subtraction and the slice / expand /
 // zero-fill / add nodes autograd would build for `mean(out[:na]) - mean(out[na:])`: 14 launches -> 2.
 __global__ void __launch_bounds__(256) mean_split_fwd_kernel(const float* __restrict__ x, long n, long na, float wa, float wb,
-                                                             float* __restrict__ loss) {
+                                                             float* __restrict__ loss, float* __restrict__ dx_unit, float ca,
+                                                             float cb) {
     __shared__ double ra[4], rb[4];
     double sa = 0, sb = 0;
     for (long e = threadIdx.x; e < n; e += 256) {
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) mean_split_fwd_kernel(const float* __rest
             sa += v;
         else
             sb += v;
+        if (dx_unit) dx_unit[e] = e < na ? ca : cb;     // the backward for an upstream gradient of exactly 1
     }
     sa = sg_wave_sum_d(sa);
     sb = sg_wave_sum_d(sb);
@@ -439,9 +441,12 @@ int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* 
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
-int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, hipStream_t stream) {
+int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, float* dx_unit,
+                           hipStream_t stream) {
     SG_CHECK_ARG(x && loss && n > 0 && n_first >= 0 && n_first <= n);
-    hipLaunchKernelGGL(mean_split_fwd_kernel, dim3(1), dim3(256), 0, stream, x, n, n_first, w_first, w_rest, loss);
+    const float ca = n_first > 0 ? (float)((double)w_first / (double)n_first) : 0.f;
+    const float cb = n > n_first ? (float)((double)w_rest / (double)(n - n_first)) : 0.f;
+    hipLaunchKernelGGL(mean_split_fwd_kernel, dim3(1), dim3(256), 0, stream, x, n, n_first, w_first, w_rest, loss, dx_unit, ca, cb);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -174,6 +174,11 @@ int sg_conv3d_k4s2p1_wgrad_cpu(const float* dy, const float* x, float* dw, int b
     return SG_OK;
 }
 
+int sg_conv3d_k4s2p1_dgrad_keep_cpu(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
+                                    int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* ws,
+                                    size_t wb, int, void* st) {     // (nothing is packed here: nothing to keep)
+    return sg_conv3d_k4s2p1_dgrad_cpu(dy, w, bias, dx, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, ws, wb, st);
+}
 int sg_convT3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
                               int ID, int IH, int IW, int act, float slope, void* ws, size_t wb, void* st) {
     return sg_conv3d_k4s2p1_dgrad_cpu(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act, slope, ws,
@@ -790,8 +795,14 @@ int sg_count_sign_mismatch_cpu(const float* a, const float* b, long n, long long
     count[0] = c;
     return SG_OK;
 }
-int sg_loss_mean_split_fwd_cpu(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, void*) {
+int sg_loss_mean_split_fwd_cpu(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, float* dx_unit,
+                               void*) {
     CPU_CHECK(x && loss && n > 0 && n_first >= 0 && n_first <= n);
+    if (dx_unit) {
+        const float ca = n_first > 0 ? (float)((double)w_first / (double)n_first) : 0.f;
+        const float cb = n > n_first ? (float)((double)w_rest / (double)(n - n_first)) : 0.f;
+        for (long e = 0; e < n; ++e) dx_unit[e] = e < n_first ? ca : cb;
+    }
     double a = 0, b = 0;
     for (long e = 0; e < n; ++e) (e < n_first ? a : b) += x[e];
     double v = 0;

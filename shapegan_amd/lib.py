@@ -30,6 +30,7 @@ SIGNATURES = {
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_conv3d_k4s2p1_dgrad_keep": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "sg_conv3d_k4s2p1_dgrad_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "sg_conv3d_k4s2p1_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_wgrad_impl": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
@@ -89,7 +90,7 @@ SIGNATURES = {
     "sg_loss_workspace_bytes": (_Z, []),
     "sg_loss_weighted_l1_fwd": (c_int, [_P, _P, _L, _F, _P, _P, _Z, _P]),
     "sg_loss_weighted_l1_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _P]),
-    "sg_loss_mean_split_fwd": (c_int, [_P, _L, _L, _F, _F, _P, _P]),
+    "sg_loss_mean_split_fwd": (c_int, [_P, _L, _L, _F, _F, _P, _P, _P]),
     "sg_loss_mean_split_bwd": (c_int, [_P, _P, _L, _L, _F, _F, _P]),
     "sg_loss_kld_fwd": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
@@ -304,14 +305,51 @@ def f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Kernels that update parameters through raw pointers do not bump tensor._version; anything that caches a
-# derived image of parameters (the SDFNet MFMA weight pack) keys on this counter as well.
+# Kernels that update parameters through raw pointers do not bump tensor._version; anything that caches a derived image of
+# parameters (the SDFNet MFMA weight pack, a kept ConvTranspose weight image) keys on an epoch as well.  PARAM_EPOCH moves with
+# every event that may have rewritten ANY parameter (graph replays, load_state_dict, clip_weights, a new optimizer); a
+# flat-buffer optimizer's step moves only the epoch of ITS buffer (param_epoch_of), so the critic's five updates per WGAN unit
+# do not invalidate the generator's images.  Every new value comes from one counter: an epoch is never seen twice.
 PARAM_EPOCH = 0
+_EPOCH_COUNTER = 0
+_PARAM_RANGES = []      # [start, end, epoch] of every live flat parameter buffer
 
 
-def bump_param_epoch():
-    global PARAM_EPOCH
-    PARAM_EPOCH += 1
+def bump_param_epoch(param_range=None):
+    """param_range: what register_param_range returned (the stepping optimizer's buffer); None: every parameter."""
+    global PARAM_EPOCH, _EPOCH_COUNTER
+    _EPOCH_COUNTER += 1
+    if param_range is None:
+        PARAM_EPOCH = _EPOCH_COUNTER
+    else:
+        param_range[2] = _EPOCH_COUNTER
+
+
+def register_param_range(start, nbytes):
+    global _EPOCH_COUNTER
+    _EPOCH_COUNTER += 1
+    r = [start, start + nbytes, _EPOCH_COUNTER]
+    _PARAM_RANGES.append(r)
+    return r
+
+
+def unregister_param_range(r):
+    try:
+        _PARAM_RANGES.remove(r)
+    except ValueError:
+        pass
+
+
+def param_epoch_of(*tensors):
+    """The newest epoch that may have changed any of `tensors` (parameters): the global one, or that of a flat buffer holding it."""
+    e = PARAM_EPOCH
+    if _PARAM_RANGES:
+        for t in tensors:
+            a = t.data_ptr()
+            for r in _PARAM_RANGES:
+                if r[0] <= a < r[1] and r[2] > e:
+                    e = r[2]
+    return e
 
 
 # ---- gradient destinations ---------------------------------------------------------------------------------------------
@@ -372,6 +410,12 @@ def backward(loss, **kwargs):
         loss.backward(**kwargs)
     finally:
         _direct_write_depth -= 1
+
+
+def is_unit_gradient(g):
+    """True when `g` is the constant 1 that `backward()` above seeds a scalar loss with (so d loss / d loss = 1 exactly)."""
+    one = _ONES.get((g.device, g.dtype))
+    return one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr()
 
 
 def grad_destination(param_tensor, shape):

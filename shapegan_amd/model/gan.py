@@ -34,9 +34,11 @@ class Generator(SavableModule):
         self.layers = nn.Sequential(*layers)
         self.to(default_device)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out (optional, without grad mode): a contiguous fp32 [B,1,32,32,32] tensor the samples are written to (and which is
+        then returned) — e.g. the fake half of the critic's batch."""
         x = x.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1))
-        return run_stack(self.layers, x, self.training)
+        return run_stack(self.layers, x, self.training, out)
 
     def generate(self, sample_size=1):
         # latents are drawn on the CPU and moved (model/gan.py:31-34): reproducible across backends

@@ -29,8 +29,8 @@ def _is_k4(m, stride, padding):
     return tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (stride,) * 3 and tuple(m.padding) == (padding,) * 3
 
 
-def _producer(m, x, act, slope):
-    """One conv / linear layer with `act` fused into its epilogue."""
+def _producer(m, x, act, slope, out=None):
+    """One conv / linear layer with `act` fused into its epilogue (out: see ops.conv_transpose3d_k4s2p1)."""
     if isinstance(m, nn.Conv3d):
         if _is_k4(m, 2, 1):
             return ops.conv3d_k4s2p1(x, m.weight, m.bias, act, slope)
@@ -41,7 +41,7 @@ def _producer(m, x, act, slope):
             return y.reshape(x.shape[0], m.out_channels, 1, 1, 1)
     elif isinstance(m, nn.ConvTranspose3d):
         if _is_k4(m, 2, 1):
-            return ops.conv_transpose3d_k4s2p1(x, m.weight, m.bias, act, slope)
+            return ops.conv_transpose3d_k4s2p1(x, m.weight, m.bias, act, slope, out)
         if _is_k4(m, 1, 0) and tuple(x.shape[2:]) == (1, 1, 1):
             # 1^3 -> 4^3: y[b, co*64+tap] = x[b,:] @ W[:, co*64+tap] + bias[co]  (model/gan.py:9, autoencoder.py:51)
             y = ops.LinearAct.apply(x.reshape(x.shape[0], -1), m.weight.reshape(m.in_channels, -1), m.bias, act, slope,
@@ -63,7 +63,9 @@ def _batchnorm(m, x, act, slope, training):
                                   act, slope)
 
 
-def run_stack(modules, x, training):
+def run_stack(modules, x, training, out=None):
+    """out: optional destination of the LAST layer's result when that is a k4 s2 p1 transposed convolution (+ activation) and grad
+    mode is off; ignored otherwise (the caller checks what it got back)."""
     mods = list(modules)
     i = 0
     while i < len(mods):
@@ -82,10 +84,10 @@ def run_stack(modules, x, training):
                 continue
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
-                x = _producer(m, x, a[0], a[1])
+                x = _producer(m, x, a[0], a[1], out if i + 2 == len(mods) else None)
                 i += 2
             else:
-                x = _producer(m, x, ACT_NONE, 0.0)
+                x = _producer(m, x, ACT_NONE, 0.0, out if i + 1 == len(mods) else None)
                 i += 1
             continue
         if isinstance(m, (nn.BatchNorm3d, nn.BatchNorm1d)):

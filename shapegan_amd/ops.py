@@ -8,6 +8,7 @@ PyTorch is used for storage (device tensors), the autograd tape and stream handl
 hot path runs in libshapegan_hip.so.  There is no CPU fallback: tensors must live on the GPU.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -53,15 +54,57 @@ def conv_fwd_impl_raw(x, w, bias, act, slope, impl, debug=0):
     return y
 
 
-def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0):
-    """dy [N,Co,O,O,O], w [Co,Ct,4,4,4] -> act(conv^T(dy, w[:, :cin]) + bias) [N,cin,2O,2O,2O]."""
+class _KeptWeightImages(object):
+    """Workspaces dedicated to one ConvTranspose3d weight each (sg_conv3d_k4s2p1_dgrad_keep): the packed image a call leaves
+    there serves the next call as long as the weight is unchanged — same storage, same tensor version, same parameter epoch of
+    the optimizer buffer it lives in (lib.param_epoch_of) — and the shapes are the same.  The WGAN generator is evaluated six
+    times per 5+1 unit (train_wgan.py:60-84) and updated once.  At most `cap` weights are remembered (oldest dropped)."""
+
+    def __init__(self, cap=32):
+        self.cap, self.entries = cap, {}
+
+    def get(self, w, nbytes, shape_key):
+        """-> (workspace, unchanged).  An entry belongs to one tensor OBJECT (weak reference): a new tensor that the allocator
+        places at a freed weight's address, with the same version and epoch, is a different weight."""
+        ident = (w.device.index, stream(), w.data_ptr())
+        state = (w._version, L.param_epoch_of(w), shape_key)
+        ent = self.entries.pop(ident, None)
+        if ent is None or ent[0].numel() < nbytes or ent[2]() is not w:
+            ent = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device), None, weakref.ref(w)]
+        unchanged = ent[1] == state
+        ent[1] = state
+        self.entries[ident] = ent            # (re-inserted last: dict order = age)
+        while len(self.entries) > self.cap:
+            self.entries.pop(next(iter(self.entries)))
+        return ent[0], unchanged
+
+
+_KEPT = _KeptWeightImages()
+
+
+def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, keep=False, out=None):
+    """dy [N,Co,O,O,O], w [Co,Ct,4,4,4] -> act(conv^T(dy, w[:, :cin]) + bias) [N,cin,2O,2O,2O].
+    keep: `w` is a layer's own weight (ConvTranspose3d forward) — its packed image is kept for the next call (_KeptWeightImages).
+    out: where to write the result (a contiguous fp32 tensor of the result's shape, e.g. one half of the critic's batch)."""
     N, Co, OD, OH, OW = dy.shape
     Ct = w.shape[1]
     if w.shape[0] != Co or cin > Ct:
         raise RuntimeError("conv dgrad: shape mismatch")
-    dx = torch.empty((N, cin, 2 * OD, 2 * OH, 2 * OW), dtype=torch.float32, device=dy.device)
+    shape = (N, cin, 2 * OD, 2 * OH, 2 * OW)
+    if out is not None:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dy.device:
+            raise RuntimeError("conv dgrad: `out` must be a contiguous fp32 tensor of shape %s on %s" % (shape, dy.device))
+        dx = out
+    else:
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
     lib = _lib()
     nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(N, cin, Co, OD, OH, OW)
+    # (one-channel layers pack nothing; a graph under capture must contain its own packing launch: its replays see new weights)
+    if keep and cin > 1 and dy.is_cuda and not torch.cuda.is_current_stream_capturing():
+        ws, unchanged = _KEPT.get(w, nb, (N, cin, Ct, Co, OD, OH, OW))
+        check(lib.sg_conv3d_k4s2p1_dgrad_keep(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
+                                              act, slope, ptr(ws), ws.numel(), int(unchanged), stream()), "conv3d_dgrad_keep")
+        return dx
     ws = workspace("dgrad", nb, dy.device)
     check(lib.sg_conv3d_k4s2p1_dgrad(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
                                      act, slope, ptr(ws), ws.numel(), stream()), "conv3d_dgrad")
@@ -333,9 +376,9 @@ class ConvDgrad(Function):
     """dx = act(conv^T(dy, w[:, :cin]) + b) — nn.Conv3d input-gradient and nn.ConvTranspose3d forward."""
 
     @staticmethod
-    def forward(ctx, dy, w, b, cin, act, slope):
+    def forward(ctx, dy, w, b, cin, act, slope, keep=False):
         dy, w = f32c(dy), f32c(w)
-        dx = conv_dgrad_raw(dy, w, b, cin, act, slope)
+        dx = conv_dgrad_raw(dy, w, b, cin, act, slope, keep)
         ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
         ctx.save_for_backward(dy, w, dx if act != ACT_NONE else None, b)
         return dx
@@ -356,7 +399,7 @@ class ConvDgrad(Function):
             g_w = conv_wgrad_raw(dy, f32c(gz), w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(dy, gz, w.shape[1])
         if want_b and g_b is None:
             g_b = channel_sum_raw(f32c(gz), L.grad_destination(b, b.shape)) if plain else ChannelSum.apply(gz)
-        return g_dy, g_w, g_b, None, None, None
+        return g_dy, g_w, g_b, None, None, None, None
 
 
 class ConvWgrad(Function):
@@ -380,9 +423,13 @@ def conv3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0):
     return ConvFwd.apply(x, w, b, act, slope)
 
 
-def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0):
-    """nn.ConvTranspose3d(k4,s2,p1): weight [Cin_T, Cout_T, 4,4,4] is the adjoint conv's [Cout, Cin] layout."""
-    return ConvDgrad.apply(x, w, b, w.shape[1], act, slope)
+def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0, out=None):
+    """nn.ConvTranspose3d(k4,s2,p1): weight [Cin_T, Cout_T, 4,4,4] is the adjoint conv's [Cout, Cin] layout.
+    out (only without grad mode): the tensor the result is written to — the generator's samples go straight into the fake half
+    of the critic's batch (train_wgan.py:62-66) instead of being copied there."""
+    if out is not None and not torch.is_grad_enabled():
+        return conv_dgrad_raw(f32c(x), f32c(w), b, w.shape[1], act, slope, True, out)
+    return ConvDgrad.apply(x, w, b, w.shape[1], act, slope, True)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -562,7 +609,7 @@ class _PackCache(object):
 
     def get(self, params, latent, kin_used):
         dev = params[0].device
-        key = (kin_used, latent, L.PARAM_EPOCH) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (kin_used, latent, L.param_epoch_of(*params)) + tuple((p.data_ptr(), p._version) for p in params)
         entry = self.entries.get(dev)
         if entry is None or entry[0] != key:
             lib = _lib()
@@ -840,14 +887,18 @@ class MeanSplit(Function):
         x = f32c(x)
         ctx.shape, ctx.args = x.shape, (x.numel(), int(n_first), float(w_first), float(w_rest))
         out = torch.empty((), dtype=torch.float32, device=x.device)
-        check(_lib().sg_loss_mean_split_fwd(ptr(x), x.numel(), int(n_first), float(w_first), float(w_rest), ptr(out), stream()),
-              "loss_mean_split_fwd")
+        # the gradient for an upstream 1 comes out of the same launch: the loss is the root of lib.backward() in every trainer
+        ctx.dx_unit = torch.empty(x.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        check(_lib().sg_loss_mean_split_fwd(ptr(x), x.numel(), int(n_first), float(w_first), float(w_rest), ptr(out),
+                                            ptr(ctx.dx_unit), stream()), "loss_mean_split_fwd")
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         n, n_first, w_first, w_rest = ctx.args
+        if ctx.dx_unit is not None and L.is_unit_gradient(g):
+            return ctx.dx_unit, None, None, None
         dx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         check(_lib().sg_loss_mean_split_bwd(ptr(f32c(g)), ptr(dx), n, n_first, w_first, w_rest, stream()), "loss_mean_split_bwd")
         return dx, None, None, None

@@ -39,6 +39,7 @@ class _Flat(object):
                 self.grad[o:o + n].copy_(p.grad.reshape(-1))
             p.grad = self.grad[o:o + n].view(p.shape)
         self.slots = [L.register_grad_slot(p, self.grad, o) for p, o in zip(self.params, self.offsets)]
+        self.range = L.register_param_range(self.flat.data_ptr(), 4 * self.total)   # this buffer's own parameter epoch
         L.bump_param_epoch()
 
     def grad_view_ok(self, i):
@@ -95,6 +96,7 @@ class _Flat(object):
     def __del__(self):
         try:
             L.unregister_grad_slots(self.slots)
+            L.unregister_param_range(self.range)
         except Exception:       # interpreter shutdown
             pass
 
@@ -157,7 +159,7 @@ class RMSprop(_Base):
             L.note_device(self.f.flat)
             check(lib.sg_rmsprop_step(base_p + 4 * o, g, base_s + 4 * o, n, self.lr, self.alpha, self.eps,
                                       self.grad_scale, self.clip, stream()), "rmsprop_step")
-        L.bump_param_epoch()
+        L.bump_param_epoch(self.f.range)
 
 
 class Adam(_Base):
@@ -208,4 +210,4 @@ class Adam(_Base):
                 L.note_device(f.flat)
                 check(lib.sg_adam_step(base_p + 4 * o, g, base_m + 4 * o, base_v + 4 * o, n, self.lr, self.betas[0],
                                        self.betas[1], self.eps, self.steps[first[o]], self.grad_scale, stream()), "adam_step")
-        L.bump_param_epoch()
+        L.bump_param_epoch(f.range)

@@ -39,12 +39,18 @@ class WGANTrainer(object):
     def critic_step(self, real, z):
         """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw."""
         self.c_opt.zero_grad()
-        with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
-            fake = self.generator(z)
         # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
-        # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.
-        n_fake = fake.shape[0]
-        out = self.critic(torch.cat([fake, real.reshape((-1,) + tuple(fake.shape[1:]))]))
+        # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.  The generator
+        # writes its samples straight into the fake half of that batch.
+        n_fake, n_real = z.shape[0], real.shape[0]
+        res = real.shape[-1]
+        both = torch.empty((n_fake + n_real, 1, res, res, res), dtype=torch.float32, device=real.device)
+        with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
+            fake = self.generator(z, out=both[:n_fake])
+            if fake.data_ptr() != both.data_ptr():
+                both[:n_fake].copy_(fake)
+            both[n_fake:].copy_(real.reshape(n_real, 1, res, res, res))
+        out = self.critic(both)
         out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
         self.c_bucket.arm()

@@ -215,6 +215,14 @@ def test_mean_difference_matches_torch(n, n_first):
     neg.backward()
     close(neg, -x.mean(), rtol=1e-6, atol=1e-6, what="neg mean")
     close(xg2.grad, torch.full_like(x, -1.0 / n), rtol=1e-6, atol=1e-9, what="d neg mean")
+    # as the root of lib.backward() (what the trainers do) the gradient comes out of the forward launch: the same values
+    from shapegan_amd import lib
+    xg3 = x.clone().to(DEV).requires_grad_(True)
+    lib.backward(ops.mean_difference(xg3, n_first))
+    xg4 = x.clone().to(DEV).requires_grad_(True)
+    ops.mean_difference(xg4, n_first).backward()
+    assert torch.equal(xg3.grad, xg4.grad)
+    close(xg3.grad, xr.grad / 1.7, rtol=1e-6, atol=1e-9, what="d mean difference, unit upstream gradient")
 
 
 def test_lerp_rows_bit_exact():

@@ -95,6 +95,69 @@ def test_conv_transpose3d(N, Ci, Co, R):
         close(bg.grad, br.grad, what="convT bias grad act%d" % act)
 
 
+def test_conv_transpose_keeps_its_weight_image_until_the_weight_changes(monkeypatch):
+    """sg_conv3d_k4s2p1_dgrad_keep: the packed weight image of a ConvTranspose3d forward is reused while the weight is unchanged
+    (the WGAN generator: six evaluations per update, train_wgan.py:60-84) and rebuilt after every kind of change — a flat-buffer
+    optimizer's raw-pointer step (its own buffer's epoch), an in-place torch update (tensor version), a new tensor at the same
+    address — but NOT after another optimizer's step."""
+    from shapegan_amd import ops, optim
+    flags = []
+    real_get = ops._KEPT.get
+
+    def spy(w, nbytes, shape_key):
+        ws, unchanged = real_get(w, nbytes, shape_key)
+        flags.append(unchanged)
+        return ws, unchanged
+    monkeypatch.setattr(ops._KEPT, "get", spy)
+    torch.manual_seed(11)
+    for Ci, Co, R in ((128, 64, 8), (256, 128, 4), (24, 12, 4)):      # halo kernel (two modes), tile-GEMM path
+        x = torch.randn(4, Ci, R, R, R)
+        w = torch.nn.Parameter((torch.randn(Ci, Co, 4, 4, 4) / (Ci * 8) ** 0.5).cuda())
+        other = torch.nn.Parameter(torch.randn(1000).cuda())
+        opt, opt_other = optim.RMSprop([w], lr=0.05), optim.RMSprop([other], lr=0.05)
+
+        def run():
+            with torch.no_grad():
+                return ops.conv_transpose3d_k4s2p1(x.cuda(), w, None)
+
+        def ref():
+            return F.conv_transpose3d(x, w.detach().cpu(), None, stride=2, padding=1)
+        del flags[:]
+        y1, y2 = run(), run()
+        assert flags == [False, True] and torch.equal(y1, y2)
+        close(y1, ref(), what="convT, fresh image")
+        other.grad = torch.ones_like(other)
+        opt_other.step()                                  # somebody else's parameters moved: image still valid
+        y3 = run()
+        assert flags[-1] is True and torch.equal(y3, y1)
+        w.grad = torch.randn_like(w)
+        opt.step()                                        # raw-pointer update of w
+        y4 = run()
+        assert flags[-1] is False and not torch.equal(y4, y1)
+        close(y4, ref(), what="convT after the optimizer step")
+        assert torch.equal(run(), y4) and flags[-1] is True
+        with torch.no_grad():
+            w.mul_(0.5)                                   # in-place torch update
+        y5 = run()
+        assert flags[-1] is False
+        close(y5, ref(), what="convT after an in-place update")
+        with torch.enable_grad():                         # grad mode shares the image (generator update after a critic update)
+            y6 = ops.conv_transpose3d_k4s2p1(x.cuda(), w, None)
+        assert flags[-1] is True and torch.equal(y6.detach(), y5)
+    # a different weight at a recycled address is not mistaken for the old one
+    w1 = torch.nn.Parameter(torch.randn(128, 64, 4, 4, 4).cuda() * 0.03)
+    x = torch.randn(2, 128, 8, 8, 8).cuda()
+    with torch.no_grad():
+        ops.conv_transpose3d_k4s2p1(x, w1, None)
+        addr = w1.data_ptr()
+        del w1
+        w2 = torch.nn.Parameter(torch.randn(128, 64, 4, 4, 4).cuda() * 0.03)
+        y = ops.conv_transpose3d_k4s2p1(x, w2, None)
+    if w2.data_ptr() == addr:
+        assert flags[-1] is False
+    close(y, F.conv_transpose3d(x.cpu(), w2.detach().cpu(), None, stride=2, padding=1), what="convT, recycled address")
+
+
 @pytest.mark.parametrize("N,Co,O,act", [(16, 64, 16, 1), (17, 24, 16, 2), (128, 64, 16, 1)])
 def test_conv_wgrad_through_activation(N, Co, O, act):
     """sg_conv3d_k4s2p1_wgrad_act: weight and bias gradient of act(conv(x) + b) for a one-channel input straight from dLoss/dy (the

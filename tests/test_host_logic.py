@@ -306,6 +306,31 @@ def test_sdfnet_backward_tile_layout_is_the_documented_function_of_n():
         assert starts[-1] == n and all(b > a for a, b in zip(starts, starts[1:]))
 
 
+def test_parameter_epochs_are_per_optimizer_buffer():
+    """lib.param_epoch_of: an optimizer's step moves the epoch of the parameters in ITS flat buffer only (the critic's five updates
+    per WGAN unit must not invalidate weight images of the generator); unscoped events (graph replay, load_state_dict,
+    clip_weights) move everybody's; an epoch value is never handed out twice."""
+    import torch
+    from shapegan_amd import optim
+    a, b = torch.nn.Parameter(torch.randn(10)), torch.nn.Parameter(torch.randn(7))
+    c = torch.nn.Parameter(torch.randn(3))            # in no optimizer
+    oa, ob = optim.RMSprop([a], lr=0.1), optim.Adam([b], lr=0.1)
+    ea, eb, ec = L.param_epoch_of(a), L.param_epoch_of(b), L.param_epoch_of(c)
+    L.bump_param_epoch(oa.f.range)
+    assert L.param_epoch_of(a) > ea and L.param_epoch_of(b) == eb and L.param_epoch_of(c) == ec
+    assert L.param_epoch_of(a, b) == L.param_epoch_of(a)
+    ea = L.param_epoch_of(a)
+    L.bump_param_epoch(ob.f.range)
+    assert L.param_epoch_of(a) == ea and L.param_epoch_of(b) > ea
+    L.bump_param_epoch()
+    e = L.param_epoch_of(c)
+    assert e > eb and L.param_epoch_of(a) == e and L.param_epoch_of(b) == e
+    del oa, ob
+    import gc
+    gc.collect()
+    assert all(r[0] != a.data_ptr() for r in L._PARAM_RANGES)
+
+
 def test_wgrad_act_path_is_refused_outside_its_limits(monkeypatch):
     """ConvFwd.backward takes the fused weight-gradient + activation-backward kernel only when
     sg_conv3d_k4s2p1_wgrad_act will really serve the call — the shape is eligible (incl. the 32-bit buffer ranges the kernel
