@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 4
+#define SG_ABI_VERSION 5
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 

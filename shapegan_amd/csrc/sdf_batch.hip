@@ -87,12 +87,35 @@ __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __r
     __shared__ int lsum[64];
     const int lane = threadIdx.x;
     const long chunk = blockIdx.x;
+    // The wave's work is a chain of memory round trips, so everything whose address is known is requested up front: the keys and
+    // batch indices of the chunk's 8 rounds together with the shape totals / chunk bases of the scan below (one round trip), then
+    // the table rows as soon as the indices are there (second round trip) — the scan and the ranks (LDS and lane traffic only)
+    // run while those are in flight.
+    int key[kSortRounds];
+    long src[kSortRounds];
+#pragma unroll
+    for (int it = 0; it < kSortRounds; ++it) {
+        const long e = chunk * kSortChunk + it * 64 + lane;
+        const bool ok = e < n;
+        key[it] = ok ? keys[e] : -1 - lane;   // distinct negative keys: match nothing
+        const long i = ok ? idx[e] : 0;
+        src[it] = i < 0 ? 0 : (i < table_rows ? i : table_rows - 1);   // (a bad index was flagged by the histogram pass)
+    }
     // exclusive scan of the shape totals: lane owns the bins [lane R, lane R + R)
     const int R = (S + 63) / 64;
     int mine = 0;
     for (int j = 0; j < R; ++j) {
         const int s = lane * R + j;
         mine += s < S ? total[s] : 0;
+    }
+    float x[kSortRounds], y[kSortRounds], z[kSortRounds], d[kSortRounds];
+#pragma unroll
+    for (int it = 0; it < kSortRounds; ++it) {
+        const float* q = points + src[it] * 3;   // (row 0 for the lanes beyond n: in range, never stored)
+        x[it] = q[0];
+        y[it] = q[1];
+        z[it] = q[2];
+        d[it] = sdf[src[it]];
     }
     lsum[lane] = mine;
     __syncthreads();
@@ -112,18 +135,7 @@ __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __r
     }
     if (chunk == 0 && lane == 63) seg_off[S] = n;
     __syncthreads();
-    // three passes over the chunk's 8 rounds so that the memory latencies overlap instead of chaining per round: all keys and
-    // batch indices first, then the ranks (LDS only), then all table rows in flight together
-    int key[kSortRounds], p[kSortRounds];
-    long src[kSortRounds];
-#pragma unroll
-    for (int it = 0; it < kSortRounds; ++it) {
-        const long e = chunk * kSortChunk + it * 64 + lane;
-        const bool ok = e < n;
-        key[it] = ok ? keys[e] : -1 - lane;   // distinct negative keys: match nothing
-        const long i = ok ? idx[e] : 0;
-        src[it] = i < 0 ? 0 : (i < table_rows ? i : table_rows - 1);   // (a bad index was flagged by the histogram pass)
-    }
+    int p[kSortRounds];
 #pragma unroll
     for (int it = 0; it < kSortRounds; ++it) {
         const bool ok = key[it] >= 0;
@@ -138,15 +150,6 @@ __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __r
         __syncthreads();
         if (ok && !later) pos[key[it]] = p[it] + 1;
         __syncthreads();
-    }
-    float x[kSortRounds], y[kSortRounds], z[kSortRounds], d[kSortRounds];
-#pragma unroll
-    for (int it = 0; it < kSortRounds; ++it) {
-        const float* q = points + src[it] * 3;   // (row 0 for the lanes beyond n: in range, never stored)
-        x[it] = q[0];
-        y[it] = q[1];
-        z[it] = q[2];
-        d[it] = sdf[src[it]];
     }
 #pragma unroll
     for (int it = 0; it < kSortRounds; ++it) {

@@ -173,7 +173,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 4:
+        if lib.sg_abi_version() != 5:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip
@@ -340,16 +340,22 @@ def unregister_param_range(r):
         pass
 
 
-def param_epoch_of(*tensors):
-    """The newest epoch that may have changed any of `tensors` (parameters): the global one, or that of a flat buffer holding it."""
+def param_epoch_of_ptrs(ptrs):
+    """The newest epoch that may have changed any of the parameters at the addresses `ptrs`: the global one, or that of a flat
+    buffer holding one of them."""
     e = PARAM_EPOCH
-    if _PARAM_RANGES:
-        for t in tensors:
-            a = t.data_ptr()
-            for r in _PARAM_RANGES:
-                if r[0] <= a < r[1] and r[2] > e:
+    for r in _PARAM_RANGES:
+        if r[2] > e:
+            lo, hi = r[0], r[1]
+            for a in ptrs:
+                if lo <= a < hi:
                     e = r[2]
+                    break
     return e
+
+
+def param_epoch_of(*tensors):
+    return param_epoch_of_ptrs([t.data_ptr() for t in tensors])
 
 
 # ---- gradient destinations ---------------------------------------------------------------------------------------------

@@ -609,7 +609,8 @@ class _PackCache(object):
 
     def get(self, params, latent, kin_used):
         dev = params[0].device
-        key = (kin_used, latent, L.param_epoch_of(*params)) + tuple((p.data_ptr(), p._version) for p in params)
+        ptrs = [p.data_ptr() for p in params]
+        key = (kin_used, latent, L.param_epoch_of_ptrs(ptrs)) + tuple(ptrs) + tuple(p._version for p in params)
         entry = self.entries.get(dev)
         if entry is None or entry[0] != key:
             lib = _lib()

