@@ -317,7 +317,9 @@ int sg_layernorm_bwd(const float* x, long ldx, const float* rowbias, long rows_p
 size_t sg_colsum_tall_workspace_bytes(long batch, long rows, int cols);
 int sg_colsum_tall(const float* x, float* out, long batch, long batch_stride, long rows, int cols, long ld, void* workspace,
                    size_t workspace_bytes, hipStream_t stream);
-int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, hipStream_t stream);
+size_t sg_segmax_workspace_bytes(long B, long P, int C);   /* scratch of sg_segmax_fwd (0 when it needs none) */
+int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream);
 int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P, int C, hipStream_t stream);
 int sg_segmax_gather(const float* x, const int* idx, float* out, long B, long P, int C, hipStream_t stream);
 /* torch_scatter.scatter_max over a ragged `batch` vector (model/point_sdf_net.py:42-43, train_point_gan_ref.py:109-110):

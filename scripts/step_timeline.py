@@ -1,5 +1,6 @@
-"""Ordered kernel list of the LAST step in a rocprofv3 kernel-trace CSV: a step ends at the last launch of `marker`
-(default: the optimizer kernel), starts after the previous such group.  Prints name, duration, idle gap before."""
+"""Ordered kernel list of one steady-state step (the one of median wall time) in a rocprofv3 kernel-trace CSV: a step ends at the
+last launch of a group of `per_step` launches of `marker` (default: the optimizer kernel) and starts after the previous group.
+Prints name, duration, idle gap before."""
 import csv, re, sys
 path, marker = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "adam_kernel")
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # marker launches per step
@@ -8,8 +9,17 @@ rows.sort()
 ends = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(ends) < 2 * per_step:
     sys.exit("marker %s seen %d times" % (marker, len(ends)))
-last, prev = ends[-1], ends[-1 - per_step]
+# every complete step = the launches between two consecutive groups of `per_step` marker launches; the one printed is the step
+# of MEDIAN wall time among those after the first two (warm-up), so that one slow launch (a clock dip, a page fault) in the last
+# step does not become "the" timeline; min / median / max of all of them are printed with it
+bounds = ends[per_step - 1::per_step]
+steps = [(bounds[k], bounds[k + 1]) for k in range(len(bounds) - 1)]
+cand = steps[2:] if len(steps) > 3 else steps
+walls = sorted((rows[b][1] - rows[a][1], a, b) for a, b in cand)
+_, prev, last = walls[len(walls) // 2]
 step = rows[prev + 1:last + 1]
+summary = "steps timed %d: wall min %.1f / median %.1f / max %.1f us" % (len(walls), walls[0][0] / 1e3, walls[len(walls) // 2][0] / 1e3,
+                                                                            walls[-1][0] / 1e3)
 def short(n):
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"void |sg::|at::native::|rocprim::ROCPRIM_\d+_NS::detail::", "", n)
@@ -22,3 +32,4 @@ for s, e, n in step:
     busy += e - s
     t0 = e
 print("busy %.1f us" % (busy / 1e3))
+print(summary)

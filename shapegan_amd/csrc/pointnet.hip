@@ -105,15 +105,41 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// out[b][j] = sum_i part[b][i][j] over nrows rows (second pass of the two-pass column sums; blockIdx.y = batch)
-__global__ void __launch_bounds__(256) colsum_small_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           int nrows, int cols) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
-    const float* p = part + (long)blockIdx.y * nrows * cols;
-    float s = 0.f;
-    for (int i = 0; i < nrows; ++i) s += p[(long)i * cols + j];
-    out[(long)blockIdx.y * cols + j] = s;
+// out[b][j] = sum_i part[b][i][j] over nrows rows (second pass of the two-pass column sums; blockIdx.y = batch).  One workgroup
+// per 64 columns: 16 waves take 16 contiguous row slices (four independent accumulators each, so four loads are in flight per
+// lane), LDS, one wave adds the 16 slice sums in a fixed order.  (Round 2's version walked all rows in ONE thread per column from
+// one or two workgroups: 1024 dependent adds behind 1024 load latencies = 164 us for a 2 MB table, 17 % of a point-GAN step.)
+// (out1: where batch 1 goes instead of out + cols — the two sums of a LayerNorm backward live in different tensors)
+__global__ void __launch_bounds__(1024) colsum_small_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            float* __restrict__ out1, int nrows, int cols) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const float* p = part + (long)blockIdx.y * nrows * cols + j;
+    const int per = (nrows + 15) / 16;
+    const int i0 = wave * per, i1 = min(nrows, i0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < cols) {
+        int i = i0;
+        for (; i + 3 < i1; i += 4) {
+            a0 += p[(long)i * cols];
+            a1 += p[(long)(i + 1) * cols];
+            a2 += p[(long)(i + 2) * cols];
+            a3 += p[(long)(i + 3) * cols];
+        }
+        for (; i < i1; ++i) a0 += p[(long)i * cols];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && j < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        if (out1 && blockIdx.y == 1)
+            out1[j] = t;
+        else
+            out[(long)blockIdx.y * cols + j] = t;
+    }
 }
 
 // first pass: workgroup g of batch b sums rows g, g + G, ... (4 row lanes x 64-column strips, coalesced) into part[b][g][cols]
@@ -131,6 +157,45 @@ __global__ void __launch_bounds__(256) colsum_tall_kernel(const float* __restric
         red[wave][lane] = s;
         __syncthreads();
         if (wave == 0 && c < cols) pb[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+// the same for cols % 4 == 0, ld % 4 == 0 and 16-byte aligned x: a lane owns 4 adjacent columns (b128 loads, a wave covers 256
+// columns of a row), two rows per step are in flight per lane; the strips of 256 columns are walked one after the other
+__global__ void __launch_bounds__(256) colsum_tall4_kernel(const float* __restrict__ x, float* __restrict__ part, long rows,
+                                                           int cols, long ld, long batch_stride) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (long)blockIdx.y * batch_stride;
+    float* pb = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * cols;
+    const long step = (long)gridDim.x * 4;
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int c = c0 + lane * 4;
+        float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (c < cols) {
+            long r = (long)blockIdx.x * 4 + wave;
+            for (; r + step < rows; r += 2 * step) {
+                const float4 u = *reinterpret_cast<const float4*>(xb + r * ld + c);
+                const float4 v = *reinterpret_cast<const float4*>(xb + (r + step) * ld + c);
+                a.x += u.x, a.y += u.y, a.z += u.z, a.w += u.w;
+                b.x += v.x, b.y += v.y, b.z += v.z, b.w += v.w;
+            }
+            if (r < rows) {
+                const float4 u = *reinterpret_cast<const float4*>(xb + r * ld + c);
+                a.x += u.x, a.y += u.y, a.z += u.z, a.w += u.w;
+            }
+        }
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        red[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && c < cols) {
+            float4 t;
+            t.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+            t.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+            t.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+            t.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+            *reinterpret_cast<float4*>(pb + c) = t;
+        }
         __syncthreads();
     }
 }
@@ -183,6 +248,87 @@ __global__ void __launch_bounds__(256) segmax_fwd_kernel(const float* __restrict
         out[b * C + c] = v;
         idx[b * C + c] = p;
     }
+}
+
+// The same reduction cut into point chunks for the b128 case (C % 4 == 0): workgroup = (256 channels, chunk, shape), a lane owns
+// 4 adjacent channels, the 4 waves take interleaved points of the chunk two at a time (two 16-byte loads in flight per lane),
+// and a second small kernel merges the chunks in ascending order (an earlier chunk wins ties, the first NaN wins): the same
+// result as the kernel above.  That one walks a shape's points in 4 waves per 64 channels — 48 workgroups and 8192 dependent
+// 4-byte loads per lane at 6 x 32768 points: 1.5 - 3.7 ms per call, 16 % of a point-GAN step, for a 400 MB read.
+constexpr int kSegNone = 0x7fffffff;
+__device__ __forceinline__ void seg_upd(float& best, int& bp, float v, int p) {
+    if (best == best && (v != v || v > best || bp == kSegNone)) {
+        best = v;
+        bp = p;
+    }
+}
+// does (u, q) beat (v, p)?  q / p are point indices (kSegNone: empty)
+__device__ __forceinline__ bool seg_beats(float u, int q, float v, int p) {
+    if (q == kSegNone) return false;
+    const bool vn = v != v, un = u != u;
+    return p == kSegNone || (un && (!vn || q < p)) || (!vn && !un && (u > v || (u == v && q < p)));
+}
+__global__ void __launch_bounds__(256) segmax_part_kernel(const float* __restrict__ x, float* __restrict__ pv,
+                                                          int* __restrict__ pi, long P, int C, int nchunk) {
+    __shared__ float4 bv[4][64];
+    __shared__ int4 bi[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int chunk = blockIdx.y;
+    const long b = blockIdx.z;
+    const long per = (P + nchunk - 1) / nchunk;
+    const long p0 = chunk * per, p1 = min(P, p0 + per);
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bp[4] = {kSegNone, kSegNone, kSegNone, kSegNone};
+    if (c < C) {
+        const float* xb = x + b * P * C + c;
+        long p = p0 + wave;
+        for (; p + 4 < p1; p += 8) {
+            const float4 u = *reinterpret_cast<const float4*>(xb + p * C);
+            const float4 v = *reinterpret_cast<const float4*>(xb + (p + 4) * C);
+            seg_upd(best[0], bp[0], u.x, (int)p), seg_upd(best[1], bp[1], u.y, (int)p);
+            seg_upd(best[2], bp[2], u.z, (int)p), seg_upd(best[3], bp[3], u.w, (int)p);
+            seg_upd(best[0], bp[0], v.x, (int)p + 4), seg_upd(best[1], bp[1], v.y, (int)p + 4);
+            seg_upd(best[2], bp[2], v.z, (int)p + 4), seg_upd(best[3], bp[3], v.w, (int)p + 4);
+        }
+        if (p < p1) {
+            const float4 u = *reinterpret_cast<const float4*>(xb + p * C);
+            seg_upd(best[0], bp[0], u.x, (int)p), seg_upd(best[1], bp[1], u.y, (int)p);
+            seg_upd(best[2], bp[2], u.z, (int)p), seg_upd(best[3], bp[3], u.w, (int)p);
+        }
+    }
+    bv[wave][lane] = make_float4(best[0], best[1], best[2], best[3]);
+    bi[wave][lane] = make_int4(bp[0], bp[1], bp[2], bp[3]);
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 u = bv[w][lane];
+            const int4 q = bi[w][lane];
+            if (seg_beats(u.x, q.x, best[0], bp[0])) best[0] = u.x, bp[0] = q.x;
+            if (seg_beats(u.y, q.y, best[1], bp[1])) best[1] = u.y, bp[1] = q.y;
+            if (seg_beats(u.z, q.z, best[2], bp[2])) best[2] = u.z, bp[2] = q.z;
+            if (seg_beats(u.w, q.w, best[3], bp[3])) best[3] = u.w, bp[3] = q.w;
+        }
+        const long o = (b * nchunk + chunk) * C + c;
+        *reinterpret_cast<float4*>(pv + o) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<int4*>(pi + o) = make_int4(bp[0], bp[1], bp[2], bp[3]);
+    }
+}
+__global__ void __launch_bounds__(256) segmax_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                           float* __restrict__ out, int* __restrict__ idx, int nchunk, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const long b = blockIdx.y;
+    if (c >= C) return;
+    float v = -INFINITY;
+    int p = kSegNone;
+    for (int k = 0; k < nchunk; ++k) {
+        const float u = pv[(b * nchunk + k) * C + c];
+        const int q = pi[(b * nchunk + k) * C + c];
+        if (seg_beats(u, q, v, p)) v = u, p = q;
+    }
+    out[b * C + c] = v;
+    idx[b * C + c] = p;
 }
 
 // dx[b][p][c] = (p == idx[b][c]) ? dy[b][c] : 0   (adjoint of the max; every element written)
@@ -244,8 +390,8 @@ int sg_layernorm_bwd(const float* x, long ldx, const float* rowbias, long rows_p
     float* part = (float*)workspace;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape, gamma, y, ldy,
                        dy, lddy, mean, rstd, dz, lddz, part, R, C, act);
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(C, 256), 1), dim3(256), 0, stream, part, dgamma, nb, C);
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(C, 256), 1), dim3(256), 0, stream, part + (long)nb * C, dbeta, nb, C);
+    // part is [2][nb][C]: both sums in one launch (blockIdx.y = which)
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(C, 64), 2), dim3(1024), 0, stream, part, dgamma, dbeta, nb, C);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -264,17 +410,50 @@ int sg_colsum_tall(const float* x, float* out, long batch, long batch_stride, lo
     if (!workspace || workspace_bytes < sg_colsum_tall_workspace_bytes(batch, rows, cols))
         SG_FAIL(SG_ERR_WORKSPACE, "sg_colsum_tall: workspace too small");
     const int nb = colsum_blocks(rows);
-    hipLaunchKernelGGL(colsum_tall_kernel, dim3(nb, (unsigned)batch), dim3(256), 0, stream, x, (float*)workspace, rows, cols,
-                       ld, batch_stride);
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(cols, 256), (unsigned)batch), dim3(256), 0, stream,
-                       (const float*)workspace, out, nb, cols);
+    if (cols % 4 == 0 && ld % 4 == 0 && batch_stride % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(colsum_tall4_kernel, dim3(nb, (unsigned)batch), dim3(256), 0, stream, x, (float*)workspace, rows, cols,
+                           ld, batch_stride);
+    else
+        hipLaunchKernelGGL(colsum_tall_kernel, dim3(nb, (unsigned)batch), dim3(256), 0, stream, x, (float*)workspace, rows, cols,
+                           ld, batch_stride);
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(cols, 64), (unsigned)batch), dim3(1024), 0, stream,
+                       (const float*)workspace, out, (float*)nullptr, nb, cols);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
 
-int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, hipStream_t stream) {
+// point chunks of the two-stage form: enough of them for >= 1024 workgroups, at least 64 points each, at most 64
+static int segmax_chunks(long B, long P, int C) {
+    if (C % 4 != 0) return 1;
+    const long base = B * sg_cdiv(C, 256);
+    long n = (1024 + base - 1) / base;
+    if (n > P / 64) n = P / 64;
+    if (n > 64) n = 64;
+    return n < 1 ? 1 : (int)n;
+}
+size_t sg_segmax_workspace_bytes(long B, long P, int C) {
+    const int n = segmax_chunks(B, P, C);
+    return n > 1 ? (size_t)B * n * C * 8 : 0;
+}
+
+int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream) {
     SG_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && P > 0 && P < 0x7fffffff && C > 0);
-    hipLaunchKernelGGL(segmax_fwd_kernel, dim3(sg_cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, x, out, idx, P, C);
+    const int nchunk = segmax_chunks(B, P, C);
+    if (C % 4 != 0 || ((uintptr_t)x & 15) != 0 || ((uintptr_t)out & 15) != 0 || ((uintptr_t)idx & 15) != 0) {
+        hipLaunchKernelGGL(segmax_fwd_kernel, dim3(sg_cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, x, out, idx, P, C);
+    } else if (nchunk == 1) {
+        hipLaunchKernelGGL(segmax_part_kernel, dim3(sg_cdiv(C, 256), 1, (unsigned)B), dim3(256), 0, stream, x, out, idx, P, C, 1);
+    } else {
+        if (!workspace || workspace_bytes < sg_segmax_workspace_bytes(B, P, C) || ((uintptr_t)workspace & 15) != 0)
+            SG_FAIL(SG_ERR_WORKSPACE, "sg_segmax_fwd: workspace too small or not 16-byte aligned");
+        float* pv = (float*)workspace;
+        int* pi = (int*)(pv + (size_t)B * nchunk * C);
+        hipLaunchKernelGGL(segmax_part_kernel, dim3(sg_cdiv(C, 256), nchunk, (unsigned)B), dim3(256), 0, stream, x, pv, pi, P, C,
+                           nchunk);
+        hipLaunchKernelGGL(segmax_merge_kernel, dim3(sg_cdiv(C, 256), (unsigned)B), dim3(256), 0, stream, pv, pi, out, idx, nchunk,
+                           C);
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

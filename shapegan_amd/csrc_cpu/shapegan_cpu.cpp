@@ -989,7 +989,7 @@ int sg_layernorm_bwd_cpu(const float* x, long ldx, const float* rowbias, long ro
     }
     return SG_OK;
 }
-int sg_segmax_fwd_cpu(const float* x, float* out, int* idx, long B, long P, int C, void*) {
+int sg_segmax_fwd_cpu(const float* x, float* out, int* idx, long B, long P, int C, void*, size_t, void*) {
     CPU_CHECK(x && out && idx && B > 0 && P > 0 && C > 0);
     for (long b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c) {

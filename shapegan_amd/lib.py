@@ -84,7 +84,8 @@ SIGNATURES = {
     "sg_layernorm_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P, _Z, _P]),
     "sg_colsum_tall_workspace_bytes": (_Z, [_L, _L, _I]),
     "sg_colsum_tall": (c_int, [_P, _P, _L, _L, _L, _I, _L, _P, _Z, _P]),
-    "sg_segmax_fwd": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "sg_segmax_workspace_bytes": (_Z, [_L, _L, _I]),
+    "sg_segmax_fwd": (c_int, [_P, _P, _P, _L, _L, _I, _P, _Z, _P]),
     "sg_segmax_scatter": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "sg_segmax_gather": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "sg_loss_workspace_bytes": (_Z, []),

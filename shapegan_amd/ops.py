@@ -1107,7 +1107,11 @@ class SegMax(Function):
         B, P, C = x.shape
         out = torch.empty((B, C), dtype=torch.float32, device=x.device)
         idx = torch.empty((B, C), dtype=torch.int32, device=x.device)
-        check(_lib().sg_segmax_fwd(ptr(x), ptr(out), ptr(idx), B, P, C, stream()), "segmax_fwd")
+        lib = _lib()
+        nb = lib.sg_segmax_workspace_bytes(B, P, C)
+        ws = workspace("segmax", nb, x.device) if nb else None
+        check(lib.sg_segmax_fwd(ptr(x), ptr(out), ptr(idx), B, P, C, ptr(ws), ws.numel() if ws is not None else 0, stream()),
+              "segmax_fwd")
         ctx.P = P
         ctx.save_for_backward(idx)
         ctx.mark_non_differentiable(idx)

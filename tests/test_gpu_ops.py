@@ -696,7 +696,8 @@ def test_layernorm_act(R, C, rps, tail, act):
         assert err < 2e-5, (name, err)
 
 
-@pytest.mark.parametrize("B,P,C", [(3, 50, 512), (1, 1, 7), (2, 1000, 130), (6, 32768, 512)])
+@pytest.mark.parametrize("B,P,C", [(3, 50, 512), (1, 1, 7), (2, 1000, 130), (6, 32768, 512), (32, 1024, 512), (4, 200, 64),
+                                   (2, 130, 260), (1, 4097, 8)])
 def test_segmax_and_adjoints(B, P, C):
     """max over points == torch.max(dim=-2) bit for bit (values AND first-occurrence indices, ties included); scatter
     and gather are each other's adjoints; double backward through the pair works."""
@@ -729,12 +730,41 @@ def test_segmax_and_adjoints(B, P, C):
     assert torch.equal(g, ops.SegMaxGather.apply(u, idx))
 
 
+@pytest.mark.parametrize("B,P,C", [(3, 50, 512), (6, 32768, 512), (4, 200, 64), (2, 1000, 130)])
+def test_segmax_nan_and_inf_follow_torch_max(B, P, C):
+    """torch.max semantics on special values, in the one-pass kernel and in the chunked two-stage form alike: a NaN wins and
+    the FIRST NaN's index is reported; -inf columns report index 0; +inf ties report the first."""
+    from shapegan_amd import ops
+    torch.manual_seed(B + P + C)
+    x = torch.randn(B, P, C)
+    x[:, :, 1] = float("-inf")
+    x[0, P // 2, 2] = float("inf")
+    x[0, P - 1, 2] = float("inf")
+    x[B - 1, P - 1, 3] = float("nan")                      # last point of the last chunk
+    x[0, min(P - 1, 70), 5] = float("nan")
+    x[0, min(P - 1, 7), 5] = float("nan")                  # an earlier NaN in the same column: this one is reported
+    want_v, want_i = x.max(dim=-2)
+    out, idx = ops.SegMax.apply(x.to(DEV))
+    out, idx = out.cpu(), idx.cpu().long()
+    assert torch.equal(torch.isnan(out), torch.isnan(want_v))
+    assert torch.equal(out[~torch.isnan(out)], want_v[~torch.isnan(want_v)])
+    assert idx[0, 5] == min(P - 1, 7) and idx[B - 1, 3] == P - 1
+    assert int(idx[0, 1]) == 0 and int(idx[0, 2]) == P // 2
+    finite = torch.isfinite(want_v)
+    first = (x == want_v.unsqueeze(1)).float().argmax(dim=1)
+    assert torch.equal(idx[finite], first[finite])
+
+
 def test_colsum_tall():
     from shapegan_amd import ops
     torch.manual_seed(5)
     x = torch.randn(5, 3000, 70, device=DEV)
     got = ops.colsum_tall_raw(x, 5, 3000 * 70, 3000, 70, 70)
     np.testing.assert_allclose(got.cpu().numpy(), x.double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    for batch, rows, cols, ld in ((3, 4099, 512, 516), (1, 7, 256, 256), (2, 131072, 64, 64)):      # the b128 form
+        y = torch.randn(batch, rows, ld, device=DEV)
+        got = ops.colsum_tall_raw(y, batch, rows * ld, rows, cols, ld)
+        np.testing.assert_allclose(got.cpu().numpy(), y[:, :, :cols].double().sum(1).cpu().numpy(), rtol=1e-5, atol=3e-3)
     g = torch.randn(100000, 256, device=DEV, requires_grad=True)
     s = ops.ColSum.apply(g)
     np.testing.assert_allclose(s.detach().cpu().numpy(), g.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
