@@ -331,6 +331,36 @@ def test_parameter_epochs_are_per_optimizer_buffer():
     assert all(r[0] != a.data_ptr() for r in L._PARAM_RANGES)
 
 
+def test_kept_weight_images_follow_object_version_epoch_and_shape():
+    """ops._KeptWeightImages (the host side of sg_conv3d_k4s2p1_dgrad_keep): an image is reused only for the same tensor object at
+    the same version / parameter epoch / shapes; at most `cap` weights are remembered.  (The GPU tier checks the results.)"""
+    import torch
+    from shapegan_amd import ops, optim
+    kept = ops._KeptWeightImages(cap=3)
+    w = torch.nn.Parameter(torch.randn(8, 4, 4, 4, 4))
+    ws, unchanged = kept.get(w, 1000, (2, 4))
+    assert not unchanged and ws.numel() >= 1000
+    ws2, unchanged = kept.get(w, 1000, (2, 4))
+    assert unchanged and ws2 is ws
+    assert kept.get(w, 1000, (3, 4))[1] is False          # other shapes
+    assert kept.get(w, 1000, (3, 4))[1] is True
+    with torch.no_grad():
+        w.mul_(2.0)                                       # tensor version
+    assert kept.get(w, 1000, (3, 4))[1] is False
+    opt = optim.RMSprop([w], lr=0.1)                      # re-points w.data into a flat buffer: another address
+    assert kept.get(w, 1000, (3, 4))[1] is False
+    assert kept.get(w, 1000, (3, 4))[1] is True
+    L.bump_param_epoch(opt.f.range)                       # what opt.step() does
+    assert kept.get(w, 1000, (3, 4))[1] is False
+    assert kept.get(w, 5000, (3, 4))[1] is False          # a larger workspace is a new buffer
+    L.bump_param_epoch()                                  # graph replay / load_state_dict / clip_weights
+    assert kept.get(w, 5000, (3, 4))[1] is False
+    others = [torch.nn.Parameter(torch.randn(4)) for _ in range(3)]
+    for o in others:
+        kept.get(o, 100, ())
+    assert len(kept.entries) == 3 and kept.get(w, 5000, (3, 4))[1] is False      # w was the oldest: dropped
+
+
 def test_wgrad_act_path_is_refused_outside_its_limits(monkeypatch):
     """ConvFwd.backward takes the fused weight-gradient + activation-backward kernel only when
     sg_conv3d_k4s2p1_wgrad_act will really serve the call — the shape is eligible (incl. the 32-bit buffer ranges the kernel
