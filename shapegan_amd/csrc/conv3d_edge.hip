@@ -583,45 +583,67 @@ struct ConvTFusedArgs {
 constexpr int kFusedTapStride = 260;                    // floats per tap row in LDS (256 positions + 4: b128 writes of 16 taps hit 64 banks)
 constexpr int kFusedGroup = 16 * kFusedTapStride;       // one kd group
 
-template <bool ALLCH>   // ALLCH: Cout == 64 (no channel masks)
-__global__ void __launch_bounds__(512, (ALLCH ? 4 : 2)) convT_c1_fused_kernel(ConvTFusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float S[];   // [kd][kh*4+kw][kFusedTapStride]
+// Round 3, second form.  The first form asked for 96 loads per lane "up front", but with the weight fragments in 64 registers
+// the compiler (128-register budget of two workgroups per CU) re-serialised them: 8 loads in flight, one more per MFMA — every
+// MFMA waited for memory (ISA listing: buffer_load / s_waitcnt / v_mfma triples).  Here
+//   * the weights live in LDS ([64 channels][kFusedWStride], zero rows beyond Cout: no masks, no clamps on the B side) and every
+//     MFMA reads its B fragment from there: the 96 load destinations + accumulators fit the budget, so ALL loads of the workgroup
+//     are in flight before the first MFMA (a sched_barrier keeps them there);
+//   * the neighbour planes come first (their loads are issued first): their two tap groups go to LDS, are gathered into the output
+//     registers, and the same 33 KB then take the plane's own two groups — 53 KB of LDS instead of 66, and the plane's 32 loads
+//     are still landing while the neighbour planes compute.
+constexpr int kFusedWStride = 80;   // floats per channel row of the LDS weight image: the four channel rows a 16x16x4 B fragment
+                                    // reads (kq) fall into four disjoint quarters of the 64 banks
+template <bool ALLCH>   // ALLCH: Cout == 64 (no channel clamps on the loads)
+__global__ void __launch_bounds__(512, 4) convT_c1_fused_kernel(ConvTFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [2 slots][16 taps][kFusedTapStride] | weights [64][kFusedWStride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kh2 = lane >> 5;     // 32x32x2 fragments
     const int i16 = lane & 15, kq = lane >> 4;    // 16x16x4 fragments
     // XCD-aware decode: workgroup b runs on XCD b % 8; all planes of a sample stay on one XCD, neighbours in dispatch order
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int n = (j / a.OD) * 8 + xcd, qd = j % a.OD;
-    if (n >= a.batch) return;
-    const int P2 = a.P2, npt = (P2 + 31) >> 5;
+    if (n >= a.batch) return;     // (the whole workgroup)
+    const int P2 = a.P2, npt = (P2 + 31) >> 5;    // <= 8 position tiles: one per wave
     const bool has_prev = qd > 0, has_next = qd + 1 < a.OD;
+    const bool active = wave < npt;
+    const int tp = wave;
+    lds_float* const Sl = (lds_float*)S;
+    lds_float* const Wl = Sl + 2 * kFusedGroup;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-    // weights as B fragments: wA[s] = W[co = 2s + kh2][tap 16 + r] (kd 1 | kd 2), wB3 / wB0[s] = W[co = 4s + kq][48 + i16] / [i16]
-    float wA[32], wB3[16], wB0[16];
+    // ---- every load of this workgroup: the weight image (64 x 64 floats, rows beyond Cout zero; coalesced rows, all eight
+    // loads of a thread issued together), then the neighbour planes, then the plane ----
+    float wv[8];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const int co = 2 * s + kh2, coc = co < a.Cout ? co : a.Cout - 1;
-        wA[s] = (ALLCH || co < a.Cout ? 1.f : 0.f) * a.w[(long)coc * a.Cin_total * 64 + 16 + r];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int co = 4 * s + kq, coc = co < a.Cout ? co : a.Cout - 1;
-        const float keep = ALLCH || co < a.Cout ? 1.f : 0.f;
-        wB3[s] = keep * a.w[(long)coc * a.Cin_total * 64 + 48 + i16];
-        wB0[s] = keep * a.w[(long)coc * a.Cin_total * 64 + i16];
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 512 * k, co = e >> 6, tap = e & 63;
+        wv[k] = co < a.Cout ? a.w[(long)co * a.Cin_total * 64 + tap] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy + (long)n * a.Cy * a.OD * P2);
     const unsigned chan = (unsigned)(a.OD * P2) * 4u;     // bytes between channels of a sample
-    lds_float* const Sl = (lds_float*)S;
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-    for (int tp = wave; tp < npt; tp += 8) {   // 8 waves: one 32-position tile each at 16 x 16
-        // ---- all loads of this position tile first (96 in flight per lane) ----
+    float bv[2][2][16];   // [plane: prev / next][16-position half][k step]
+    float av[32];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const bool have = active && (pl == 0 ? has_prev : has_next);
+        const int plane = pl == 0 ? qd - 1 : qd + 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pB = tp * 32 + h * 16 + i16;
+            const unsigned offB = (have && pB < P2) ? (unsigned)((long)plane * P2 + pB) * 4u : kBufOutside;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (ALLCH)
+                    bv[pl][h][s] = buf_load(dres, offB + (unsigned)kq * chan, (unsigned)(4 * s) * chan);
+                else   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight row is zero
+                    bv[pl][h][s] = buf_load(dres, offB + (unsigned)min(4 * s + kq, a.Cout - 1) * chan, 0u);
+            }
+        }
+    }
+    {
         const int pA = tp * 32 + r;
-        // channels beyond Cout (ALLCH == false): the lane reads channel Cout-1 instead — its weight fragment is zero — so that no
-        // per-load masks (32 + 64 SGPR pairs, spilled) are needed
-        const unsigned offA = pA < P2 ? (unsigned)((long)qd * P2 + pA) * 4u : kBufOutside;
-        float av[32];
+        const unsigned offA = (active && pA < P2) ? (unsigned)((long)qd * P2 + pA) * 4u : kBufOutside;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             if (ALLCH)
@@ -629,69 +651,23 @@ __global__ void __launch_bounds__(512, (ALLCH ? 4 : 2)) convT_c1_fused_kernel(Co
             else
                 av[s] = buf_load(dres, offA + (unsigned)min(2 * s + kh2, a.Cout - 1) * chan, 0u);
         }
-        float bv[2][2][16];   // [plane: prev / next][16-position half][k step]
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const bool have = pl == 0 ? has_prev : has_next;
-            const int plane = pl == 0 ? qd - 1 : qd + 1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pB = tp * 32 + h * 16 + i16;
-                const unsigned offB = (have && pB < P2) ? (unsigned)((long)plane * P2 + pB) * 4u : kBufOutside;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (ALLCH)
-                        bv[pl][h][s] = buf_load(dres, offB + (unsigned)kq * chan, (unsigned)(4 * s) * chan);
-                    else
-                        bv[pl][h][s] = buf_load(dres, offB + (unsigned)min(4 * s + kq, a.Cout - 1) * chan, 0u);
-                }
-            }
-        }
-        // ---- plane qd: [32 positions] x [kd 1 | kd 2] ----
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wA[s], acc, 0, 0, 0);
-        {
-            // column r = tap: group kd = 1 + (r >> 4), tap row r & 15; rows of the fragment = positions 8c + 4 kh2 + (0..3)
-            lds_float* dst = Sl + (1 + (r >> 4)) * kFusedGroup + (r & 15) * kFusedTapStride + tp * 32 + 4 * kh2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4v v = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                *(__attribute__((address_space(3))) f32x4v*)(dst + 8 * c) = v;
-            }
-        }
-        // ---- planes qd-1 (kd 3) and qd+1 (kd 0): [16 positions] x [16 taps], K = 4 channels per step ----
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const bool have = pl == 0 ? has_prev : has_next;
-            if (!have) continue;     // (workgroup-uniform)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4v c4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[pl][h][s], pl == 0 ? wB3[s] : wB0[s], c4, 0, 0, 0);
-                // column i16 = tap row, fragment rows 4 kq + (0..3) = positions
-                lds_float* dst = Sl + (pl == 0 ? 3 : 0) * kFusedGroup + i16 * kFusedTapStride + tp * 32 + h * 16 + 4 * kq;
-                *(__attribute__((address_space(3))) f32x4v*)dst = c4;
-            }
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 512 * k;
+        Wl[(e >> 6) * kFusedWStride + (e & 63)] = wv[k];
     }
     __syncthreads();
-    // ---- gather: thread = (q position of the plane, output d-parity), its 2 x 2 outputs take 8 taps each ----
+
+    // gather of one slot pair into the thread's 2 x 2 outputs: thread = (q position of the plane, output d-parity pd); slot pd
+    // holds the tap group this parity takes in the current phase
     const int qi = tid & 255, pd = tid >> 8;
-    if (qi < P2) {
-        const int qh = qi / a.OW, qw = qi - qh * a.OW;
-        float o[2][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) (&o[0][0])[i] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            // d-parity 0 takes kd 1 (plane qd) and kd 3 (plane qd-1), d-parity 1 takes kd 2 (plane qd) and kd 0 (plane qd+1)
-            const int kd = pd == 0 ? (t == 0 ? 1 : 3) : (t == 0 ? 2 : 0);
-            if ((kd == 0 && !has_next) || (kd == 3 && !has_prev)) continue;
+    const int qh = qi / a.OW, qw = qi - qh * a.OW;
+    float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    auto gather = [&](bool have) {
+        if (qi < P2 && have) {
+            const lds_float* G = Sl + pd * kFusedGroup;
 #pragma unroll
             for (int kh = 0; kh < 4; ++kh) {
                 const int ph = (kh & 1) ? 0 : 1, dh = (kh == 0) ? 1 : (kh == 3 ? -1 : 0);
@@ -702,10 +678,54 @@ __global__ void __launch_bounds__(512, (ALLCH ? 4 : 2)) convT_c1_fused_kernel(Co
                     const int pw = (kw & 1) ? 0 : 1, dw_ = (kw == 0) ? 1 : (kw == 3 ? -1 : 0);
                     const int ow = qw + dw_;
                     if ((unsigned)ow >= (unsigned)a.OW) continue;
-                    o[ph][pw] += Sl[kd * kFusedGroup + (kh * 4 + kw) * kFusedTapStride + oh * a.OW + ow];
+                    o[ph][pw] += G[(kh * 4 + kw) * kFusedTapStride + oh * a.OW + ow];
                 }
             }
         }
+    };
+
+    // ---- planes qd-1 (kd 3 -> slot 0) and qd+1 (kd 0 -> slot 1): [16 positions] x [16 taps], K = 4 channels per step ----
+    if (active) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const bool have = pl == 0 ? has_prev : has_next;
+            if (!have) continue;     // (workgroup-uniform)
+            const lds_float* wb = Wl + kq * kFusedWStride + (pl == 0 ? 48 : 0) + i16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4v c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[pl][h][s], wb[4 * s * kFusedWStride], c4, 0, 0, 0);
+                // column i16 = tap row, fragment rows 4 kq + (0..3) = positions
+                lds_float* dst = Sl + pl * kFusedGroup + i16 * kFusedTapStride + tp * 32 + h * 16 + 4 * kq;
+                *(__attribute__((address_space(3))) f32x4v*)dst = c4;
+            }
+        }
+    }
+    __syncthreads();
+    // d-parity 0 takes kd 3 of plane qd-1, d-parity 1 takes kd 0 of plane qd+1
+    gather(pd == 0 ? has_prev : has_next);
+    __syncthreads();
+    // ---- plane qd: [32 positions] x [kd 1 (slot 0) | kd 2 (slot 1)] ----
+    if (active) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        const lds_float* wa = Wl + kh2 * kFusedWStride + 16 + r;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wa[2 * s * kFusedWStride], acc, 0, 0, 0);
+        // column r = tap: slot r >> 4, tap row r & 15; rows of the fragment = positions 8c + 4 kh2 + (0..3)
+        lds_float* dst = Sl + (r >> 4) * kFusedGroup + (r & 15) * kFusedTapStride + tp * 32 + 4 * kh2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4v v = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+            *(__attribute__((address_space(3))) f32x4v*)(dst + 8 * c) = v;
+        }
+    }
+    __syncthreads();
+    gather(true);     // d-parity 0: kd 1, d-parity 1: kd 2
+    if (qi < P2) {
         const float b0 = a.bias ? a.bias[0] : 0.f;
         const int IH = 2 * a.OH, IW = 2 * a.OW;
         float* out = a.dx + (long)n * a.dx_sample;
@@ -861,7 +881,7 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
         f.batch = batch;
         f.act = act;
         f.slope = slope;
-        const size_t lds = (size_t)4 * kFusedGroup * sizeof(float);
+        const size_t lds = (size_t)(2 * kFusedGroup + 64 * kFusedWStride) * sizeof(float);
         static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
         if (attr_once.begin()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_fused_kernel<true>),
