@@ -288,8 +288,11 @@ struct EdgeWgradArgs {
 // read from the sign of the activated output as sg_act_bwd does — and the bias gradient (channel sums of dz) comes out of the same
 // pass.  For the critic's first layer, whose input needs no gradient, dz then never exists in memory: the separate activation
 // backward (read dy + y, write dz: 402 MB at 128 x 64 x 16^3) and this kernel's read of dz become one read of dy + y.
+#ifndef SG_WGRAD_C1_WAVES
+#define SG_WGRAD_C1_WAVES 1   // (A/B: waves per SIMD the register allocation must admit)
+#endif
 template <int MT, int FUSE>
-__global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
+__global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(EdgeWgradArgs a) {
     constexpr int kLd = 36;                       // floats per staged row
     constexpr int kStage = MT * 32 * kLd;         // floats per wave
     __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // staging (<= 4 x 2304 floats), then the cross-wave sum
