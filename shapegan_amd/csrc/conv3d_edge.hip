@@ -332,9 +332,15 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
     float rs[MT * 4];     // FUSE: running sums of dz over this lane's pieces (channel i*8 + crow)
 #pragma unroll
     for (int i = 0; i < MT * 4; ++i) rs[i] = 0.f;
-    float bv[2][16];
-    auto issue = [&](int ps) __attribute__((always_inline)) {
-        uint32_t n, pp, seg, q1, od, oh;
+    float bv[2][16];      // the patch operand: 16 positions of this lane's two taps
+    // The dy / y pieces of the next pass are requested before the MFMA block and land in cv / yv (which the staging copy has
+    // just freed); the patch values of the next pass are requested INSIDE the block, each right behind the MFMA group that read
+    // its register last, and the A fragments are read from the staging tile one 4-position group ahead.  (The first version
+    // kept a second copy of the patch operand and all 32 A-fragment registers across the block: 290 registers with FUSE = one
+    // wave per SIMD; a register cap instead of this restructuring spilled 56 of them and took 115 instead of 76 us.)
+    unsigned xo[2], xl[2], xr[2];     // next pass's patch offsets: middle positions, first (left edge), last (right edge)
+    auto issue_dy = [&](int ps) __attribute__((always_inline)) {
+        uint32_t n, pp;
         a.dpps.divmod((uint32_t)ps, n, pp);
         const unsigned dbase = (unsigned)((long)n * a.Cy * O3 + pp * 32 + ccol) * 4u;
 #pragma unroll
@@ -343,27 +349,36 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
             cv[i] = buf_load4v(dres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
             if (FUSE) yv[i] = buf_load4v(yres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
         }
+    };
+    auto plan_x = [&](int ps, bool valid) __attribute__((always_inline)) {
+        uint32_t n, pp, seg, q1, od, oh;
+        a.dpps.divmod((uint32_t)ps, n, pp);
         const uint32_t p0 = pp * 32 + 16 * kh2;   // this lane half's 16 positions: one row segment (od, oh, ow0 .. ow0+15)
         a.dOW16.divmod(p0 >> 4, q1, seg);
         a.dOH.divmod(q1, od, oh);
         const unsigned xbase = (unsigned)((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * oh) * a.IW + 32 * seg) * 4u;
-        const bool hout = (lkh == 0 && oh == 0) || (lkh == 3 && (int)oh == a.OH - 1);
+        const bool hout = !valid || (lkh == 0 && oh == 0) || (lkh == 3 && (int)oh == a.OH - 1);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int kd = 2 * nt + lkd0;
             const bool out = hout || (kd == 0 && od == 0) || (kd == 3 && (int)od == a.OD - 1);
-            const unsigned off = out ? kBufOutside : xbase + tapoff[nt];
+            xo[nt] = out ? kBufOutside : xbase + tapoff[nt];
             // w = 2 (16 seg + j) + kw - 1: left of the row for (kw 0, first position), right of it for (kw 3, last position)
-            const unsigned offl = (lkw == 0 && seg == 0) ? kBufOutside : off;
-            const unsigned offr = (lkw == 3 && (int)seg == nseg - 1) ? kBufOutside : off;
-            bv[nt][0] = buf_load(xres, offl, 0u);
-#pragma unroll
-            for (int j = 1; j < 15; ++j) bv[nt][j] = buf_load(xres, off, 8u * j);
-            bv[nt][15] = buf_load(xres, offr, 8u * 15);
+            xl[nt] = (lkw == 0 && seg == 0) ? kBufOutside : xo[nt];
+            xr[nt] = (lkw == 3 && (int)seg == nseg - 1) ? kBufOutside : xo[nt];
         }
     };
+    auto load_x = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bv[nt][j] = buf_load(xres, j == 0 ? xl[nt] : (j == 15 ? xr[nt] : xo[nt]), 8u * j);
+    };
     int ps = blockIdx.x * 4 + wave;
-    if (ps < a.total_passes) issue(ps);
+    if (ps < a.total_passes) {
+        issue_dy(ps);
+        plan_x(ps, true);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) load_x(j);
+    }
     for (; ps < a.total_passes; ps += nwaves) {
         if (FUSE) {
             const float neg = FUSE == SG_ACT_LEAKY ? a.slope : 0.f;
@@ -376,25 +391,33 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
         }
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(stage + (i * 8 + crow) * kLd + ccol) = cv[i];
-        float bc[2][16];
+        const bool more = ps + nwaves < a.total_passes;
+        if (more) issue_dy(ps + nwaves);          // next pass's dy / y fly during the MFMAs
+        plan_x(more ? ps + nwaves : ps, more);    // (no next pass: every offset out of range, the loads below fetch nothing)
+        f32x4 avc[MT], avn[MT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bc[nt][j] = bv[nt][j];
-        f32x4 av[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) av[mt][c] = *reinterpret_cast<const f32x4*>(stage + (mt * 32 + r) * kLd + 16 * kh2 + 4 * c);
-        if (ps + nwaves < a.total_passes) issue(ps + nwaves);   // next pass's global loads fly during the MFMAs
+        for (int mt = 0; mt < MT; ++mt) avc[mt] = *reinterpret_cast<const f32x4*>(stage + (mt * 32 + r) * kLd + 16 * kh2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
+                    avn[mt] = *reinterpret_cast<const f32x4*>(stage + (mt * 32 + r) * kLd + 16 * kh2 + 4 * (c + 1));
+            }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j >> 2][j & 3], bc[nt][j], acc[mt][nt], 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * c + jj;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[mt][jj], bv[nt][j], acc[mt][nt], 0, 0, 0);
+                load_x(j);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) avc[mt] = avn[mt];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     // cross-wave sum in a fixed order, then one partial tile per workgroup
