@@ -105,6 +105,148 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// ---- the same two kernels for rows that are 16-byte addressable (C, ldx, ldy ... multiples of 4, aligned bases): a lane owns
+// 4 ADJACENT channels per 256-channel group (b128 loads / stores: one instruction per row and tensor where the kernels above
+// issue four), statistics and formulas unchanged.  NQ = groups of 256 channels (C <= 512).
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <int NQ>
+__global__ void __launch_bounds__(256) layernorm_fwd4_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ rowbias, long rows_per_shape,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, long R, int C, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    float4 gm[NQ], bt[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = (q * 64 + lane) * 4;
+        gm[q] = c < C ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[q] = c < C ? ld4(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+        const float* xr = x + r * ldx;
+        const float* zb = rowbias ? rowbias + (r / rows_per_shape) * C : nullptr;
+        float4 v[NQ];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                v[q] = ld4(xr + c);
+                if (zb) {
+                    const float4 z = ld4(zb + c);
+                    v[q].x += z.x, v[q].y += z.y, v[q].z += z.z, v[q].w += z.w;
+                }
+            }
+            s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        }
+        const float mu = sg_wave_sum(s) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            if (c < C) {
+                const float a = v[q].x - mu, b = v[q].y - mu, cc = v[q].z - mu, d = v[q].w - mu;
+                sq += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rs = rsqrtf(sg_wave_sum(sq) / (float)C + eps);
+        float* yr = y + r * ldy;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            if (c < C) {
+                float4 o;
+                o.x = sg_apply_act((v[q].x - mu) * rs * gm[q].x + bt[q].x, act, 0.f);
+                o.y = sg_apply_act((v[q].y - mu) * rs * gm[q].y + bt[q].y, act, 0.f);
+                o.z = sg_apply_act((v[q].z - mu) * rs * gm[q].z + bt[q].z, act, 0.f);
+                o.w = sg_apply_act((v[q].w - mu) * rs * gm[q].w + bt[q].w, act, 0.f);
+                *reinterpret_cast<float4*>(yr + c) = o;
+            }
+        }
+        if (lane == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) layernorm_bwd4_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ rowbias, long rows_per_shape,
+                                                             const float* __restrict__ gamma, const float* __restrict__ y,
+                                                             long ldy, const float* __restrict__ dy, long lddy,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dz, long lddz, float* __restrict__ part,
+                                                             long R, int C, int act) {
+    __shared__ float red[2][4][kLNMaxPerLane * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gm[NQ], ag[NQ], ab[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = (q * 64 + lane) * 4;
+        gm[q] = c < C ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[q] = ab[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+        const float* xr = x + r * ldx;
+        const float* zb = rowbias ? rowbias + (r / rows_per_shape) * C : nullptr;
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[NQ], gh[NQ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            xh[q] = gh[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                float4 g = ld4(dy + r * lddy + c);
+                if (act == SG_ACT_RELU) {
+                    const float4 yy = ld4(y + r * ldy + c);
+                    g.x = yy.x > 0.f ? g.x : 0.f, g.y = yy.y > 0.f ? g.y : 0.f, g.z = yy.z > 0.f ? g.z : 0.f, g.w = yy.w > 0.f ? g.w : 0.f;
+                }
+                float4 xv = ld4(xr + c);
+                if (zb) {
+                    const float4 z = ld4(zb + c);
+                    xv.x += z.x, xv.y += z.y, xv.z += z.z, xv.w += z.w;
+                }
+                xh[q] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gh[q] = make_float4(g.x * gm[q].x, g.y * gm[q].y, g.z * gm[q].z, g.w * gm[q].w);
+                ag[q].x += g.x * xh[q].x, ag[q].y += g.y * xh[q].y, ag[q].z += g.z * xh[q].z, ag[q].w += g.w * xh[q].w;
+                ab[q].x += g.x, ab[q].y += g.y, ab[q].z += g.z, ab[q].w += g.w;
+                s1 += (gh[q].x + gh[q].y) + (gh[q].z + gh[q].w);
+                s2 += (gh[q].x * xh[q].x + gh[q].y * xh[q].y) + (gh[q].z * xh[q].z + gh[q].w * xh[q].w);
+            }
+        }
+        const float m1 = sg_wave_sum(s1) / (float)C, m2 = sg_wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            if (c < C) {
+                float4 o;
+                o.x = rs * (gh[q].x - m1 - xh[q].x * m2);
+                o.y = rs * (gh[q].y - m1 - xh[q].y * m2);
+                o.z = rs * (gh[q].z - m1 - xh[q].z * m2);
+                o.w = rs * (gh[q].w - m1 - xh[q].w * m2);
+                *reinterpret_cast<float4*>(dz + r * lddz + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = (q * 64 + lane) * 4;
+        if (c < C) {
+            *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[q];
+            *reinterpret_cast<float4*>(&red[1][wave][c]) = ab[q];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[(long)blockIdx.x * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        part[((long)gridDim.x + blockIdx.x) * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
 // out[b][j] = sum_i part[b][i][j] over nrows rows (second pass of the two-pass column sums; blockIdx.y = batch).  One workgroup
 // per 64 columns: 16 waves take 16 contiguous row slices (four independent accumulators each, so four loads are in flight per
 // lane), LDS, one wave adds the 16 slice sums in a fixed order.  (Round 2's version walked all rows in ONE thread per column from
@@ -354,6 +496,13 @@ __global__ void __launch_bounds__(256) segmax_gather_kernel(const float* __restr
     }
 }
 
+// the b128 forms: every row start of every tensor involved is 16-byte addressable
+static bool ln_vec4(int C, long l0, long l1, long l2, long l3) {
+    return C % 4 == 0 && l0 % 4 == 0 && l1 % 4 == 0 && l2 % 4 == 0 && l3 % 4 == 0;
+}
+static bool ln_aligned(const void* a, const void* b, const void* c, const void* d, const void* e) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0;   // (a null pointer is aligned)
+}
 static int ln_blocks(long R) {
     long b = (R + 3) / 4;
     return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
@@ -370,8 +519,17 @@ int sg_layernorm_fwd(const float* x, long ldx, const float* rowbias, long rows_p
                      hipStream_t stream) {
     SG_CHECK_ARG(x && gamma && beta && y && mean && rstd && R > 0 && C > 0 && C <= 64 * kLNMaxPerLane);
     SG_CHECK_ARG(ldx >= C && ldy >= C && (!rowbias || rows_per_shape > 0) && (act == SG_ACT_NONE || act == SG_ACT_RELU));
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ln_blocks(R)), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape,
-                       gamma, beta, y, ldy, mean, rstd, R, C, eps, act);
+    if (ln_vec4(C, ldx, ldy, ldx, ldx) && ln_aligned(x, y, rowbias, gamma, beta)) {
+        if (C <= 256)
+            hipLaunchKernelGGL((layernorm_fwd4_kernel<1>), dim3(ln_blocks(R)), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape,
+                               gamma, beta, y, ldy, mean, rstd, R, C, eps, act);
+        else
+            hipLaunchKernelGGL((layernorm_fwd4_kernel<2>), dim3(ln_blocks(R)), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape,
+                               gamma, beta, y, ldy, mean, rstd, R, C, eps, act);
+    } else {
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ln_blocks(R)), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape,
+                           gamma, beta, y, ldy, mean, rstd, R, C, eps, act);
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -388,8 +546,18 @@ int sg_layernorm_bwd(const float* x, long ldx, const float* rowbias, long rows_p
         SG_FAIL(SG_ERR_WORKSPACE, "sg_layernorm_bwd: workspace too small");
     const int nb = ln_blocks(R);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape, gamma, y, ldy,
-                       dy, lddy, mean, rstd, dz, lddz, part, R, C, act);
+    if (ln_vec4(C, ldx, act == SG_ACT_RELU ? ldy : 4, lddy, lddz) && ln_aligned(x, act == SG_ACT_RELU ? y : x, rowbias, gamma, dy) &&
+        ((uintptr_t)dz & 15) == 0) {
+        if (C <= 256)
+            hipLaunchKernelGGL((layernorm_bwd4_kernel<1>), dim3(nb), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape, gamma, y,
+                               ldy, dy, lddy, mean, rstd, dz, lddz, part, R, C, act);
+        else
+            hipLaunchKernelGGL((layernorm_bwd4_kernel<2>), dim3(nb), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape, gamma, y,
+                               ldy, dy, lddy, mean, rstd, dz, lddz, part, R, C, act);
+    } else {
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, ldx, rowbias, rows_per_shape, gamma, y, ldy,
+                           dy, lddy, mean, rstd, dz, lddz, part, R, C, act);
+    }
     // part is [2][nb][C]: both sums in one launch (blockIdx.y = which)
     hipLaunchKernelGGL(colsum_small_kernel, dim3(sg_cdiv(C, 64), 2), dim3(1024), 0, stream, part, dgamma, dbeta, nb, C);
     SG_CHECK_LAUNCH();

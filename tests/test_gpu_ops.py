@@ -665,7 +665,8 @@ def test_voxel_batches_equal_dataloader(tmp_path, mode):
 
 # ---- PointNet-discriminator GAN family ---------------------------------------------------------
 @pytest.mark.parametrize("R,C,rps,tail,act", [(7, 256, 7, 0, 2), (300, 256, 100, 3, 2), (130, 64, 13, 0, 0), (64, 200, 64, 0, 2),
-                                              (4096, 256, 1024, 3, 2)])
+                                              (4096, 256, 1024, 3, 2), (1000, 512, 250, 0, 2), (33, 260, 11, 0, 2), (50, 130, 10, 0, 0),
+                                              (8192, 256, 2048, 0, 2)])
 def test_layernorm_act(R, C, rps, tail, act):
     """y = act(LN(x + zrow[r // rps])) (+ tail columns) and its backward vs torch fp64."""
     from shapegan_amd import ops
