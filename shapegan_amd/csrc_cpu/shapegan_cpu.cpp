@@ -991,15 +991,18 @@ int sg_layernorm_bwd_cpu(const float* x, long ldx, const float* rowbias, long ro
 }
 int sg_segmax_fwd_cpu(const float* x, float* out, int* idx, long B, long P, int C, void*, size_t, void*) {
     CPU_CHECK(x && out && idx && B > 0 && P > 0 && C > 0);
+    // torch.max semantics: first occurrence of the maximum; a NaN wins and the first NaN is reported
     for (long b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c) {
             float best = x[(b * P) * C + c];
             int arg = 0;
-            for (long p = 1; p < P; ++p)
-                if (x[(b * P + p) * C + c] > best) {
-                    best = x[(b * P + p) * C + c];
+            for (long p = 1; p < P && best == best; ++p) {
+                const float v = x[(b * P + p) * C + c];
+                if (v != v || v > best) {
+                    best = v;
                     arg = (int)p;
                 }
+            }
             out[b * C + c] = best;
             idx[b * C + c] = arg;
         }

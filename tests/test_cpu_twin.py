@@ -132,6 +132,8 @@ def test_layernorm_segmax_colsum(on_cpu):
     OPS.test_layernorm_act(300, 256, 100, True, 2)
     OPS.test_layernorm_act(64, 64, 64, False, 0)
     OPS.test_segmax_and_adjoints(3, 50, 64)
+    OPS.test_segmax_nan_and_inf_follow_torch_max(3, 50, 512)
+    OPS.test_segmax_nan_and_inf_follow_torch_max(2, 1000, 130)
     OPS.test_colsum_tall()
 
 
