@@ -160,6 +160,7 @@ def test_losses_and_blends(on_cpu):
 # ---- modules and training steps (bodies from tests/test_gpu_modules.py: reference-made fixtures + CPU oracle) ----------------
 def test_generator_and_discriminator(on_cpu, golden_modules):
     M.test_generator(golden_modules)
+    M.test_generator_writes_into_a_given_tensor_without_grad_mode()
     M.test_discriminator(golden_modules)
 
 

@@ -135,6 +135,30 @@ def test_generator(golden_modules):
                   lambda P, z: O.generator_forward(P, z, True))
 
 
+def test_generator_writes_into_a_given_tensor_without_grad_mode():
+    """Generator.forward(z, out=): under no_grad the samples land in the given tensor (the fake half of the critic's batch,
+    train_wgan.py:62-66) and equal a plain forward bit for bit; with grad mode on, `out` is ignored and the graph is intact."""
+    from shapegan_amd.model.gan import Generator
+    torch.manual_seed(21)
+    g = Generator()
+    dev_ = next(g.parameters()).device
+    z = torch.randn(3, 128, device=dev_)
+    both = torch.full((6, 1, 32, 32, 32), 7.0, device=dev_)
+    state = {k: v.clone() for k, v in g.state_dict().items()}
+    with torch.no_grad():
+        want = g(z)
+        g.load_state_dict(state)                       # the BatchNorm running statistics moved: same starting point again
+        got = g(z, out=both[:3])
+    assert got.data_ptr() == both.data_ptr() and torch.equal(both[:3], want) and bool((both[3:] == 7.0).all())
+    g.load_state_dict(state)
+    y = g(z, out=both[3:])                             # grad mode: an ordinary differentiable forward
+    assert y.data_ptr() != both[3:].data_ptr() and y.requires_grad and torch.equal(y.detach(), want)
+    assert bool((both[3:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            g(z, out=both[:2])                         # wrong shape
+
+
 def test_discriminator(golden_modules):
     from shapegan_amd.model.gan import Discriminator
 
