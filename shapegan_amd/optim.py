@@ -30,7 +30,12 @@ class _Flat(object):
             off += (n + 3) // 4 * 4
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        # The gradient buffer is preceded by a small header, one float per parameter ("this rank has a gradient for it"): a
+        # data-parallel exchange of the head slice carries it along for free, so the ranks can tell whether they all skip the
+        # same parameters (shapegan_amd.parallel.GradBucket).  Kernels and the optimizer only ever see `grad`.
+        self.header_len = (len(self.params) + 3) // 4 * 4
+        self.grad_store = torch.zeros(self.header_len + off, dtype=torch.float32, device=dev)
+        self.header, self.grad = self.grad_store[:self.header_len], self.grad_store[self.header_len:]
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
@@ -120,7 +125,7 @@ class _Base(object):
         gaps between slices hold zeros), one segment per parameter whose gradient lives elsewhere, nothing for a parameter
         without a gradient (torch.optim skips those).  `keys[i]` (optional) must also be equal within a run."""
         f = self.f
-        if f.coherent():
+        if f.coherent() and (keys is None or len(set(keys)) <= 1):
             return [(0, f.total, f.grad.data_ptr())]
         segs, run = [], None
         for i, (p, o) in enumerate(zip(f.params, f.offsets)):

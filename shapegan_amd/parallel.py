@@ -11,6 +11,7 @@ import atexit
 import os
 import sys
 import threading
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -34,6 +35,17 @@ def init_distributed(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class CommInitTimeout(RuntimeError):
+    """ncclCommInitRank did not return: the helper thread is still inside RCCL holding the device, so nothing that follows on
+    this device (in particular torch.distributed's own NCCL collectives) can be trusted not to hang.  Fatal — never a fallback."""
+
+
+def _close_weak(ref):
+    comm = ref()
+    if comm is not None:
+        comm.close()
 
 
 class NativeComm(object):
@@ -74,11 +86,11 @@ class NativeComm(object):
         th.start()
         th.join(init_timeout)
         if th.is_alive():
-            raise RuntimeError("shapegan_comm: ncclCommInitRank did not return within %.0f s (rank %d of %d)" % (init_timeout, rank, world))
+            raise CommInitTimeout("shapegan_comm: ncclCommInitRank did not return within %.0f s (rank %d of %d)" % (init_timeout, rank, world))
         if result["rc"] != 0:
             raise RuntimeError("shapegan_comm init failed (%d): %s" % (result["rc"], result["msg"]))
         self.handle, self.rank, self.world = handle, rank, world
-        atexit.register(self.close)
+        atexit.register(_close_weak, weakref.ref(self))      # a weak reference: the registry must not pin the communicator
 
     def info(self):
         """What the communicator reports about itself: {"ranks": ncclCommCount, "rank", "device", "rccl_version": "2.26.6"}."""
@@ -126,7 +138,12 @@ def negotiate_native(make_comm, verify, agree=None, log=None):
     comm, reason = None, ""
     try:
         comm = make_comm()
-    except Exception as e:       # noqa: BLE001 — any failure means "fall back"
+    except CommInitTimeout as e:
+        # the helper thread is still blocked inside ncclCommInitRank with the device: agree() (a torch.distributed collective on
+        # the same device) could hang behind it.  A rank that never joins is a broken job, not a reason to switch transports.
+        log("shapegan_amd.parallel: FATAL — %s" % e)
+        raise
+    except Exception as e:       # noqa: BLE001 — any other failure means "fall back"
         reason = "init: %s" % e
     if not agree(comm is not None):
         if comm is not None:
@@ -173,15 +190,19 @@ def native_comm():
     if world_size() < 2:
         return None
     _native_tried = True
-    if os.environ.get("SG_NATIVE_ALLREDUCE", "1") == "0":
+    mode = os.environ.get("SG_NATIVE_ALLREDUCE", "1")
+    if mode == "0":
         TRANSPORT.update(name="torch-" + dist.get_backend(), reason="SG_NATIVE_ALLREDUCE=0")
         return None
-    if not torch.cuda.is_available() or dist.get_backend() != "nccl":
+    # SG_NATIVE_ALLREDUCE=force: negotiate the C-ABI exchange under any backend (torch.distributed stays the out-of-band and
+    # fallback channel).  With several ranks on ONE device (the gloo rehearsal on a 1-GPU box) RCCL refuses the communicator
+    # ("duplicate GPU") on every rank — which is exactly the loud, uniform fallback the negotiation exists for, and how it is tested.
+    if not torch.cuda.is_available() or (dist.get_backend() != "nccl" and mode != "force"):
         TRANSPORT.update(name="torch-" + dist.get_backend(), reason="backend is not nccl")
         return None
     _native, reason = negotiate_native(NativeComm, _verify_against_torch)
     if _native is None:
-        TRANSPORT.update(name="torch-nccl", reason="fallback: " + reason)
+        TRANSPORT.update(name="torch-" + dist.get_backend(), reason="fallback: " + reason)
     else:
         TRANSPORT.update(name="native-rccl", reason="", **_native.info())
     return _native
@@ -207,6 +228,8 @@ class GradBucket(object):
         self.tail_params = []
         self.hooks = []
         self.native = native_comm()
+        self._pattern = None        # which parameters had a gradient at the last exchange (this rank)
+        self._pattern_dev = None    # the same as floats on the device: copied into the header before every exchange
         optimizer.grad_scale = 1.0 / world_size()
         if overlap and world_size() > 1:
             self._plan(tail_fraction)
@@ -254,8 +277,11 @@ class GradBucket(object):
     def finish(self):
         """Call right after loss.backward(): exchanges whatever has not gone out yet and waits."""
         self.armed = False
+        check = False
         if world_size() > 1:
             f = self.opt.f
+            check = self._stage_pattern()
+            h = f.header_len
             if getattr(self, "tail_done", False):
                 a, _ = self.tail
                 f.adopt_grads(range(0, self.tail_index[0]))
@@ -263,14 +289,45 @@ class GradBucket(object):
                 # left the reduced slice behind)
                 if not all(f.grad_view_ok(i) for i in self.tail_index):
                     raise RuntimeError("GradBucket: a gradient changed after its slice was exchanged")
-                self._exchange(self.opt.flat_grad[:a])
+                self._exchange(f.grad_store[:h + a])          # header + head slice: one contiguous piece
             else:
                 # module.zero_grad() (grads -> None), stock autograd tensors or an out-of-place accumulation leave p.grad
                 # outside the flat buffer: the optimizer would step on p.grad while the exchange summed a stale slice
                 f.adopt_grads()
-                self._exchange(self.opt.flat_grad)
+                self._exchange(f.grad_store)
         self.tail_done = False
         self.wait()
+        if check:
+            self._check_pattern()
+
+    def _stage_pattern(self):
+        """Writes "this rank has a gradient for parameter i" into the header that travels with the head slice.  A parameter
+        without a gradient is skipped by step() (torch.optim semantics); if another rank HAS a gradient for it, that rank would
+        step it with the summed gradient and the replicas would diverge silently.  The summed header says whether the
+        ranks agree: every entry must come back as 0 or world_size.  Steady state costs one tiny device copy per exchange; the
+        header is read back (a host synchronisation) only when THIS rank's pattern differs from its previous exchange — the first
+        step and, e.g., a progressive-GAN stage switch — which is when a disagreement can begin; the rank whose pattern changed
+        is the one that raises."""
+        f = self.opt.f
+        pattern = tuple(p.grad is not None for p in f.params)
+        changed = pattern != self._pattern
+        if changed:
+            host = torch.zeros(f.header_len, dtype=torch.float32)
+            host[:len(pattern)] = torch.tensor(pattern, dtype=torch.float32)
+            self._pattern_dev = host.to(f.header.device)
+            self._pattern = pattern
+        f.header.copy_(self._pattern_dev)
+        return changed
+
+    def _check_pattern(self):
+        f = self.opt.f
+        got = f.header[:len(f.params)].cpu().tolist()
+        w = float(world_size())
+        bad = [i for i, v in enumerate(got) if v != 0.0 and v != w]
+        if bad:
+            raise RuntimeError("GradBucket: the ranks disagree on which parameters have a gradient (parameter indices %s: %s of %d "
+                               "ranks have one); a rank without it would skip the update the others apply and the replicas "
+                               "would diverge" % (bad[:8], [int(got[i]) for i in bad[:8]], int(w)))
 
     def _exchange(self, t):
         """In-place SUM of a slice of the flat gradient buffer across ranks, asynchronous w.r.t. the compute stream."""
@@ -304,3 +361,7 @@ def broadcast_parameters(module, src=0):
     if world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+        # a write through .data moves neither tensor._version nor a parameter epoch: weight images derived before the broadcast
+        # (kept ConvTranspose images, the SDFNet pack) would keep serving the pre-broadcast weights on the non-source ranks
+        from . import lib as L
+        L.bump_param_epoch()

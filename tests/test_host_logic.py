@@ -492,6 +492,39 @@ def test_optimizer_skips_parameters_without_gradient_and_merges_runs():
         opt.step()
 
 
+def test_adam_keeps_per_parameter_step_counters_when_all_grads_are_flat_views():
+    """with every gradient a flat-buffer view (the GPU direct-write case, and the state after every
+    GradBucket.finish() -> adopt_grads()) but DIFFERENT per-parameter step counters (a parameter had no gradient on earlier
+    steps), the update must still use each parameter's own bias-correction step: one segment per run of equal counters, not one
+    launch with steps[0].  CPU twin, against torch.optim.Adam."""
+    from shapegan_amd import optim
+    L.load_cpu()
+    torch.manual_seed(3)
+    shapes = [(6,), (5, 2), (3,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a, b = optim.Adam(ps, lr=1e-2), torch.optim.Adam(qs, lr=1e-2)
+    for step in range(6):
+        a.zero_grad()
+        b.zero_grad(set_to_none=True)
+        for i, (p, q, s) in enumerate(zip(ps, qs, shapes)):
+            if i == 0 and step < 3:
+                continue                         # parameter 0 joins late
+            g = torch.randn(s)
+            q.grad = g.clone()
+            p.grad = g.clone()                   # a stray tensor; adopt_grads() moves it into the flat slice
+        a.f.adopt_grads()
+        if step >= 3:
+            assert a.f.coherent()
+            assert len(a._segments(keys=[st + 1 for st in a.steps])) == 2      # [param 0] and [params 1, 2]
+        a.step()
+        b.step()
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6,
+                                       msg=lambda m: "step %d param %d: %s" % (step, i, m))
+    assert a.steps == [3, 6, 6]
+
+
 def test_autograd_grad_returns_ordinary_tensors_not_flat_slices():
     """torch.autograd.grad(loss, params) hands gradients to the caller, who may keep them; they must not alias the
     optimizer's flat gradient buffer (the next backward writes there).  Direct slice writes happen only inside lib.backward()."""

@@ -95,3 +95,51 @@ def test_sdf_autodecoder_sorted_step_world2_cpu(tmp_path):
     import test_gpu_dp as DP
     mp.spawn(DP._sdf_worker, args=(2, _free_port(), str(tmp_path), "cpu", 4096), nprocs=2, join=True)
     DP.check_sdf(tmp_path)
+
+
+def _pattern_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from shapegan_amd import lib as L
+    from shapegan_amd import optim, parallel
+    L.load_cpu()
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = optim.Adam(ps, lr=1e-2)
+    bucket = parallel.GradBucket(opt)
+    msgs = []
+    # step 0: every rank has every gradient; step 1: every rank lacks parameter 1 (an unused stage: consistent, fine);
+    # step 2: rank 1 suddenly has one (a data-dependent branch) -> rank 1's pattern changed, it reads the header back and raises
+    for step, missing in enumerate(((), (1,), (1,) if rank == 0 else ())):
+        opt.zero_grad()
+        for i, p in enumerate(ps):
+            if i not in missing:
+                p.grad = torch.full_like(p, float(rank + 1))
+        try:
+            bucket.finish()
+            msgs.append("ok")
+            if step == 1:
+                assert ps[1].grad is None and float(opt.f.header[1]) == 0.0 and float(opt.f.header[0]) == world
+                assert torch.equal(ps[0].grad, torch.full_like(ps[0], 3.0))        # 1 + 2: the head slice after the header is intact
+        except RuntimeError as e:
+            msgs.append(str(e))
+        opt.step()
+    with open(os.path.join(out_dir, "pattern%d.txt" % rank), "w") as fh:
+        fh.write("\n".join(msgs))
+    # broadcast_parameters is a raw .data write: it must move the parameter epochs
+    before = L.param_epoch_of(ps[0])
+    parallel.broadcast_parameters(torch.nn.ParameterList(ps))
+    assert L.param_epoch_of(ps[0]) != before
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_disagreeing_on_missing_gradients_is_an_error_not_a_divergence(tmp_path):
+    """a parameter without a gradient is skipped by step(); if the ranks disagree about it the replicas diverge.  The
+    header that rides with the flat gradient exchange makes the rank whose pattern changed raise."""
+    mp.spawn(_pattern_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "pattern0.txt").read_text().split("\n")
+    r1 = (tmp_path / "pattern1.txt").read_text().split("\n")
+    assert r0 == ["ok", "ok", "ok"]                      # rank 0's own pattern did not change at step 2: no read-back, no cost
+    assert r1[:2] == ["ok", "ok"] and "disagree on which parameters have a gradient" in r1[2] and "[1]" in r1[2]
