@@ -122,19 +122,49 @@ def conv_kernel_table():
     return rows
 
 
+PROFILE_TAGS = ("r04", "r03", "r02")     # newest committed profile pass first (scripts/profile_round.sh + collect_profiles.py)
+
+
+def dominant_kernel(rows):
+    """The row of `rows` whose kernel has the largest share of the WGAN step's kernel time according to the newest committed
+    `profiles/rNN_wgan_step_kernel_stats.csv` (rocprofv3 --kernel-trace --stats of the step: "Name", ..., "Percentage"), and that
+    share.  The table's kernel names are matched against the profiler's (e.g. "conv_dgrad_halo_kernel<0>" inside
+    "void sg::conv_dgrad_halo_kernel<0>(sg::HaloDgradArgs)"); without a profile file, the first row."""
+    import csv
+    for tag in PROFILE_TAGS:
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_wgan_step_kernel_stats.csv")) as fh:
+                stats = sorted(((float(r["Percentage"]), r["Name"]) for r in csv.DictReader(fh)), reverse=True)
+        except (OSError, KeyError, ValueError):
+            continue
+        for share, name in stats:
+            squeezed = name.replace(" ", "")
+            for row in rows:
+                if "sg::" + row["kernel"].replace(" ", "") + "(" in squeezed:
+                    return row, share, tag
+            break      # the top kernel is not in the table: say so rather than report a smaller one as dominant
+        return rows[0], None, tag
+    return rows[0], None, None
+
+
 def roofline_and_kernels():
     rows = conv_kernel_table()
-    dom = rows[0]   # conv_dgrad_halo_kernel<0>: the largest share of the step's kernel time (profiles/r02_wgan_step_kernel_stats.csv)
+    dom, share, tag = dominant_kernel(rows)
     traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (cannot be read in-process)
-    for tag in ("r03", "r02"):     # the newest committed counter pass (scripts/profile_round.sh + collect_profiles.py)
+    for t in PROFILE_TAGS:
         try:
-            with open(os.path.join(ROOT, "profiles", tag + "_dominant_kernel_hbm.json")) as fh:
-                traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+            with open(os.path.join(ROOT, "profiles", t + "_dominant_kernel_hbm.json")) as fh:
+                rec = json.load(fh)
+            if dom["kernel"].replace(" ", "") in rec.get("kernel", "").replace(" ", ""):
+                traffic = float(rec["hbm_bytes_per_launch"])
             break
         except (OSError, KeyError, ValueError):
             pass
-    roof = {"bound": "mfma", "kernel": dom["kernel"] + " (" + dom["name"] + "; the largest share of the step's kernel time)",
-            "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+    why = "the largest share of the step's kernel time" + ("" if share is None else ": %.1f %% in profiles/%s_wgan_step_kernel_stats.csv" % (share, tag))
+    roof = {"bound": dom["bound"], "kernel": dom["kernel"] + " (" + dom["name"] + "; " + why + ")",
+            "achieved": dom["tflops"] if dom["bound"] == "mfma" else dom["gb_per_s"],
+            "peak": F32_MFMA_PEAK_TFLOPS if dom["bound"] == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s", "frac": dom["frac"], "traffic": traffic,
             "launch_ms": round(dom["us"] / 1e3, 4), "flop_per_launch": dom["flop"]}
     return roof, rows
 
@@ -293,7 +323,8 @@ def make_wgan(rank):
     reals = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(5)]
     zs = [torch.randn(BATCH, 128, generator=gen).cuda() for _ in range(5)]
     zg = torch.randn(BATCH, 128, generator=gen).cuda()
-    info = {"metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
+    info = {"optimizers": [trainer.c_opt, trainer.g_opt],
+            "metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
             "unit": "steps/s", "units_per_step": 1.0,
             "workload": "train_wgan.py 32^3 voxel WGAN, fp32, batch=64 synthetic SDF grids (BASELINE configs[1])",
             "batch": BATCH, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
@@ -320,7 +351,8 @@ def make_hybrid_progressive(rank):
         tr.generator_step(zs[5])
         for real, z, alpha in zip(reals, zs, alphas):
             tr.discriminator_step(real, z, alpha)
-    info = {"metric": "hybrid progressive WGAN-GP train steps/sec @64^3 (1 generator + 5 discriminator updates, batch 16/GPU)",
+    info = {"optimizers": [tr.d_opt, tr.g_opt],
+            "metric": "hybrid progressive WGAN-GP train steps/sec @64^3 (1 generator + 5 discriminator updates, batch 16/GPU)",
             "unit": "steps/s", "units_per_step": 1.0,
             "workload": "train_hybrid_progressive_gan.py iteration=3 (64^3), SDFNet generator + progressive 3D-CNN discriminator, "
                         "WGAN-GP double backward, fp32, batch=16 (BASELINE configs[3])",
@@ -347,7 +379,8 @@ def make_hybrid_wgan(rank):
             tr.critic_step(real, z)
             if i == 0:
                 tr.generator_step(zs[5])
-    info = {"metric": "hybrid WGAN train steps/sec @32^3 (5 critic + 1 generator updates, batch 8/GPU)", "unit": "steps/s",
+    info = {"optimizers": [tr.c_opt, tr.g_opt],
+            "metric": "hybrid WGAN train steps/sec @32^3 (5 critic + 1 generator updates, batch 8/GPU)", "unit": "steps/s",
             "units_per_step": 1.0,
             "workload": "train_hybrid_wgan.py, SDFNet generator sampled to 32^3 + 3D-CNN critic, fp32, batch=8 (BASELINE configs[4])",
             "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
@@ -367,7 +400,8 @@ def make_sdf(rank):
     table = (torch.randn(shapes, lat, generator=torch.Generator().manual_seed(7)) * 1e-2).cuda()   # replicated table
     tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), table, pts, sdf, pointcloud_size=pc)
     idx = torch.randint(0, shapes * pc, (npts,), generator=gen).cuda()
-    info = {"metric": "SDFNet auto-decoder training Mpoints/sec (train_sdf_autodecoder.py, latent 256, 200 000 points/step/GPU)",
+    info = {"optimizers": [tr.net_opt, tr.lat_opt],
+            "metric": "SDFNet auto-decoder training Mpoints/sec (train_sdf_autodecoder.py, latent 256, 200 000 points/step/GPU)",
             "unit": "Mpoints/s", "units_per_step": npts / 1e6,
             "workload": "train_sdf_autodecoder.py DeepSDF, latent=256, 200k (xyz,sdf) points/step, fp32 (BASELINE configs[2])",
             "batch": npts, "extra": {},
@@ -402,6 +436,16 @@ def other_configs(steps=4, warmup=3):
         del step
     torch.cuda.empty_cache()
     return out
+
+
+def replica_digests(optimizers, world):
+    """[world][len(optimizers)] int64 digests of every rank's flat parameter buffers (the fp32 words summed as integers: equal
+    digests <=> bit-identical replicas, up to a collision).  Data-parallel replicas start identical by seed and apply the same
+    all-reduced gradient, so after any number of steps they must still be bit-identical; the line reports whether they are."""
+    mine = torch.stack([o.f.flat.view(torch.int32).to(torch.int64).sum() for o in optimizers])
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(everyone, mine)
+    return [e.cpu().tolist() for e in everyone]
 
 
 WORKLOADS = {"wgan": make_wgan, "hybrid_progressive": make_hybrid_progressive, "hybrid_wgan": make_hybrid_wgan, "sdf": make_sdf}
@@ -440,10 +484,12 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    digests = None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        digests = replica_digests(info["optimizers"], world)      # after the timed region
 
     if rank == 0:
         config = {"workload": info["workload"], "global_batch": info["batch"] * world, "parallelism": "dp%d" % world}
@@ -459,13 +505,16 @@ def main():
             line["comm"] = dict(parallel.TRANSPORT, transport=parallel.TRANSPORT["name"], world=world,
                                 allreduce_bytes_per_step=info.get("allreduce_bytes_per_step"))
             line["comm"].pop("name", None)
+            line["comm"]["replicas_bit_identical"] = all(d == digests[0] for d in digests)
+            line["comm"]["parameter_digests_rank0"] = digests[0]
         if args.config == "wgan":
             line["critic_updates_per_s"] = round(world * args.steps * 5 / elapsed, 3)
-            if not args.no_extras:
+            if world == 1 and not args.no_extras:
+                # single-kernel and side measurements belong to the N = 1 line only: at N > 1 the other ranks would sit in the
+                # closing barrier while rank 0 measures
                 line["roofline"], line["kernels"] = roofline_and_kernels()
                 line["sdfnet"] = sdfnet_numbers()
-                if world == 1:
-                    line["other_configs"] = other_configs()
+                line["other_configs"] = other_configs()
             if world == 1 and not args.no_cpu_baseline:
                 reals, zs, zg, (g_state, c_state) = wgan_data
                 line["cpu_baseline"] = cpu_baseline(reals, zs, zg, g_state, c_state)

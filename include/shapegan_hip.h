@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 5
+#define SG_ABI_VERSION 6
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 
@@ -257,6 +257,29 @@ int sg_loss_weighted_l1_bwd(const float* out, const float* target, const float* 
 int sg_loss_mean_split_fwd(const float* x, long n, long n_first, float w_first, float w_rest, float* loss, float* dx_unit,
                            hipStream_t stream);   /* dx_unit (optional, [n]): the backward for gloss == 1, from the same launch */
 int sg_loss_mean_split_bwd(const float* gloss, float* dx, long n, long n_first, float w_first, float w_rest, hipStream_t stream);
+/* Classic-GAN losses on the [B] vector of discriminator outputs, train_gan.py:30,78,84 (torch.nn.functional.binary_cross_entropy
+ * against a constant target: mean of -(t max(log p, -100) + (1 - t) max(log(1 - p), -100)), backward g (p - t) / max((1 - p) p,
+ * 1e-12) / n as torch computes it) and train_gan.py:65 (-torch.mean(torch.log(p))). */
+int sg_loss_bce_fwd(const float* p, long n, float target, float* loss, hipStream_t stream);
+int sg_loss_bce_bwd(const float* p, const float* gloss, float* dp, long n, float target, hipStream_t stream);
+int sg_loss_neg_mean_log_fwd(const float* p, long n, float* loss, hipStream_t stream);
+int sg_loss_neg_mean_log_bwd(const float* p, const float* gloss, float* dp, long n, hipStream_t stream);
+/* VAE reparameterisation, model/autoencoder.py:77-82: z = mean + exp(0.5 log_variance) * eps (eps drawn by the caller);
+ * backward: d mean = gz (no kernel), d log_variance = gz * eps * 0.5 * exp(0.5 log_variance). */
+int sg_vae_reparam_fwd(const float* mean, const float* log_variance, const float* eps, float* z, long n, hipStream_t stream);
+int sg_vae_reparam_bwd(const float* log_variance, const float* eps, const float* gz, float* dlog_variance, long n,
+                       hipStream_t stream);
+/* The critic's last layer together with the activation below it, model/gan.py:54-55 (LeakyReLU -> Conv3d(256 -> 1, kernel 4,
+ * stride 1) on a 4^3 grid = one dot product over K = C * 64 values per sample):
+ *   fwd  y[n] = bias[0] + sum_k act(z[n, k]) * w[k]          z [N, K] = the PRE-activation of the layer below, act in {none,
+ *                                                            leaky, relu} is applied on load
+ *   bwd  gz[n, k] = gy[n] * w[k] * act'(z[n, k]);  gw[k] = sum_n gy[n] * act(z[n, k]);  gb[0] = sum_n gy[n];
+ *        gbz[c] = sum_{n, s} gz[n, c * S + s]  (the bias gradient of the layer below)     gw / gb / gbz optional, S must be 64
+ * One streaming pass each way; every sum in a fixed order. */
+int sg_head_dot_fwd(const float* z, const float* w, const float* bias, float* y, int N, long K, int act, float slope,
+                    hipStream_t stream);
+int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, int N, int C,
+                    int S, int act, float slope, hipStream_t stream);
 int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
                     hipStream_t stream);
 int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* gloss, float* dmean, float* dlog_variance,

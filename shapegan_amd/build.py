@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libshapegan_hip.so")
-SOURCES = ["conv3d.hip", "conv3d_halo.hip", "conv3d_edge.hip", "gemm.hip", "sdfnet.hip", "batchnorm.hip", "elementwise.hip", "pointnet.hip", "losses.hip", "sdf_batch.hip"]
+SOURCES = ["conv3d.hip", "conv3d_halo.hip", "conv3d_edge.hip", "gemm.hip", "sdfnet.hip", "batchnorm.hip", "elementwise.hip", "pointnet.hip", "losses.hip", "sdf_batch.hip", "head.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_tile.h"), os.path.join(CSRC, "conv_common.h"),
            os.path.join(HERE, "..", "include", "shapegan_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -82,6 +82,50 @@ __global__ void __launch_bounds__(256) mean_split_bwd_kernel(const float* __rest
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) dx[e] = g * (e < na ? ca : cb);
 }
 
+// ---- classic-GAN losses on the [B] vector of discriminator outputs (train_gan.py:30,65,78,84) and the VAE reparameterisation
+// (model/autoencoder.py:77-82): single-workgroup launches, double accumulation in a fixed order ------------------------------
+// binary_cross_entropy(p, full_like(p, t)) = mean_i -( t max(log p_i, -100) + (1 - t) max(log(1 - p_i), -100) )  (torch clamps
+// the logarithms at -100); MODE 1: -mean(log p) without the clamp (train_gan.py:65)
+template <int MODE>
+__global__ void __launch_bounds__(256) bce_fwd_kernel(const float* __restrict__ p, long n, float t, float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s = 0;
+    for (long e = threadIdx.x; e < n; e += 256) {
+        const float v = p[e];
+        if (MODE == 1)
+            s -= (double)logf(v);
+        else
+            s -= (double)(t * fmaxf(logf(v), -100.f) + (1.f - t) * fmaxf(logf(1.f - v), -100.f));
+    }
+    s = sg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+}
+// torch's backward: g (p - t) / max((1 - p) p, 1e-12) / n;  MODE 1: -g / (n p)
+template <int MODE>
+__global__ void __launch_bounds__(256) bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ gloss,
+                                                      float* __restrict__ dp, long n, float t, float inv_n) {
+    const float g = gloss[0] * inv_n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = p[e];
+        dp[e] = MODE == 1 ? -g / v : g * (v - t) / fmaxf((1.f - v) * v, 1e-12f);
+    }
+}
+// z = mean + exp(0.5 logvar) eps;   d logvar = gz eps 0.5 exp(0.5 logvar)   (d mean = gz, d eps is never needed)
+__global__ void __launch_bounds__(256) reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                          const float* __restrict__ eps, float* __restrict__ z, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float sd = expf(lv[e] * 0.5f);
+        z[e] = __fadd_rn(mu[e], __fmul_rn(sd, eps[e]));      // two roundings, as the reference's `mean + standard_deviation * eps`
+    }
+}
+__global__ void __launch_bounds__(256) reparam_bwd_kernel(const float* __restrict__ lv, const float* __restrict__ eps,
+                                                          const float* __restrict__ gz, float* __restrict__ dlv, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+        dlv[e] = gz[e] * eps[e] * (0.5f * expf(lv[e] * 0.5f));
+}
+
 // ---- weighted L1 ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wl1_fwd_kernel(const float* __restrict__ o, const float* __restrict__ t, long n,
                                                       float negw, double* __restrict__ partial) {
@@ -455,6 +499,43 @@ int sg_loss_mean_split_bwd(const float* gloss, float* dx, long n, long n_first, 
     const float ca = n_first > 0 ? (float)((double)w_first / (double)n_first) : 0.f;
     const float cb = n > n_first ? (float)((double)w_rest / (double)(n - n_first)) : 0.f;
     hipLaunchKernelGGL(mean_split_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, gloss, dx, n, n_first, ca, cb);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_bce_fwd(const float* p, long n, float target, float* loss, hipStream_t stream) {
+    SG_CHECK_ARG(p && loss && n > 0);
+    hipLaunchKernelGGL(bce_fwd_kernel<0>, dim3(1), dim3(256), 0, stream, p, n, target, loss);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_bce_bwd(const float* p, const float* gloss, float* dp, long n, float target, hipStream_t stream) {
+    SG_CHECK_ARG(p && gloss && dp && n > 0);
+    hipLaunchKernelGGL(bce_bwd_kernel<0>, dim3(ew_blocks(n)), dim3(256), 0, stream, p, gloss, dp, n, target, (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_neg_mean_log_fwd(const float* p, long n, float* loss, hipStream_t stream) {
+    SG_CHECK_ARG(p && loss && n > 0);
+    hipLaunchKernelGGL(bce_fwd_kernel<1>, dim3(1), dim3(256), 0, stream, p, n, 1.f, loss);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_neg_mean_log_bwd(const float* p, const float* gloss, float* dp, long n, hipStream_t stream) {
+    SG_CHECK_ARG(p && gloss && dp && n > 0);
+    hipLaunchKernelGGL(bce_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, stream, p, gloss, dp, n, 1.f, (float)(1.0 / (double)n));
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_vae_reparam_fwd(const float* mean, const float* log_variance, const float* eps, float* z, long n, hipStream_t stream) {
+    SG_CHECK_ARG(mean && log_variance && eps && z && n > 0);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mean, log_variance, eps, z, n);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_vae_reparam_bwd(const float* log_variance, const float* eps, const float* gz, float* dlog_variance, long n,
+                       hipStream_t stream) {
+    SG_CHECK_ARG(log_variance && eps && gz && dlog_variance && n > 0);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, log_variance, eps, gz, dlog_variance, n);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

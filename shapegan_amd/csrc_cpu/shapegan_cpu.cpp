@@ -818,6 +818,92 @@ int sg_loss_mean_split_bwd_cpu(const float* gloss, float* dx, long n, long n_fir
     for (long e = 0; e < n; ++e) dx[e] = gloss[0] * (e < n_first ? ca : cb);
     return SG_OK;
 }
+// ---- classic-GAN losses on the [B] vector of discriminator outputs; VAE reparameterisation; the critic's last layer ---------
+int sg_loss_bce_fwd_cpu(const float* p, long n, float t, float* loss, void*) {
+    CPU_CHECK(p && loss && n > 0);
+    double s = 0;
+    for (long e = 0; e < n; ++e)
+        s -= (double)(t * std::max(logf(p[e]), -100.f) + (1.f - t) * std::max(logf(1.f - p[e]), -100.f));
+    loss[0] = (float)(s / (double)n);
+    return SG_OK;
+}
+int sg_loss_bce_bwd_cpu(const float* p, const float* gloss, float* dp, long n, float t, void*) {
+    CPU_CHECK(p && gloss && dp && n > 0);
+    const float g = gloss[0] * (float)(1.0 / (double)n);
+    for (long e = 0; e < n; ++e) dp[e] = g * (p[e] - t) / std::max((1.f - p[e]) * p[e], 1e-12f);
+    return SG_OK;
+}
+int sg_loss_neg_mean_log_fwd_cpu(const float* p, long n, float* loss, void*) {
+    CPU_CHECK(p && loss && n > 0);
+    double s = 0;
+    for (long e = 0; e < n; ++e) s -= (double)logf(p[e]);
+    loss[0] = (float)(s / (double)n);
+    return SG_OK;
+}
+int sg_loss_neg_mean_log_bwd_cpu(const float* p, const float* gloss, float* dp, long n, void*) {
+    CPU_CHECK(p && gloss && dp && n > 0);
+    const float g = gloss[0] * (float)(1.0 / (double)n);
+    for (long e = 0; e < n; ++e) dp[e] = -g / p[e];
+    return SG_OK;
+}
+int sg_vae_reparam_fwd_cpu(const float* mu, const float* lv, const float* eps, float* z, long n, void*) {
+    CPU_CHECK(mu && lv && eps && z && n > 0);
+    for (long e = 0; e < n; ++e) {
+        const float sd = expf(lv[e] * 0.5f);
+        volatile float prod = sd * eps[e];     // two roundings, as the reference's `mean + standard_deviation * eps`
+        z[e] = mu[e] + prod;
+    }
+    return SG_OK;
+}
+int sg_vae_reparam_bwd_cpu(const float* lv, const float* eps, const float* gz, float* dlv, long n, void*) {
+    CPU_CHECK(lv && eps && gz && dlv && n > 0);
+    for (long e = 0; e < n; ++e) dlv[e] = gz[e] * eps[e] * (0.5f * expf(lv[e] * 0.5f));
+    return SG_OK;
+}
+static inline float head_act_cpu(float v, int act, float slope) {
+    return act == ACT_LEAKY ? (v > 0.f ? v : v * slope) : (act == ACT_RELU ? (v > 0.f ? v : 0.f) : v);
+}
+int sg_head_dot_fwd_cpu(const float* z, const float* w, const float* bias, float* y, int N, long K, int act, float slope, void*) {
+    CPU_CHECK(z && w && y && N > 0 && K > 0 && K % 4 == 0);
+    CPU_CHECK(act == ACT_NONE || act == ACT_LEAKY || act == ACT_RELU);
+#pragma omp parallel for
+    for (int n = 0; n < N; ++n) {
+        double s = 0;
+        for (long k = 0; k < K; ++k) s += (double)head_act_cpu(z[(long)n * K + k], act, slope) * (double)w[k];
+        y[n] = (float)s + (bias ? bias[0] : 0.f);
+    }
+    return SG_OK;
+}
+int sg_head_dot_bwd_cpu(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, int N,
+                        int C, int S, int act, float slope, void*) {
+    CPU_CHECK(z && w && gy && gz && N > 0 && C > 0 && S == 64);
+    CPU_CHECK(act == ACT_NONE || act == ACT_LEAKY || act == ACT_RELU);
+    const long K = (long)C * S;
+#pragma omp parallel for
+    for (int c = 0; c < C; ++c) {
+        double cz = 0;
+        for (int s = 0; s < S; ++s) {
+            const long k = (long)c * S + s;
+            double aw = 0;
+            for (int n = 0; n < N; ++n) {
+                const float v = z[(long)n * K + k];
+                const float d = act == ACT_LEAKY ? (v > 0.f ? 1.f : slope) : (act == ACT_RELU ? (v > 0.f ? 1.f : 0.f) : 1.f);
+                const float o = gy[n] * w[k] * d;
+                gz[(long)n * K + k] = o;
+                cz += (double)o;
+                aw += (double)gy[n] * (double)head_act_cpu(v, act, slope);
+            }
+            if (gw) gw[k] = (float)aw;
+        }
+        if (gbz) gbz[c] = (float)cz;
+    }
+    if (gb) {
+        double t = 0;
+        for (int n = 0; n < N; ++n) t += (double)gy[n];
+        gb[0] = (float)t;
+    }
+    return SG_OK;
+}
 int sg_loss_kld_fwd_cpu(const float* mu, const float* lv, long n, float* loss, void*, size_t, void*) {
     CPU_CHECK(mu && lv && loss && n > 0);
     double s = 0;

@@ -93,6 +93,14 @@ SIGNATURES = {
     "sg_loss_weighted_l1_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _P]),
     "sg_loss_mean_split_fwd": (c_int, [_P, _L, _L, _F, _F, _P, _P, _P]),
     "sg_loss_mean_split_bwd": (c_int, [_P, _P, _L, _L, _F, _F, _P]),
+    "sg_loss_bce_fwd": (c_int, [_P, _L, _F, _P, _P]),
+    "sg_loss_bce_bwd": (c_int, [_P, _P, _P, _L, _F, _P]),
+    "sg_loss_neg_mean_log_fwd": (c_int, [_P, _L, _P, _P]),
+    "sg_loss_neg_mean_log_bwd": (c_int, [_P, _P, _P, _L, _P]),
+    "sg_vae_reparam_fwd": (c_int, [_P, _P, _P, _P, _L, _P]),
+    "sg_vae_reparam_bwd": (c_int, [_P, _P, _P, _P, _L, _P]),
+    "sg_head_dot_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _I, _F, _P]),
+    "sg_head_dot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "sg_loss_kld_fwd": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),
@@ -174,7 +182,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 5:
+        if lib.sg_abi_version() != 6:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip

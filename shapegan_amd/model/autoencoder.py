@@ -11,6 +11,7 @@ import torch.nn as nn
 from ..util import device as default_device
 from ..util import standard_normal_distribution
 from . import LATENT_CODE_SIZE, Lambda, SavableModule
+from .. import ops
 from .stack import run_stack
 
 AUTOENCODER_MODEL_COMPLEXITY_MULTIPLIER = 24
@@ -64,9 +65,9 @@ class Autoencoder(SavableModule):
         mean = run_stack([self.encode_mean], x, self.training).squeeze()
         if self.training or return_mean_and_log_variance:
             log_variance = run_stack([self.encode_log_variance], x, self.training).squeeze()
-            standard_deviation = torch.exp(log_variance * 0.5)
             eps = standard_normal_distribution.sample(mean.shape).to(x.device)  # CPU draw, as the reference
-        x = mean + standard_deviation * eps if self.training else mean
+        # mean + exp(0.5 * log_variance) * eps (model/autoencoder.py:77-82) as one native op (sg_vae_reparam_*)
+        x = ops.vae_reparam(mean, log_variance, eps) if self.training else mean
         if return_mean_and_log_variance:
             return x, mean, log_variance
         return x

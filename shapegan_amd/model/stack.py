@@ -83,6 +83,15 @@ def run_stack(modules, x, training, out=None):
                     i += 2
                 continue
             a = _act_of(nxt) if nxt is not None else None
+            head = mods[i + 2] if a is not None and i + 2 < len(mods) else None
+            if (isinstance(m, nn.Conv3d) and _is_k4(m, 2, 1) and isinstance(head, nn.Conv3d) and _is_k4(head, 1, 0)
+                    and x.dim() == 5 and ops.head_dot_served(x, head.weight, a[0])):
+                # Conv3d(k4 s2 p1) -> activation -> Conv3d(C -> 1, k4 s1) on the 4^3 grid (model/gan.py:53-55): one node; the
+                # activation rides in the head's loads, its backward and both bias gradients in the head's one backward pass
+                y = ops.conv_head(x, m.weight, m.bias, a[0], a[1], head.weight, head.bias)
+                x = y.reshape(x.shape[0], 1, 1, 1, 1)
+                i += 3
+                continue
             if a is not None:
                 x = _producer(m, x, a[0], a[1], out if i + 2 == len(mods) else None)
                 i += 2

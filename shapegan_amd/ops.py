@@ -433,6 +433,70 @@ def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0, out=None):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# the critic's tail: Conv3d(k4 s2 p1) -> activation -> Conv3d(C -> 1, k4 s1) on the 4^3 grid (model/gan.py:53-55)
+# --------------------------------------------------------------------------------------------------------------
+def head_dot_served(x, w_head, act):
+    """Whether sg_head_dot_* takes the layer pair: the producing convolution leaves a 4^3 grid, the head has ONE output channel
+    over all of it, and the activation between them is one the kernels apply on load."""
+    return (w_head.shape[0] == 1 and tuple(w_head.shape[2:]) == (4, 4, 4) and tuple(x.shape[2:]) == (8, 8, 8)
+            and act in (ACT_NONE, ACT_LEAKY, ACT_RELU))
+
+
+class ConvHead(Function):
+    """y[n] = bh + sum_k act(z[n, k]) * wh[k],  z = conv3d_k4s2p1(x, w) + b  — the last two layers of gan.Discriminator as one
+    node.  Forward: the convolution stores its PRE-activation and sg_head_dot_fwd applies the activation on load.  Backward
+    (plain): ONE streaming pass (sg_head_dot_bwd) yields the gradient w.r.t. z, the head's weight and bias gradients and the
+    convolution's bias gradient; then the convolution's input / weight gradients as usual.  With create_graph the backward is
+    composed of the differentiable Functions of this module instead (closed under differentiation like everything here)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope, wh, bh):
+        x, w, wh = f32c(x), f32c(w), f32c(wh)
+        z = conv_fwd_raw(x, w, b, ACT_NONE, 0.0)
+        N, C = z.shape[0], z.shape[1]
+        y = torch.empty(N, dtype=torch.float32, device=x.device)
+        check(_lib().sg_head_dot_fwd(ptr(z), ptr(wh), ptr(bh), ptr(y), N, C * 64, act, slope, stream()), "head_dot_fwd")
+        ctx.cfg = (act, slope, b is not None, bh is not None)
+        ctx.save_for_backward(x, w, b, wh, bh, z)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, b, wh, bh, z = ctx.saved_tensors
+        act, slope, has_b, has_bh = ctx.cfg
+        need_x, need_w, need_b, need_wh, need_bh = (ctx.needs_input_grad[i] for i in (0, 1, 2, 5, 6))
+        need_b, need_bh = need_b and has_b, need_bh and has_bh
+        N, C = z.shape[0], z.shape[1]
+        if torch.is_grad_enabled():
+            # create_graph: gradients that can be differentiated again
+            zf = z.reshape(N, C * 64)
+            gcol = gy.reshape(N, 1)
+            gz = ActBwd.apply(z, Gemm.apply(gcol, wh.reshape(1, C * 64), False, False).reshape(z.shape), act, slope) \
+                if act != ACT_NONE else Gemm.apply(gcol, wh.reshape(1, C * 64), False, False).reshape(z.shape)
+            gwh = Gemm.apply(gcol, Act.apply(zf, act, slope) if act != ACT_NONE else zf, True, False).reshape(wh.shape) if need_wh else None
+            gbh = ColSum.apply(gcol) if need_bh else None
+            gx = ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0) if need_x else None
+            gw = ConvWgrad.apply(gz, x, w.shape[1]) if need_w else None
+            gb = ChannelSum.apply(gz) if need_b else None
+            return gx, gw, gb, None, None, gwh, gbh
+        gy = f32c(gy)
+        dev = z.device
+        gz = torch.empty_like(z)
+        gwh = _param_grad_out(wh, wh.shape, dev) if need_wh else None
+        gbh = _param_grad_out(bh, bh.shape, dev) if need_bh else None
+        gb = _param_grad_out(b, b.shape, dev) if need_b else None
+        check(_lib().sg_head_dot_bwd(ptr(z), ptr(wh), ptr(gy), ptr(gz), ptr(gwh), ptr(gbh), ptr(gb), N, C, 64, act, slope,
+                                     stream()), "head_dot_bwd")
+        gx = conv_dgrad_raw(gz, w, None, x.shape[1]) if need_x else None
+        gw = conv_wgrad_raw(gz, x, w.shape[1], L.grad_destination(w, w.shape)) if need_w else None
+        return gx, gw, gb, None, None, gwh, gbh
+
+
+def conv_head(x, w, b, act, slope, wh, bh):
+    return ConvHead.apply(x, w, b, act, slope, wh, bh)
+
+
+# --------------------------------------------------------------------------------------------------------------
 # GEMM / Linear
 # --------------------------------------------------------------------------------------------------------------
 class Gemm(Function):
@@ -1215,6 +1279,83 @@ class KLD(Function):
 
 def kld(mean, log_variance):
     return KLD.apply(mean, log_variance)
+
+
+class BCEConst(Function):
+    """torch.nn.functional.binary_cross_entropy(p, full_like(p, target)) on the [B] vector of discriminator outputs
+    (train_gan.py:30,78,84), logarithms clamped at -100 and the backward exactly as torch computes them."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        p = f32c(p)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        check(_lib().sg_loss_bce_fwd(ptr(p), p.numel(), float(target), ptr(loss), stream()), "loss_bce_fwd")
+        ctx.target = float(target)
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        check(_lib().sg_loss_bce_bwd(ptr(p), ptr(f32c(g)), ptr(dp), p.numel(), ctx.target, stream()), "loss_bce_bwd")
+        return dp, None
+
+
+def bce_const(p, target):
+    return BCEConst.apply(p, target)
+
+
+class NegMeanLog(Function):
+    """-torch.mean(torch.log(p))  (the classic GAN's generator loss, train_gan.py:65)."""
+
+    @staticmethod
+    def forward(ctx, p):
+        p = f32c(p)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        check(_lib().sg_loss_neg_mean_log_fwd(ptr(p), p.numel(), ptr(loss), stream()), "loss_neg_mean_log_fwd")
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        check(_lib().sg_loss_neg_mean_log_bwd(ptr(p), ptr(f32c(g)), ptr(dp), p.numel(), stream()), "loss_neg_mean_log_bwd")
+        return dp
+
+
+def neg_mean_log(p):
+    return NegMeanLog.apply(p)
+
+
+class VAEReparam(Function):
+    """z = mean + exp(0.5 * log_variance) * eps  (model/autoencoder.py:77-82; eps is drawn by the caller)."""
+
+    @staticmethod
+    def forward(ctx, mean, log_variance, eps):
+        mean, log_variance, eps = f32c(mean), f32c(log_variance), f32c(eps)
+        z = torch.empty_like(mean)
+        check(_lib().sg_vae_reparam_fwd(ptr(mean), ptr(log_variance), ptr(eps), ptr(z), mean.numel(), stream()), "vae_reparam_fwd")
+        ctx.save_for_backward(log_variance, eps)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz):
+        lv, eps = ctx.saved_tensors
+        gz = f32c(gz)
+        dl = None
+        if ctx.needs_input_grad[1]:
+            dl = torch.empty_like(lv)
+            check(_lib().sg_vae_reparam_bwd(ptr(lv), ptr(eps), ptr(gz), ptr(dl), lv.numel(), stream()), "vae_reparam_bwd")
+        return (gz if ctx.needs_input_grad[0] else None), dl, None
+
+
+def vae_reparam(mean, log_variance, eps):
+    return VAEReparam.apply(mean, log_variance, eps)
 
 
 class MeanSq(Function):

@@ -386,7 +386,7 @@ class HybridProgressiveGANTrainer(object):
 class ClassicGANTrainer(object):
     """train_gan.py: gan.Generator (Adam 1e-3) against gan.Discriminator with its sigmoid
     (Adam 1e-5, binary cross-entropy), batch 64; per batch one generator update (:57-67), one discriminator update on
-    fakes (:75-80) and one on reals (:82-86).  The BCE / log compositions act on [B] vectors (torch glue)."""
+    fakes (:75-80) and one on reals (:82-86).  BCE and -mean(log) are native single-launch ops on the [B] score vector."""
 
     def __init__(self, generator, discriminator, g_lr=0.001, d_lr=0.00001):
         self.generator, self.discriminator = generator, discriminator
@@ -404,7 +404,7 @@ class ClassicGANTrainer(object):
         fake = self.generate(z)
         with frozen(self.discriminator):
             out = self.discriminator(fake)
-        loss = -torch.mean(torch.log(out))
+        loss = ops.neg_mean_log(out)                 # -torch.mean(torch.log(out)), train_gan.py:65
         self.g_bucket.arm()
         lib.backward(loss)
         self.g_bucket.finish()
@@ -414,7 +414,7 @@ class ClassicGANTrainer(object):
     def _discriminator_update(self, sample, target_value):
         self.d_opt.zero_grad()
         out = self.discriminator(sample)
-        loss = torch.nn.functional.binary_cross_entropy(out, torch.full_like(out, target_value))
+        loss = ops.bce_const(out, target_value)      # binary_cross_entropy against a constant target, train_gan.py:78,84
         self.d_bucket.arm()
         lib.backward(loss)
         self.d_bucket.finish()

@@ -250,3 +250,19 @@ def test_config3_and_config4_step_checks_at_cpu_size(on_cpu):
     finishes in seconds: iteration 1 (16^3) with fade-in, batch 3; hybrid WGAN at batch 1."""
     FULL.hybrid_progressive_case(1, 3, 0.5, 2000)
     FULL.hybrid_wgan_case(1)
+
+
+# ---- round 4: the critic's tail, the classic-GAN losses, the VAE reparameterisation on the twin -----------------------------------
+@pytest.mark.parametrize("N,C,act", [(6, 16, 1), (17, 8, 0), (3, 4, 2)])
+def test_head_dot_cpu(on_cpu, N, C, act):
+    LOSS.test_head_dot_forward_and_backward(N, C, act)
+
+
+def test_conv_head_node_cpu(on_cpu):
+    LOSS.test_conv_head_node_matches_the_two_layer_composition()
+
+
+def test_bce_neg_mean_log_and_reparam_cpu(on_cpu):
+    for n in (64, 1):
+        LOSS.test_bce_and_neg_mean_log_match_torch(n)
+    LOSS.test_vae_reparameterisation_matches_torch()

@@ -556,3 +556,120 @@ def test_native_allreduce_single_rank_stream_order():
         assert float(y[0]) == 3.0 * (it + 1) and float(y[-1]) == 3.0 * (it + 1)
     torch.cuda.synchronize()
     comm.close()
+
+
+# ---- round 4: the critic's tail as one node, the classic-GAN losses, the VAE reparameterisation ---------------------------------
+@pytest.mark.parametrize("N,C,act", [(128, 256, 1), (64, 256, 1), (5, 24, 2), (17, 8, 0), (1, 4, 1)])
+def test_head_dot_forward_and_backward(N, C, act):
+    """sg_head_dot_fwd / _bwd (model/gan.py:54-55: LeakyReLU -> Conv3d(C -> 1, k4 s1) on the 4^3 grid) against the torch
+    composition in fp64: scores, gradient w.r.t. the pre-activation, head weight / bias gradients and the bias gradient of the
+    layer below (channel sums of gz) — at the critic's shapes (128 and 64 samples x 256 channels) and ragged ones."""
+    from shapegan_amd import lib as L
+    from shapegan_amd.ops import check, ptr, stream
+    torch.manual_seed(N * 31 + C)
+    slope = 0.2
+    z = torch.randn(N, C, 4, 4, 4)
+    w = torch.randn(1, C, 4, 4, 4) * 0.05
+    b = torch.randn(1)
+    gy = torch.randn(N)
+    zd = z.double().requires_grad_()
+    wd, bd = w.double().requires_grad_(), b.double().requires_grad_()
+    a = F.leaky_relu(zd, slope) if act == 1 else (F.relu(zd) if act == 2 else zd)
+    yref = F.conv3d(a, wd, bd).reshape(N)
+    (yref * gy.double()).sum().backward()
+    lib = L.load()
+    zg, wg, bg, gyg = z.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    y = torch.empty(N, device=DEV)
+    check(lib.sg_head_dot_fwd(ptr(zg), ptr(wg), ptr(bg), ptr(y), N, C * 64, act, slope, stream()), "head_dot_fwd")
+    close(y, yref, rtol=1e-5, what="head scores")
+    gz, gw, gb, gbz = torch.empty_like(zg), torch.empty_like(wg), torch.empty(1, device=DEV), torch.empty(C, device=DEV)
+    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz), ptr(gw), ptr(gb), ptr(gbz), N, C, 64, act, slope, stream()),
+          "head_dot_bwd")
+    close(gz, zd.grad, rtol=1e-6, what="d / d pre-activation")
+    close(gw, wd.grad, rtol=1e-5, what="head weight gradient")
+    close(gb, bd.grad, rtol=1e-5, what="head bias gradient")
+    close(gbz, zd.grad.sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-5 * float(zd.grad.abs().sum(dim=(0, 2, 3, 4)).mean()),
+          what="bias gradient of the layer below")
+    # optional outputs (a frozen critic in the generator update): only gz
+    gz2 = torch.empty_like(zg)
+    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz2), None, None, None, N, C, 64, act, slope, stream()), "head_dot_bwd")
+    assert torch.equal(gz2, gz)
+
+
+def test_conv_head_node_matches_the_two_layer_composition():
+    """ops.conv_head (what model/stack.py dispatches gan.Discriminator's last two layers to) against ConvFwd + LinearAct, the
+    path it replaces: outputs and every gradient, plain backward and the create_graph form (gradient penalty)."""
+    from shapegan_amd import ops
+    torch.manual_seed(11)
+    N = 6
+    x = torch.randn(N, 16, 8, 8, 8)
+    w, b = torch.randn(32, 16, 4, 4, 4) * 0.05, torch.randn(32) * 0.1
+    wh, bh = torch.randn(1, 32, 4, 4, 4) * 0.05, torch.randn(1)
+    gy = torch.randn(N)
+
+    def run(fused, create_graph):
+        leaves = [t.clone().to(DEV).requires_grad_() for t in (x, w, b, wh, bh)]
+        xx, ww, bb, wwh, bbh = leaves
+        if fused:
+            y = ops.conv_head(xx, ww, bb, 1, 0.2, wwh, bbh)
+        else:
+            h = ops.conv3d_k4s2p1(xx, ww, bb, 1, 0.2)
+            y = ops.LinearAct.apply(h.reshape(N, -1), wwh.reshape(1, -1), bbh, 0, 0.0, False, 0).reshape(N)
+        if not create_graph:
+            (y * gy.to(DEV)).sum().backward()
+            return [y] + [t.grad for t in leaves]
+        (gx,) = torch.autograd.grad(y, xx, grad_outputs=torch.ones_like(y), create_graph=True)
+        pen = ((gx.reshape(N, -1).norm(dim=1) - 1) ** 2).mean()
+        pen.backward()
+        return [pen, gx] + [leaves[i].grad for i in (1, 3)]     # the penalty reaches the two weights
+    for cg in (False, True):
+        for got, ref, name in zip(run(True, cg), run(False, cg), "abcdefg"):
+            close_mostly(got, ref, rtol=2e-5, max_bad_frac=2e-3, what="conv_head create_graph=%s output %s" % (cg, name))
+
+
+@pytest.mark.parametrize("n", [64, 8, 1, 777])
+def test_bce_and_neg_mean_log_match_torch(n):
+    """sg_loss_bce_* / sg_loss_neg_mean_log_* against torch.nn.functional.binary_cross_entropy with constant targets and
+    -torch.mean(torch.log(p)) (train_gan.py:30,65,78,84), values and gradients, including saturated scores (the -100 clamp of the
+    logarithm and the 1e-12 floor of the backward's denominator)."""
+    from shapegan_amd import ops
+    torch.manual_seed(n)
+    p = torch.rand(n).clamp(1e-4, 1 - 1e-4)
+    if n >= 8:
+        p[0], p[1], p[2] = 1.0, 0.0, 1e-30       # saturated discriminator outputs
+    for target in (0.0, 1.0):
+        pr = p.clone().requires_grad_()
+        ref = F.binary_cross_entropy(pr, torch.full_like(pr, target))
+        (ref * 1.7).backward()
+        pg = p.clone().to(DEV).requires_grad_()
+        got = ops.bce_const(pg, target)
+        (got * 1.7).backward()
+        close(got, ref, rtol=1e-6, what="bce target %g" % target)
+        torch.testing.assert_close(pg.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-30, msg=lambda m: "bce grad target %g: %s" % (target, m))
+    q = torch.rand(n).clamp(1e-3, 1.0)
+    qr = q.clone().requires_grad_()
+    ref = -torch.mean(torch.log(qr))
+    ref.backward()
+    qg = q.clone().to(DEV).requires_grad_()
+    got = ops.neg_mean_log(qg)
+    got.backward()
+    close(got, ref, rtol=1e-6, what="-mean(log)")
+    close(qg.grad, qr.grad, rtol=1e-5, what="-mean(log) grad")
+
+
+def test_vae_reparameterisation_matches_torch():
+    """sg_vae_reparam_* against `mean + torch.exp(log_variance * 0.5) * eps` (model/autoencoder.py:77-82) and its autograd."""
+    from shapegan_amd import ops
+    torch.manual_seed(3)
+    for shape in ((32, 128), (4, 128), (128,)):
+        mu, lv, eps = torch.randn(shape), torch.randn(shape) * 2, torch.randn(shape)
+        g = torch.randn(shape)
+        mr, lr = mu.clone().requires_grad_(), lv.clone().requires_grad_()
+        ref = mr + torch.exp(lr * 0.5) * eps
+        (ref * g).sum().backward()
+        mg, lg = mu.clone().to(DEV).requires_grad_(), lv.clone().to(DEV).requires_grad_()
+        got = ops.vae_reparam(mg, lg, eps.to(DEV))
+        (got * g.to(DEV)).sum().backward()
+        torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(mg.grad.cpu(), mr.grad, rtol=0, atol=0)
+        torch.testing.assert_close(lg.grad.cpu(), lr.grad, rtol=1e-5, atol=1e-7)
