@@ -21,6 +21,31 @@ __device__ __forceinline__ long chan_addr(long e, int c, int C, long S) {
     return (n * C + c) * S + s;
 }
 
+// the same walk without a 64-bit division per element: a float4 group at flat index e (e % 4 == 0, S % 4 == 0 so a group never
+// straddles two samples) and steps of `step` elements
+struct ChanWalk {
+    long n, s, S;
+    int c, C;
+    __device__ ChanWalk(long e, int c_, int C_, long S_) : S(S_), c(c_), C(C_) {
+        n = e / S_;
+        s = e - n * S_;
+    }
+    __device__ __forceinline__ long addr() const { return (n * C + c) * S + s; }
+    __device__ __forceinline__ void advance(long step) {
+        s += step;
+        if (s >= S) {
+            if (step <= S) {
+                s -= S;
+                ++n;
+            } else {
+                const long k = s / S;
+                n += k;
+                s -= k * S;
+            }
+        }
+    }
+};
+
 // partial[c][split] = {sum(x-K), sum((x-K)^2)}
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int N,
                                                        int C, long S, int nsplit) {
@@ -182,12 +207,45 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restri
     const long beg = sp * chunk, end = min(total, beg + chunk);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
     float s1 = 0.f, s2 = 0.f;
-    for (long e = beg + threadIdx.x; e < end; e += 256) {
-        const long ad = chan_addr(e, c, C, S);
-        const float xh = (x[ad] - mu) * is;
-        const float gg = bn_act_grad(xh, g, b, dy[ad], act, slope);
-        s1 += gg;
-        s2 += gg * xh;
+    if ((S & 3) == 0 && (beg & 3) == 0) {
+        // b128 loads of both operands, two groups in flight per lane (the scalar form with a 64-bit division per element read
+        // 134 MB in 54 us at 64 x 64 x 16^3)
+        ChanWalk w(beg + (long)threadIdx.x * 4, c, C, S);
+        long e = beg + (long)threadIdx.x * 4;
+        for (; e + 1024 < end; e += 2048) {
+            const long a0 = w.addr();
+            w.advance(1024);
+            const long a1 = w.addr();
+            w.advance(1024);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + a0), d0 = *reinterpret_cast<const f32x4*>(dy + a0);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + a1), d1 = *reinterpret_cast<const f32x4*>(dy + a1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh0 = (x0[j] - mu) * is, xh1 = (x1[j] - mu) * is;
+                const float g0 = bn_act_grad(xh0, g, b, d0[j], act, slope), g1 = bn_act_grad(xh1, g, b, d1[j], act, slope);
+                s1 += g0 + g1;
+                s2 += g0 * xh0 + g1 * xh1;
+            }
+        }
+        if (e < end) {
+            const long a0 = w.addr();
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + a0), d0 = *reinterpret_cast<const f32x4*>(dy + a0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh0 = (x0[j] - mu) * is;
+                const float g0 = bn_act_grad(xh0, g, b, d0[j], act, slope);
+                s1 += g0;
+                s2 += g0 * xh0;
+            }
+        }
+    } else {
+        for (long e = beg + threadIdx.x; e < end; e += 256) {
+            const long ad = chan_addr(e, c, C, S);
+            const float xh = (x[ad] - mu) * is;
+            const float gg = bn_act_grad(xh, g, b, dy[ad], act, slope);
+            s1 += gg;
+            s2 += gg * xh;
+        }
     }
     __shared__ double red[2][4];
     double d1 = sg_wave_sum_d((double)s1), d2 = sg_wave_sum_d((double)s2);
@@ -234,6 +292,25 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_apply_kernel(const float*
     const long total = (long)N * S;
     const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
     const long beg = sp * chunk, end = min(total, beg + chunk);
+    if ((S & 3) == 0 && (beg & 3) == 0) {
+        ChanWalk w(beg + (long)threadIdx.x * 4, c, C, S);
+        for (long e = beg + (long)threadIdx.x * 4; e < end; e += 1024) {
+            const long ad = w.addr();
+            w.advance(1024);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ad), dv = *reinterpret_cast<const f32x4*>(dy + ad);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mu) * is;
+                const float gg = bn_act_grad(xh, g, b, dv[j], act, slope);
+                float v = gg;
+                if (train) v = gg - db - xh * dg;
+                o[j] = g * is * v;
+            }
+            *reinterpret_cast<f32x4*>(dx + ad) = o;
+        }
+        return;
+    }
     for (long e = beg + threadIdx.x; e < end; e += 256) {
         const long ad = chan_addr(e, c, C, S);
         const float xh = (x[ad] - mu) * is;

@@ -765,6 +765,177 @@ __global__ void __launch_bounds__(512, 4) convT_c1_fused_kernel(ConvTFusedArgs a
     }
 }
 
+// ---- input gradient, plane-streaming form (round 4) --------------------------------------------------------------------------
+// The fused kernel above gives every (sample, plane) its own workgroup: all 512 resident workgroups load together, compute
+// together, gather together, and each plane is fetched by three of them (0.30 of the HBM roofline, MFMA-busy 0.33: neither
+// bandwidth- nor matrix-bound).  Here a workgroup owns one OUTPUT PARITY PAIR (pd, ph) of one sample and walks all its
+// input planes qd = 0 .. OD-1:
+//   * the output planes of d-parity pd take, per input plane, exactly two kd taps ("cur": kd = 1 + pd, lands on output plane
+//     2 qd + pd; "far": kd = 3 (pd 0) -> output plane 2 qd + 2, kd = 0 (pd 1) -> output plane 2 qd - 1), output rows of h-parity ph
+//     two kh taps, every kw: 16 of the 64 taps.  So the four workgroups of a sample split the tap planes without overlap — no
+//     halo plane is recomputed, no partial result crosses workgroups — and each computes S[16 taps][P2 positions] per plane as
+//     [16 positions] x [16 taps] x K = 4 channels v_mfma_f32_16x16x4_f32 tiles;
+//   * the plane's 16 tap rows go to one of two LDS buffers (16.6 KB each), ONE barrier per plane, every thread gathers one output
+//     (position q, column parity pw) from them: 4 reads for the cur taps, 4 for the far taps; the far (pd 0) / cur (pd 1) sum is
+//     carried in a register to the next plane, where the output plane it belongs to is completed and stored as whole rows;
+//   * the A fragments of plane qd + 1 (32 dword loads per lane) are requested before the MFMAs of plane qd: loads, matrix work
+//     and the gather of consecutive planes overlap inside every workgroup, not by luck of the dispatch;
+//   * a sample's activations are read by its four workgroups (same XCD, dispatched together: the L2 serves three of the four).
+// Optional input transform (PRE): dy is taken through  act_in(dy * in_scale[c] + in_shift[c])  on the way into the fragments — a
+// BatchNorm3d (+ LeakyReLU) between the producing layer and this one (model/gan.py:18-21) never becomes a pass of its own.
+struct ConvTStreamArgs {
+    const float* dy;     // [batch][Cy][OD][P2]
+    const float* w;      // [Cout][Cin_total][64], channel 0
+    const float* bias;   // optional [1]
+    float* dx;           // [batch][dx_sample], channel 0 written
+    const float* in_scale;   // PRE: [Cout] scale / shift of the input transform
+    const float* in_shift;
+    float in_slope;          // PRE: max(t, in_slope * t) after the affine map (LeakyReLU slope; ReLU 0; none 1)
+    int Cout, Cy, Cin_total;
+    int OD, OH, OW, P2;
+    long dx_sample;
+    int batch, act;
+    float slope;
+};
+
+// ALLCH: Cout == 64 (sixteen full k-steps, no channel clamps); FULL: P2 == 256 (every wave owns two whole position tiles).
+// The plane loop is kept free of data-dependent branches between the prefetch and the MFMAs: s_waitcnt vmcnt counts loads in
+// issue order, and at a control-flow join the compiler must assume the path with the FEWEST younger loads in flight — with an
+// `if (more planes) prefetch` it waited for the just-issued loads of plane qd + 1 before the first MFMA of plane qd (ISA listing:
+// vmcnt(31) .. vmcnt(0) instead of vmcnt(63) .. vmcnt(32)), i.e. no overlap at all.  The prefetch behind the last plane is issued
+// anyway with an out-of-range scalar offset (returns zeros without touching memory).
+template <bool ALLCH, bool PRE, bool FULL>
+__global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [2 buffers][16 taps][stride]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    // XCD-aware decode: workgroup b runs on XCD b % 8; the four workgroups of a sample are neighbours in dispatch order on one XCD
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int n = (j >> 2) * 8 + xcd, pd = (j >> 1) & 1, ph = j & 1;
+    if (n >= a.batch) return;     // (the whole workgroup)
+    const int P2 = a.P2, OW = a.OW, OH = a.OH, OD = a.OD;
+    const int ntiles = (P2 + 15) >> 4;                 // <= 16: tiles `wave` and `wave + 8`
+    const int stride = ntiles * 16 + 4;                // floats per tap row
+    lds_float* const Sl = (lds_float*)S;
+    const int nks = ALLCH ? 16 : (a.Cout + 3) >> 2;    // k-steps of 4 channels
+
+    // B fragments: column i16 = tap (g2 = cur / far, khi = same row / neighbour row, kw), k row kq = channel 4 s + kq
+    const int g2 = i16 >> 3, khi = (i16 >> 2) & 1, kw = i16 & 3;
+    const int kd = g2 == 0 ? (pd == 0 ? 1 : 2) : (pd == 0 ? 3 : 0);
+    const int kh = khi == 0 ? (ph == 0 ? 1 : 2) : (ph == 0 ? 3 : 0);
+    float wfr[16], psc[PRE ? 16 : 1], psh[PRE ? 16 : 1];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int co = 4 * s + kq;
+        const bool have = s < nks && co < a.Cout;
+        wfr[s] = have ? a.w[(long)co * a.Cin_total * 64 + kd * 16 + kh * 4 + kw] : 0.f;
+        if (PRE) {
+            psc[s] = have ? a.in_scale[co] : 0.f;
+            psh[s] = have ? a.in_shift[co] : 0.f;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.dy + (long)n * a.Cy * OD * P2);
+    const unsigned chan = (unsigned)(OD * P2) * 4u;     // bytes between channels of a sample
+    // lane offsets of the two position tiles at plane 0 (out of range beyond the plane)
+    unsigned voff[2];
+    bool tile_on[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = wave + 8 * t, p = tile * 16 + i16;
+        tile_on[t] = tile < ntiles;
+        voff[t] = (tile_on[t] && p < P2) ? (unsigned)p * 4u + (unsigned)kq * chan : kBufOutside;
+    }
+    auto load_plane = [&](int qd, float (&dst)[2][16]) __attribute__((always_inline)) {
+        const unsigned pshift = qd < OD ? (unsigned)(qd * P2) * 4u : kBufOutside;   // behind the last plane: nothing is fetched
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (ALLCH) {
+                    dst[t][s] = buf_load(dres, voff[t], (unsigned)(4 * s) * chan + pshift);
+                } else {   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight is zero
+                    const int co = min(4 * s + kq, a.Cout - 1);
+                    const unsigned off = voff[t] == kBufOutside ? kBufOutside : voff[t] - (unsigned)kq * chan + (unsigned)co * chan;
+                    dst[t][s] = buf_load(dres, s < nks ? off : kBufOutside, pshift);
+                }
+            }
+    };
+    // gather role of this thread: output (qh, qw, pw) of the plane pair row 2 qh + ph
+    const int q = tid >> 1, pw = tid & 1;
+    const int qh = q / OW, qw = q - qh * OW;
+    const bool gather_on = q < P2;
+    // the four (khi, kwi) taps of a group: row qh (+ dh for khi 1), column qw (+ dw for kwi 1)
+    const int dh = ph == 0 ? -1 : 1, dw = pw == 0 ? -1 : 1;
+    const int kw_same = pw == 0 ? 1 : 2, kw_nb = pw == 0 ? 3 : 0;
+    const bool row_nb = (unsigned)(qh + dh) < (unsigned)OH, col_nb = (unsigned)(qw + dw) < (unsigned)OW;
+    // LDS offsets (floats) of the cur group's taps (far group: + 8 * stride).  A tap whose source position lies outside the plane
+    // reads the thread's own position instead and is multiplied by 0: no branches in the gather.
+    const int qc = gather_on ? q : 0;
+    const int qrow = row_nb ? dh * OW : 0, qcol = col_nb ? dw : 0;
+    int goff[4];
+    goff[0] = (0 * 4 + kw_same) * stride + qc;
+    goff[1] = (0 * 4 + kw_nb) * stride + qc + qcol;
+    goff[2] = (1 * 4 + kw_same) * stride + qc + qrow;
+    goff[3] = (1 * 4 + kw_nb) * stride + qc + qrow + qcol;
+    const float gmul[4] = {1.f, col_nb ? 1.f : 0.f, row_nb ? 1.f : 0.f, (row_nb && col_nb) ? 1.f : 0.f};
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+    const int IH = 2 * OH, IW = 2 * OW;
+    float* const out = a.dx + (long)n * a.dx_sample + (long)(2 * qh + ph) * IW + 2 * qw + pw;
+    float carry = 0.f;
+
+    float A0[2][16], A1[2][16];
+    load_plane(0, A0);
+    auto plane = [&](int qd, float (&cur)[2][16], float (&nxt)[2][16]) __attribute__((always_inline)) {
+        load_plane(qd + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_float* const buf = Sl + (qd & 1) * 16 * stride;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!FULL && !tile_on[t]) continue;     // (wave-uniform)
+            f32x4v c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (!ALLCH && s >= nks) break;
+                float v = cur[t][s];
+                if (PRE) {
+                    v = fmaf(v, psc[s], psh[s]);
+                    v = fmaxf(v, v * a.in_slope);     // LeakyReLU with 0 <= slope <= 1 (ReLU: 0, none: 1) as max(t, slope t)
+                }
+                c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[s], c4, 0, 0, 0);
+            }
+            // column i16 = tap row, fragment rows 4 kq + (0..3) = positions of the tile
+            *(__attribute__((address_space(3))) f32x4v*)(buf + i16 * stride + (wave + 8 * t) * 16 + 4 * kq) = c4;
+        }
+        __syncthreads();
+        {
+            float tc[4], tf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tc[g] = buf[goff[g]];
+                tf[g] = buf[goff[g] + 8 * stride];
+            }
+            const float sc = (tc[0] + tc[1] * gmul[1]) + (tc[2] * gmul[2] + tc[3] * gmul[3]);
+            const float sf = (tf[0] + tf[1] * gmul[1]) + (tf[2] * gmul[2] + tf[3] * gmul[3]);
+            if (!gather_on) {
+            } else if (pd == 0) {
+                // output plane 2 qd: the far taps (kd 3) of plane qd - 1 (carried) + the cur taps (kd 1) of this plane
+                out[(long)(2 * qd) * IH * IW] = sg_apply_act(carry + sc + b0, a.act, a.slope);
+                carry = sf;
+            } else {
+                // output plane 2 qd - 1: the cur taps (kd 2) of plane qd - 1 (carried) + the far taps (kd 0) of this plane
+                if (qd > 0) out[(long)(2 * qd - 1) * IH * IW] = sg_apply_act(carry + sf + b0, a.act, a.slope);
+                carry = sc;
+            }
+        }
+    };
+    for (int qd = 0; qd < OD; qd += 2) {
+        plane(qd, A0, A1);
+        if (qd + 1 < OD) plane(qd + 1, A1, A0);
+    }
+    if (pd == 1 && gather_on) out[(long)(2 * OD - 1) * IH * IW] = sg_apply_act(carry + b0, a.act, a.slope);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 size_t edge_fwd_workspace_bytes(int, int, int, int) { return 0; }   // the forward reads the grid in place
 size_t edge_wgrad_workspace_bytes(int, int, int, int) { return (size_t)512 * kEdgePartial * sizeof(float); }   // partial tiles
@@ -882,12 +1053,61 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     return 1;
 }
 
+// Conv3d(1 -> Cout <= 64) input gradient = ConvTranspose3d(Cout -> 1) forward through the plane-streaming kernel; optionally with
+// the input transform act_in(dy * in_scale[c] + in_shift[c]) folded into the loads (in_act: none / LeakyReLU / ReLU).
+int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                          const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
+                          const float* in_shift, int in_act, float in_slope) {
+    const long O3 = g.O3();
+    if (Cin != 1 || Cout > 64 || g.OH * g.OW > 256 || (size_t)g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
+    const bool pre = in_scale != nullptr;
+    if (pre && (!in_shift || (in_act != SG_ACT_NONE && in_act != SG_ACT_LEAKY && in_act != SG_ACT_RELU) ||
+                (in_act == SG_ACT_LEAKY && (in_slope < 0.f || in_slope > 1.f))))
+        return 0;
+    ConvTStreamArgs f;
+    f.dy = dy;
+    f.w = w;
+    f.bias = bias;
+    f.dx = dx;
+    f.in_scale = in_scale;
+    f.in_shift = in_shift;
+    f.in_slope = in_act == SG_ACT_LEAKY ? in_slope : (in_act == SG_ACT_RELU ? 0.f : 1.f);
+    f.Cout = Cout;
+    f.Cy = g.Cy;
+    f.Cin_total = Cin_total;
+    f.OD = g.OD;
+    f.OH = g.OH;
+    f.OW = g.OW;
+    f.P2 = g.OH * g.OW;
+    f.dx_sample = (long)g.Cx * g.I3();
+    f.batch = batch;
+    f.act = act;
+    f.slope = slope;
+    const int ntiles = (f.P2 + 15) / 16;
+    const size_t lds = (size_t)2 * 16 * (ntiles * 16 + 4) * sizeof(float);
+    const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4);
+#define SG_CONVT_STREAM(ALL_, PRE_, FULL_) \
+    hipLaunchKernelGGL((convT_c1_stream_kernel<ALL_, PRE_, FULL_>), dim3(wgs), dim3(512), lds, stream, f)
+    if (Cout == 64 && f.P2 == 256) {
+        if (pre) SG_CONVT_STREAM(true, true, true); else SG_CONVT_STREAM(true, false, true);
+    } else {
+        if (pre) SG_CONVT_STREAM(false, true, false); else SG_CONVT_STREAM(false, false, false);
+    }
+#undef SG_CONVT_STREAM
+    return 1;
+}
+
 // Conv3d(1 -> Cout <= 64) input gradient = ConvTranspose3d(Cout -> 1) forward: dx [batch][Cx][I3] (channel 0 written).
 int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64) return 0;
+    // plane-streaming kernel (round 4); SG_NO_EDGE bit 16 restores the per-plane fused kernel below (A/B)
+    static const bool stream_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 16);
+    if (!stream_off && g.OH * g.OW <= 256 && (force || (long)batch * O3 >= 512) &&
+        edge_dgrad_stream_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, stream, nullptr, nullptr, 0, 0.f) == 1)
+        return 1;
     // fused kernel: a whole (OH x OW) plane of the four tap groups fits in LDS
     static const bool fused_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 8);
     if (!fused_off && g.OH * g.OW <= 256 && (size_t)g.Cy * O3 * 4 < (size_t)kBufRange && (force || (long)batch * O3 >= 512)) {

@@ -89,4 +89,8 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
                    hipStream_t stream, int force = 0);
 
+int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
+                          const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
+                          const float* in_shift, int in_act, float in_slope);
+
 }  // namespace sg

@@ -196,11 +196,32 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __re
     }
 }
 
-// two-stage deterministic sum: partial[block] then final
+// two-stage deterministic sum: partial[block] then final.  Every element is accumulated in double; four b128 loads are in flight
+// per lane (the scalar-load form streamed 2.3 TB/s where a read-only pass of this box does 4.0, profiles/r03_stream_calibration.json)
 __global__ void __launch_bounds__(256) sum_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, long n) {
-    double s = 0;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += (double)x[e];
-    s = sg_wave_sum_d(s);
+    double s0 = 0, s1 = 0;
+    const long stride = (long)gridDim.x * 256;
+    long done = 0;
+    if ((((uintptr_t)x) & 15) == 0) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        const long n4 = n >> 2;
+        long e = (long)blockIdx.x * 256 + threadIdx.x;
+        for (; e + 3 * stride < n4; e += 4 * stride) {
+            const f32x4 v0 = __builtin_nontemporal_load(x4 + e), v1 = __builtin_nontemporal_load(x4 + e + stride);
+            const f32x4 v2 = __builtin_nontemporal_load(x4 + e + 2 * stride), v3 = __builtin_nontemporal_load(x4 + e + 3 * stride);
+            s0 += ((double)v0[0] + (double)v0[1]) + ((double)v0[2] + (double)v0[3]);
+            s1 += ((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3]);
+            s0 += ((double)v2[0] + (double)v2[1]) + ((double)v2[2] + (double)v2[3]);
+            s1 += ((double)v3[0] + (double)v3[1]) + ((double)v3[2] + (double)v3[3]);
+        }
+        for (; e < n4; e += stride) {
+            const f32x4 v = x4[e];
+            s0 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+        }
+        done = n4 << 2;
+    }
+    for (long e = done + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) s1 += (double)x[e];
+    double s = sg_wave_sum_d(s0 + s1);
     __shared__ double red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

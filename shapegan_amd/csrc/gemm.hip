@@ -58,32 +58,48 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x
 
 // out[r] = sum_{e<len} x[r*ld + e]: one 256-thread workgroup per row (float4 stream, wave shuffles, LDS across waves).
 // Bias gradients of the SDFNet layers are rows of 20 000 - 4 000 000 points: one wave per row was 30 % of the
-// auto-decoder step.
+// auto-decoder step.  Four b128 loads are requested before the first add (one load per loop trip left a lane with a single
+// request in flight: 51 us per call at the progressive discriminator's 32 768-element rows).
+__device__ __forceinline__ float rowsum_lane_part(const float* __restrict__ p, long len, int t, int nt) {
+    float s = 0.f;
+    if ((((uintptr_t)p) & 15) == 0 && (len & 3) == 0) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+        const long n4 = len >> 2;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        long e = t;
+        for (; e + 3 * nt < n4; e += 4 * nt) {
+            const f32x4 v0 = __builtin_nontemporal_load(p4 + e), v1 = __builtin_nontemporal_load(p4 + e + nt);
+            const f32x4 v2 = __builtin_nontemporal_load(p4 + e + 2 * nt), v3 = __builtin_nontemporal_load(p4 + e + 3 * nt);
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+        }
+        for (; e < n4; e += nt) a0 += p4[e];
+        const f32x4 a = (a0 + a1) + (a2 + a3);
+        s = (a[0] + a[1]) + (a[2] + a[3]);
+    } else {
+        for (long e = t; e < len; e += nt) s += p[e];
+    }
+    return s;
+}
 __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
                                                      long len, long ld) {
     const long r = blockIdx.x;
-    const float* p = x + r * ld;
-    float s = 0.f;
-    if ((((uintptr_t)p) & 15) == 0 && (len & 3) == 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        const long n4 = len >> 2;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (long e = threadIdx.x; e < n4; e += 256) {
-            const float4 v = p4[e];
-            s0 += v.x;
-            s1 += v.y;
-            s2 += v.z;
-            s3 += v.w;
-        }
-        s = (s0 + s1) + (s2 + s3);
-    } else {
-        for (long e = threadIdx.x; e < len; e += 256) s += p[e];
-    }
+    float s = rowsum_lane_part(x + r * ld, len, threadIdx.x, 256);
     s = sg_wave_sum(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[r] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// short rows (conv bias gradients on 4^3 .. 16^3 grids: 64 .. 4096 elements): one WAVE per row, four rows per workgroup
+__global__ void __launch_bounds__(256) rowsum_wave_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                          long len, long ld) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float s = sg_wave_sum(rowsum_lane_part(x + r * ld, len, threadIdx.x & 63, 64));
+    if ((threadIdx.x & 63) == 0) out[r] = s;
 }
 
 // The same with the rows split into up to 8 equal groups that go to different destinations (the seven bias gradients of
@@ -95,22 +111,7 @@ struct RowsumDst {
 __global__ void __launch_bounds__(256) rowsum_multi_kernel(const float* __restrict__ x, RowsumDst dst, long rows_per_dst,
                                                            long len, long ld) {
     const long r = blockIdx.x;
-    const float* p = x + r * ld;
-    float s = 0.f;
-    if ((((uintptr_t)p) & 15) == 0 && (len & 3) == 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (long e = threadIdx.x; e < (len >> 2); e += 256) {
-            const float4 v = p4[e];
-            s0 += v.x;
-            s1 += v.y;
-            s2 += v.z;
-            s3 += v.w;
-        }
-        s = (s0 + s1) + (s2 + s3);
-    } else {
-        for (long e = threadIdx.x; e < len; e += 256) s += p[e];
-    }
+    float s = rowsum_lane_part(x + r * ld, len, threadIdx.x, 256);
     s = sg_wave_sum(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -397,7 +398,10 @@ int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream
 
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream) {
     SG_CHECK_ARG(x && out && rows > 0 && len > 0);
-    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, out, rows, len, ld);
+    if (len <= 4096 && rows >= 1024)      // many short rows: one wave per row
+        hipLaunchKernelGGL(rowsum_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, out, rows, len, ld);
+    else
+        hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, out, rows, len, ld);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
