@@ -94,6 +94,14 @@ int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, 
 int sg_convT3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
                           int ID, int IH, int IW, int act, float slope, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
+/* The same for C -> 1 channel (C <= 64, planes of at most 256 positions) with the INPUT taken through
+ * act_in(x * in_scale[c] + in_shift[c]) inside the kernel's loads: a BatchNorm3d + LeakyReLU between the producing layer and this
+ * one (model/gan.py:18-21, model/autoencoder.py:60-63) then never is a pass of its own — sg_bn_train_stats supplies
+ * scale / shift.  in_act: none, LeakyReLU (0 <= in_slope <= 1) or ReLU. */
+int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW);
+int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                              const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
+                              float slope, hipStream_t stream);
 int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                             int IW, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_convT3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin_T, int Cout_T, int ID, int IH,
@@ -136,6 +144,12 @@ int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float
                     float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S,
                     float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
                     hipStream_t stream);
+/* Batch statistics WITHOUT the normalised output: mean / invstd, the running-statistics update exactly as sg_bn_train_fwd does
+ * it, and the affine map scale[c] = gamma[c] * invstd[c], shift[c] = beta[c] - mean[c] * scale[c] that a consumer applies on its
+ * loads (sg_convT3d_k4s2p1_to1_pre). */
+int sg_bn_train_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift, int N,
+                      int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_bn_eval_fwd(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,
                    const float* running_var, float* save_mean, float* save_invstd, int N, int C, long S, float eps,
                    int act, float slope, hipStream_t stream);

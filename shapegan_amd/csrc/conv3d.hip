@@ -822,6 +822,27 @@ int sg_convT3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, flo
     return sg_conv3d_k4s2p1_dgrad(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act,
                                   slope, workspace, workspace_bytes, stream);
 }
+// ConvTranspose3d(C -> 1, k4 s2 p1) with the INPUT taken through act_in(x * in_scale[c] + in_shift[c]) on the way into the kernel
+// (a BatchNorm3d + LeakyReLU between the producing layer and this one, model/gan.py:18-21, folded into the loads of
+// convT_c1_stream_kernel): x [batch, C, I^3] -> y [batch, 1, (2I)^3].  Served for C <= 64 and planes of at most 256 positions.
+int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW) {
+    return batch > 0 && C > 0 && C <= 64 && ID > 0 && IH > 0 && IW > 0 && IH * IW <= 256 &&
+           (size_t)C * ID * IH * IW * 4 < (size_t)kBufRange && (long)batch * 8 * ID * IH * IW < (1L << 31);
+}
+int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                              const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
+                              float slope, hipStream_t stream) {
+    SG_CHECK_ARG(x && w && y && in_scale && in_shift);
+    if (!sg_convT3d_k4s2p1_to1_pre_eligible(batch, C, ID, IH, IW))
+        SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: shape not served (C <= 64, IH * IW <= 256)");
+    SG_CHECK_ARG(in_act == SG_ACT_NONE || in_act == SG_ACT_RELU || (in_act == SG_ACT_LEAKY && in_slope >= 0.f && in_slope <= 1.f));
+    ConvGeom g;
+    if (make_geom(g, 2 * ID, 2 * IH, 2 * IW, 1, C)) SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: bad spatial dims");
+    if (edge_dgrad_stream_try(x, w, bias, y, batch, 1, 1, g, C, act, slope, stream, in_scale, in_shift, in_act, in_slope) != 1)
+        SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: not served");
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
 int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                             int IW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return sg_conv3d_k4s2p1_fwd(dy, w, nullptr, dx, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW,

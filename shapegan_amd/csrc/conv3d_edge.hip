@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     const int n = (j >> 2) * 8 + xcd, pd = (j >> 1) & 1, ph = j & 1;
     if (n >= a.batch) return;     // (the whole workgroup)
     const int P2 = a.P2, OW = a.OW, OH = a.OH, OD = a.OD;
-    const int ntiles = (P2 + 15) >> 4;                 // <= 16: tiles `wave` and `wave + 8`
+    const int ntiles = (P2 + 15) >> 4;                 // <= 16: tiles 2 wave and 2 wave + 1 (together one 128-byte line per channel)
     const int stride = ntiles * 16 + 4;                // floats per tap row
     lds_float* const Sl = (lds_float*)S;
     const int nks = ALLCH ? 16 : (a.Cout + 3) >> 2;    // k-steps of 4 channels
@@ -842,24 +842,23 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     bool tile_on[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int tile = wave + 8 * t, p = tile * 16 + i16;
+        const int tile = 2 * wave + t, p = tile * 16 + i16;
         tile_on[t] = tile < ntiles;
         voff[t] = (tile_on[t] && p < P2) ? (unsigned)p * 4u + (unsigned)kq * chan : kBufOutside;
     }
-    auto load_plane = [&](int qd, float (&dst)[2][16]) __attribute__((always_inline)) {
-        const unsigned pshift = qd < OD ? (unsigned)(qd * P2) * 4u : kBufOutside;   // behind the last plane: nothing is fetched
+    // one k-step of a plane's A fragments (both tiles); behind the last plane nothing is fetched (out-of-range scalar offset)
+    auto load_step = [&](int qd, int s, float (&dst)[2][16]) __attribute__((always_inline)) {
+        const unsigned pshift = qd < OD ? (unsigned)(qd * P2) * 4u : kBufOutside;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (ALLCH) {
-                    dst[t][s] = buf_load(dres, voff[t], (unsigned)(4 * s) * chan + pshift);
-                } else {   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight is zero
-                    const int co = min(4 * s + kq, a.Cout - 1);
-                    const unsigned off = voff[t] == kBufOutside ? kBufOutside : voff[t] - (unsigned)kq * chan + (unsigned)co * chan;
-                    dst[t][s] = buf_load(dres, s < nks ? off : kBufOutside, pshift);
-                }
+        for (int t = 0; t < 2; ++t) {
+            if (ALLCH) {
+                dst[t][s] = buf_load(dres, voff[t], (unsigned)(4 * s) * chan + pshift);
+            } else {   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight is zero
+                const int co = min(4 * s + kq, a.Cout - 1);
+                const unsigned off = voff[t] == kBufOutside ? kBufOutside : voff[t] - (unsigned)kq * chan + (unsigned)co * chan;
+                dst[t][s] = buf_load(dres, s < nks ? off : kBufOutside, pshift);
             }
+        }
     };
     // gather role of this thread: output (qh, qw, pw) of the plane pair row 2 qh + ph
     const int q = tid >> 1, pw = tid & 1;
@@ -885,28 +884,35 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     float carry = 0.f;
 
     float A0[2][16], A1[2][16];
-    load_plane(0, A0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) load_step(0, s, A0);
     auto plane = [&](int qd, float (&cur)[2][16], float (&nxt)[2][16]) __attribute__((always_inline)) {
-        load_plane(qd + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
+        // The loads of plane qd + 1 are issued BETWEEN the MFMAs of plane qd, one k-step (two dword loads) per MFMA pair: all
+        // eight waves of the workgroup run in lockstep (one barrier per plane), so a block of 32 loads per wave up front was a
+        // phase in which the texture addresser worked and the matrix pipe idled (first version: 36.8 us at 64 samples, no better
+        // than one workgroup per plane).
         lds_float* const buf = Sl + (qd & 1) * 16 * stride;
+        f32x4v c4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (!FULL && !tile_on[t]) continue;     // (wave-uniform)
-            f32x4v c4 = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 16; ++s) {
+            load_step(qd + 1, s, nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (!ALLCH && s >= nks) break;
+            for (int t = 0; t < 2; ++t) {
                 float v = cur[t][s];
                 if (PRE) {
                     v = fmaf(v, psc[s], psh[s]);
                     v = fmaxf(v, v * a.in_slope);     // LeakyReLU with 0 <= slope <= 1 (ReLU: 0, none: 1) as max(t, slope t)
                 }
-                c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[s], c4, 0, 0, 0);
+                c4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[s], c4[t], 0, 0, 0);
             }
-            // column i16 = tap row, fragment rows 4 kq + (0..3) = positions of the tile
-            *(__attribute__((address_space(3))) f32x4v*)(buf + i16 * stride + (wave + 8 * t) * 16 + 4 * kq) = c4;
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // column i16 = tap row, fragment rows 4 kq + (0..3) = positions of the tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (FULL || tile_on[t])
+                *(__attribute__((address_space(3))) f32x4v*)(buf + i16 * stride + (2 * wave + t) * 16 + 4 * kq) = c4[t];
         __syncthreads();
         {
             float tc[4], tf[4];

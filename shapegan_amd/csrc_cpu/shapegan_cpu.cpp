@@ -184,6 +184,20 @@ int sg_convT3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias,
     return sg_conv3d_k4s2p1_dgrad_cpu(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act, slope, ws,
                                       wb, st);
 }
+int sg_convT3d_k4s2p1_to1_pre_cpu(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                  const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                  int act, float slope, void* st) {
+    CPU_CHECK(x && w && y && in_scale && in_shift && batch > 0 && C > 0 && C <= 64 && IH * IW <= 256);
+    CPU_CHECK(in_act == ACT_NONE || in_act == ACT_LEAKY || in_act == ACT_RELU);
+    const long S = (long)ID * IH * IW, total = (long)batch * C * S;
+    std::vector<float> t((size_t)total);
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < total; ++e) {
+        const int c = (int)((e / S) % C);
+        t[(size_t)e] = apply_act(x[e] * in_scale[c] + in_shift[c], in_act, in_slope);
+    }
+    return sg_conv3d_k4s2p1_dgrad_cpu(t.data(), w, bias, y, batch, 1, 1, 1, C, 2 * ID, 2 * IH, 2 * IW, act, slope, nullptr, 0, st);
+}
 int sg_convT3d_k4s2p1_dgrad_cpu(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                                 int IW, void* ws, size_t wb, void* st) {
     return sg_conv3d_k4s2p1_fwd_cpu(dy, w, nullptr, dx, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, ACT_NONE, 0.f,
@@ -319,6 +333,35 @@ int sg_bn_train_fwd_cpu(const float* x, const float* gamma, const float* beta, f
             float* q = y + ((long)n * C + c) * S;
             for (long e = 0; e < S; ++e) q[e] = apply_act(gamma[c] * ((p[e] - (float)mu) * is) + beta[c], act, slope);
         }
+    }
+    if (num_batches_tracked) *num_batches_tracked += 1;
+    return SG_OK;
+}
+int sg_bn_train_stats_cpu(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
+                          int N, int C, long S, float eps, float momentum, void*, size_t, void*) {
+    CPU_CHECK(x && gamma && beta && save_mean && save_invstd && scale && shift && N > 0 && C > 0 && S > 0);
+    const double cnt = (double)N * S;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+        double s = 0, s2 = 0;
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) s += p[e];
+        }
+        const double mu = s / cnt;
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * S;
+            for (long e = 0; e < S; ++e) s2 += (p[e] - mu) * (p[e] - mu);
+        }
+        const double var = s2 / cnt;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[c] = (float)mu;
+        save_invstd[c] = is;
+        scale[c] = gamma[c] * is;
+        shift[c] = beta[c] - (float)mu * scale[c];
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(cnt > 1 ? s2 / (cnt - 1) : var);
     }
     if (num_batches_tracked) *num_batches_tracked += 1;
     return SG_OK;

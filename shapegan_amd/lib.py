@@ -38,6 +38,8 @@ SIGNATURES = {
     "sg_conv3d_k4s2p1_wgrad_act_eligible": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_wgrad_act": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_convT3d_k4s2p1_to1_pre_eligible": (c_int, [_I, _I, _I, _I, _I]),
+    "sg_convT3d_k4s2p1_to1_pre": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _P]),
     "sg_convT3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_gemm_workspace_bytes": (_Z, [_I, _I]),
@@ -48,6 +50,7 @@ SIGNATURES = {
     "sg_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P]),
     "sg_bn_workspace_bytes": (_Z, [_I]),
     "sg_bn_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
+    "sg_bn_train_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P, _Z, _P]),
     "sg_bn_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _F, _P]),
     "sg_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _Z, _P]),
     "sg_act_fwd": (c_int, [_P, _P, _L, _I, _F, _P]),
@@ -162,7 +165,7 @@ def check_comm(rc, what=""):
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
     "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-    "sg_conv3d_k4s2p1_wgrad_act_eligible"}
+    "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible"}
 CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
 
 _hip = None

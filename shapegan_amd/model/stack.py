@@ -63,6 +63,42 @@ def _batchnorm(m, x, act, slope, training):
                                   act, slope)
 
 
+# Switch for the inference-mode fusion below (A/B, and for tests that replay a RECORDED fp32 trajectory: a different rounding of
+# the generator's samples may flip a LeakyReLU pre-activation that sits within 1e-7 of zero in the critic, DESIGN.md 3.3 "kinks")
+FUSE_BN_INTO_LAST_CONV_TRANSPOSE = True
+
+
+def _bn_into_last_conv_transpose(mods, i, raw, training, out):
+    """[.., BatchNorm3d, LeakyReLU / ReLU, ConvTranspose3d(C -> 1, k4 s2 p1) (, activation)] at the end of a generator / decoder
+    (model/gan.py:18-22, model/autoencoder.py:60-63) WITHOUT grad mode and with batch statistics: the statistics are taken from
+    the producer's raw output `raw` (running buffers updated as torch does), and normalisation + activation are applied inside the
+    last transposed convolution's loads — the normalised tensor (67 MB at batch 64) is neither written nor read back.  Returns
+    (result, next index) or None when the pattern / mode does not apply (the unfused path is taken)."""
+    import torch
+    bn = mods[i + 1]
+    if not FUSE_BN_INTO_LAST_CONV_TRANSPOSE or torch.is_grad_enabled() or not isinstance(bn, nn.BatchNorm3d) or i + 3 >= len(mods):
+        return None
+    if not (training or not bn.track_running_stats) or bn.momentum is None or not bn.affine:
+        return None
+    a = _act_of(mods[i + 2])
+    last = mods[i + 3]
+    if a is None or a[0] not in (ACT_LEAKY, ACT_RELU) or not (0.0 <= a[1] <= 1.0):
+        return None
+    if not (isinstance(last, nn.ConvTranspose3d) and _is_k4(last, 2, 1) and last.out_channels == 1
+            and ops.convT_to1_pre_served(raw, last.weight)):
+        return None
+    nxt_i = i + 4
+    a2 = _act_of(mods[nxt_i]) if nxt_i < len(mods) else None
+    if a2 is not None:
+        nxt_i += 1
+    scale, shift = ops.bn_train_stats_affine(raw, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             bn.num_batches_tracked if bn.track_running_stats else None, bn.eps, bn.momentum)
+    y = ops.conv_transpose3d_to1_pre_raw(raw, scale, shift, a[0], a[1], last.weight, last.bias,
+                                         a2[0] if a2 is not None else ACT_NONE, a2[1] if a2 is not None else 0.0,
+                                         out if nxt_i == len(mods) else None)
+    return y, nxt_i
+
+
 def run_stack(modules, x, training, out=None):
     """out: optional destination of the LAST layer's result when that is a k4 s2 p1 transposed convolution (+ activation) and grad
     mode is off; ignored otherwise (the caller checks what it got back)."""
@@ -74,6 +110,10 @@ def run_stack(modules, x, training, out=None):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, (nn.BatchNorm3d, nn.BatchNorm1d)):
                 x = _producer(m, x, ACT_NONE, 0.0)
+                fused = _bn_into_last_conv_transpose(mods, i, x, training, out)
+                if fused is not None:
+                    x, i = fused
+                    continue
                 a = _act_of(mods[i + 2]) if i + 2 < len(mods) else None
                 if a is not None:
                     x = _batchnorm(nxt, x, a[0], a[1], training)

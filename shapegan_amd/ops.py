@@ -432,6 +432,46 @@ def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0, out=None):
     return ConvDgrad.apply(x, w, b, w.shape[1], act, slope, True)
 
 
+def convT_to1_pre_served(x, w):
+    """Whether sg_convT3d_k4s2p1_to1_pre takes ConvTranspose3d(C -> 1) on x [N,C,D,H,W] (weight [C,1,4,4,4])."""
+    return (w.shape[1] == 1 and x.dim() == 5 and
+            bool(_lib().sg_convT3d_k4s2p1_to1_pre_eligible(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4])))
+
+
+def bn_train_stats_affine(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum):
+    """Batch statistics of x [N,C,*S] with torch's running-statistics update, WITHOUT writing the normalised tensor: returns
+    (scale, shift) with batch_norm(x)[:, c] == x[:, c] * scale[c] + shift[c] (sg_bn_train_stats).  No autograd: inference-mode
+    generator evaluations only."""
+    x = f32c(x)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    lib = _lib()
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    ws = workspace("bn", lib.sg_bn_workspace_bytes(C), x.device)
+    check(lib.sg_bn_train_stats(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                ptr(num_batches_tracked), ptr(scale), ptr(shift), N, C, S, eps, momentum, ptr(ws), ws.numel(),
+                                stream()), "bn_train_stats")
+    return scale, shift
+
+
+def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=ACT_NONE, slope=0.0, out=None):
+    """act(conv_transpose3d_k4s2p1(act_in(x * scale[c] + shift[c]), w) + b) for w [C,1,4,4,4]: the BatchNorm + activation between
+    the producing layer and the last transposed convolution ride in this kernel's loads (no autograd)."""
+    x, w = f32c(x), f32c(w)
+    N, C, D, H, W = x.shape
+    shape = (N, 1, 2 * D, 2 * H, 2 * W)
+    if out is not None:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise RuntimeError("conv_transpose3d_to1_pre: `out` must be a contiguous fp32 tensor of shape %s on %s" % (shape, x.device))
+        y = out
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(_lib().sg_convT3d_k4s2p1_to1_pre(ptr(x), ptr(w), ptr(b), ptr(y), ptr(scale), ptr(shift), in_act, in_slope, N, C, D, H, W,
+                                           act, slope, stream()), "convT3d_to1_pre")
+    return y
+
+
 # --------------------------------------------------------------------------------------------------------------
 # the critic's tail: Conv3d(k4 s2 p1) -> activation -> Conv3d(C -> 1, k4 s1) on the 4^3 grid (model/gan.py:53-55)
 # --------------------------------------------------------------------------------------------------------------
@@ -468,7 +508,10 @@ class ConvHead(Function):
         need_b, need_bh = need_b and has_b, need_bh and has_bh
         N, C = z.shape[0], z.shape[1]
         if torch.is_grad_enabled():
-            # create_graph: gradients that can be differentiated again
+            # create_graph: gradients that can be differentiated again.  The pre-activation is recomputed as a graph node (the
+            # saved z is an intermediate without history): the activation mask then hangs on the convolution's inputs, and a
+            # parameter the penalty reaches only through that mask (this layer's bias) gets the zero gradient torch gives it
+            z = ConvFwd.apply(x, w, b, ACT_NONE, 0.0)
             zf = z.reshape(N, C * 64)
             gcol = gy.reshape(N, 1)
             gz = ActBwd.apply(z, Gemm.apply(gcol, wh.reshape(1, C * 64), False, False).reshape(z.shape), act, slope) \

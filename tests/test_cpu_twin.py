@@ -44,7 +44,7 @@ def test_twin_exports_every_entry_point():
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
             "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-            "sg_conv3d_k4s2p1_wgrad_act_eligible")
+            "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible")
 
 
 def test_dispatch_is_by_tensor_device_only(on_cpu):
@@ -179,10 +179,10 @@ def test_sdfnet_module_and_gradient_penalty(on_cpu, golden_modules):
     M.test_gradient_penalty_double_backward(golden_modules)
 
 
-def test_training_trajectories(on_cpu, golden_steps):
+def test_training_trajectories(on_cpu, golden_steps, monkeypatch):
     """train_wgan.py, train_autoencoder.py (configs[0]'s loop body), train_sdf_autodecoder.py, train_hybrid_wgan.py steps
     on the native optimizers and modules, all on the CPU twin, against the reference-made trajectories."""
-    M.test_wgan_trajectory(golden_steps)
+    M.test_wgan_trajectory(golden_steps, monkeypatch)
     M.test_autoencoder_trajectory(golden_steps)
     M.test_sdf_autodecoder_trajectory(golden_steps)
     M.test_hybrid_wgan_trajectory(golden_steps)
@@ -266,3 +266,8 @@ def test_bce_neg_mean_log_and_reparam_cpu(on_cpu):
     for n in (64, 1):
         LOSS.test_bce_and_neg_mean_log_match_torch(n)
     LOSS.test_vae_reparameterisation_matches_torch()
+
+
+@pytest.mark.parametrize("batch", [5])
+def test_generator_fused_inference_cpu(on_cpu, batch):
+    M.test_generator_fused_inference_matches_the_unfused_form(batch)

@@ -152,7 +152,10 @@ def test_generator_writes_into_a_given_tensor_without_grad_mode():
     assert got.data_ptr() == both.data_ptr() and torch.equal(both[:3], want) and bool((both[3:] == 7.0).all())
     g.load_state_dict(state)
     y = g(z, out=both[3:])                             # grad mode: an ordinary differentiable forward
-    assert y.data_ptr() != both[3:].data_ptr() and y.requires_grad and torch.equal(y.detach(), want)
+    assert y.data_ptr() != both[3:].data_ptr() and y.requires_grad
+    # (without grad mode the last BatchNorm + LeakyReLU ride in the final transposed convolution's loads, model/stack.py: the two
+    # modes differ by rounding, not bit for bit)
+    torch.testing.assert_close(y.detach(), want, rtol=1e-5, atol=2e-6)
     assert bool((both[3:] == 7.0).all())
     with pytest.raises(RuntimeError):
         with torch.no_grad():
@@ -251,6 +254,35 @@ def _cpu_state(module, dtype=torch.float32):
             for k, v in module.state_dict().items()}
 
 
+@pytest.mark.parametrize("batch", [64, 5])
+def test_generator_fused_inference_matches_the_unfused_form(batch):
+    """Without grad mode the generator takes its last BatchNorm3d + LeakyReLU through sg_bn_train_stats and the loads of
+    sg_convT3d_k4s2p1_to1_pre (model/stack.py): samples, BatchNorm running statistics and batch counters must equal the unfused
+    path's (same statistics kernel, so the buffers are bit-equal; the samples to fp32 rounding), and both the fp64 oracle."""
+    from shapegan_amd.model import stack
+    from shapegan_amd.model.gan import Generator
+    torch.manual_seed(60 + batch)
+    g = Generator()
+    state = {k: v.clone() for k, v in g.state_dict().items()}
+    z = torch.randn(batch, 128)
+    ref = O.generator_forward({k: v.detach().cpu().double() for k, v in state.items()}, z.double(), True).reshape(batch, 1, 32, 32, 32)
+    outs, bufs = [], []
+    for fuse in (True, False):
+        g.load_state_dict(state)
+        stack.FUSE_BN_INTO_LAST_CONV_TRANSPOSE = fuse
+        try:
+            with torch.no_grad():
+                outs.append(g(z.cuda()).cpu())
+        finally:
+            stack.FUSE_BN_INTO_LAST_CONV_TRANSPOSE = True
+        bufs.append({k: v.detach().cpu().clone() for k, v in g.state_dict().items() if "running" in k or "tracked" in k})
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=3e-6)
+    for o in outs:
+        torch.testing.assert_close(o.double(), ref, rtol=1e-4, atol=3e-5)
+    for k in bufs[0]:
+        torch.testing.assert_close(bufs[0][k], bufs[1][k], rtol=1e-6, atol=1e-7, msg=lambda m: k + ": " + m)
+
+
 def _check_updates(module, init, P32, P64, what, golden=None, prefix=None, anchor_rtol=2e-3, **kw):
     """Compares the parameter UPDATES (final - initial) of the HIP run with the fp64 / fp32 oracle trajectories.
     RMSprop/Adam turn a gradient of any magnitude into a step of about lr (the first step is lr * sign(g) * const),
@@ -274,10 +306,18 @@ def _check_updates(module, init, P32, P64, what, golden=None, prefix=None, ancho
             assert abs(got - float(ref[1])) <= anchor_rtol * abs(float(ref[1])) + 1e-12, (prefix, k, got, float(ref[1]))
 
 
-def test_wgan_trajectory(golden_steps):
-    """train_wgan.py steps (2 critic + 1 generator) from the reference's seed-51 init."""
+def test_wgan_trajectory(golden_steps, monkeypatch):
+    """train_wgan.py steps (2 critic + 1 generator) from the reference's seed-51 init.
+
+    The recorded trajectory has a critic pre-activation 8e-8 from zero (layers.4, first batch): which side of the LeakyReLU kink
+    an fp32 implementation puts it on decides 0.2 % of every gradient below it, and RMSprop's sign-like first steps turn that
+    into whole steps.  The inference-mode generator's fused last BatchNorm (model/stack.py) rounds the samples differently (9e-7)
+    and lands on the other side; the replay therefore pins the unfused form, whose side is the recording's.  The fused form's
+    forward is tested on its own (test_generator_fused_inference_matches_the_unfused_form)."""
+    from shapegan_amd.model import stack
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
+    monkeypatch.setattr(stack, "FUSE_BN_INTO_LAST_CONV_TRANSPOSE", False)
     torch.manual_seed(51)
     g, c = Generator(), Discriminator()
     g0, c0 = _cpu_state(g), _cpu_state(c)
