@@ -9,8 +9,6 @@
 // through LDS; the partials are combined in double at the head of the second pass (finalize + apply in one launch), whose
 // (channel, 0) workgroup also updates the running statistics.
 // Sums are shifted by the channel's first element so E[x^2]-E[x]^2 does not cancel when |mean| >> std.
-#include <stdlib.h>
-
 #include "common.h"
 #include "../../include/shapegan_hip.h"
 
@@ -180,82 +178,6 @@ __global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __r
             y[ad] = sg_apply_act(fmaf(x[ad], sc, sh), act, slope);
         }
     }
-}
-
-// ---- training forward in ONE launch for channels of at most 32 768 elements (N * S) ------------------------------------------------
-// The two-pass form costs two launches of ~5 us each for tensors of a few MB (the generator's first two BatchNorm3d layers,
-// model/gan.py:10,14: 4 and 17 MB — 25 us per generator evaluation, six evaluations per WGAN step).  Here one 512-thread workgroup
-// per channel keeps the channel's elements in registers (<= 16 float4 per thread): statistics (shifted by the channel's first
-// element, partial sums in fp32 per thread, combined in double in a fixed order), running-statistics update, normalisation +
-// activation, store — the tensor is read once and written once.
-constexpr int kBnOneMaxGroups = 16;     // float4 groups per thread
-__global__ void __launch_bounds__(512) bn_onepass_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
-                                                         float* running_var, long long* num_batches_tracked, int N, int C, long S,
-                                                         float eps, float momentum, int act, float slope) {
-    const int c = blockIdx.x;
-    const long total = (long)N * S, ngroups = total >> 2;
-    const float K = x[(long)c * S];
-    f32x4 v[kBnOneMaxGroups];
-    long ad[kBnOneMaxGroups];
-    ChanWalk w((long)threadIdx.x * 4, c, C, S);
-#pragma unroll
-    for (int u = 0; u < kBnOneMaxGroups; ++u) {
-        const bool on = (long)threadIdx.x + 512L * u < ngroups;
-        ad[u] = on ? w.addr() : -1;
-        w.advance(2048);
-        if (on) v[u] = *reinterpret_cast<const f32x4*>(x + ad[u]);
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < kBnOneMaxGroups; ++u)
-        if (ad[u] >= 0) {
-            const float a0 = v[u][0] - K, a1 = v[u][1] - K, a2 = v[u][2] - K, a3 = v[u][3] - K;
-            s1 += (a0 + a1) + (a2 + a3);
-            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-    __shared__ double red[2][8];
-    __shared__ float stat[2];
-    const double d1 = sg_wave_sum_d((double)s1), d2 = sg_wave_sum_d((double)s2);
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = d1;
-        red[1][threadIdx.x >> 6] = d2;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t1 = 0, t2 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            t1 += red[0][i];
-            t2 += red[1][i];
-        }
-        const double n = (double)total;
-        const double m = t1 / n;
-        double var = t2 / n - m * m;
-        if (var < 0) var = 0;
-        const float mu = (float)((double)K + m), is = (float)(1.0 / sqrt(var + (double)eps));
-        stat[0] = mu;
-        stat[1] = is;
-        mean[c] = mu;
-        invstd[c] = is;
-        if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-            const double unbiased = n > 1 ? var * n / (n - 1) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    }
-    __syncthreads();
-    const float sc = gamma[c] * stat[1], sh = beta[c] - stat[0] * sc;
-#pragma unroll
-    for (int u = 0; u < kBnOneMaxGroups; ++u)
-        if (ad[u] >= 0) {
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = sg_apply_act(fmaf(v[u][j], sc, sh), act, slope);
-            *reinterpret_cast<f32x4*>(y + ad[u]) = o;
-        }
 }
 
 // Statistics WITHOUT the apply pass: finalize of bn_stats_kernel's partials into mean / invstd, the running statistics, and the
@@ -479,13 +401,6 @@ int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float
                     hipStream_t stream) {
     SG_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && N > 0 && C > 0 && S > 0);
     if (!workspace || workspace_bytes < sg_bn_workspace_bytes(C)) SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_fwd: workspace too small");
-    static const bool onepass_off = getenv("SG_BN_TWO_PASS") != nullptr;     // A/B switch
-    if (!onepass_off && (S & 3) == 0 && (long)N * S <= 4L * 512 * kBnOneMaxGroups && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-        hipLaunchKernelGGL(bn_onepass_kernel, dim3(C), dim3(512), 0, stream, x, y, gamma, beta, save_mean, save_invstd, running_mean,
-                           running_var, num_batches_tracked, N, C, S, eps, momentum, act, slope);
-        SG_CHECK_LAUNCH();
-        return SG_OK;
-    }
     const int ns = bn_nsplit(N, C, S);
     double* part = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, stream, x, part, N, C, S, ns);

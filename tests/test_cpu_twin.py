@@ -271,3 +271,7 @@ def test_bce_neg_mean_log_and_reparam_cpu(on_cpu):
 @pytest.mark.parametrize("batch", [5])
 def test_generator_fused_inference_cpu(on_cpu, batch):
     M.test_generator_fused_inference_matches_the_unfused_form(batch)
+
+
+def test_conv_transpose3d_to_one_channel_with_input_transform_cpu(on_cpu):
+    OPS.test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes()

@@ -232,6 +232,47 @@ def test_conv_transpose3d_to_one_channel_random_shapes():
         close(got, ref, what="convT C->1 N=%d C=%d R=%d" % (N, C, R))
 
 
+def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
+    """The plane-streaming ConvTranspose3d(C -> 1) kernel (four workgroups per sample, one output parity pair each): through the
+    input-transform entry sg_convT3d_k4s2p1_to1_pre — act_in(x * scale[c] + shift[c]) folded into the loads, as the inference-mode
+    generator uses it for its last BatchNorm3d + LeakyReLU — at random channel counts, odd plane sizes (8-byte loads at 4-byte
+    alignment, partial blocks), batch sizes that are no multiple of the XCD count, every output activation form; and through the
+    plain entry at batch sizes that take it (>= 48 samples)."""
+    import random
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+    random.seed(7)
+    for it in range(16):
+        N, C, R = random.randint(1, 19), random.choice((1, 2, 7, 24, 33, 63, 64)), random.choice((1, 2, 3, 5, 6, 9, 12, 13, 16))
+        in_act, in_slope = random.choice(((ACT_LEAKY, 0.2), (ACT_RELU, 0.0), (ACT_NONE, 0.0)))
+        act = random.choice((ACT_TANH, ACT_NONE, ACT_SIGMOID))
+        torch.manual_seed(100 + it)
+        x = torch.randn(N, C, R, R, R)
+        w = torch.randn(C, 1, 4, 4, 4) / (C * 8) ** 0.5
+        b = torch.randn(1)
+        scale, shift = torch.randn(C), torch.randn(C) * 0.3
+        t = x * scale.view(1, C, 1, 1, 1) + shift.view(1, C, 1, 1, 1)
+        t = F.leaky_relu(t, in_slope) if in_act == ACT_LEAKY else (F.relu(t) if in_act == ACT_RELU else t)
+        ref = F.conv_transpose3d(t, w, b, stride=2, padding=1)
+        ref = torch.tanh(ref) if act == ACT_TANH else (torch.sigmoid(ref) if act == ACT_SIGMOID else ref)
+        assert ops.convT_to1_pre_served(dev(x), dev(w))
+        got = ops.conv_transpose3d_to1_pre_raw(dev(x), dev(scale), dev(shift), in_act, in_slope, dev(w), dev(b), act, 0.0)
+        close(got, ref, what="convT C->1 with input transform N=%d C=%d R=%d in_act=%d act=%d" % (N, C, R, in_act, act))
+    for N, C, R in ((48, 64, 4), (50, 24, 6), (67, 64, 16), (53, 5, 3)):
+        torch.manual_seed(N)
+        x = torch.randn(N, C, R, R, R)
+        w = torch.randn(C, 1, 4, 4, 4) / (C * 8) ** 0.5
+        b = torch.randn(1)
+        ref = torch.tanh(F.conv_transpose3d(x, w, b, stride=2, padding=1))
+        got = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0)
+        close(got, ref, what="convT C->1 (streaming kernel) N=%d C=%d R=%d" % (N, C, R))
+        out = torch.full((N + 1, 1, 2 * R, 2 * R, 2 * R), 7.0)
+        out = dev(out)
+        with torch.no_grad():
+            got2 = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0, out=out[:N])
+        assert got2.data_ptr() == out.data_ptr() and torch.equal(got2, got.detach()) and bool((out[N] == 7.0).all())
+
+
 def test_conv_from_sdf_zero_channels():
     """First progressive stage: conv over [x, 0, ..., 0] == conv over channel 0 only; dW of the zero channels is 0."""
     from shapegan_amd import ops
