@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
     unsigned yoff[1];
     lane_offsets(t, L, yoff);
     float* const tw = tl[wave];
-    float c0[16], c1[16], n0[16], n1[16];
+    float c0[16], c1[16];
     load_patch(L, c0, c1);
 
     // Software pipeline: the epilogue of tile t-1 (bias + activation, the trip through the LDS staging tile, the stores) is cut
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
             buf_store4(yres, row < a.Cout ? yprev : kBufOutside, (unsigned)(8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
         }
     };
-    auto tile_mfma = [&](auto with_epilogue) __attribute__((always_inline)) {
+    auto tile_mfma = [&](auto with_epilogue, const float (&c0)[16], const float (&c1)[16]) __attribute__((always_inline)) {
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -230,36 +230,39 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) pv[nt][q] = acc[nt][q];
     };
-    auto advance = [&](int tcur) __attribute__((always_inline)) {   // issue the patch loads of tile tcur + 1 (or re-read tcur: unused)
-        TileLane Ln = L;
-        unsigned yn[1] = {yoff[0]};
-        if (tcur + 1 < t_end) lane_offsets(tcur + 1, Ln, yn);
+    // issue the patch loads of tile tcur + 1 into (n0, n1).  Behind the last tile the lane offsets are all out of range (nothing
+    // is fetched) — NOT skipped by a branch: s_waitcnt vmcnt counts in issue order and at a control-flow join the compiler assumes
+    // the path with the fewest younger loads in flight.
+    auto advance = [&](int tcur, float (&n0)[16], float (&n1)[16]) __attribute__((always_inline)) {
+        TileLane Ln;
+        unsigned yn[1];
+        lane_offsets(tcur + 1 < t_end ? tcur + 1 : tcur, Ln, yn);
+        if (tcur + 1 >= t_end) Ln.o0 = Ln.o1 = kBufOutside;
         load_patch(Ln, n0, n1);
         yprev = yoff[0];       // where tile tcur's output goes (its epilogue runs during tile tcur + 1)
         L = Ln;
         yoff[0] = yn[0];
     };
-    auto rotate = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            c0[g] = n0[g];
-            c1[g] = n1[g];
-        }
-    };
-    // first tile: nothing to drain yet
-    advance(t);
-    __builtin_amdgcn_sched_barrier(0);
-    tile_mfma(IntTag<0>());
-    rotate();
-    for (++t; t < t_end; ++t) {
-        const unsigned ydone = yprev;     // output offsets of tile t - 1, whose epilogue runs inside this tile's MFMA groups
-        advance(t);
+    // One tile: loads of the next tile into (n0, n1), then this tile's MFMAs on (c0, c1) with the previous tile's epilogue between
+    // them.  The loop below alternates two register sets instead of copying next -> current at the end of every tile: the copy
+    // needed the loads it had just issued, so every tile ended in s_waitcnt vmcnt(8) — a full memory latency per tile with
+    // nothing to cover it (ISA listing, round 4; 45 us at 128 samples = 0.42 of the HBM roofline with the matrix pipe 45 % busy).
+    auto tile_step = [&](int tt, auto with_epilogue, const float (&c0)[16], const float (&c1)[16], float (&n0)[16],
+                         float (&n1)[16]) __attribute__((always_inline)) {
+        const unsigned ydone = yprev;     // output offsets of tile tt - 1, whose epilogue runs inside this tile's MFMA groups
+        advance(tt, n0, n1);
         const unsigned ynext = yprev;
         yprev = ydone;
         __builtin_amdgcn_sched_barrier(0);
-        tile_mfma(IntTag<1>());
+        tile_mfma(with_epilogue, c0, c1);
         yprev = ynext;
-        rotate();
+    };
+    float d0[16], d1[16];
+    // first tile: nothing to drain yet
+    tile_step(t, IntTag<0>(), c0, c1, d0, d1);
+    for (++t; t < t_end; t += 2) {
+        tile_step(t, IntTag<1>(), d0, d1, c0, c1);
+        if (t + 1 < t_end) tile_step(t + 1, IntTag<1>(), c0, c1, d0, d1);
     }
     // drain: the epilogue of the last tile
 #pragma unroll

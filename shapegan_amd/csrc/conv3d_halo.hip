@@ -1291,12 +1291,25 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo4_kernel(HaloWgradArgs a) 
 // sums the split partials [nsplit][Cout][Cin*64] into dw[Cout][Cin_total*64]
 __global__ void __launch_bounds__(256) wgrad_halo_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Cout, int ncol, long ldw, int nsplit) {
-    const long total = (long)Cout * ncol;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < nsplit; ++s) v += ws[(long)s * total + e];
+    // 16-byte pieces (ncol = Cin * 64 and ldw are multiples of 4; the partial images and dw rows are 16-byte aligned), up to four
+    // partials requested before the first add; partials are summed in ascending split order for every element
+    const long total = (long)Cout * ncol, total4 = total >> 2;
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(ws) + e4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 3 < nsplit; s += 4) {
+            const f32x4 a0 = p[(long)s * total4], a1 = p[(long)(s + 1) * total4], a2 = p[(long)(s + 2) * total4],
+                        a3 = p[(long)(s + 3) * total4];
+            v += a0;
+            v += a1;
+            v += a2;
+            v += a3;
+        }
+        for (; s < nsplit; ++s) v += p[(long)s * total4];
+        const long e = e4 << 2;
         const long co = e / ncol, c = e - co * ncol;
-        dw[co * ldw + c] = v;
+        *reinterpret_cast<f32x4*>(dw + co * ldw + c) = v;
     }
 }
 
@@ -1377,7 +1390,7 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     }
     if (!direct) {
         const long total = (long)Cout * Cin * 64;
-        int fb = (int)((total + 255) / 256);
+        int fb = (int)((total / 4 + 255) / 256);
         if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(wgrad_halo_finalize_kernel, dim3(fb), dim3(256), 0, stream, (const float*)part, dw, Cout, Cin * 64,
                            (long)Cin_total * 64, nsplit);

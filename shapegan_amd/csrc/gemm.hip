@@ -161,7 +161,8 @@ struct GemmNtArgs {
     long lda, ldb, ldc;
     int M, N;
     long K, kchunk;  // kchunk: multiple of kNtKC
-    int nsplit;      // grid z = batch * nsplit
+    int nsplit;      // groups = batch * nsplit
+    int ngroups;
     long a_off[kNtMaxBatch], b_off[kNtMaxBatch];   // element offsets of the batch members' operands
 };
 
@@ -171,8 +172,17 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kh = lane >> 5;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const int bz = blockIdx.z / a.nsplit, sz = blockIdx.z - bz * a.nsplit;   // batch member, K split
+    // XCD-aware decode of a 1-D grid.  The tiles of one (batch member, K split) group read the same operand slices — every
+    // 128-row slice of A serves the tiles of a tile row, every slice of B those of a tile column — and a 3-D grid spread them over
+    // different XCDs (workgroup b runs on XCD b % 8): each XCD's L2 then fetched its own copy, 6.44 GB per launch against 3.22 GB
+    // of operands at 262 144 points (profiles/r03_configs_hbm_traffic.json), HBM co-limiting a kernel the matrix pipe should
+    // bound.  Here the tiles of a group are consecutive workgroups of ONE XCD, dispatched together: one fetch, the rest L2 hits.
+    const int tiles_n = (a.N + 127) >> 7, tiles = tiles_n * ((a.M + 127) >> 7);
+    const int xcd = blockIdx.x & 7, qx = blockIdx.x >> 3;
+    const int grp = (qx / tiles) * 8 + xcd, tile = qx % tiles;          // group = batch member * nsplit + K split
+    if (grp >= a.ngroups) return;
+    const int i0 = (tile / tiles_n) * 128, j0 = (tile % tiles_n) * 128;
+    const int bz = grp / a.nsplit, sz = grp - bz * a.nsplit;   // batch member, K split
     const long kbeg = (long)sz * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
     const int nstage = (int)((kend - kbeg + kNtKC - 1) / kNtKC);
 
@@ -293,7 +303,7 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
         if (nstage & 1) stage(IntTag<0>(), nstage - 1);
     }
 
-    float* out = a.out + (long)blockIdx.z * a.M * a.ldc;   // partial image (batch member, split); C itself if there is one
+    float* out = a.out + (long)grp * a.M * a.ldc;   // partial image (batch member, split); C itself if there is one
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -461,7 +471,9 @@ static int gemm_nt_launch(const float* A, const long* a_off, long lda, const flo
                                   (int)lds);
         attr_once.end();
     }
-    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(sg_cdiv(N, 128), sg_cdiv(M, 128), batch * nsplit), dim3(256), lds, stream, a);
+    a.ngroups = batch * nsplit;
+    const unsigned wgs = (unsigned)((a.ngroups + 7) / 8 * 8 * sg_cdiv(N, 128) * sg_cdiv(M, 128));
+    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(wgs), dim3(256), lds, stream, a);
     if (!direct) {
         GemmNtOut o;
         for (int b = 0; b < kNtMaxBatch; ++b) {
