@@ -21,7 +21,7 @@
 #define SG_RING 8
 #endif
 #ifndef SG_ABLATE
-#define SG_ABLATE 0   // tuning experiments only (scripts/ablate.sh): 1 no copy loads, 2 no copy, 4 no weight loads
+#define SG_ABLATE 0   // tuning experiments only (scripts/ablate.sh of rounds 1-3: git history): 1 no copy loads, 2 no copy, 4 no weight loads
 #endif
 
 namespace sg {
@@ -459,13 +459,13 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
     // configuration: 128 output channels per workgroup as 8 waves x 1 tile (variant 0, more waves per SIMD to hide the
     // copy / weight-load latency) or 4 waves x 2 tiles (variant 1); 64 channels as 4 waves x 1 tile
-    // measured (scripts/halo_bench.py): 4 waves x 2 tiles wins below ~1024 workgroups, 8 waves x 1 tile above
+    // measured (scripts/halo_bench.py of rounds 1-3: git history): 4 waves x 2 tiles wins below ~1024 workgroups, 8 waves x 1 tile above
     int variant = (debug >> 4) & 3;
     const int rows = (Cout > 64 && ((debug >> 4) & 3) != 3) ? 128 : 64;   // variant 3: 64-row tiles, twice the workgroups
     const int ntw = g.OW / 8, nth = g.OH / 8;
     const long tiles = (long)batch * g.OD * nth * ntw;
     const int mtiles = sg_cdiv(Cout, rows);
-    // auto-dispatch only where it wins (A/B on MI355X, scripts/halo_bench.py): enough workgroups to fill the chip;
+    // auto-dispatch only where it wins (A/B on MI355X, rounds 1-3): enough workgroups to fill the chip;
     // below that the split-K gather kernel is faster
     if (!force && tiles * mtiles < 384) return 0;
     if (tiles >= (1L << 31)) return 0;
@@ -1346,7 +1346,7 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     int nslice, nsplit, mtiles;
     wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
     const int ntiles = ((Cin + 1) / 2) * mtiles;
-    // auto-dispatch where it wins (scripts/conv_bench.py): full 128-row tiles and enough workgroups
+    // auto-dispatch where it wins (round-1 A/B): full 128-row tiles and enough workgroups
     if (!force && (Cout <= 64 || (long)ntiles * nsplit < 384)) return 0;
     const size_t need = halo_wgrad_workspace_bytes(batch, Cin, Cout, g.OD, g.OH, g.OW);
     if (!workspace || workspace_bytes < need) return 0;
