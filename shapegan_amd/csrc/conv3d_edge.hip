@@ -342,15 +342,24 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
     // kept a second copy of the patch operand and all 32 A-fragment registers across the block: 290 registers with FUSE = one
     // wave per SIMD; a register cap instead of this restructuring spilled 56 of them and took 115 instead of 76 us.)
     unsigned xo[2], xl[2], xr[2];     // next pass's patch offsets: middle positions, first (left edge), last (right edge)
-    auto issue_dy = [&](int ps) __attribute__((always_inline)) {
+    // (valid = false: behind the last pass every offset is out of range and nothing is fetched.  NOT an `if (more)` around the
+    // call: s_waitcnt vmcnt counts in issue order and at the join behind a skipped block of loads the compiler assumes the path
+    // with the fewest younger loads in flight — every pass then began with vmcnt(0), i.e. waited for the dy / y pieces of the NEXT
+    // pass it had just requested: no overlap of the 285 MB stream with the MFMAs at all, ISA listing of round 4)
+    auto issue_dy = [&](int ps, bool valid) __attribute__((always_inline)) {
         uint32_t n, pp;
-        a.dpps.divmod((uint32_t)ps, n, pp);
+        a.dpps.divmod((uint32_t)(valid ? ps : 0), n, pp);
         const unsigned dbase = (unsigned)((long)n * a.Cy * O3 + pp * 32 + ccol) * 4u;
+        // the invalid case as a bit OR-ed into the offsets (top bit set = out of range), hidden from the optimizer: written as a
+        // select on `valid` the compiler unswitched it back into two copies of the loads under a branch
+        unsigned inval = valid ? 0u : kBufOutside;
+        asm volatile("" : "+v"(inval));
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) {
             const int co = i * 8 + crow;
-            cv[i] = buf_load4v(dres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
-            if (FUSE) yv[i] = buf_load4v(yres, co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside, 0);
+            const unsigned off = (co < a.Cout ? dbase + (unsigned)co * O3 * 4u : kBufOutside) | inval;
+            cv[i] = buf_load4v(dres, off, 0);
+            if (FUSE) yv[i] = buf_load4v(yres, off, 0);
         }
     };
     auto plan_x = [&](int ps, bool valid) __attribute__((always_inline)) {
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
     };
     int ps = blockIdx.x * 4 + wave;
     if (ps < a.total_passes) {
-        issue_dy(ps);
+        issue_dy(ps, true);
         plan_x(ps, true);
 #pragma unroll
         for (int j = 0; j < 16; ++j) load_x(j);
@@ -395,7 +404,7 @@ __global__ void __launch_bounds__(256, SG_WGRAD_C1_WAVES) conv_wgrad_c1_kernel(E
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(stage + (i * 8 + crow) * kLd + ccol) = cv[i];
         const bool more = ps + nwaves < a.total_passes;
-        if (more) issue_dy(ps + nwaves);          // next pass's dy / y fly during the MFMAs
+        issue_dy(ps + nwaves, more);              // next pass's dy / y fly during the MFMAs
         plan_x(more ? ps + nwaves : ps, more);    // (no next pass: every offset out of range, the loads below fetch nothing)
         f32x4 avc[MT], avn[MT];
 #pragma unroll

@@ -713,18 +713,22 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
     mask_store(6, IntTag<-1>(), IntTag<0>());      // (H7 itself is in registers: the w8 gradient above needs its values)
     __syncthreads();
     // dZ_layer+1 (LDS) -> dZ_layer; tnext: transposed pack of the following step (-1: none)
-    auto back_step = [&](int layer, long tnext, auto xtag) __attribute__((always_inline)) {
+    // (whether a next step exists is a COMPILE-TIME tag: as a run-time test of the pack offset it was a branch around the ring start,
+    // and at the join behind it the compiler — s_waitcnt vmcnt counts in issue order, a join takes the path with the fewest
+    // younger loads — waited vmcnt(0) for the mask word: i.e. for the ring loads it had just issued, a full weight-fetch latency
+    // in front of every epilogue, which is exactly what starting the ring early was meant to hide)
+    auto back_step = [&](int layer, long tnext, auto xtag, auto has_next) __attribute__((always_inline)) {
         zero_acc();
 #ifdef SG_SDF_NO_MASK   // A/B build (scripts/ab_build.sh): ReLU' from the fp32 images, as before round 3
         mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_h(layer); });
         __syncthreads();
-        if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
+        if (decltype(has_next)::value) wring_start(wr, wtile_t(tnext), lane);
         __builtin_amdgcn_sched_barrier(0);
         mask_store(layer, xtag, IntTag<0>());
 #else
         mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_mask(layer); });
         __syncthreads();   // every wave is done reading the tile
-        if (tnext >= 0) wring_start(wr, wtile_t(tnext), lane);
+        if (decltype(has_next)::value) wring_start(wr, wtile_t(tnext), lane);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) mk[t] = pok[t] ? mk[t] : 0u;
@@ -732,12 +736,12 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
 #endif
         __syncthreads();
     };
-    back_step(5, a.lay.T6, IntTag<-1>());    // dH6 -> dZ6
-    back_step(4, a.lay.T5x, IntTag<11>());   // dZ5 (+ point columns of dW5)
-    back_step(3, a.lay.T4, IntTag<-1>());    // dZ4
-    back_step(2, a.lay.T3, IntTag<-1>());    // dZ3
-    back_step(1, a.lay.T2, IntTag<-1>());    // dZ2
-    back_step(0, -1, IntTag<8>());           // dZ1 (+ point columns of dW1)
+    back_step(5, a.lay.T6, IntTag<-1>(), IntTag<1>());    // dH6 -> dZ6
+    back_step(4, a.lay.T5x, IntTag<11>(), IntTag<1>());   // dZ5 (+ point columns of dW5)
+    back_step(3, a.lay.T4, IntTag<-1>(), IntTag<1>());    // dZ4
+    back_step(2, a.lay.T3, IntTag<-1>(), IntTag<1>());    // dZ3
+    back_step(1, a.lay.T2, IntTag<-1>(), IntTag<1>());    // dZ2
+    back_step(0, -1, IntTag<8>(), IntTag<0>());           // dZ1 (+ point columns of dW1)
     // (element indexing of the dX part below)
     constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
     constexpr int RSTEP = 512 / P;
