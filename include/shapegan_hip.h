@@ -102,6 +102,13 @@ int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW)
 int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
                               const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
                               float slope, hipStream_t stream);
+/* Several independent batches in one pass ("groups" of samples_per_group samples: e.g. the generator evaluations of four
+ * consecutive critic updates, train_wgan.py:60-63, whose BatchNorm statistics are per evaluation): sample n takes row n /
+ * samples_per_group of in_scale / in_shift ([groups][C]) and is written at y + (n / samples_per_group) * y_group_stride +
+ * (n % samples_per_group) * (2I)^3 — each group into its own destination (the fake half of its critic batch). */
+int sg_convT3d_k4s2p1_to1_pre_grouped(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                      const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                      int act, float slope, int samples_per_group, long y_group_stride, hipStream_t stream);
 int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                             int IW, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_convT3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch, int Cin_T, int Cout_T, int ID, int IH,
@@ -150,6 +157,17 @@ int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float
 int sg_bn_train_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
                       float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift, int N,
                       int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* The two above for a tensor [groups][N][C][S] whose groups are independent batches (statistics per group; save_mean / save_invstd
+ * / scale / shift are [groups][C]; workspace: groups * sg_bn_workspace_bytes(C)).  The running statistics receive the groups'
+ * updates one after the other, exactly as `groups` separate calls would apply them; num_batches_tracked += groups. */
+int sg_bn_train_fwd_grouped(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, int groups, int N, int C,
+                            long S, float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream);
+int sg_bn_train_stats_grouped(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                              float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
+                              int groups, int N, int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream);
 int sg_bn_eval_fwd(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,
                    const float* running_var, float* save_mean, float* save_invstd, int N, int C, long S, float eps,
                    int act, float slope, hipStream_t stream);

@@ -47,9 +47,13 @@ struct ChanWalk {
 };
 
 // partial[c][split] = {sum(x-K), sum((x-K)^2)}
+// (grid z = group: the tensor is [groups][N][C][S] and every group of N samples has statistics of its own — several generator
+// evaluations batched into one pass, shapegan_amd.train_steps.WGANTrainer.step; partial[group][c][split])
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int N,
                                                        int C, long S, int nsplit) {
     const int c = blockIdx.x, sp = blockIdx.y;
+    x += (long)blockIdx.z * N * C * S;
+    partial += (long)blockIdx.z * C * nsplit * 2;
     const long total = (long)N * S;
     const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
     const long beg = sp * chunk, end = min(total, beg + chunk);
@@ -122,6 +126,48 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
 // double: a fixed order, so all workgroups of a channel — and every run — get bit-identical statistics), then streams its slice
 // of the channel.  Workgroup (c, 0) publishes mean / invstd and updates the running statistics; (0, 0) bumps the batch counter.
 // (One launch less per BatchNorm and no per-element `e / S % C`.)
+// the statistics of (group, channel) from its partials: one wave, fixed order (bit-identical in every workgroup and run)
+__device__ __forceinline__ void bn_group_stats(const float* __restrict__ x, const double* __restrict__ partial, int g, int c, int N,
+                                               int C, long S, int nparts, float eps, float& mu, float& is, double& var_out) {
+    const int lane = threadIdx.x & 63;
+    const double* p = partial + ((long)g * C + c) * nparts * 2;
+    double s1 = lane < nparts ? p[lane * 2] : 0.0;
+    double s2 = lane < nparts ? p[lane * 2 + 1] : 0.0;
+    s1 = sg_wave_sum_d(s1);
+    s2 = sg_wave_sum_d(s2);
+    const double n = (double)N * (double)S;
+    const double K = (double)x[((long)g * N * C + c) * S];
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0) var = 0;
+    mu = (float)(K + m);
+    is = (float)(1.0 / sqrt(var + (double)eps));
+    var_out = var;
+}
+// running statistics after `groups` batches, applied one after the other exactly as `groups` separate calls would (same fp32
+// operations in the same order); one wave of workgroup (c, 0, 0)
+__device__ __forceinline__ void bn_update_running(const float* __restrict__ x, const double* __restrict__ partial, int c, int N, int C,
+                                                  long S, int nparts, int groups, float eps, float momentum, float* running_mean,
+                                                  float* running_var, long long* num_batches_tracked) {
+    const double n = (double)N * (double)S;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        float mu, is;
+        double var;
+        bn_group_stats(x, partial, g, c, N, C, S, nparts, eps, mu, is, var);
+        const double unbiased = n > 1 ? var * n / (n - 1) : var;
+        rm = (1.f - momentum) * rm + momentum * mu;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (running_mean) {
+            running_mean[c] = rm;
+            running_var[c] = rv;
+        }
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += groups;
+    }
+}
+
 __global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 const double* __restrict__ partial,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -129,35 +175,26 @@ __global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __r
                                                                 float* running_mean, float* running_var,
                                                                 long long* num_batches_tracked, int N, int C, long S, int nparts,
                                                                 int nsplit, float eps, float momentum, int act, float slope) {
-    const int c = blockIdx.x, sp = blockIdx.y;
+    const int c = blockIdx.x, sp = blockIdx.y, g = blockIdx.z, groups = gridDim.z;
     __shared__ float stat[2];
     if (threadIdx.x < 64) {      // nparts <= 64: one wave
-        double s1 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2] : 0.0;
-        double s2 = threadIdx.x < nparts ? partial[((long)c * nparts + threadIdx.x) * 2 + 1] : 0.0;
-        s1 = sg_wave_sum_d(s1);
-        s2 = sg_wave_sum_d(s2);
+        float mu, is;
+        double var;
+        bn_group_stats(x, partial, g, c, N, C, S, nparts, eps, mu, is, var);
         if (threadIdx.x == 0) {
-            const double n = (double)N * (double)S;
-            const double K = (double)x[(long)c * S];
-            const double m = s1 / n;
-            double var = s2 / n - m * m;
-            if (var < 0) var = 0;
-            const float mu = (float)(K + m), is = (float)(1.0 / sqrt(var + (double)eps));
             stat[0] = mu;
             stat[1] = is;
             if (sp == 0) {
-                mean[c] = mu;
-                invstd[c] = is;
-                if (running_mean) {
-                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-                    const double unbiased = n > 1 ? var * n / (n - 1) : var;
-                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-                }
-                if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+                mean[(long)g * C + c] = mu;
+                invstd[(long)g * C + c] = is;
             }
         }
+        if (sp == 0 && g == 0)
+            bn_update_running(x, partial, c, N, C, S, nparts, groups, eps, momentum, running_mean, running_var, num_batches_tracked);
     }
     __syncthreads();
+    x += (long)g * N * C * S;
+    y += (long)g * N * C * S;
     const float sc = gamma[c] * stat[1], sh = beta[c] - stat[0] * sc;
     const long total = (long)N * S;
     const long chunk = ((total + nsplit - 1) / nsplit + 3) & ~3L;
@@ -191,31 +228,19 @@ __global__ void __launch_bounds__(256) bn_finalize_affine_kernel(const float* __
                                                                  long long* num_batches_tracked, float* __restrict__ scale,
                                                                  float* __restrict__ shift, int N, int C, long S, int nparts,
                                                                  float eps, float momentum) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = blockIdx.y, groups = gridDim.y;
     if (c >= C) return;
-    double s1 = lane < nparts ? partial[((long)c * nparts + lane) * 2] : 0.0;
-    double s2 = lane < nparts ? partial[((long)c * nparts + lane) * 2 + 1] : 0.0;
-    s1 = sg_wave_sum_d(s1);
-    s2 = sg_wave_sum_d(s2);
+    float mu, is;
+    double var;
+    bn_group_stats(x, partial, g, c, N, C, S, nparts, eps, mu, is, var);
     if (lane == 0) {
-        const double n = (double)N * (double)S;
-        const double K = (double)x[(long)c * S];
-        const double m = s1 / n;
-        double var = s2 / n - m * m;
-        if (var < 0) var = 0;
-        const float mu = (float)(K + m), is = (float)(1.0 / sqrt(var + (double)eps));
-        mean[c] = mu;
-        invstd[c] = is;
+        mean[(long)g * C + c] = mu;
+        invstd[(long)g * C + c] = is;
         const float sc = gamma[c] * is;
-        scale[c] = sc;
-        shift[c] = beta[c] - mu * sc;
-        if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-            const double unbiased = n > 1 ? var * n / (n - 1) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        scale[(long)g * C + c] = sc;
+        shift[(long)g * C + c] = beta[c] - mu * sc;
     }
+    if (g == 0) bn_update_running(x, partial, c, N, C, S, nparts, groups, eps, momentum, running_mean, running_var, num_batches_tracked);
 }
 
 __device__ __forceinline__ float bn_act_grad(float xhat, float g, float b, float dy, int act, float slope) {
@@ -395,37 +420,54 @@ extern "C" {
 
 size_t sg_bn_workspace_bytes(int C) { return (size_t)C * 64 * 2 * sizeof(double); }
 
-int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-                    float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S,
-                    float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
-                    hipStream_t stream) {
-    SG_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && N > 0 && C > 0 && S > 0);
-    if (!workspace || workspace_bytes < sg_bn_workspace_bytes(C)) SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_fwd: workspace too small");
+int sg_bn_train_fwd_grouped(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, int groups, int N, int C,
+                            long S, float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream) {
+    SG_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && groups > 0 && groups <= 64 && N > 0 && C > 0 && S > 0);
+    if (!workspace || workspace_bytes < (size_t)groups * sg_bn_workspace_bytes(C))
+        SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_fwd: workspace too small");
     const int ns = bn_nsplit(N, C, S);
     double* part = (double*)workspace;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, stream, x, part, N, C, S, ns);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns, groups), dim3(256), 0, stream, x, part, N, C, S, ns);
     // finalize + apply in one launch; the apply pass may use more slices per channel than the statistics pass
     const int na = bn_apply_split(N, C, S);
-    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, na), dim3(256), 0, stream, x, y, (const double*)part, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, na, groups), dim3(256), 0, stream, x, y, (const double*)part, gamma, beta,
                        save_mean, save_invstd, running_mean, running_var, num_batches_tracked, N, C, S, ns, na, eps, momentum, act,
                        slope);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
+int sg_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, int N, int C, long S,
+                    float eps, float momentum, int act, float slope, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+    return sg_bn_train_fwd_grouped(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, 1, N,
+                                   C, S, eps, momentum, act, slope, workspace, workspace_bytes, stream);
+}
 
-int sg_bn_train_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
-                      float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift, int N,
-                      int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    SG_CHECK_ARG(x && gamma && beta && save_mean && save_invstd && scale && shift && N > 0 && C > 0 && S > 0);
-    if (!workspace || workspace_bytes < sg_bn_workspace_bytes(C)) SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_stats: workspace too small");
+int sg_bn_train_stats_grouped(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                              float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
+                              int groups, int N, int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream) {
+    SG_CHECK_ARG(x && gamma && beta && save_mean && save_invstd && scale && shift && groups > 0 && groups <= 64 && N > 0 && C > 0 &&
+                 S > 0);
+    if (!workspace || workspace_bytes < (size_t)groups * sg_bn_workspace_bytes(C))
+        SG_FAIL(SG_ERR_WORKSPACE, "sg_bn_train_stats: workspace too small");
     const int ns = bn_nsplit(N, C, S);
     double* part = (double*)workspace;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, stream, x, part, N, C, S, ns);
-    hipLaunchKernelGGL(bn_finalize_affine_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, x, (const double*)part, gamma, beta,
-                       save_mean, save_invstd, running_mean, running_var, num_batches_tracked, scale, shift, N, C, S, ns, eps,
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns, groups), dim3(256), 0, stream, x, part, N, C, S, ns);
+    hipLaunchKernelGGL(bn_finalize_affine_kernel, dim3((C + 3) / 4, groups), dim3(256), 0, stream, x, (const double*)part, gamma,
+                       beta, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, scale, shift, N, C, S, ns, eps,
                        momentum);
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+int sg_bn_train_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift, int N,
+                      int C, long S, float eps, float momentum, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return sg_bn_train_stats_grouped(x, gamma, beta, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, scale,
+                                     shift, 1, N, C, S, eps, momentum, workspace, workspace_bytes, stream);
 }
 
 int sg_bn_eval_fwd(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,

@@ -829,19 +829,27 @@ int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW)
     return batch > 0 && C > 0 && C <= 64 && ID > 0 && IH > 0 && IW > 0 && IH * IW <= 256 &&
            (size_t)C * ID * IH * IW * 4 < (size_t)kBufRange && (long)batch * 8 * ID * IH * IW < (1L << 31);
 }
-int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
-                              const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
-                              float slope, hipStream_t stream) {
-    SG_CHECK_ARG(x && w && y && in_scale && in_shift);
+int sg_convT3d_k4s2p1_to1_pre_grouped(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                      const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                      int act, float slope, int samples_per_group, long y_group_stride, hipStream_t stream) {
+    SG_CHECK_ARG(x && w && y && in_scale && in_shift && samples_per_group > 0 && batch % samples_per_group == 0);
+    SG_CHECK_ARG(y_group_stride >= (long)samples_per_group * 8 * ID * IH * IW);
     if (!sg_convT3d_k4s2p1_to1_pre_eligible(batch, C, ID, IH, IW))
         SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: shape not served (C <= 64, IH * IW <= 256)");
     SG_CHECK_ARG(in_act == SG_ACT_NONE || in_act == SG_ACT_RELU || (in_act == SG_ACT_LEAKY && in_slope >= 0.f && in_slope <= 1.f));
     ConvGeom g;
     if (make_geom(g, 2 * ID, 2 * IH, 2 * IW, 1, C)) SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: bad spatial dims");
-    if (edge_dgrad_stream_try(x, w, bias, y, batch, 1, 1, g, C, act, slope, stream, in_scale, in_shift, in_act, in_slope) != 1)
+    if (edge_dgrad_stream_try(x, w, bias, y, batch, 1, 1, g, C, act, slope, stream, in_scale, in_shift, in_act, in_slope,
+                              samples_per_group, y_group_stride) != 1)
         SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: not served");
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                              const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
+                              float slope, hipStream_t stream) {
+    return sg_convT3d_k4s2p1_to1_pre_grouped(x, w, bias, y, in_scale, in_shift, in_act, in_slope, batch, C, ID, IH, IW, act, slope,
+                                             batch, (long)batch * 8 * ID * IH * IW, stream);
 }
 int sg_convT3d_k4s2p1_dgrad(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                             int IW, void* workspace, size_t workspace_bytes, hipStream_t stream) {

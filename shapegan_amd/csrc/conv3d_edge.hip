@@ -803,6 +803,8 @@ struct ConvTStreamArgs {
     const float* in_scale;   // PRE: [Cout] scale / shift of the input transform
     const float* in_shift;
     float in_slope;          // PRE: max(t, in_slope * t) after the affine map (LeakyReLU slope; ReLU 0; none 1)
+    int spg;                 // samples per group: sample n uses in_scale / in_shift row n / spg ([groups][Cout]) ...
+    long out_group_stride;   // ... and is written at dx + (n / spg) * out_group_stride + (n % spg) * dx_sample
     int Cout, Cy, Cin_total;
     int OD, OH, OW, P2;
     long dx_sample;
@@ -872,7 +874,8 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     {
         // branch-free: channels beyond Cout carry an out-of-range offset (weight, scale and shift read as 0)
         const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.w);
-        const __amdgpu_buffer_rsrc_t sres = make_rsrc(PRE ? a.in_scale : a.w), hres = make_rsrc(PRE ? a.in_shift : a.w);
+        const long grow = (long)(n / a.spg) * a.Cout;     // this sample's group row of the input transform
+        const __amdgpu_buffer_rsrc_t sres = make_rsrc(PRE ? a.in_scale + grow : a.w), hres = make_rsrc(PRE ? a.in_shift + grow : a.w);
         const unsigned wtap = (unsigned)(kd * 16 + kh * 4 + kw) * 4u, wrow = (unsigned)a.Cin_total * 256u;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -908,7 +911,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     const int IH = 2 * OH, IW = 2 * OW;
     // outputs leave through a raw buffer on the sample: lane offset = (row 2 qh + ph, column 2 qw + pw), scalar offset = output
     // plane; a lane / plane with nothing to store carries an out-of-range offset instead of a branch
-    const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)n * a.dx_sample);
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)(n / a.spg) * a.out_group_stride + (long)(n % a.spg) * a.dx_sample);
     const unsigned ovoff = gather_on ? (unsigned)((2 * qh + ph) * IW + 2 * qw + pw) * 4u : kBufOutside;
     const unsigned oplane = (unsigned)(IH * IW) * 4u;
     float carry = 0.f;
@@ -1133,7 +1136,7 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
 // the input transform act_in(dy * in_scale[c] + in_shift[c]) folded into the loads (in_act: none / LeakyReLU / ReLU).
 int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                           const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
-                          const float* in_shift, int in_act, float in_slope) {
+                          const float* in_shift, int in_act, float in_slope, int samples_per_group, long out_group_stride) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64 || g.OH * g.OW > 256 || (size_t)g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
     const bool pre = in_scale != nullptr;
@@ -1159,6 +1162,8 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     f.batch = batch;
     f.act = act;
     f.slope = slope;
+    f.spg = samples_per_group > 0 ? samples_per_group : batch;
+    f.out_group_stride = samples_per_group > 0 ? out_group_stride : (long)batch * f.dx_sample;
     const int nblocks = (f.P2 + 31) / 32;
     const size_t lds = (size_t)2 * 16 * (nblocks * 32 + 4) * sizeof(float);
     const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4);
@@ -1191,7 +1196,7 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     // (the streaming kernel runs four workgroups per sample for the whole depth of the grid: below ~48 samples it leaves CUs
     // idle and the one-workgroup-per-plane kernel is faster — 17.8 vs 22.6 us at 32 samples, 32.0 vs 22.7 at 64, 114 vs 92 at 256)
     if (!stream_off && g.OH * g.OW <= 256 && (force || (long)batch * O3 >= 512) && batch >= 48 &&
-        edge_dgrad_stream_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, stream, nullptr, nullptr, 0, 0.f) == 1)
+        edge_dgrad_stream_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, stream, nullptr, nullptr, 0, 0.f, 0, 0) == 1)
         return 1;
     // fused kernel: a whole (OH x OW) plane of the four tap groups fits in LDS
     static const bool fused_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 8);

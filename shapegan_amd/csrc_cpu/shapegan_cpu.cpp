@@ -198,6 +198,19 @@ int sg_convT3d_k4s2p1_to1_pre_cpu(const float* x, const float* w, const float* b
     }
     return sg_conv3d_k4s2p1_dgrad_cpu(t.data(), w, bias, y, batch, 1, 1, 1, C, 2 * ID, 2 * IH, 2 * IW, act, slope, nullptr, 0, st);
 }
+int sg_convT3d_k4s2p1_to1_pre_grouped_cpu(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                          const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH,
+                                          int IW, int act, float slope, int spg, long y_group_stride, void* st) {
+    CPU_CHECK(spg > 0 && batch % spg == 0);
+    const long S = (long)ID * IH * IW;
+    for (int g = 0; g < batch / spg; ++g) {
+        const int rc = sg_convT3d_k4s2p1_to1_pre_cpu(x + (long)g * spg * C * S, w, bias, y + (long)g * y_group_stride,
+                                                     in_scale + (long)g * C, in_shift + (long)g * C, in_act, in_slope, spg, C, ID, IH,
+                                                     IW, act, slope, st);
+        if (rc) return rc;
+    }
+    return SG_OK;
+}
 int sg_convT3d_k4s2p1_dgrad_cpu(const float* dy, const float* w, float* dx, int batch, int Cin_T, int Cout_T, int ID, int IH,
                                 int IW, void* ws, size_t wb, void* st) {
     return sg_conv3d_k4s2p1_fwd_cpu(dy, w, nullptr, dx, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, ACT_NONE, 0.f,
@@ -364,6 +377,33 @@ int sg_bn_train_stats_cpu(const float* x, const float* gamma, const float* beta,
         if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(cnt > 1 ? s2 / (cnt - 1) : var);
     }
     if (num_batches_tracked) *num_batches_tracked += 1;
+    return SG_OK;
+}
+int sg_bn_train_fwd_grouped_cpu(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                float* save_invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                int groups, int N, int C, long S, float eps, float momentum, int act, float slope, void* ws, size_t wb,
+                                void* st) {
+    CPU_CHECK(groups > 0);
+    for (int g = 0; g < groups; ++g) {     // the groups are independent batches, applied one after the other
+        const long off = (long)g * N * C * S;
+        const int rc = sg_bn_train_fwd_cpu(x + off, gamma, beta, y + off, save_mean + (long)g * C, save_invstd + (long)g * C,
+                                           running_mean, running_var, num_batches_tracked, N, C, S, eps, momentum, act, slope, ws, wb,
+                                           st);
+        if (rc) return rc;
+    }
+    return SG_OK;
+}
+int sg_bn_train_stats_grouped_cpu(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, float* scale,
+                                  float* shift, int groups, int N, int C, long S, float eps, float momentum, void* ws, size_t wb,
+                                  void* st) {
+    CPU_CHECK(groups > 0);
+    for (int g = 0; g < groups; ++g) {
+        const int rc = sg_bn_train_stats_cpu(x + (long)g * N * C * S, gamma, beta, save_mean + (long)g * C, save_invstd + (long)g * C,
+                                             running_mean, running_var, num_batches_tracked, scale + (long)g * C,
+                                             shift + (long)g * C, N, C, S, eps, momentum, ws, wb, st);
+        if (rc) return rc;
+    }
     return SG_OK;
 }
 int sg_bn_eval_fwd_cpu(const float* x, const float* gamma, const float* beta, float* y, const float* running_mean,

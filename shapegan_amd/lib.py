@@ -40,6 +40,7 @@ SIGNATURES = {
     "sg_convT3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_to1_pre_eligible": (c_int, [_I, _I, _I, _I, _I]),
     "sg_convT3d_k4s2p1_to1_pre": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "sg_convT3d_k4s2p1_to1_pre_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _I, _L, _P]),
     "sg_convT3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_gemm_workspace_bytes": (_Z, [_I, _I]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     "sg_bn_workspace_bytes": (_Z, [_I]),
     "sg_bn_train_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
     "sg_bn_train_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P, _Z, _P]),
+    "sg_bn_train_fwd_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _F, _F, _I, _F, _P, _Z, _P]),
+    "sg_bn_train_stats_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _F, _F, _P, _Z, _P]),
     "sg_bn_eval_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _F, _P]),
     "sg_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _Z, _P]),
     "sg_act_fwd": (c_int, [_P, _P, _L, _I, _F, _P]),

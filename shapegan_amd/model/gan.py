@@ -12,7 +12,7 @@ from ..lib import ACT_SIGMOID
 from ..util import device as default_device
 from ..util import standard_normal_distribution
 from . import LATENT_CODE_SIZE, Lambda, SavableModule
-from .stack import run_stack
+from .stack import run_stack, run_stack_groups
 
 # (in, out, stride, padding) of the four transposed convolutions, model/gan.py:9-21
 _G_CONVS = ((LATENT_CODE_SIZE, 256, 1, 0), (256, 128, 2, 1), (128, 64, 2, 1), (64, 1, 2, 1))
@@ -39,6 +39,22 @@ class Generator(SavableModule):
         then returned) — e.g. the fake half of the critic's batch."""
         x = x.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1))
         return run_stack(self.layers, x, self.training, out)
+
+    def forward_groups(self, zs, outs):
+        """Several independent evaluations in one pass, without grad mode and in training mode (batch statistics): zs[g] [B,128]
+        -> outs[g] ([B,1,32,32,32], equally spaced contiguous fp32 tensors), each evaluation with its own BatchNorm statistics and
+        the running buffers updated evaluation after evaluation — the same results as `for z, o in zip(zs, outs): self(z, out=o)`
+        with every convolution launched once (model/stack.py:run_stack_groups).  Falls back to exactly that loop when the fused
+        path does not apply (grad mode, eval mode, CPU tensors of odd shapes, ...)."""
+        if (not torch.is_grad_enabled() and self.training and len(zs) > 1 and len({tuple(z.shape) for z in zs}) == 1):
+            x = torch.cat([z.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1)) for z in zs])
+            if run_stack_groups(self.layers, x, len(zs), list(outs)):
+                return outs
+        for z, o in zip(zs, outs):
+            y = self(z, out=o)
+            if y.data_ptr() != o.data_ptr():
+                o.copy_(y)
+        return outs
 
     def generate(self, sample_size=1):
         # latents are drawn on the CPU and moved (model/gan.py:31-34): reproducible across backends

@@ -157,3 +157,50 @@ def run_stack(modules, x, training, out=None):
             raise NotImplementedError("shapegan_amd has no HIP kernel for %r" % (m,))
         i += 1
     return x
+
+
+def run_stack_groups(modules, x, groups, outs):
+    """`groups` independent evaluations of a generator / decoder stack in ONE pass, WITHOUT grad mode and with batch statistics:
+    x [groups * B, ...] holds the groups' inputs one after the other; every BatchNorm3d normalises each group with that group's own
+    statistics and updates its running buffers group after group (sg_bn_train_fwd_grouped), so the result equals `groups`
+    separate calls — but every convolution runs once on groups * B samples and the BatchNorm passes are one launch pair for all
+    groups.  The stack must end in [BatchNorm3d, LeakyReLU / ReLU, ConvTranspose3d(C -> 1, k4 s2 p1) (, activation)] (model/gan.py
+    :18-22); group g's samples are written to outs[g].  Returns False when the stack does not have that shape (the caller then
+    evaluates the groups one by one)."""
+    import torch
+    mods = list(modules)
+    if torch.is_grad_enabled() or not FUSE_BN_INTO_LAST_CONV_TRANSPOSE or groups < 2:
+        return False
+    # shape check first: [producer, BN3d, act] * k, then ConvTranspose3d(C -> 1) (+ act)
+    i, plan = 0, []
+    while i + 2 < len(mods) and isinstance(mods[i], (nn.Conv3d, nn.ConvTranspose3d, nn.Linear)) \
+            and isinstance(mods[i + 1], nn.BatchNorm3d) and _act_of(mods[i + 2]) is not None:
+        bn = mods[i + 1]
+        if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+            return False
+        plan.append((mods[i], bn, _act_of(mods[i + 2])))
+        i += 3
+    if not plan or i >= len(mods):
+        return False
+    last = mods[i]
+    a_out = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+    if i + 1 + (a_out is not None) != len(mods):
+        return False
+    if not (isinstance(last, nn.ConvTranspose3d) and _is_k4(last, 2, 1) and last.out_channels == 1):
+        return False
+    a_in = plan[-1][2]
+    if a_in[0] not in (ACT_LEAKY, ACT_RELU) or not (0.0 <= a_in[1] <= 1.0):
+        return False
+    for k, (m, bn, a) in enumerate(plan):
+        x = _producer(m, x, ACT_NONE, 0.0)
+        if k + 1 < len(plan):
+            x = ops.bn_train_fwd_grouped_raw(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                             bn.momentum, a[0], a[1], groups)
+    if not ops.convT_to1_pre_served(x, last.weight):
+        raise RuntimeError("run_stack_groups: the last layer's shape is not served by sg_convT3d_k4s2p1_to1_pre")
+    bn = plan[-1][1]
+    scale, shift = ops.bn_train_stats_affine(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                             bn.momentum, groups)
+    ops.conv_transpose3d_to1_pre_raw(x, scale, shift, a_in[0], a_in[1], last.weight, last.bias,
+                                     a_out[0] if a_out is not None else ACT_NONE, a_out[1] if a_out is not None else 0.0, outs=outs)
+    return True

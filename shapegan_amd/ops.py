@@ -438,28 +438,66 @@ def convT_to1_pre_served(x, w):
             bool(_lib().sg_convT3d_k4s2p1_to1_pre_eligible(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4])))
 
 
-def bn_train_stats_affine(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum):
+def bn_train_stats_affine(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, groups=1):
     """Batch statistics of x [N,C,*S] with torch's running-statistics update, WITHOUT writing the normalised tensor: returns
     (scale, shift) with batch_norm(x)[:, c] == x[:, c] * scale[c] + shift[c] (sg_bn_train_stats).  No autograd: inference-mode
-    generator evaluations only."""
+    generator evaluations only.  groups > 1: x holds `groups` independent batches of N / groups samples (statistics per batch,
+    running statistics updated batch after batch); scale / shift are [groups, C]."""
     x = f32c(x)
     N, C = x.shape[0], x.shape[1]
+    if N % groups:
+        raise RuntimeError("bn_train_stats_affine: %d samples in %d groups" % (N, groups))
     S = x.numel() // (N * C)
     lib = _lib()
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
     invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-    ws = workspace("bn", lib.sg_bn_workspace_bytes(C), x.device)
-    check(lib.sg_bn_train_stats(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
-                                ptr(num_batches_tracked), ptr(scale), ptr(shift), N, C, S, eps, momentum, ptr(ws), ws.numel(),
-                                stream()), "bn_train_stats")
-    return scale, shift
+    ws = workspace("bn", groups * lib.sg_bn_workspace_bytes(C), x.device)
+    check(lib.sg_bn_train_stats_grouped(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                        ptr(num_batches_tracked), ptr(scale), ptr(shift), groups, N // groups, C, S, eps, momentum,
+                                        ptr(ws), ws.numel(), stream()), "bn_train_stats")
+    return (scale, shift) if groups > 1 else (scale[0], shift[0])
 
 
-def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=ACT_NONE, slope=0.0, out=None):
+def bn_train_fwd_grouped_raw(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, act, slope, groups):
+    """act(batch_norm(x)) for x = `groups` independent batches stacked along dim 0, each normalised with its own batch statistics
+    (sg_bn_train_fwd_grouped; running statistics updated batch after batch).  No autograd."""
+    x = f32c(x)
+    N, C = x.shape[0], x.shape[1]
+    if N % groups:
+        raise RuntimeError("bn_train_fwd_grouped: %d samples in %d groups" % (N, groups))
+    S = x.numel() // (N * C)
+    lib = _lib()
+    y = torch.empty_like(x)
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = workspace("bn", groups * lib.sg_bn_workspace_bytes(C), x.device)
+    check(lib.sg_bn_train_fwd_grouped(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
+                                      ptr(running_var), ptr(num_batches_tracked), groups, N // groups, C, S, eps, momentum, act,
+                                      slope, ptr(ws), ws.numel(), stream()), "bn_train_fwd_grouped")
+    return y
+
+
+def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=ACT_NONE, slope=0.0, out=None, outs=None):
     """act(conv_transpose3d_k4s2p1(act_in(x * scale[c] + shift[c]), w) + b) for w [C,1,4,4,4]: the BatchNorm + activation between
-    the producing layer and the last transposed convolution ride in this kernel's loads (no autograd)."""
+    the producing layer and the last transposed convolution ride in this kernel's loads (no autograd).
+    outs (with scale / shift [groups, C]): x holds `groups` independent batches; batch g is written to outs[g] (equally spaced
+    contiguous fp32 tensors [N / groups, 1, 2D, 2H, 2W], e.g. the fake halves of consecutive critic batches)."""
     x, w = f32c(x), f32c(w)
     N, C, D, H, W = x.shape
+    if outs is not None:
+        groups = len(outs)
+        per = N // groups
+        want = (per, 1, 2 * D, 2 * H, 2 * W)
+        stride = (outs[1].data_ptr() - outs[0].data_ptr()) // 4 if groups > 1 else per * 8 * D * H * W
+        for g, o in enumerate(outs):
+            if (tuple(o.shape) != want or o.dtype != torch.float32 or not o.is_contiguous() or o.device != x.device
+                    or o.data_ptr() != outs[0].data_ptr() + 4 * stride * g):
+                raise RuntimeError("conv_transpose3d_to1_pre: `outs` must be equally spaced contiguous fp32 tensors of shape %s" % (want,))
+        if N % groups or tuple(scale.shape) != (groups, C) or stride < per * 8 * D * H * W:
+            raise RuntimeError("conv_transpose3d_to1_pre: %d samples, %d groups, scale %s" % (N, groups, tuple(scale.shape)))
+        check(_lib().sg_convT3d_k4s2p1_to1_pre_grouped(ptr(x), ptr(w), ptr(b), ptr(outs[0]), ptr(scale), ptr(shift), in_act, in_slope,
+                                                       N, C, D, H, W, act, slope, per, stride, stream()), "convT3d_to1_pre_grouped")
+        return outs
     shape = (N, 1, 2 * D, 2 * H, 2 * W)
     if out is not None:
         if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:

@@ -35,20 +35,23 @@ class WGANTrainer(object):
         self.g_opt = optim.RMSprop(generator.parameters(), lr=lr)    # :45
         self.c_opt = optim.RMSprop(critic.parameters(), lr=lr, clip=clip)  # :46 + clip_weights :71 fused
         self.g_bucket, self.c_bucket = GradBucket(self.g_opt), GradBucket(self.c_opt)
+        self._batches = None      # `step`: the critic batches whose fake halves one grouped generator pass fills
 
-    def critic_step(self, real, z):
-        """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw."""
+    def critic_step(self, real, z, both=None):
+        """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw.  `both` (optional): a [n_fake + n_real, 1,
+        R, R, R] batch whose fake half already holds generator(z) (see `step`)."""
         self.c_opt.zero_grad()
         # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
         # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.  The generator
         # writes its samples straight into the fake half of that batch.
         n_fake, n_real = z.shape[0], real.shape[0]
         res = real.shape[-1]
-        both = torch.empty((n_fake + n_real, 1, res, res, res), dtype=torch.float32, device=real.device)
         with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
-            fake = self.generator(z, out=both[:n_fake])
-            if fake.data_ptr() != both.data_ptr():
-                both[:n_fake].copy_(fake)
+            if both is None:
+                both = torch.empty((n_fake + n_real, 1, res, res, res), dtype=torch.float32, device=real.device)
+                fake = self.generator(z, out=both[:n_fake])
+                if fake.data_ptr() != both.data_ptr():
+                    both[:n_fake].copy_(fake)
             both[n_fake:].copy_(real.reshape(n_real, 1, res, res, res))
         out = self.critic(both)
         out_fake, out_real = out[:n_fake], out[n_fake:]
@@ -74,12 +77,33 @@ class WGANTrainer(object):
         return loss.detach(), out.detach()
 
     def step(self, reals, zs_critic, z_gen):
-        """One 5+1 unit: batch_index % 5 == 0 trains the critic and the generator, the next four batches the critic."""
+        """One 5+1 unit: batch_index % 5 == 0 trains the critic and the generator, the next four batches the critic.
+
+        The generator changes once per unit (right after the first critic update), so the samples of the remaining critic updates
+        depend on nothing those updates compute: they are generated in ONE pass behind the generator update
+        (Generator.forward_groups): every transposed convolution runs once on 4 x B latents, every BatchNorm3d normalises each of the
+        four batches with its own statistics and updates its running buffers batch after batch — the same samples and buffers as
+        four separate evaluations (tests/test_gpu_modules.py), a third of the launches and the convolutions at a batch size they are
+        more efficient at."""
+        same = len({(tuple(r.shape), tuple(z.shape)) for r, z in zip(reals[1:], zs_critic[1:])}) == 1
+        if len(reals) < 3 or not same or not self.generator.training:
+            last = None
+            for i, (real, z) in enumerate(zip(reals, zs_critic)):
+                last = self.critic_step(real, z)
+                if i == 0:
+                    self.generator_step(z_gen)
+            return last
+        self.critic_step(reals[0], zs_critic[0])
+        self.generator_step(z_gen)
+        rest, n_fake, n_real, res = len(reals) - 1, zs_critic[1].shape[0], reals[1].shape[0], reals[1].shape[-1]
+        shape = (rest, n_fake + n_real, 1, res, res, res)
+        if self._batches is None or tuple(self._batches.shape) != shape or self._batches.device != reals[1].device:
+            self._batches = torch.empty(shape, dtype=torch.float32, device=reals[1].device)      # kept between units
+        with torch.no_grad():
+            self.generator.forward_groups(list(zs_critic[1:]), [self._batches[g, :n_fake] for g in range(rest)])
         last = None
-        for i, (real, z) in enumerate(zip(reals, zs_critic)):
-            last = self.critic_step(real, z)
-            if i == 0:
-                self.generator_step(z_gen)
+        for g, (real, z) in enumerate(zip(reals[1:], zs_critic[1:])):
+            last = self.critic_step(real, z, self._batches[g])
         return last
 
 

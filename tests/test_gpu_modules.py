@@ -340,6 +340,73 @@ def test_wgan_trajectory(golden_steps, monkeypatch):
     _check_updates(g, g0, o32.G, o64.G, "wgan generator", golden_steps, "wgan/g_final")
 
 
+def test_wgan_step_with_grouped_generator_pass_equals_the_updates_one_by_one(n_units=2):
+    """WGANTrainer.step evaluates the generator for critic updates 2..5 in one grouped pass (Generator.forward_groups: per-batch
+    BatchNorm statistics, running buffers updated batch after batch).  Against calling critic_step / generator_step one by one
+    from the same state and inputs: BatchNorm buffers to rounding (the first layer's GEMM runs at 4 x B rows: another split of its
+    K loop), the critic and generator parameters after two units the same up to that rounding through RMSprop's sign-like steps
+    (all but a sliver of the entries)."""
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
+    gen = torch.Generator().manual_seed(77)
+    B = 8
+    units = [([(torch.rand(B, 32, 32, 32, generator=gen) * 2 - 1).to(DEV) for _ in range(5)],
+              [torch.randn(B, 128, generator=gen).to(DEV) for _ in range(5)], torch.randn(B, 128, generator=gen).to(DEV))
+             for _ in range(n_units)]
+
+    def run(by_hand):
+        torch.manual_seed(78)
+        g, c = Generator(), Discriminator()
+        tr = WGANTrainer(g, c)
+        for reals, zs, zg in units:
+            if by_hand:
+                for i, (real, z) in enumerate(zip(reals, zs)):
+                    tr.critic_step(real, z)
+                    if i == 0:
+                        tr.generator_step(zg)
+            else:
+                tr.step(reals, zs, zg)
+        state = {("g", k): v.detach().cpu().clone() for k, v in g.state_dict().items()}
+        state.update({("c", k): v.detach().cpu().clone() for k, v in c.state_dict().items()})
+        return state
+    grouped, hand = run(False), run(True)
+    for k in grouped:
+        a, b = grouped[k].double(), hand[k].double()
+        if "tracked" in k[1]:
+            assert torch.equal(a, b), k
+        elif "running" in k[1]:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7, msg=lambda m: "%s: %s" % (k, m))
+        else:
+            bad = (a - b).abs() > 1e-6 + 1e-4 * b.abs()
+            assert float(bad.double().mean()) < 2e-2, "%s: %.3f %% of the entries differ" % (k, 100 * float(bad.double().mean()))
+
+
+@pytest.mark.parametrize("groups,B", [(4, 64), (3, 5)])
+def test_generator_forward_groups_equals_separate_evaluations(groups, B):
+    """Generator.forward_groups against `groups` separate inference-mode evaluations from the same state: samples (written into
+    equally spaced slices of one tensor, nothing else touched), running statistics and batch counters."""
+    from shapegan_amd.model.gan import Generator
+    torch.manual_seed(90 + groups)
+    g = Generator()
+    state = {k: v.clone() for k, v in g.state_dict().items()}
+    zs = [torch.randn(B, 128).to(DEV) for _ in range(groups)]
+    big = torch.full((groups, 2 * B, 1, 32, 32, 32), 7.0).to(DEV)
+    with torch.no_grad():
+        g.forward_groups(zs, [big[i, :B] for i in range(groups)])
+    after = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+    g.load_state_dict(state)
+    with torch.no_grad():
+        ref = [g(z).cpu() for z in zs]
+    assert bool((big[:, B:] == 7.0).all())
+    for i in range(groups):
+        torch.testing.assert_close(big[i, :B].cpu(), ref[i], rtol=1e-5, atol=3e-6, msg=lambda m: "group %d: %s" % (i, m))
+    for k, v in g.state_dict().items():
+        if "tracked" in k:
+            assert int(after[k]) == int(v), k
+        elif "running" in k:
+            torch.testing.assert_close(after[k], v.cpu(), rtol=1e-5, atol=1e-7, msg=lambda m: k + ": " + m)
+
+
 def test_autoencoder_trajectory(golden_steps):
     """BASELINE config 1: train_autoencoder.py classic, batch 4, three Adam steps."""
     from shapegan_amd.model.autoencoder import Autoencoder
