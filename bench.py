@@ -108,16 +108,16 @@ def conv_kernel_table():
     b1 = torch.zeros(64, device="cuda")
     y16 = torch.randn(nb, 64, 16, 16, 16, device="cuda")
     f1 = 2.0 * 64 * 64 * 4096 * nb
-    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv1 forward", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
+    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv_fwd_c1_kernel<2,1>", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
         lambda: ops.conv_fwd_raw(x32, w1, b1, 1, 0.2))
-    hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv1 wgrad", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
+    hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv_wgrad_c1_kernel<2,0>", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
         lambda: ops.conv_wgrad_raw(y16, x32, 1))
     ya = torch.randn(nb, 64, 16, 16, 16, device="cuda")
     hbm("Conv3d 1->64 weight + bias gradient through LeakyReLU (the critic's first layer: reads dy and y), 128 samples",
         "conv_wgrad_c1_kernel<2,LEAKY>", 4.0 * (x32.numel() + 2 * y16.numel() + w1.numel()), f1,
         lambda: ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2))
     y16g = y16[:BATCH].contiguous()
-    hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "dgrad_out1", 4.0 * (y16g.numel() + BATCH * 32768 + w1.numel()),
+    hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "convT_c1_stream_kernel<true,false,true,0>", 4.0 * (y16g.numel() + BATCH * 32768 + w1.numel()),
         f1 / 2, lambda: ops.conv_dgrad_raw(y16g, w1, None, 1))
     return rows
 

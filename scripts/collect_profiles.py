@@ -17,7 +17,7 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
-             "sdf20k_step_timeline.txt"):
+             "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json"):
     f = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
@@ -40,9 +40,11 @@ def mfma_table(name):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v["SQ_VALU_MFMA_BUSY_CYCLES"][0] > 1e6:
             busy, gui = v["SQ_VALU_MFMA_BUSY_CYCLES"][0], v["GRBM_GUI_ACTIVE"][0]
             ns = v["GRBM_GUI_ACTIVE"][1]
-            out.append({"kernel": k, "launches": v["GRBM_GUI_ACTIVE"][2], "dispatch_us": round(ns / 1e3, 1),
-                        "mfma_busy_cycles": busy, "gui_active_cycles_all_xcd": gui,
-                        "mfma_util": round(busy / (gui / 8.0 * 1024.0), 4), "clock_ghz_while_profiled": round(gui / 8.0 / ns, 3)})
+            row = {"kernel": k, "launches": v["GRBM_GUI_ACTIVE"][2], "dispatch_us": round(ns / 1e3, 1),
+                   "mfma_busy_cycles": busy, "gui_active_cycles_all_xcd": gui, "mfma_util": round(busy / (gui / 8.0 * 1024.0), 4)}
+            if ns >= 200000:      # GUI_ACTIVE / dispatch time is no clock estimate for short kernels (2.98 "GHz" at 30 us)
+                row["clock_ghz_while_profiled"] = round(gui / 8.0 / ns, 3)
+            out.append(row)
     out.sort(key=lambda r: -r["mfma_busy_cycles"])
     return out
 
@@ -71,13 +73,116 @@ if cfg_m:
     json.dump(cfg_m, open(os.path.join(dst, tag + "_configs_mfma_utilisation.json"), "w"), indent=1)
 if cfg_h:
     json.dump(cfg_h, open(os.path.join(dst, tag + "_configs_hbm_traffic.json"), "w"), indent=1)
-dom = [r for r in rows if "conv_dgrad_halo_kernel<0>" in r["kernel"]]
+# the kernel with the largest share of the WGAN step (the same rule bench.py's `roofline` follows)
+dom_name = None
+stats = os.path.join(dst, tag + "_wgan_step_kernel_stats.csv")
+if os.path.exists(stats):
+    top = max(csv.DictReader(open(stats)), key=lambda r: float(r["Percentage"]))
+    dom_name = top["Name"].split("(")[0].replace("void ", "").strip()
+dom = [r for r in rows if dom_name and dom_name.replace(" ", "") in r["kernel"].replace(" ", "")]
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_read_bytes"] + dom[0]["hbm_write_bytes"],
                "read": dom[0]["hbm_read_bytes"], "write": dom[0]["hbm_write_bytes"],
-               "note": "median over the launches of two WGAN steps (128- and 64-sample shapes mixed; the median launch is the "
-                       "128-sample critic shape: WRITE = dx [128,64,16^3] fp32 = 134 MB)"},
+               "note": "median over the launches of two WGAN steps (shapes of 64 / 128 / 256 samples mixed)"},
               open(os.path.join(dst, tag + "_dominant_kernel_hbm.json"), "w"), indent=1)
+
+
+# ---- markdown tables generated from the files above: profiles/README.md and DESIGN.md quote THESE, nothing is typed by hand ------
+def md_tables():
+    L = ["<!-- generated by scripts/collect_profiles.py %s from the files named in each heading; do not edit -->" % tag, ""]
+    bl = os.path.join(dst, tag + "_bench_line.json")
+    if os.path.exists(bl):
+        d = json.loads([ln for ln in open(bl).read().splitlines() if ln.startswith("{")][-1])
+        L += ["### `%s_bench_line.json` (`python bench.py`, N = 1)" % tag, "",
+              "| quantity | value |", "|---|---|",
+              "| %s | **%.2f %s** (%.3f ms per step) |" % (d["metric"], d["value"], d["unit"], d["ms_per_step"]),
+              "| roofline kernel | %s: %.1f %s of %.1f = **%.3f** |" % (d["roofline"]["kernel"].split(" (")[0], d["roofline"]["achieved"],
+                                                                       d["roofline"]["unit"], d["roofline"]["peak"], d["roofline"]["frac"])]
+        s_ = d["sdfnet"]
+        L += ["| SDFNet fused forward, 8 x 32^3, no grad | %.1f Mpoints/s = %.3f of the fp32 MFMA peak (executed FLOPs) |"
+              % (s_["fwd_mpoints_per_s"], s_["fwd_frac_of_f32_mfma_peak_executed"])]
+        for key, what in (("train_ref_20k_L128", "auto-decoder step, 20 000 points, L = 128, one captured graph"),
+                          ("train_ref_20k_L128_eager", "the same launched eagerly"),
+                          ("train_cfg_200k_L256", "auto-decoder step, 200 000 points, L = 256 (configs[2])")):
+            L += ["| %s | %.3f ms = %.2f Mpoints/s = %.3f executed |" % (what, s_[key]["ms_per_step"], s_[key]["mpoints_per_s"],
+                                                                       s_[key]["frac_of_f32_mfma_peak_executed"])]
+        for key, v in d.get("other_configs", {}).items():
+            L += ["| other_configs.%s | %.4g %s (%.3f ms per step) |" % (key, v["value"], v["unit"], v["ms_per_step"])]
+        cb = d.get("cpu_baseline")
+        if cb:
+            L += ["| cpu_baseline | %.3f %s on %d of %d host threads, kind `%s` |" % (cb["value"], cb["unit"], cb["cores"],
+                                                                                    cb.get("host_cores", 0), cb["kind"])]
+        L += ["", "| conv form (`kernels`) | kernel | us | rate | fraction of its roofline |", "|---|---|---|---|---|"]
+        for k in d["kernels"]:
+            rate = "%.1f TFLOP/s" % k["tflops"] if k["bound"] == "mfma" else "%.0f GB/s" % k["gb_per_s"]
+            L += ["| %s | `%s` | %.1f | %s | %.3f (%s) |" % (k["name"], k["kernel"], k["us"], rate, k["frac"],
+                                                           "fp32 MFMA 157.3 TF" if k["bound"] == "mfma" else "HBM 8 TB/s")]
+        L += [""]
+    b2 = os.path.join(dst, tag + "_bench_line_2ranks_gloo_one_gpu.json")
+    if os.path.exists(b2):
+        lines = [ln for ln in open(b2).read().splitlines() if ln.startswith("{")]
+        if lines:
+            d = json.loads(lines[-1])
+            L += ["### `%s_bench_line_2ranks_gloo_one_gpu.json` (the driver's multi-GPU command with two ranks on ONE GPU, gloo)" % tag, "",
+                  "n_gpus %d, parallelism %s, %.2f %s aggregate (both ranks share one GPU: a rehearsal of the code path, not a scaling "
+                  "number); comm: %s" % (d["n_gpus"], d["config"]["parallelism"], d["value"], d["unit"], json.dumps(d.get("comm"))), ""]
+    tl = os.path.join(dst, tag + "_wgan_step_timeline.txt")
+    if os.path.exists(tl):
+        import re
+        rows_ = [(float(m.group(1)), m.group(2).strip()) for m in
+                 (re.match(r"\s*[\d.]+\s+\+\s+[-\d.]+ gap\s+([\d.]+) us\s+(.*)", ln) for ln in open(tl)) if m]
+        halo = sum(d_ for d_, n in rows_ if "halo_kernel" in n or "halo4_kernel" in n)
+        tot = sum(d_ for d_, n in rows_)
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for d_, n in rows_:
+            agg[n[:70]][0] += 1
+            agg[n[:70]][1] += d_
+        L += ["### `%s_wgan_step_timeline.txt` (one 5+1 WGAN step under `rocprofv3 --kernel-trace`)" % tag, "",
+              "%d launches, %.2f ms of kernel time: LDS-halo MFMA convolutions %.2f ms, everything else (\"tail\") %.2f ms" %
+              (len(rows_), tot / 1e3, halo / 1e3, (tot - halo) / 1e3), "", "| kernel | launches | us per step |", "|---|---|---|"]
+        for n, (c_, t_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+            L += ["| `%s` | %d | %.1f |" % (n, c_, t_)]
+        L += [""]
+    for name, title in (("_mfma_utilisation.json", "MFMA utilisation (`SQ_VALU_MFMA_BUSY_CYCLES` / (`GRBM_GUI_ACTIVE` per XCD x 1024 SIMDs), median launch)"),
+                        ("_configs_mfma_utilisation.json", "the same for the kernels of configs[2] / [3] / [4]")):
+        f = os.path.join(dst, tag + name)
+        if os.path.exists(f):
+            L += ["### `%s%s`: %s" % (tag, name, title), "", "| kernel | launches | dispatch us | MFMA busy |", "|---|---|---|---|"]
+            for r in json.load(open(f)):
+                L += ["| `%s` | %d | %.1f | %.3f |" % (r["kernel"][:90], r["launches"], r["dispatch_us"], r["mfma_util"])]
+            L += [""]
+    for name, title in (("_hbm_traffic.json", "HBM bytes per launch (`FETCH_SIZE` x 2 + `WRITE_SIZE`, separate passes, median launch)"),
+                        ("_configs_hbm_traffic.json", "the same for the kernels of configs[2] / [3] / [4]")):
+        f = os.path.join(dst, tag + name)
+        if os.path.exists(f):
+            L += ["### `%s%s`: %s" % (tag, name, title), "", "| kernel | launches | dispatch us | read MB | written MB | GB/s |", "|---|---|---|---|---|---|"]
+            for r in json.load(open(f))[:22]:
+                L += ["| `%s` | %d | %.1f | %.1f | %.1f | %.0f |" % (r["kernel"][:90], r["launches"], r["dispatch_us"], r["hbm_read_bytes"] / 1e6,
+                                                                  r["hbm_write_bytes"] / 1e6, r["hbm_gb_per_s"])]
+            L += [""]
+    f = os.path.join(dst, tag + "_stream_calibration.json")
+    if os.path.exists(f):
+        L += ["### `%s_stream_calibration.json` (`python scripts/stream_calibration.py`)" % tag, "", "| pass | kernel | us | TB/s |", "|---|---|---|---|"]
+        for r in json.load(open(f))["passes"]:
+            L += ["| %s | %s | %.1f | %.2f |" % (r["pass"], r["kernel"], r["us"], r["tb_per_s"])]
+        L += [""]
+    f = os.path.join(dst, tag + "_edge_kernels_by_batch.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_edge_kernels_by_batch.json` (`python scripts/edge_ab.py`: one-channel kernels, us per launch)" % tag, "",
+              "| entry | " + " | ".join(k for k in d if k != "lib") + " |", "|---|" + "---|" * (len(d) - 1),
+              "| us | " + " | ".join(str(v) for k, v in d.items() if k != "lib") + " |", ""]
+    f = os.path.join(dst, tag + "_cpu_baseline_reference_vs_port.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_cpu_baseline_reference_vs_port.json` (`python scripts/cpu_baseline_compare.py`, authoring container, no GPU)" % tag, "",
+              "reference modules %.4f steps/s, port (oracle/torch_oracle.py) %.4f steps/s on the same %d threads: ratio %.3f; first critic "
+              "loss bit-equal: %s" % (d["reference"]["steps_per_s"], d["port"]["steps_per_s"], d["cores"], d["port_over_reference"],
+                                      d["first_critic_loss_equal"]), ""]
+    open(os.path.join(dst, tag + "_tables.md"), "w").write("\n".join(L) + "\n")
+
+
+md_tables()
 for r in out:
     print("%-60s util %.3f  %.0f us" % (r["kernel"][:60], r["mfma_util"], r["dispatch_us"]))
 for r in rows[:14]:

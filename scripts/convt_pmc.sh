@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 counter passes for the ConvT(64->1) kernel (each counter group in its own run, kernel-trace only)
 repo=$(pwd); out=$repo/gpurun_out/convt_pmc; mkdir -p $out
+echo "# rocprofv3 --kernel-trace --pmc <group> -- python scripts/convt_pmc.py: median counter value and dispatch time per grid size"
+echo "# (grid 131072 = 64 samples: convT_c1_stream_kernel; 65536 = 32 samples: convT_c1_fused_kernel; 524288 = 256 samples: stream)"
 cd /tmp && export TMPDIR=/tmp
 run_pmc() { name=$1; ctrs=$2
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/cp/$name -o $name -- python $repo/scripts/convt_pmc.py > $out/$name.log 2>&1

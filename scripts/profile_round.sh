@@ -37,6 +37,11 @@ cd $repo
 python scripts/stream_calibration.py > $out/${tag}_stream_calibration.json 2> $out/stream.err
 python scripts/edge_ab.py > $out/${tag}_edge_kernels_by_batch.json 2> $out/edge_ab.err
 python scripts/point_gan_bench.py > $out/${tag}_point_gan_bench.txt 2> $out/point_gan.err
+# the plane-streaming ConvT(64 -> 1) kernel alone: SQ / TCC / LDS counter groups at 64, 32 (old kernel) and 256 samples
+bash scripts/convt_pmc.sh > $out/${tag}_convT_c1_counters.txt 2> $out/convt_pmc.err
+# the driver's own command, and the rehearsal of its multi-GPU form on this one GPU (gloo, two ranks on cuda:0)
+python bench.py > $out/${tag}_bench_line.json 2> $out/bench_line.err
+SG_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --no-extras > $out/${tag}_bench_line_2ranks_gloo_one_gpu.json 2> $out/bench_2ranks.err
 # ordered launch lists of one steady-state step
 bash scripts/timeline_run.sh > $out/timeline.log 2>&1
 for n in wgan sdf200k sdf20k; do cp gpurun_out/timeline/$n.txt $out/${tag}_${n}_step_timeline.txt; done

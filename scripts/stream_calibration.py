@@ -71,6 +71,14 @@ def main():
     small_c = torch.randn(64 * 64 * 4096, device="cuda")
     add("read-only 67 MB (fused ConvT's dy at 64 samples)", "sg::sum_partial_kernel", small_c.numel() * 4.0, 0.0,
         lambda: check(lib.sg_reduce_sum(ptr(small_c), ptr(scalar), small_c.numel(), 1.0, ptr(ws), ws.numel(), stream()), "reduce_sum"))
+    # bias-gradient row sums at the shapes of BASELINE configs[3] (progressive discriminator, batch 32 at 64^3) and of the WGAN critic
+    for nrows, length, what in ((32 * 32, 32768, "configs[3] stage 3: [32,32,32^3]"), (32 * 64, 4096, "configs[3] stage 2: [32,64,16^3]"),
+                                (32 * 128, 512, "configs[3] stage 1: [32,128,8^3]"), (128 * 128, 512, "WGAN critic layer 2: [128,128,8^3]"),
+                                (128 * 256, 64, "WGAN critic layer 3: [128,256,4^3]")):
+        g = torch.randn(nrows, length, device="cuda")
+        o = torch.empty(nrows, device="cuda")
+        add("row sums " + what, "sg::rowsum_kernel / rowsum_wave_kernel (sg_rowsum)", g.numel() * 4.0, nrows * 4.0,
+            lambda: check(lib.sg_rowsum(ptr(g), ptr(o), nrows, length, length, stream()), "rowsum"))
     print(json.dumps({"device": torch.cuda.get_device_name(0), "hbm_peak_tb_per_s": 8.0, "passes": rows}, indent=1))
 
 
