@@ -48,6 +48,15 @@ size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD
 int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                          int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
                          size_t workspace_bytes, hipStream_t stream);
+/* Kept weight images (see sg_conv3d_k4s2p1_dgrad_keep below) for the forward form, and the images of up to 8 forthcoming
+ * _keep calls packed in ONE launch: a critic update packs four images of two weights (model/gan.py:51-53 forward and input
+ * gradient), one small launch each before.  kinds[i]: 0 forward, 1 input gradient; dims[8 i ..] = {batch, Cin, Cin_total, Cx, Cout,
+ * ID, IH, IW} of call i; served[i] = 1: make call i with weights_unchanged = 1. */
+int sg_conv3d_k4s2p1_fwd_keep(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                              int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                              size_t workspace_bytes, int weights_unchanged, hipStream_t stream);
+int sg_conv3d_k4s2p1_pack_images(int n, const int* kinds, const float* const* weights, void* const* workspaces,
+                                 const size_t* workspace_bytes, const int* dims, int* served, hipStream_t stream);
 /* testing / tuning: force one forward implementation (0 = gather implicit GEMM, 1 = LDS-halo implicit GEMM) */
 int sg_conv3d_k4s2p1_fwd_impl(const float* x, const float* w, const float* bias, float* y, int batch, int Cin,
                               int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,

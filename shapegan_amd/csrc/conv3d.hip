@@ -555,9 +555,12 @@ static int check_sizes(const ConvGeom& g, int batch, const char* who) {
     return 0;
 }
 
-int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
-                         int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
-                         size_t workspace_bytes, hipStream_t stream) {
+}  // extern "C"
+
+// packed_already: the LDS-halo kernel's weight image of this call is still in `workspace` (sg_conv3d_k4s2p1_fwd_keep)
+static int fwd_call(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                    int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream, bool packed_already) {
     SG_CHECK_ARG(x && w && y && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
     ConvGeom g;
     if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_fwd: spatial dims must be even and >= 2");
@@ -570,7 +573,7 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
     }
     {
         const int rc = halo_fwd_try(x, w, bias, y, batch, Cin, Cin_total, g, Cout, act, slope, workspace, workspace_bytes,
-                                    stream);
+                                    stream, 0, 0, packed_already);
         if (rc < 0) return rc;
         if (rc == 1) {
             SG_CHECK_LAUNCH();
@@ -587,6 +590,23 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
     launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, (float*)workspace, workspace ? workspace_bytes : 0, stream);
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+
+extern "C" {
+
+int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                         int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+    return fwd_call(x, w, bias, y, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, workspace, workspace_bytes, stream, false);
+}
+// The same with the weight image KEPT in a workspace the caller dedicates to this weight (see sg_conv3d_k4s2p1_dgrad_keep):
+// weights_unchanged != 0 promises that the image of exactly this call (same weight values, same shapes) is in place — left by
+// an earlier call on the workspace or by sg_conv3d_k4s2p1_pack_images.
+int sg_conv3d_k4s2p1_fwd_keep(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                              int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
+                              size_t workspace_bytes, int weights_unchanged, hipStream_t stream) {
+    return fwd_call(x, w, bias, y, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, workspace, workspace_bytes, stream,
+                    weights_unchanged != 0);
 }
 
 // Forces one implementation of the forward (testing / tuning): impl 0 = gather kernel, 1 = LDS-halo kernel
@@ -719,6 +739,40 @@ int sg_conv3d_k4s2p1_dgrad_keep(const float* dy, const float* w, const float* bi
                                 void* workspace, size_t workspace_bytes, int weights_unchanged, hipStream_t stream) {
     return dgrad_call(dy, w, bias, dx, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, workspace, workspace_bytes, stream,
                       weights_unchanged != 0);
+}
+
+// The weight images of up to 8 forthcoming calls in ONE launch.  Call i is described by kinds[i] (0: sg_conv3d_k4s2p1_fwd_keep, 1:
+// sg_conv3d_k4s2p1_dgrad_keep) and dims[8 i ..] = {batch, Cin, Cin_total, Cx, Cout, ID, IH, IW} exactly as it will be made, with the
+// workspace it will be given.  served[i] = 1: the image is in place, make the call with weights_unchanged = 1;  0: that call is
+// not served by a kernel with a kept image (one-channel layers, small shapes on the gather kernels) — make it with
+// weights_unchanged = 0.  Planning is done by the same code that serves the calls.
+int sg_conv3d_k4s2p1_pack_images(int n, const int* kinds, const float* const* weights, void* const* workspaces,
+                                 const size_t* workspace_bytes, const int* dims, int* served, hipStream_t stream) {
+    SG_CHECK_ARG(n > 0 && n <= 8 && kinds && weights && workspaces && workspace_bytes && dims && served);
+    PackJobs jobs;
+    static const float dummy = 0.f;       // operand pointers are only stored in collect mode, never dereferenced
+    for (int i = 0; i < n; ++i) {
+        const int* d = dims + 8 * i;
+        const int batch = d[0], Cin = d[1], Cin_total = d[2], Cx = d[3], Cout = d[4];
+        served[i] = 0;
+        SG_CHECK_ARG(weights[i] && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0 && (kinds[i] == 0 || kinds[i] == 1));
+        ConvGeom g;
+        if (make_geom(g, d[5], d[6], d[7], Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_pack_images: bad spatial dims");
+        if (check_sizes(g, batch, "sg_conv3d_k4s2p1_pack_images")) return SG_ERR_ARG;
+        if (Cin == 1) continue;          // the one-channel kernels read the weights in place
+        int rc;
+        if (kinds[i] == 0)
+            rc = halo_fwd_try(&dummy, weights[i], nullptr, const_cast<float*>(&dummy), batch, Cin, Cin_total, g, Cout, SG_ACT_NONE, 0.f,
+                              workspaces[i], workspace_bytes[i], stream, 0, 0, false, &jobs);
+        else
+            rc = halo_dgrad_try(&dummy, weights[i], nullptr, const_cast<float*>(&dummy), batch, Cin, Cin_total, g, Cout, SG_ACT_NONE, 0.f,
+                                workspaces[i], workspace_bytes[i], stream, 0, false, &jobs);
+        if (rc < 0) return rc;
+        served[i] = rc == 1;
+    }
+    halo_pack_jobs_launch(jobs, stream);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
 }
 
 // testing / tuning: impl 1 forces the LDS-halo dgrad kernel (SG_ERR_ARG if the shape is not eligible)

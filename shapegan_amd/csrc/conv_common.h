@@ -58,18 +58,36 @@ static inline int make_geom(ConvGeom& g, int ID, int IH, int IW, int Cx, int Cy)
 }
 
 
+// Packing jobs of the LDS-halo kernels' weight images, collected by halo_fwd_try / halo_dgrad_try in collect mode and launched
+// together (conv3d_halo.hip: pack_images_kernel, sg_conv3d_k4s2p1_pack_images)
+struct PackJob {
+    const float* w;
+    float4* wp;
+    int kind, Cout, Cin_total, Cin, nt;     // kind 0: forward image (nt = 32-row tiles), 1: input-gradient image (nt = MT)
+};
+struct PackJobs {
+    PackJob job[8];
+    int n = 0;
+    int add(int kind, const float* w, float4* wp, int Cout, int Cin_total, int Cin, int nt) {
+        if (n >= 8) return 0;
+        job[n++] = PackJob{w, wp, kind, Cout, Cin_total, Cin, nt};
+        return 1;
+    }
+};
+int halo_pack_jobs_launch(const PackJobs& jobs, hipStream_t stream);
+
 // conv3d_halo.hip: LDS-halo forward kernel.  Returns 1 if it handled the call, 0 if the shape is not eligible
 // (the caller then uses the generic gather kernel), <0 on error.
 size_t halo_fwd_workspace_bytes(int Cin, int Cout);
 int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                  const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream, int force = 0, int debug = 0);
+                 hipStream_t stream, int force = 0, int debug = 0, bool packed_already = false, PackJobs* collect = nullptr);
 
 size_t halo_dgrad_workspace_bytes(int Cin, int Cout);
 // (packed_already: the workspace still holds this weight's fragment image from an earlier call — sg_conv3d_k4s2p1_dgrad_keep)
 int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                    const ConvGeom& g, int Cout, int act, float slope, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream, int force = 0, bool packed_already = false);
+                   hipStream_t stream, int force = 0, bool packed_already = false, PackJobs* collect = nullptr);
 
 size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,

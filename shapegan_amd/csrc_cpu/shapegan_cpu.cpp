@@ -179,6 +179,16 @@ int sg_conv3d_k4s2p1_dgrad_keep_cpu(const float* dy, const float* w, const float
                                     size_t wb, int, void* st) {     // (nothing is packed here: nothing to keep)
     return sg_conv3d_k4s2p1_dgrad_cpu(dy, w, bias, dx, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, ws, wb, st);
 }
+int sg_conv3d_k4s2p1_fwd_keep_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
+                                  int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* ws, size_t wb, int, void* st) {
+    return sg_conv3d_k4s2p1_fwd_cpu(x, w, bias, y, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, act, slope, ws, wb, st);
+}
+int sg_conv3d_k4s2p1_pack_images_cpu(int n, const int* kinds, const float* const* weights, void* const* workspaces,
+                                     const size_t* workspace_bytes, const int* dims, int* served, void*) {
+    CPU_CHECK(n > 0 && n <= 8 && kinds && weights && workspaces && workspace_bytes && dims && served);
+    for (int i = 0; i < n; ++i) served[i] = 0;     // the twin reads the weights in place: there is no image to keep
+    return SG_OK;
+}
 int sg_convT3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
                               int ID, int IH, int IW, int act, float slope, void* ws, size_t wb, void* st) {
     return sg_conv3d_k4s2p1_dgrad_cpu(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act, slope, ws,

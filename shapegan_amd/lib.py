@@ -26,6 +26,8 @@ SIGNATURES = {
     "sg_last_error": (c_char_p, []),
     "sg_conv3d_k4s2p1_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "sg_conv3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "sg_conv3d_k4s2p1_fwd_keep": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
+    "sg_conv3d_k4s2p1_pack_images": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "sg_conv3d_k4s2p1_fwd_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _I, _P]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),

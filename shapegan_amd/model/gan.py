@@ -78,6 +78,8 @@ class Discriminator(SavableModule):
         layers.append(Lambda(lambda t: ops.Act.apply(t, ACT_SIGMOID, 0.0) if self.use_sigmoid else t))
         self.layers = nn.Sequential(*layers)
         self.to(default_device)
+        # the critic's weights change together (one optimizer step per update): their packed images are rebuilt in one launch
+        ops.register_pack_group([m.weight for m in self.layers if isinstance(m, nn.Conv3d) and m.in_channels > 1])
 
     def forward(self, x):
         if len(x.shape) < 5:

@@ -25,16 +25,24 @@ def _lib():
 # --------------------------------------------------------------------------------------------------------------
 # raw launches (no autograd)
 # --------------------------------------------------------------------------------------------------------------
-def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0):
-    """x [N,Cx,D,H,W], w [Co,Ct,4,4,4] -> act(conv_k4s2p1(x, w[:, :Cx]) + bias) [N,Co,D/2,H/2,W/2]."""
+def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0, keep=False):
+    """x [N,Cx,D,H,W], w [Co,Ct,4,4,4] -> act(conv_k4s2p1(x, w[:, :Cx]) + bias) [N,Co,D/2,H/2,W/2].
+    keep: `w` is a layer's own weight — its packed image lives in a workspace of its own (_KeptWeightImages) and is rebuilt only
+    when the weight changed, together with the other stale images of its pack group (register_pack_group)."""
     N, Cx, D, H, W = x.shape
     Co, Ct = w.shape[0], w.shape[1]
     if Cx > Ct:
         raise RuntimeError("conv: input has %d channels, weight expects %d" % (Cx, Ct))
     ptr(x)  # fail loudly on CPU tensors before anything else
+    L.reset_call_state()
     y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
     lib = _lib()
     nb = lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Cx, Co, D // 2, H // 2, W // 2)
+    if keep and Cx > 1 and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        ws, unchanged = _KEPT.get(w, nb, (N, Cx, Ct, Cx, Co, D, H, W), kind=0)
+        check(lib.sg_conv3d_k4s2p1_fwd_keep(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope, ptr(ws),
+                                            ws.numel(), int(unchanged), stream()), "conv3d_fwd_keep")
+        return y
     ws = workspace("splitk", nb, x.device) if nb else None
     check(lib.sg_conv3d_k4s2p1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope, ptr(ws),
                                    ws.numel() if ws is not None else 0, stream()), "conv3d_fwd")
@@ -55,31 +63,90 @@ def conv_fwd_impl_raw(x, w, bias, act, slope, impl, debug=0):
 
 
 class _KeptWeightImages(object):
-    """Workspaces dedicated to one ConvTranspose3d weight each (sg_conv3d_k4s2p1_dgrad_keep): the packed image a call leaves
-    there serves the next call as long as the weight is unchanged — same storage, same tensor version, same parameter epoch of
-    the optimizer buffer it lives in (lib.param_epoch_of) — and the shapes are the same.  The WGAN generator is evaluated six
-    times per 5+1 unit (train_wgan.py:60-84) and updated once.  At most `cap` weights are remembered (oldest dropped)."""
+    """Workspaces dedicated to one weight and one packed form each (sg_conv3d_k4s2p1_fwd_keep / _dgrad_keep): the image a call
+    leaves there serves the next call as long as the weight is unchanged — same storage, same tensor version, same parameter epoch
+    of the optimizer buffer it lives in (lib.param_epoch_of) — and the call's shapes are the same.  The WGAN generator is evaluated
+    six times per 5+1 unit (train_wgan.py:60-84) and updated once.  At most `cap` images are remembered (oldest dropped).
 
-    def __init__(self, cap=32):
-        self.cap, self.entries = cap, {}
+    Pack groups (register_pack_group): the weights of one network change together (one optimizer step), so when a call finds its
+    image stale, every OTHER stale image of the group whose call shapes are known from earlier calls is rebuilt in the same launch
+    (sg_conv3d_k4s2p1_pack_images) — a critic update of train_wgan.py then packs its four images (two weights, forward and
+    input-gradient form) with one launch instead of four."""
 
-    def get(self, w, nbytes, shape_key):
-        """-> (workspace, unchanged).  An entry belongs to one tensor OBJECT (weak reference): a new tensor that the allocator
-        places at a freed weight's address, with the same version and epoch, is a different weight."""
-        ident = (w.device.index, stream(), w.data_ptr())
-        state = (w._version, L.param_epoch_of(w), shape_key)
+    def __init__(self, cap=64):
+        self.cap, self.entries, self.groups = cap, {}, {}
+
+    def _ident(self, w, kind):
+        return (w.device.index, stream(), w.data_ptr(), kind)
+
+    def _state(self, w, shape_key):
+        return (w._version, L.param_epoch_of(w), shape_key)
+
+    def get(self, w, nbytes, shape_key, kind=1):
+        """-> (workspace, unchanged).  kind: 0 forward image, 1 input-gradient image; shape_key = (batch, Cin, Cin_total, Cx, Cout,
+        ID, IH, IW) of the call.  An entry belongs to one tensor OBJECT (weak reference): a new tensor that the allocator places at
+        a freed weight's address, with the same version and epoch, is a different weight."""
+        ident = self._ident(w, kind)
+        state = self._state(w, shape_key)
         ent = self.entries.pop(ident, None)
         if ent is None or ent[0].numel() < nbytes or ent[2]() is not w:
             ent = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device), None, weakref.ref(w)]
         unchanged = ent[1] == state
+        if not unchanged:
+            unchanged = self._pack_group(w, kind, ent, shape_key)
         ent[1] = state
         self.entries[ident] = ent            # (re-inserted last: dict order = age)
         while len(self.entries) > self.cap:
             self.entries.pop(next(iter(self.entries)))
         return ent[0], unchanged
 
+    def _pack_group(self, w, kind, ent, shape_key):
+        """The stale image (w, kind) and every other stale image of w's pack group with known call shapes, in one launch.  Returns
+        whether (w, kind) itself is in place now."""
+        group = self.groups.get(id(w))
+        if group is None or group[1]() is not w:
+            return False
+        jobs = [(w, kind, ent, shape_key)]
+        for ref in group[0]:
+            v = ref()
+            if v is None or v.device != w.device:
+                continue
+            for k2 in (0, 1):
+                if v is w and k2 == kind:
+                    continue
+                e2 = self.entries.get(self._ident(v, k2))
+                if e2 is None or e2[2]() is not v or e2[1] is None:
+                    continue
+                if e2[1] != self._state(v, e2[1][2]):          # stale, shapes known from its last call
+                    jobs.append((v, k2, e2, e2[1][2]))
+        if len(jobs) < 2:
+            return False                     # nothing to share the launch with: the call packs its own image as before
+        jobs = jobs[:8]
+        n = len(jobs)
+        kinds = (ctypes.c_int * n)(*[j[1] for j in jobs])
+        wptr = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+        wsp = (ctypes.c_void_p * n)(*[j[2][0].data_ptr() for j in jobs])
+        wsb = (ctypes.c_size_t * n)(*[j[2][0].numel() for j in jobs])
+        dims = (ctypes.c_int * (8 * n))(*[int(d) for j in jobs for d in j[3]])
+        served = (ctypes.c_int * n)()
+        L.note_device(w)
+        check(_lib().sg_conv3d_k4s2p1_pack_images(n, kinds, wptr, wsp, wsb, dims, served, stream()), "conv3d_pack_images")
+        for j, ok in zip(jobs[1:], list(served)[1:]):
+            j[2][1] = self._state(j[0], j[3]) if ok else None
+        return bool(served[0])
+
+    def register_group(self, weights):
+        refs = [weakref.ref(w) for w in weights]
+        for w in weights:
+            self.groups[id(w)] = (refs, weakref.ref(w))
+
 
 _KEPT = _KeptWeightImages()
+
+
+def register_pack_group(weights):
+    """Declares conv weights that change together (the parameters of one network): their kept images are rebuilt in one launch."""
+    _KEPT.register_group(list(weights))
 
 
 def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, keep=False, out=None):
@@ -101,7 +168,7 @@ def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, keep=False, out=No
     nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(N, cin, Co, OD, OH, OW)
     # (one-channel layers pack nothing; a graph under capture must contain its own packing launch: its replays see new weights)
     if keep and cin > 1 and dy.is_cuda and not torch.cuda.is_current_stream_capturing():
-        ws, unchanged = _KEPT.get(w, nb, (N, cin, Ct, Co, OD, OH, OW))
+        ws, unchanged = _KEPT.get(w, nb, (N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW), kind=1)
         check(lib.sg_conv3d_k4s2p1_dgrad_keep(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
                                               act, slope, ptr(ws), ws.numel(), int(unchanged), stream()), "conv3d_dgrad_keep")
         return dx
@@ -340,7 +407,7 @@ class ConvFwd(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
         x, w = f32c(x), f32c(w)
-        y = conv_fwd_raw(x, w, b, act, slope)
+        y = conv_fwd_raw(x, w, b, act, slope, keep=True)
         ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None, b)
         return y
@@ -363,7 +430,10 @@ class ConvFwd(Function):
             gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope, L.grad_destination(b, b.shape))
         else:
             gz = ActBwd.apply(y, gy, ctx.act, ctx.slope) if ctx.act != ACT_NONE else gy
-        gx = ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # plain backward: the raw kernel with this layer's kept input-gradient image (nothing differentiates it again)
+            gx = conv_dgrad_raw(f32c(gz), w, None, x.shape[1], keep=True) if plain else ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0)
         gw = None
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad_raw(f32c(gz), x, w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(gz, x, w.shape[1])
@@ -530,7 +600,7 @@ class ConvHead(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, slope, wh, bh):
         x, w, wh = f32c(x), f32c(w), f32c(wh)
-        z = conv_fwd_raw(x, w, b, ACT_NONE, 0.0)
+        z = conv_fwd_raw(x, w, b, ACT_NONE, 0.0, keep=True)
         N, C = z.shape[0], z.shape[1]
         y = torch.empty(N, dtype=torch.float32, device=x.device)
         check(_lib().sg_head_dot_fwd(ptr(z), ptr(wh), ptr(bh), ptr(y), N, C * 64, act, slope, stream()), "head_dot_fwd")
@@ -568,7 +638,7 @@ class ConvHead(Function):
         gb = _param_grad_out(b, b.shape, dev) if need_b else None
         check(_lib().sg_head_dot_bwd(ptr(z), ptr(wh), ptr(gy), ptr(gz), ptr(gwh), ptr(gbh), ptr(gb), N, C, 64, act, slope,
                                      stream()), "head_dot_bwd")
-        gx = conv_dgrad_raw(gz, w, None, x.shape[1]) if need_x else None
+        gx = conv_dgrad_raw(gz, w, None, x.shape[1], keep=True) if need_x else None
         gw = conv_wgrad_raw(gz, x, w.shape[1], L.grad_destination(w, w.shape)) if need_w else None
         return gx, gw, gb, None, None, gwh, gbh
 

@@ -104,8 +104,8 @@ def test_conv_transpose_keeps_its_weight_image_until_the_weight_changes(monkeypa
     flags = []
     real_get = ops._KEPT.get
 
-    def spy(w, nbytes, shape_key):
-        ws, unchanged = real_get(w, nbytes, shape_key)
+    def spy(w, nbytes, shape_key, **kw):
+        ws, unchanged = real_get(w, nbytes, shape_key, **kw)
         flags.append(unchanged)
         return ws, unchanged
     monkeypatch.setattr(ops._KEPT, "get", spy)
@@ -271,6 +271,45 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
         with torch.no_grad():
             got2 = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0, out=out[:N])
         assert got2.data_ptr() == out.data_ptr() and torch.equal(got2, got.detach()) and bool((out[N] == 7.0).all())
+
+
+def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monkeypatch):
+    """gan.Discriminator registers its conv weights as a pack group (ops.register_pack_group): after an optimizer step the first
+    convolution that finds its kept image stale rebuilds ALL stale images of the group (forward and input-gradient forms, shapes
+    known from the previous update) with one sg_conv3d_k4s2p1_pack_images call; every later call of the update is told its image is
+    in place.  Outputs and gradients must equal those of a fresh critic (no kept state) holding the same weights — after one and
+    after two optimizer steps, and when the batch size changes in between."""
+    from shapegan_amd import ops, optim
+    from shapegan_amd import lib as L
+    from shapegan_amd.model.gan import Discriminator
+    if DEV != "cuda":
+        pytest.skip("kept images exist on the GPU only")
+    torch.manual_seed(31)
+    d = Discriminator()
+    d.use_sigmoid = False
+    opt = optim.RMSprop(d.parameters(), lr=1e-3)
+    calls = []
+    real = L.load().sg_conv3d_k4s2p1_pack_images
+    monkeypatch.setattr(L.load(), "sg_conv3d_k4s2p1_pack_images", lambda n, *a: (calls.append(n), real(n, *a))[1])
+    for it, nb in enumerate((8, 8, 8, 4, 8)):
+        x = (torch.rand(nb, 32, 32, 32) * 2 - 1).cuda().requires_grad_()
+        opt.zero_grad()
+        del calls[:]
+        out = d(x)
+        L.backward(out.mean())
+        if it >= 2 and nb == 8:
+            assert calls == [4], "update %d: expected one launch for the four stale images, got %r" % (it, calls)
+        fresh = Discriminator()
+        fresh.load_state_dict({k: v.clone() for k, v in d.state_dict().items()})
+        fresh.use_sigmoid = False
+        xf = x.detach().clone().requires_grad_()
+        of = fresh(xf)
+        of.mean().backward()
+        assert torch.equal(out.detach(), of.detach()), "update %d: outputs differ from a fresh critic's" % it
+        assert torch.equal(x.grad, xf.grad), "update %d: input gradient" % it
+        for (k, p), (_, q) in zip(d.named_parameters(), fresh.named_parameters()):
+            assert torch.equal(p.grad, q.grad), "update %d: gradient of %s" % (it, k)
+        opt.step()
 
 
 def test_conv_from_sdf_zero_channels():
