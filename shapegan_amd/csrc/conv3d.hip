@@ -587,7 +587,12 @@ static int fwd_call(const float* x, const float* w, const float* bias, float* y,
     lb.x = x;
     lb.g = g;
     FwdEpi epi{y, bias, g.O3(), Cout, FastDiv((uint32_t)g.O3()), act, slope};
-    launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    // the split-K plan depends on how many partial images fit: use at most what the size query asks for, so that the same call
+    // sums in the same order whether it is given a workspace of exactly that size (a kept one) or a larger shared one
+    size_t ws_use = workspace ? workspace_bytes : 0;
+    const size_t ws_query = sg_conv3d_k4s2p1_fwd_workspace_bytes(batch, Cin, Cout, g.OD, g.OH, g.OW);
+    if (ws_use > ws_query) ws_use = ws_query;
+    launch_tile_gemm(la, lb, epi, Cout, (int)npos, Cin * 64, (float*)workspace, ws_use, stream);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
