@@ -92,6 +92,17 @@ int sg_conv3d_k4s2p1_wgrad(const float* dy, const float* x, float* dw, int batch
  * weight-gradient kernel (act'(y) from the activated output, as sg_act_bwd), db[co] = sum of dz over batch and positions.  For a
  * layer whose input needs no gradient (the critic's first layer, model/gan.py:49 under train_wgan.py:69) the activation backward
  * then is no pass of its own.  Served shapes: sg_conv3d_k4s2p1_wgrad_act_eligible (one-channel layers, LeakyReLU / ReLU). */
+/* The incoming gradient's fragment image of the LDS-halo weight-gradient kernel written by the gradient's PRODUCER:
+ * sg_conv3d_k4s2p1_wgrad_dy_image says whether the weight-gradient call (dy [batch, Cout, O^3], the workspace it will get) is served
+ * that way (1: the image is [mt_total][nslice][8][64] float4 at the start of that workspace; 0: use sg_conv3d_k4s2p1_wgrad);
+ * sg_act_bwd_rowsum_pack8 = sg_act_bwd_rowsum on [N, C, 8, 8, 8] tensors (LeakyReLU / ReLU) + the image; sg_head_dot_bwd writes it
+ * for 4^3 grids; sg_conv3d_k4s2p1_wgrad_prepacked = sg_conv3d_k4s2p1_wgrad without its packing launch. */
+int sg_conv3d_k4s2p1_wgrad_dy_image(int batch, int Cin, int Cout, int OD, int OH, int OW, size_t workspace_bytes, int* mt_total,
+                                    long* nslice);
+int sg_act_bwd_rowsum_pack8(const float* y, const float* dy, float* dz, float* rowsum, void* dz_image, long N, int C, long nslice,
+                            int act, float slope, hipStream_t stream);
+int sg_conv3d_k4s2p1_wgrad_prepacked(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                                     int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act);
 int sg_conv3d_k4s2p1_wgrad_act(const float* dy, const float* y, const float* x, float* dw, float* db, int batch, int Cin,
                                int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
@@ -319,8 +330,10 @@ int sg_vae_reparam_bwd(const float* log_variance, const float* eps, const float*
  * One streaming pass each way; every sum in a fixed order. */
 int sg_head_dot_fwd(const float* z, const float* w, const float* bias, float* y, int N, long K, int act, float slope,
                     hipStream_t stream);
-int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, int N, int C,
-                    int S, int act, float slope, hipStream_t stream);
+int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, void* gz_image,
+                    int N, int C, int S, int act, float slope, hipStream_t stream);
+/* gz_image (optional; C a multiple of 128): gz once more, in the A-fragment order of the LDS-halo weight-gradient kernel for 4^3
+ * grids, so that the convolution below needs no packing pass over gz — see sg_conv3d_k4s2p1_wgrad_dy_image. */
 int sg_loss_kld_fwd(const float* mean, const float* log_variance, long n, float* loss, void* workspace, size_t workspace_bytes,
                     hipStream_t stream);
 int sg_loss_kld_bwd(const float* mean, const float* log_variance, const float* gloss, float* dmean, float* dlog_variance,

@@ -813,6 +813,45 @@ int sg_conv3d_k4s2p1_wgrad_impl(const float* dy, const float* x, float* dw, int 
 // Weight + bias gradient of act(conv(x) + b) taken straight from the gradient w.r.t. the activated output: dz = dy * act'(y) is
 // formed inside the weight-gradient kernel (one-channel layers, LeakyReLU / ReLU), so the activation backward is not a pass of
 // its own.  sg_conv3d_k4s2p1_wgrad_act_eligible says whether a shape is served (host code, no GPU needed).
+// The incoming gradient's A-fragment image of the LDS-halo weight-gradient kernel, written by the kernel that produces the
+// gradient instead of by a packing pass of its own (conv3d_halo.hip).  sg_conv3d_k4s2p1_wgrad_dy_image: 1 if the call (batch, Cin,
+// Cout, O^3 grid of dy, the workspace it will be given) is served that way — then the image occupies the START of that workspace,
+// [mt_total][nslice][8][64] float4 — else 0.  sg_act_bwd_rowsum_pack8 = sg_act_bwd_rowsum for [N][C][8^3] tensors that also writes the
+// image; sg_head_dot_bwd takes the image pointer for 4^3 grids.  sg_conv3d_k4s2p1_wgrad_prepacked = sg_conv3d_k4s2p1_wgrad that
+// trusts the image in its workspace.
+int sg_conv3d_k4s2p1_wgrad_dy_image(int batch, int Cin, int Cout, int OD, int OH, int OW, size_t workspace_bytes, int* mt_total,
+                                    long* nslice) {
+    if (batch <= 0 || Cin <= 0 || Cout <= 0 || !mt_total || !nslice) return 0;
+    ConvGeom g;
+    if (make_geom(g, 2 * OD, 2 * OH, 2 * OW, Cin, Cout)) return 0;
+    if (Cin == 1 && Cout <= 64) return 0;      // the one-channel kernels
+    return halo_wgrad_dy_image_plan(batch, Cin, Cout, g, workspace_bytes, mt_total, nslice);
+}
+int sg_act_bwd_rowsum_pack8(const float* y, const float* dy, float* dz, float* rowsum, void* dz_image, long N, int C, long nslice,
+                            int act, float slope, hipStream_t stream) {
+    SG_CHECK_ARG(y && dy && dz && rowsum && dz_image && N > 0 && C > 0 && C % 128 == 0 && nslice == N * 8);
+    SG_CHECK_ARG(act == SG_ACT_LEAKY || act == SG_ACT_RELU);
+    SG_CHECK_ARG((((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)dz_image) & 15) == 0);
+    halo_act_bwd_pack8_launch(y, dy, dz, rowsum, dz_image, N * C, C, nslice, act, slope, stream);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_conv3d_k4s2p1_wgrad_prepacked(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                                     int Cout, int ID, int IH, int IW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(dy && x && dw && batch > 0 && Cin > 0 && Cin <= Cin_total && Cin <= Cx && Cout > 0);
+    ConvGeom g;
+    if (make_geom(g, ID, IH, IW, Cx, Cout)) SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_prepacked: bad spatial dims");
+    if (check_sizes(g, batch, "sg_conv3d_k4s2p1_wgrad_prepacked")) return SG_ERR_ARG;
+    int mt;
+    long ns;
+    if (!halo_wgrad_dy_image_plan(batch, Cin, Cout, g, workspace_bytes, &mt, &ns))
+        SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_prepacked: this call is not served with a producer-written image");
+    if (halo_wgrad_try(dy, x, dw, batch, Cin, Cin_total, g, Cout, workspace, workspace_bytes, stream, 0, true) != 1)
+        SG_FAIL(SG_ERR_ARG, "sg_conv3d_k4s2p1_wgrad_prepacked: not served");
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
 int sg_conv3d_k4s2p1_wgrad_act_eligible(int batch, int Cin, int Cout, int OD, int OH, int OW, int act) {
     // the same refusal conditions as edge_wgrad_try: 32-bit buffer ranges of the one-channel grid (read in place; the
     // resource starts (IH + 1) rows + 1 element before it) and of dy / y

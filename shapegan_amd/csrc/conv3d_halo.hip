@@ -1401,8 +1401,63 @@ size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, 
     return pack + part + 256;
 }
 
+// ---- the packed dy image written by the kernel that PRODUCES dy ---------------------------------------------------------------------
+// pack_wgrad_dy(4)_kernel re-reads the incoming gradient of a layer right after the activation backward wrote it (67 MB each way at
+// the critic's second layer: 18 us, 0.15 ms per WGAN step with the 4^3 form).  When the halo weight-gradient kernel will serve the
+// call and the grid is 8^3 or 4^3 with Cout a multiple of 128 (no padded row tiles), the producer writes the image itself:
+// sg_act_bwd_rowsum_pack8 (activation backward + bias row sums + image, 8^3) and sg_head_dot_bwd (4^3), then
+// sg_conv3d_k4s2p1_wgrad_prepacked skips the packing launch.  halo_wgrad_dy_image_plan answers whether, and with which MT / nslice.
+int halo_wgrad_dy_image_plan(int batch, int Cin, int Cout, const ConvGeom& g, size_t workspace_bytes, int* mt_total, long* nslice_out) {
+    const bool mode4 = wgrad_mode4(g);
+    if (!(mode4 || (g.OD == 8 && g.OH == 8 && g.OW == 8)) || Cout % 128 != 0 || Cin < 2) return 0;
+    if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31) || (long)2 * g.ID * g.IH * g.IW * 4 >= (1L << 26)) return 0;
+    int nslice, nsplit, mtiles;
+    wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
+    const int ntiles = ((Cin + 1) / 2) * mtiles;
+    if (Cout <= 64 || (long)ntiles * nsplit < 384) return 0;      // (the auto-dispatch rule of halo_wgrad_try)
+    if (workspace_bytes < halo_wgrad_workspace_bytes(batch, Cin, Cout, g.OD, g.OH, g.OW)) return 0;
+    *mt_total = mtiles * 4;
+    *nslice_out = nslice;
+    return 1;
+}
+
+// dz = dy * act'(y), row sums of dz, and dz in the halo weight-gradient kernel's A-fragment order, for [N][C][8][8][8] tensors: one
+// WAVE per (sample, channel) row of 512 voxels, lane = one (od, oh) line of 8: two b128 loads per operand, two b128 stores of dz,
+// and the line's even / odd columns as the two float4 of pack_wgrad_dy_kernel's layout (nth = ntw = 1: slice = n * 8 + od, group = oh).
+__global__ void __launch_bounds__(256) act_bwd_pack8_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                            float* __restrict__ dz, float* __restrict__ rowsum,
+                                                            float4* __restrict__ ap, long rows, int C, long nslice, int act, float slope) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long base = row * 512 + lane * 8;
+    const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + base), y1 = *reinterpret_cast<const f32x4*>(y + base + 4);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + base), g1 = *reinterpret_cast<const f32x4*>(dy + base + 4);
+    f32x4 z0, z1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        z0[j] = act == SG_ACT_LEAKY ? (y0[j] > 0.f ? g0[j] : g0[j] * slope) : (y0[j] > 0.f ? g0[j] : 0.f);
+        z1[j] = act == SG_ACT_LEAKY ? (y1[j] > 0.f ? g1[j] : g1[j] * slope) : (y1[j] > 0.f ? g1[j] : 0.f);
+    }
+    *reinterpret_cast<f32x4*>(dz + base) = z0;
+    *reinterpret_cast<f32x4*>(dz + base + 4) = z1;
+    const float s = sg_wave_sum(((z0[0] + z0[1]) + (z0[2] + z0[3])) + ((z1[0] + z1[1]) + (z1[2] + z1[3])));
+    if (lane == 0) rowsum[row] = s;
+    const long n = row / C;
+    const int co = (int)(row - n * C), mt = co >> 5, r = co & 31, od = lane >> 3, oh = lane & 7;
+    const long e = (((long)mt * nslice + n * 8 + od) * 8 + oh) * 64 + r;
+    ap[e] = make_float4(z0[0], z0[2], z1[0], z1[2]);          // columns 0, 2, 4, 6 (lane half 0 of the fragment)
+    ap[e + 32] = make_float4(z0[1], z0[3], z1[1], z1[3]);     // columns 1, 3, 5, 7
+}
+int halo_act_bwd_pack8_launch(const float* y, const float* dy, float* dz, float* rowsum, void* ap, long rows, int C, long nslice,
+                              int act, float slope, hipStream_t stream) {
+    hipLaunchKernelGGL(act_bwd_pack8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, y, dy, dz, rowsum, (float4*)ap,
+                       rows, C, nslice, act, slope);
+    return 1;
+}
+
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force) {
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force, bool dy_packed) {
     const bool mode4 = wgrad_mode4(g);
     if ((!mode4 && (g.OW % 8 != 0 || g.OH % 8 != 0)) || Cin < 2 || Cout < 32) return 0;
     if ((long)batch * g.Cx * g.ID * g.IH * g.IW >= (1L << 31)) return 0;
@@ -1421,7 +1476,7 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     float4* ap = (float4*)workspace;
     const size_t pack_floats4 = (size_t)mtiles * 4 * nslice * 8 * 64;
     float* part = (float*)(ap + pack_floats4);
-    {
+    if (!dy_packed) {
         int blocks = (int)((pack_floats4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;
         if (mode4)

@@ -91,7 +91,11 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
 
 size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, int OW);
 int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, const ConvGeom& g, int Cout,
-                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0);
+                   void* workspace, size_t workspace_bytes, hipStream_t stream, int force = 0, bool dy_packed = false);
+// the packed-dy image of the halo weight-gradient kernel written by dy's producer (conv3d_halo.hip)
+int halo_wgrad_dy_image_plan(int batch, int Cin, int Cout, const ConvGeom& g, size_t workspace_bytes, int* mt_total, long* nslice);
+int halo_act_bwd_pack8_launch(const float* y, const float* dy, float* dz, float* rowsum, void* ap, long rows, int C, long nslice,
+                              int act, float slope, hipStream_t stream);
 
 // conv3d_edge.hip: layers with one channel on the voxel-grid side (Cin == 1).  Same return convention as the halo_*_try.
 size_t edge_fwd_workspace_bytes(int batch, int OD, int OH, int OW);

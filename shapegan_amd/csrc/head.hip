@@ -67,13 +67,24 @@ constexpr int kHeadS = 64;
 __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                            const float* __restrict__ gy, float* __restrict__ gz,
                                                            float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gbz,
-                                                           int N, long K, int act, float slope) {
+                                                           float4* __restrict__ ap, int N, long K, int act, float slope) {
     const int c = blockIdx.x;
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long k0 = (long)c * kHeadS + 4 * col;
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k0);
     f32x4 aw = {0.f, 0.f, 0.f, 0.f};   // this thread's part of gw[k0 .. k0+3]
     float az = 0.f;                    // this thread's part of gbz[c]
+    // ap (optional): gz in the A-fragment order of conv_wgrad_halo4_kernel (pack_wgrad_dy4_kernel's layout with nslice = N): the
+    // 8-float chunk (position group gq = col / 2) of channel c is split into its even columns (fragment lane r = c % 32) and its odd
+    // columns (lane r + 32); the two threads that hold the chunk's halves exchange them (adjacent lanes) and write one float4 each
+    auto pack = [&](const f32x4& o, int nn) __attribute__((always_inline)) {
+        f32x4 p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = __shfl_xor(o[j], 1, 64);
+        const f32x4 v = (col & 1) ? f32x4{p[1], p[3], o[1], o[3]} : f32x4{o[0], o[2], p[0], p[2]};
+        const long e = ((((long)(c >> 5) * N + nn) * 8 + (col >> 1)) * 64) + (col & 1) * 32 + (c & 31);
+        ap[e] = make_float4(v[0], v[1], v[2], v[3]);
+    };
     int n = grp;
     for (; n + 7 * 16 < N; n += 8 * 16) {
         f32x4 zv[8];
@@ -93,6 +104,7 @@ __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restri
             }
             az += (o[0] + o[1]) + (o[2] + o[3]);
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(gz + (long)(n + 16 * u) * K + k0));
+            if (ap) pack(o, n + 16 * u);
         }
     }
     for (; n < N; n += 16) {
@@ -106,6 +118,7 @@ __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restri
         }
         az += (o[0] + o[1]) + (o[2] + o[3]);
         *reinterpret_cast<f32x4*>(gz + (long)n * K + k0) = o;
+        if (ap) pack(o, n);
     }
     // fixed-order sums over the 16 sample groups (gw) and over everything (gbz)
     __shared__ f32x4 redw[16][16];
@@ -148,14 +161,15 @@ int sg_head_dot_fwd(const float* z, const float* w, const float* bias, float* y,
     return SG_OK;
 }
 
-int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, int N, int C,
-                    int S, int act, float slope, hipStream_t stream) {
+int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, void* gz_image,
+                    int N, int C, int S, int act, float slope, hipStream_t stream) {
     SG_CHECK_ARG(z && w && gy && gz && N > 0 && C > 0);      // gw / gb / gbz: optional outputs
     SG_CHECK_ARG(S == kHeadS);     // a 4^3 grid per channel (model/gan.py:55); other shapes take the GEMM path
     SG_CHECK_ARG(act == SG_ACT_NONE || act == SG_ACT_LEAKY || act == SG_ACT_RELU);
     SG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)gz & 15) == 0 && ((uintptr_t)gw & 15) == 0);
-    hipLaunchKernelGGL(head_dot_bwd_kernel, dim3((unsigned)C), dim3(256), 0, stream, z, w, gy, gz, gw, gb, gbz, N, (long)C * S,
-                       act, slope);
+    SG_CHECK_ARG(!gz_image || C % 128 == 0);     // the image has no padded row tiles
+    hipLaunchKernelGGL(head_dot_bwd_kernel, dim3((unsigned)C), dim3(256), 0, stream, z, w, gy, gz, gw, gb, gbz, (float4*)gz_image, N,
+                       (long)C * S, act, slope);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -189,6 +189,26 @@ int sg_conv3d_k4s2p1_pack_images_cpu(int n, const int* kinds, const float* const
     for (int i = 0; i < n; ++i) served[i] = 0;     // the twin reads the weights in place: there is no image to keep
     return SG_OK;
 }
+// (the twin's weight-gradient loops read dy in place: sg_conv3d_k4s2p1_wgrad_dy_image is a host query of the HIP library and
+// answers for GPU tensors only; these two exist so that every entry point has its twin)
+int sg_act_bwd_rowsum_pack8_cpu(const float* y, const float* dy, float* dz, float* rowsum, void*, long N, int C, long, int act,
+                                float slope, void*) {
+    CPU_CHECK(y && dy && dz && rowsum && N > 0 && C > 0);
+    for (long r = 0; r < N * C; ++r) {
+        double s = 0;
+        for (int e = 0; e < 512; ++e) {
+            const float v = act_grad_out(y[r * 512 + e], dy[r * 512 + e], act, slope);
+            dz[r * 512 + e] = v;
+            s += (double)v;
+        }
+        rowsum[r] = (float)s;
+    }
+    return SG_OK;
+}
+int sg_conv3d_k4s2p1_wgrad_prepacked_cpu(const float* dy, const float* x, float* dw, int batch, int Cin, int Cin_total, int Cx,
+                                         int Cout, int ID, int IH, int IW, void* ws, size_t wb, void* st) {
+    return sg_conv3d_k4s2p1_wgrad_cpu(dy, x, dw, batch, Cin, Cin_total, Cx, Cout, ID, IH, IW, ws, wb, st);
+}
 int sg_convT3d_k4s2p1_fwd_cpu(const float* x, const float* w, const float* bias, float* y, int batch, int Cin_T, int Cout_T,
                               int ID, int IH, int IW, int act, float slope, void* ws, size_t wb, void* st) {
     return sg_conv3d_k4s2p1_dgrad_cpu(x, w, bias, y, batch, Cout_T, Cout_T, Cout_T, Cin_T, 2 * ID, 2 * IH, 2 * IW, act, slope, ws,
@@ -967,7 +987,7 @@ int sg_head_dot_fwd_cpu(const float* z, const float* w, const float* bias, float
     }
     return SG_OK;
 }
-int sg_head_dot_bwd_cpu(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, int N,
+int sg_head_dot_bwd_cpu(const float* z, const float* w, const float* gy, float* gz, float* gw, float* gb, float* gbz, void*, int N,
                         int C, int S, int act, float slope, void*) {
     CPU_CHECK(z && w && gy && gz && N > 0 && C > 0 && S == 64);
     CPU_CHECK(act == ACT_NONE || act == ACT_LEAKY || act == ACT_RELU);

@@ -108,7 +108,10 @@ SIGNATURES = {
     "sg_vae_reparam_fwd": (c_int, [_P, _P, _P, _P, _L, _P]),
     "sg_vae_reparam_bwd": (c_int, [_P, _P, _P, _P, _L, _P]),
     "sg_head_dot_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _I, _F, _P]),
-    "sg_head_dot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "sg_head_dot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "sg_conv3d_k4s2p1_wgrad_dy_image": (c_int, [_I, _I, _I, _I, _I, _I, _Z, _P, _P]),
+    "sg_act_bwd_rowsum_pack8": (c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _I, _F, _P]),
+    "sg_conv3d_k4s2p1_wgrad_prepacked": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_loss_kld_fwd": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_loss_kld_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "sg_loss_meansq_fwd": (c_int, [_P, _P, _L, _I, _D, _P, _P, _Z, _P]),
@@ -170,7 +173,7 @@ def check_comm(rc, what=""):
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
     "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-    "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible"}
+    "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image"}
 CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
 
 _hip = None

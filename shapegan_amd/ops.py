@@ -223,6 +223,46 @@ def conv_wgrad_raw(dy, x, ct, out=None):
     return dw
 
 
+def _wgrad_dy_image(N, Cx, Co, O, device):
+    """(workspace, mt_total, nslice) if the weight-gradient call dy [N, Co, O^3] x [N, Cx, (2O)^3] is served with a packed-dy image
+    its PRODUCER writes (sg_conv3d_k4s2p1_wgrad_dy_image), else None."""
+    if device.type != "cuda":
+        return None
+    lib = _lib()
+    nb = min(lib.sg_conv3d_k4s2p1_wgrad_workspace_bytes(N, Cx, Co, O, O, O), _WGRAD_WS_CAP)
+    ws = workspace("splitk", nb, device)
+    mt, ns = ctypes.c_int(0), ctypes.c_long(0)
+    if not lib.sg_conv3d_k4s2p1_wgrad_dy_image(N, Cx, Co, O, O, O, ws.numel(), ctypes.byref(mt), ctypes.byref(ns)):
+        return None
+    return ws, mt.value, ns.value
+
+
+def conv_wgrad_prepacked_raw(dy, x, ct, ws, out=None):
+    """conv_wgrad_raw for a call whose packed-dy image is already at the start of `ws` (written by dy's producer)."""
+    N, Co = dy.shape[0], dy.shape[1]
+    Cx = x.shape[1]
+    dw = out if out is not None else torch.empty((Co, ct, 4, 4, 4), dtype=torch.float32, device=dy.device)
+    if Cx < ct:
+        raise RuntimeError("conv_wgrad_prepacked: partial input channels are not served")
+    check(_lib().sg_conv3d_k4s2p1_wgrad_prepacked(ptr(dy), ptr(x), ptr(dw), N, Cx, ct, Cx, Co, x.shape[2], x.shape[3], x.shape[4],
+                                                  ptr(ws), ws.numel(), stream()), "conv3d_wgrad_prepacked")
+    return dw
+
+
+def act_bwd_rowsum_pack8_raw(y, dy, act, slope, ws, nslice, gb_out=None):
+    """act_bwd_rowsum_raw for [N, C, 8, 8, 8] tensors that also writes dz in the weight-gradient kernel's fragment order to `ws`."""
+    y, dy = f32c(y), f32c(dy)
+    N, C = y.shape[0], y.shape[1]
+    lib = _lib()
+    dz = torch.empty_like(y)
+    rows = torch.empty(N * C, dtype=torch.float32, device=y.device)
+    check(lib.sg_act_bwd_rowsum_pack8(ptr(y), ptr(dy), ptr(dz), ptr(rows), ptr(ws), N, C, nslice, act, slope, stream()),
+          "act_bwd_rowsum_pack8")
+    gb = torch.empty(C, dtype=torch.float32, device=y.device) if gb_out is None else gb_out
+    check(lib.sg_colsum(ptr(rows), ptr(gb), N, C, C, stream()), "colsum")
+    return dz, gb
+
+
 def conv_wgrad_act_raw(dy, y, x, act, slope, dw_out=None, db_out=None):
     """(dw, db) of y = act(conv(x) + b) from dy = dLoss/dy in one pass (sg_conv3d_k4s2p1_wgrad_act)."""
     N, Co, OD, OH, OW = dy.shape
@@ -425,7 +465,14 @@ class ConvFwd(Function):
             gw, gb = conv_wgrad_act_raw(f32c(gy), y, x, ctx.act, ctx.slope, L.grad_destination(w, w.shape),
                                         L.grad_destination(b, b.shape))
             return None, gw, gb, None, None
-        if ctx.act != ACT_NONE and want_b and plain and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
+        image = None
+        if (ctx.act in (ACT_LEAKY, ACT_RELU) and want_b and plain and ctx.needs_input_grad[1] and tuple(y.shape[2:]) == (8, 8, 8)
+                and w.shape[1] == x.shape[1] and y.shape[1] % 128 == 0):
+            image = _wgrad_dy_image(x.shape[0], x.shape[1], w.shape[0], 8, y.device)
+        if image is not None:
+            # activation backward + bias sums + the weight-gradient kernel's packed image of gz in one pass
+            gz, gb = act_bwd_rowsum_pack8_raw(y, gy, ctx.act, ctx.slope, image[0], image[2], L.grad_destination(b, b.shape))
+        elif ctx.act != ACT_NONE and want_b and plain and y.shape[2] * y.shape[3] * y.shape[4] >= 512:
             # activation + bias sums in one pass
             gz, gb = act_bwd_rowsum_raw(y, gy, ctx.act, ctx.slope, L.grad_destination(b, b.shape))
         else:
@@ -436,7 +483,10 @@ class ConvFwd(Function):
             gx = conv_dgrad_raw(f32c(gz), w, None, x.shape[1], keep=True) if plain else ConvDgrad.apply(gz, w, None, x.shape[1], ACT_NONE, 0.0)
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad_raw(f32c(gz), x, w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(gz, x, w.shape[1])
+            if image is not None:
+                gw = conv_wgrad_prepacked_raw(gz, x, w.shape[1], image[0], L.grad_destination(w, w.shape))
+            else:
+                gw = conv_wgrad_raw(f32c(gz), x, w.shape[1], L.grad_destination(w, w.shape)) if plain else ConvWgrad.apply(gz, x, w.shape[1])
         if want_b and gb is None:
             gb = channel_sum_raw(f32c(gz), L.grad_destination(b, b.shape)) if plain else ChannelSum.apply(gz)
         return gx, gw, gb, None, None
@@ -636,10 +686,15 @@ class ConvHead(Function):
         gwh = _param_grad_out(wh, wh.shape, dev) if need_wh else None
         gbh = _param_grad_out(bh, bh.shape, dev) if need_bh else None
         gb = _param_grad_out(b, b.shape, dev) if need_b else None
-        check(_lib().sg_head_dot_bwd(ptr(z), ptr(wh), ptr(gy), ptr(gz), ptr(gwh), ptr(gbh), ptr(gb), N, C, 64, act, slope,
-                                     stream()), "head_dot_bwd")
+        # with the convolution's weight gradient to come, gz is also written in that kernel's fragment order (no packing pass)
+        image = _wgrad_dy_image(N, x.shape[1], C, 4, dev) if (need_w and C % 128 == 0 and w.shape[1] == x.shape[1]) else None
+        check(_lib().sg_head_dot_bwd(ptr(z), ptr(wh), ptr(gy), ptr(gz), ptr(gwh), ptr(gbh), ptr(gb),
+                                     ptr(image[0]) if image is not None else None, N, C, 64, act, slope, stream()), "head_dot_bwd")
         gx = conv_dgrad_raw(gz, w, None, x.shape[1], keep=True) if need_x else None
-        gw = conv_wgrad_raw(gz, x, w.shape[1], L.grad_destination(w, w.shape)) if need_w else None
+        gw = None
+        if need_w:
+            gw = conv_wgrad_prepacked_raw(gz, x, w.shape[1], image[0], L.grad_destination(w, w.shape)) if image is not None \
+                else conv_wgrad_raw(gz, x, w.shape[1], L.grad_destination(w, w.shape))
         return gx, gw, gb, None, None, gwh, gbh
 
 

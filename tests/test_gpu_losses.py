@@ -583,7 +583,7 @@ def test_head_dot_forward_and_backward(N, C, act):
     check(lib.sg_head_dot_fwd(ptr(zg), ptr(wg), ptr(bg), ptr(y), N, C * 64, act, slope, stream()), "head_dot_fwd")
     close(y, yref, rtol=1e-5, what="head scores")
     gz, gw, gb, gbz = torch.empty_like(zg), torch.empty_like(wg), torch.empty(1, device=DEV), torch.empty(C, device=DEV)
-    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz), ptr(gw), ptr(gb), ptr(gbz), N, C, 64, act, slope, stream()),
+    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz), ptr(gw), ptr(gb), ptr(gbz), None, N, C, 64, act, slope, stream()),
           "head_dot_bwd")
     close(gz, zd.grad, rtol=1e-6, what="d / d pre-activation")
     close(gw, wd.grad, rtol=1e-5, what="head weight gradient")
@@ -592,7 +592,7 @@ def test_head_dot_forward_and_backward(N, C, act):
           what="bias gradient of the layer below")
     # optional outputs (a frozen critic in the generator update): only gz
     gz2 = torch.empty_like(zg)
-    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz2), None, None, None, N, C, 64, act, slope, stream()), "head_dot_bwd")
+    check(lib.sg_head_dot_bwd(ptr(zg), ptr(wg), ptr(gyg), ptr(gz2), None, None, None, None, N, C, 64, act, slope, stream()), "head_dot_bwd")
     assert torch.equal(gz2, gz)
 
 

@@ -312,6 +312,51 @@ def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monke
         opt.step()
 
 
+@pytest.mark.parametrize("N", [128, 64, 37])
+def test_producer_written_dy_images_equal_the_packing_pass(N):
+    """sg_act_bwd_rowsum_pack8 (8^3 grids) and sg_head_dot_bwd (4^3 grids) write the incoming gradient in the LDS-halo
+    weight-gradient kernel's fragment order themselves; sg_conv3d_k4s2p1_wgrad_prepacked then skips pack_wgrad_dy(4)_kernel.  The
+    weight gradients must be BIT-equal to sg_conv3d_k4s2p1_wgrad on the same gradient (same kernel, same image), dz / row sums /
+    bias gradients equal to the unfused ops, at the critic's shapes (128 / 64 samples) and a ragged batch."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    if DEV != "cuda":
+        pytest.skip("the image is a property of the HIP kernels")
+    torch.manual_seed(N)
+    # layer 2 of the critic: y [N,128,8^3] = lrelu(conv(x [N,64,16^3]))
+    x = torch.randn(N, 64, 16, 16, 16, device="cuda")
+    y = torch.randn(N, 128, 8, 8, 8, device="cuda")
+    gy = torch.randn(N, 128, 8, 8, 8, device="cuda")
+    image = ops._wgrad_dy_image(N, 64, 128, 8, x.device)
+    if N >= 64:
+        assert image is not None
+    if image is not None:
+        gz_ref, gb_ref = ops.act_bwd_rowsum_raw(y, gy, ACT_LEAKY, 0.2)
+        dw_ref = ops.conv_wgrad_raw(gz_ref, x, 64)
+        gz, gb = ops.act_bwd_rowsum_pack8_raw(y, gy, ACT_LEAKY, 0.2, image[0], image[2])
+        dw = ops.conv_wgrad_prepacked_raw(gz, x, 64, image[0])
+        assert torch.equal(gz, gz_ref) and torch.equal(dw, dw_ref)
+        close(gb, gb_ref, rtol=1e-5, what="bias gradient")
+    # layer 3 + head: z [N,256,4^3] = conv(x8 [N,128,8^3]); gz from sg_head_dot_bwd
+    x8 = torch.randn(N, 128, 8, 8, 8, device="cuda")
+    z = torch.randn(N, 256, 4, 4, 4, device="cuda")
+    wh = torch.randn(1, 256, 4, 4, 4, device="cuda") * 0.05
+    g = torch.randn(N, device="cuda")
+    lib = ops.L.load()
+    image = ops._wgrad_dy_image(N, 128, 256, 4, x8.device)
+    if N >= 64:
+        assert image is not None
+    if image is not None:
+        gz0, gz1 = torch.empty_like(z), torch.empty_like(z)
+        ops.check(lib.sg_head_dot_bwd(ops.ptr(z), ops.ptr(wh), ops.ptr(g), ops.ptr(gz0), None, None, None, None, N, 256, 64, 1, 0.2,
+                                      ops.stream()), "head_dot_bwd")
+        dw_ref = ops.conv_wgrad_raw(gz0, x8, 128)
+        ops.check(lib.sg_head_dot_bwd(ops.ptr(z), ops.ptr(wh), ops.ptr(g), ops.ptr(gz1), None, None, None, ops.ptr(image[0]), N, 256, 64,
+                                      1, 0.2, ops.stream()), "head_dot_bwd")
+        dw = ops.conv_wgrad_prepacked_raw(gz1, x8, 128, image[0])
+        assert torch.equal(gz0, gz1) and torch.equal(dw, dw_ref)
+
+
 def test_conv_from_sdf_zero_channels():
     """First progressive stage: conv over [x, 0, ..., 0] == conv over channel 0 only; dW of the zero channels is 0."""
     from shapegan_amd import ops
