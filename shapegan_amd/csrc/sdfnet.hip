@@ -271,10 +271,16 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     float* Hs = smem;                // [256][P]
     float* Xs = Hs + kH * P;         // [KUp][LDX]
     float* red = Xs + a.lay.KUp * LDX;  // [16][P]
+    float* Bl = red + 16 * P;           // [7][256]: the bias vectors (see init_acc_lds)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
     const int KU = a.lay.KU, KUp = a.lay.KUp;
+    // The seven bias vectors go to LDS once per tile.  A layer used to start with four 16-byte global loads of its bias into the
+    // accumulators and an s_waitcnt for them in front of its first MFMA — and vmcnt counts in issue order, so that wait also drained
+    // everything older: the weight ring of the layer (started early on purpose) and, in training, the 32 activation-image stores
+    // of the previous write-back (ISA listing, round 4).  From LDS the accumulators are initialised under lgkmcnt only.
+    for (int e = tid; e < 7 * kH; e += 512) Bl[e] = (a.packed + a.lay.B)[e];
 
     // ---- stage X = [xyz | latent] feature-major ----
     for (int e = tid; e < 3 * P; e += 512) {
@@ -315,6 +321,15 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float bv = b[wave * 32 + frag_row(q, kh)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][q] = bv;
+        }
+    };
+    auto init_acc_lds = [&](int layer) {      // the same from the LDS copy of bias vector `layer`
+        const lds_float* b = (const lds_float*)Bl + layer * kH + wave * 32;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float bv = b[frag_row(q, kh)];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t][q] = bv;
         }
@@ -397,7 +412,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     if (SHAPE_BIAS && a.sid)
         init_acc_sid(a.zb1);
     else
-        init_acc(SHAPE_BIAS ? a.zb1 + shape * kH : bias);
+        SHAPE_BIAS ? init_acc(a.zb1 + shape * kH) : init_acc_lds(0);
     mlp_gemm<NT>(acc, wtile(a.lay.F1, KUp / 8), KUp / 8, Xs, LDX, lane);
     // the weight ring of the next 256-wide layer is started before each write-back (its stores would otherwise sit in front of
     // the first weight loads in the in-order return queue, see WRing)
@@ -413,7 +428,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     const long Fnext[3] = {a.lay.F3, a.lay.F4, a.lay.F5x};
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        init_acc(bias + (l + 1) * kH);
+        init_acc_lds(l + 1);
         mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
         next_ring(Fnext[l]);
         writeback(l + 1);
@@ -422,17 +437,17 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     if (SHAPE_BIAS && a.sid)
         init_acc_sid(a.zb5);
     else
-        init_acc(SHAPE_BIAS ? a.zb5 + shape * kH : bias + 4 * kH);
+        SHAPE_BIAS ? init_acc(a.zb5 + shape * kH) : init_acc_lds(4);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     mlp_gemm<NT>(acc, wtile(a.lay.F5i, KUp / 8), KUp / 8, Xs, LDX, lane);
     next_ring(a.lay.F6);
     writeback(4);
     // layers 6, 7
-    init_acc(bias + 5 * kH);
+    init_acc_lds(5);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     next_ring(a.lay.F7);
     writeback(5);
-    init_acc(bias + 6 * kH);
+    init_acc_lds(6);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     writeback(6);
     // layer 8: 256 -> 1, tanh.  The dot product is cut into sixteen 16-row groups summed in a fixed order, whatever the tile
@@ -925,7 +940,7 @@ static TilePlan tile_plan(long N, int P, long slots) {
 constexpr long kFwdSlots = kCUs;       // one workgroup per CU (LDS)
 constexpr long kBwdSlots = 2 * kCUs;   // two per CU
 
-static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P) * sizeof(float); }
+static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P + 7 * kH) * sizeof(float); }
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
 
 template <class K>
