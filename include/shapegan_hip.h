@@ -269,12 +269,17 @@ int sg_scatter_add_rows(const float* rows, long rows_ld, const int64_t* idx, flo
  * nshapes <= sg_sdf_batch_sort_max_shapes(); an index outside [0, nshapes*pointcloud_size) — an IndexError in the reference —
  * sets *bad_index_flag and is clamped.  The flag is an int the kernel can write — device memory, or pinned host memory (what the
  * Python shell passes: the host then polls it with a plain load, no copy / launch / synchronisation per step); sticky, caller-zeroed,
- * written only when an index is bad. */
+ * written only when an index is bad: it receives bad_index_value (!= 0; e.g. a call sequence number).  bad_index_device (optional):
+ * a second sticky word, in DEVICE memory, set together with the first — the `skip_if_nonzero` word of sg_adam_step_guarded: the
+ * reference raises before any update (train_sdf_autodecoder.py:79 -> :90-91), here the optimizer kernels behind the sort in the same
+ * stream turn into no-ops from that batch on and the host raises when it next looks at the first word.  With the device word
+ * given, both words keep the value of the FIRST call that met a bad index until the caller zeroes them. */
 int sg_sdf_batch_sort_max_shapes(void);
 size_t sg_sdf_batch_sort_workspace_bytes(long n, long nshapes);
 int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points,
                       const float* sdf, float* out_points, float* out_sdf, int* out_shape, int64_t* seg_off, float* counts,
-                      int* bad_index_flag, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                      int* bad_index_flag, int* bad_index_device, int bad_index_value, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream);
 int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float lr, float alpha, float eps,
                     float grad_scale, float clip, hipStream_t stream);
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
@@ -283,6 +288,13 @@ int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, lo
  * the call has no host-side state that changes between steps, so a captured hipGraph of a training step replays it. */
 int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                      float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream);
+/* The two Adam entries with a guard word (device memory, may be NULL = unguarded): when *skip_if_nonzero != 0 at the time the
+ * kernels run, parameters, both moments and (…_dev) the device step counter are left exactly as they were. */
+int sg_adam_step_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, long step, float grad_scale, const int* skip_if_nonzero, hipStream_t stream);
+int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                             float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
+                             const int* skip_if_nonzero, hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
 
 /* ---- K8/K9: loss compositions, gradient-penalty pieces, fade-in blend ---------------------------

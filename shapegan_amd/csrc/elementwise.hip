@@ -116,7 +116,10 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, con
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                   float gscale) {
+                                                   float gscale, const int* __restrict__ skip) {
+    // `skip` (optional): a device word an earlier kernel of the stream sets when this step's batch must not be applied
+    // (sg_sdf_batch_sort's bad-index word): the update is then a no-op — parameters and both moments keep their values
+    if (skip && *skip) return;
     const float step = lr / bc1;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float gg = g[e] * gscale;
@@ -130,7 +133,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 
 // Graph-capturable Adam: the step counter lives on the device.  One thread advances it and derives the two bias
 // corrections in double (as torch does on the host); the update kernel reads them from memory instead of its arguments.
-__global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restrict__ corr, float b1, float b2) {
+__global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restrict__ corr, float b1, float b2,
+                                    const int* __restrict__ skip) {
+    if (skip && *skip) return;           // a skipped step does not age the optimizer either
     const long long t = *step + 1;
     *step = t;
     corr[0] = (float)(1.0 - pow((double)b1, (double)t));
@@ -139,7 +144,8 @@ __global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restr
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                        float b1, float b2, float eps, const float* __restrict__ corr,
-                                                       float gscale) {
+                                                       float gscale, const int* __restrict__ skip) {
+    if (skip && *skip) return;
     const float step = lr / corr[0], bc2_sqrt = corr[1];
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float gg = g[e] * gscale;
@@ -270,20 +276,30 @@ int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float l
 }
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                  float eps, long step, float grad_scale, hipStream_t stream) {
+    return sg_adam_step_guarded(p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, nullptr, stream);
+}
+int sg_adam_step_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, long step, float grad_scale, const int* skip_if_nonzero, hipStream_t stream) {
     SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step > 0);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale, skip_if_nonzero);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
 int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                      float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream) {
+    return sg_adam_step_dev_guarded(p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step_dev, corr_dev, grad_scale, nullptr,
+                                    stream);
+}
+int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                             float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
+                             const int* skip_if_nonzero, hipStream_t stream) {
     SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_dev && corr_dev);
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, stream, step_dev, corr_dev, beta1, beta2);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, stream, step_dev, corr_dev, beta1, beta2, skip_if_nonzero);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, (const float*)corr_dev, grad_scale);
+                       beta2, eps, (const float*)corr_dev, grad_scale, skip_if_nonzero);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

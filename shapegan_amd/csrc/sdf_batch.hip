@@ -23,7 +23,7 @@ constexpr int kSortMaxShapes = 16384;   // one int of LDS per shape
 
 __global__ void __launch_bounds__(64) sdf_sort_hist_kernel(const int64_t* __restrict__ idx, long n, long pc, int S,
                                                            int* __restrict__ keys, int* __restrict__ hist,
-                                                           int* __restrict__ flag) {
+                                                           int* __restrict__ flag, int* __restrict__ flag_dev, int flag_value) {
     extern __shared__ int cnt[];
     const int lane = threadIdx.x;
     const long chunk = blockIdx.x;
@@ -36,7 +36,15 @@ __global__ void __launch_bounds__(64) sdf_sort_hist_kernel(const int64_t* __rest
             const long i = idx[e];
             long k = i >= 0 ? (long)((unsigned long long)i / (unsigned long long)pc) : -1;
             if (k < 0 || k >= S) {   // reference: an index error of latent_codes[model_indices]; here a sticky flag, memory stays safe
-                *flag = 1;
+                // flag_dev: the word the guarded optimizer kernels of the same stream read (sg_adam_step_guarded).  Both words keep
+                // the value of the FIRST launch that met a bad index (launches are stream-ordered; within a launch every writer
+                // stores the same value)
+                if (!flag_dev) {
+                    *flag = flag_value;
+                } else if (*flag_dev == 0 || *flag_dev == flag_value) {
+                    *flag_dev = flag_value;
+                    *flag = flag_value;
+                }
                 k = k < 0 ? 0 : S - 1;
             }
             keys[e] = (int)k;
@@ -181,8 +189,10 @@ size_t sg_sdf_batch_sort_workspace_bytes(long n, long nshapes) {
 
 int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points,
                       const float* sdf, float* out_points, float* out_sdf, int* out_shape, int64_t* seg_off, float* counts,
-                      int* bad_index_flag, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                      int* bad_index_flag, int* bad_index_device, int bad_index_value, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream) {
     SG_CHECK_ARG(indices && points && sdf && out_points && out_sdf && out_shape && seg_off && counts && bad_index_flag);
+    SG_CHECK_ARG(bad_index_value != 0);
     SG_CHECK_ARG(n > 0 && n < (1L << 31) && pointcloud_size > 0 && nshapes > 0 && nshapes <= kSortMaxShapes);
     if (!workspace || workspace_bytes < sg_sdf_batch_sort_workspace_bytes(n, nshapes))
         SG_FAIL(SG_ERR_WORKSPACE, "sg_sdf_batch_sort: workspace too small");
@@ -201,7 +211,7 @@ int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long
             SG_FAIL(SG_ERR_HIP, "sg_sdf_batch_sort: cannot reserve %zu B LDS", lds);
     }
     hipLaunchKernelGGL(sdf_sort_hist_kernel, dim3((unsigned)nc), dim3(64), lds, stream, indices, n, pointcloud_size, S, keys,
-                       hist, bad_index_flag);
+                       hist, bad_index_flag, bad_index_device, bad_index_value);
     hipLaunchKernelGGL(sdf_sort_prefix_kernel, dim3((unsigned)((S + 63) / 64)), dim3(1024), 0, stream, hist, base, total, nc, S);
     hipLaunchKernelGGL(sdf_sort_scatter_kernel, dim3((unsigned)nc), dim3(64), lds, stream, indices, keys, base, total, n, S,
                        nshapes * pointcloud_size, points, sdf, out_points, out_sdf, out_shape, seg_off, counts);

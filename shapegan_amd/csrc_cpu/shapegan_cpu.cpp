@@ -799,14 +799,19 @@ int sg_scatter_add_rows_cpu(const float* rows, long rows_ld, const int64_t* idx,
 // stable counting sort of the batch on the shape id (header: sg_sdf_batch_sort)
 int sg_sdf_batch_sort_cpu(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points, const float* sdf,
                           float* out_points, float* out_sdf, int* out_shape, int64_t* seg_off, float* counts, int* bad_index_flag,
-                          void*, size_t, void*) {
+                          int* bad_index_device, int bad_index_value, void*, size_t, void*) {
     CPU_CHECK(indices && points && sdf && out_points && out_sdf && out_shape && seg_off && counts && bad_index_flag);
-    CPU_CHECK(n > 0 && pointcloud_size > 0 && nshapes > 0);
+    CPU_CHECK(n > 0 && pointcloud_size > 0 && nshapes > 0 && bad_index_value != 0);
     std::vector<int64_t> next(nshapes + 1, 0);
     auto shape_of = [&](int64_t i) {
         int64_t k = i >= 0 ? i / pointcloud_size : -1;
         if (k < 0 || k >= nshapes) {
-            *bad_index_flag = 1;
+            if (!bad_index_device) {
+                *bad_index_flag = bad_index_value;
+            } else if (*bad_index_device == 0 || *bad_index_device == bad_index_value) {
+                *bad_index_device = bad_index_value;
+                *bad_index_flag = bad_index_value;
+            }
             k = k < 0 ? 0 : nshapes - 1;
         }
         return k;
@@ -850,21 +855,31 @@ static void adam_update(float* p, const float* g, float* m, float* v, long n, fl
         p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
 }
-int sg_adam_step_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, long step,
-                     float gscale, void*) {
+int sg_adam_step_guarded_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                             long step, float gscale, const int* skip, void*) {
     CPU_CHECK(p && g && m && v && n > 0 && step > 0);
+    if (skip && *skip) return SG_OK;
     adam_update(p, g, m, v, n, lr, b1, b2, eps, (float)(1.0 - pow((double)b1, (double)step)),
                 (float)sqrt(1.0 - pow((double)b2, (double)step)), gscale);
     return SG_OK;
 }
-int sg_adam_step_dev_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                         long long* step_dev, float* corr_dev, float gscale, void*) {
+int sg_adam_step_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, long step,
+                     float gscale, void* stream) {
+    return sg_adam_step_guarded_cpu(p, g, m, v, n, lr, b1, b2, eps, step, gscale, nullptr, stream);
+}
+int sg_adam_step_dev_guarded_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                                 long long* step_dev, float* corr_dev, float gscale, const int* skip, void*) {
     CPU_CHECK(p && g && m && v && n > 0 && step_dev && corr_dev);
+    if (skip && *skip) return SG_OK;
     const long long t = ++*step_dev;
     corr_dev[0] = (float)(1.0 - pow((double)b1, (double)t));
     corr_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
     adam_update(p, g, m, v, n, lr, b1, b2, eps, corr_dev[0], corr_dev[1], gscale);
     return SG_OK;
+}
+int sg_adam_step_dev_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                         long long* step_dev, float* corr_dev, float gscale, void* stream) {
+    return sg_adam_step_dev_guarded_cpu(p, g, m, v, n, lr, b1, b2, eps, step_dev, corr_dev, gscale, nullptr, stream);
 }
 int sg_clamp_cpu(float* p, long n, float lo, float hi, void*) {
     CPU_CHECK(p && n > 0);

@@ -77,10 +77,12 @@ SIGNATURES = {
     "sg_scatter_add_rows": (c_int, [_P, _L, _P, _P, _L, _I, _P]),
     "sg_sdf_batch_sort_max_shapes": (c_int, []),
     "sg_sdf_batch_sort_workspace_bytes": (_Z, [_L, _L]),
-    "sg_sdf_batch_sort": (c_int, [_P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "sg_sdf_batch_sort": (c_int, [_P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _Z, _P]),
     "sg_rmsprop_step": (c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "sg_adam_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P]),
     "sg_adam_step_dev": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P]),
+    "sg_adam_step_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P, _P]),
+    "sg_adam_step_dev_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P, _P]),
     "sg_clamp": (c_int, [_P, _L, _F, _F, _P]),
     "sg_voxel_prepare": (c_int, [_P, _P, _L, _F, _F, _P]),
     "sg_gemm_nt_workspace_bytes": (_Z, [_I, _I, _L]),

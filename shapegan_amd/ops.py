@@ -1243,20 +1243,58 @@ def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf):
     out_shape = torch.empty(n, dtype=torch.int32, device=dev)
     seg_off = torch.empty(shapes + 1, dtype=torch.int64, device=dev)
     counts = torch.empty(shapes, dtype=torch.float32, device=dev)
-    flag = _bad_index_flags.get(dev)
-    if flag is None:
-        # the sticky "bad index" word lives in PINNED HOST memory (device-accessible under unified addressing): the kernel
-        # touches it only when an index is out of range, and the host reads it with a plain load — no copy, no launch, no
-        # synchronisation per step, nothing to capture
+    flag, guard = _bad_index_words(dev)
+    seq = _sort_sequence[guard.device] = _sort_sequence.get(guard.device, 0) % 0x7fffffff + 1     # this call's number (never 0)
+    ws = workspace("sdf_batch_sort", lib.sg_sdf_batch_sort_workspace_bytes(n, shapes), dev)
+    check(lib.sg_sdf_batch_sort(ptr(indices), n, pointcloud_size, shapes, ptr(points), ptr(sdf), ptr(out_points), ptr(out_sdf),
+                                ptr(out_shape), ptr(seg_off), ptr(counts), flag.data_ptr(), ptr(guard), seq, ptr(ws), ws.numel(),
+                                stream()), "sdf_batch_sort")
+    return out_points, out_sdf, out_shape, seg_off, counts
+
+
+_sort_sequence = {}
+
+
+def batch_sort_sequence(dev):
+    """The number of the latest sdf_batch_sort call on `dev` (1, 2, …; 0 before the first).  The IndexError of a bad batch carries
+    the number of the FIRST call that saw one (`.sort_sequence`)."""
+    return _sort_sequence.get(_bad_index_words(dev)[1].device, 0)
+
+
+def _bad_index_words(dev):
+    """(host word, device word) of `dev`, both sticky and set together by the sort kernel when an index is out of range.
+    The host word lives in PINNED HOST memory (device-accessible under unified addressing): the kernel touches it only on error and
+    the host reads it with a plain load — no copy, no launch, no synchronisation per step, nothing to capture.  The device word is
+    what guarded optimizer kernels read (`batch_index_guard`)."""
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    words = _bad_index_flags.get(dev)
+    if words is None:
         flag = torch.zeros(1, dtype=torch.int32)
         if dev.type == "cuda":
             flag = flag.pin_memory()
-        _bad_index_flags[dev] = flag
-    ws = workspace("sdf_batch_sort", lib.sg_sdf_batch_sort_workspace_bytes(n, shapes), dev)
-    check(lib.sg_sdf_batch_sort(ptr(indices), n, pointcloud_size, shapes, ptr(points), ptr(sdf), ptr(out_points), ptr(out_sdf),
-                                ptr(out_shape), ptr(seg_off), ptr(counts), flag.data_ptr(), ptr(ws), ws.numel(), stream()),
-          "sdf_batch_sort")
-    return out_points, out_sdf, out_shape, seg_off, counts
+        words = _bad_index_flags[dev] = (flag, torch.zeros(1, dtype=torch.int32, device=dev))
+    return words
+
+
+def batch_index_guard(dev):
+    """The device word of `dev` that is non-zero from the moment a sort kernel met an out-of-range batch index until the host has
+    raised for it.  optim.Adam(…).guard = this tensor makes the update of such a batch a no-op (sg_adam_step_guarded): the reference
+    raises its IndexError before any update (train_sdf_autodecoder.py:79), here the error surfaces one step late but the state it
+    leaves behind is the one before the bad batch."""
+    return _bad_index_words(dev)[1]
+
+
+def _raise_bad_index(dev, words, synchronise):
+    if synchronise and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(dev)
+    err = IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+    err.sort_sequence = int(words[0][0])
+    words[0][0] = 0
+    if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        words[1].zero_()
+    raise err
 
 
 def sdf_batch_sort_max_shapes():
@@ -1265,25 +1303,21 @@ def sdf_batch_sort_max_shapes():
 
 def check_batch_indices():
     """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables."""
-    for dev, flag in _bad_index_flags.items():
+    for dev, words in _bad_index_flags.items():
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
-        if int(flag[0]) != 0:
-            flag[0] = 0
-            raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+        if int(words[0][0]) != 0:
+            _raise_bad_index(dev, words, False)
 
 
 def poll_batch_indices():
     """The same check without a synchronisation, for use on EVERY step: a plain read of the pinned host word the sort kernels set.
     An out-of-range index is reported as soon as the kernel that saw it has run — in practice at the next step (the reference
-    raises at once; the batch in question was computed on clamped rows).  Costs nothing on the device and is safe inside a stream
-    capture (there is nothing to record)."""
-    for dev, flag in _bad_index_flags.items():
-        if int(flag[0]) != 0:
-            if dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-                torch.cuda.synchronize(dev)
-            flag[0] = 0
-            raise IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+    raises at once; the batch in question was computed on clamped rows, and an optimizer guarded by `batch_index_guard` did not
+    apply it).  Costs nothing on the device and is safe inside a stream capture (there is nothing to record)."""
+    for dev, words in _bad_index_flags.items():
+        if int(words[0][0]) != 0:
+            _raise_bad_index(dev, words, True)
 
 
 # --------------------------------------------------------------------------------------------------------------

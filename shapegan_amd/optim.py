@@ -10,6 +10,8 @@ The constructor re-points every parameter's `.data` (and `.grad`) at slices of t
 state_dict keys and shapes are unchanged.  Parameters whose `.grad` is None at step time are skipped exactly like
 torch.optim does (unused progressive-GAN stages).
 """
+import collections
+
 import torch
 
 from . import lib as L
@@ -182,6 +184,18 @@ class Adam(_Base):
         self.exp_avg_sq = torch.zeros_like(self.f.flat)
         # torch keeps one step counter per parameter; a parameter that never had a grad never advances
         self.steps = [0] * len(self.f.params)
+        # optional int32 device word: while it is non-zero, step() leaves parameters, moments and the device step counter untouched
+        # (ops.batch_index_guard — the auto-decoder's out-of-range batch index); the host counters are taken back by `unstep`
+        self.guard = None
+        self._advanced = collections.deque(maxlen=4096)     # per step(): the parameters whose host counter it advanced
+
+    def unstep(self, count=1):
+        """Takes back the host-side step counters of the last `count` step() calls — for a caller that learned afterwards that the
+        guard word was set while those steps' kernels ran (they did nothing).  The capturable variant has nothing to take back: its
+        counter is on the device and was not advanced."""
+        for _ in range(min(count, len(self._advanced))):
+            for i in self._advanced.pop():
+                self.steps[i] -= 1
 
     def step(self):
         lib = L.load()
@@ -189,6 +203,7 @@ class Adam(_Base):
         f.check_storage()
         base_p, base_m, base_v = f.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         uniform = f.coherent() and len(set(self.steps)) == 1
+        guard = self.guard.data_ptr() if self.guard is not None else None
         if self.capturable:
             if not f.coherent():
                 if any(p.grad is None for p in f.params):
@@ -196,23 +211,25 @@ class Adam(_Base):
                                        "parameter needs a gradient on every step (torch.optim would skip the missing ones)")
                 f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
             L.note_device(f.flat)
-            check(lib.sg_adam_step_dev(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
-                                       self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
-                                       self.grad_scale, stream()), "adam_step_dev")
+            check(lib.sg_adam_step_dev_guarded(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
+                                               self.grad_scale, guard, stream()), "adam_step_dev")
         elif uniform:
             self.steps = [s + 1 for s in self.steps]
+            self._advanced.append(range(len(self.steps)))
             L.note_device(f.flat)
-            check(lib.sg_adam_step(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
-                                   self.betas[1], self.eps, self.steps[0], self.grad_scale, stream()), "adam_step")
+            check(lib.sg_adam_step_guarded(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
+                                           self.betas[1], self.eps, self.steps[0], self.grad_scale, guard, stream()), "adam_step")
         else:
             # per-parameter step counters, as torch: a parameter without a gradient neither moves nor ages
-            for i, p in enumerate(f.params):
-                if p.grad is not None:
-                    self.steps[i] += 1
+            self._advanced.append([i for i, p in enumerate(f.params) if p.grad is not None])
+            for i in self._advanced[-1]:
+                self.steps[i] += 1
             first = {o: i for i, o in enumerate(f.offsets)}
             for seg in self._segments(keys=self.steps):
                 o, n, g = seg[0], seg[1], seg[2]
                 L.note_device(f.flat)
-                check(lib.sg_adam_step(base_p + 4 * o, g, base_m + 4 * o, base_v + 4 * o, n, self.lr, self.betas[0],
-                                       self.betas[1], self.eps, self.steps[first[o]], self.grad_scale, stream()), "adam_step")
+                check(lib.sg_adam_step_guarded(base_p + 4 * o, g, base_m + 4 * o, base_v + 4 * o, n, self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.steps[first[o]], self.grad_scale, guard, stream()),
+                      "adam_step")
         L.bump_param_epoch(f.range)

@@ -5,6 +5,7 @@ shapegan_amd.optim.  Each method cites the reference lines it restates; random d
 arguments so that parity tests can inject the reference's values.  Data-parallel runs insert exactly one flat
 gradient all-reduce per optimizer step (shapegan_amd.parallel.GradBucket); single-process runs skip it.
 """
+import collections
 import contextlib
 
 import torch
@@ -196,6 +197,24 @@ class SDFAutoDecoderTrainer(object):
         self.capturable = capturable
         self._graph, self._graph_idx, self._graph_loss, self._graph_calls = None, None, None, 0
         self._sorted_calls = 0
+        # An out-of-range batch index is an IndexError BEFORE any update in the reference (train_sdf_autodecoder.py:79).  Here it is
+        # noticed without a host synchronisation, one step late (`_poll_indices`) — so both optimizers are guarded by the device
+        # word the sort kernel sets in the same stream: the bad batch's update is a no-op on parameters, moments and step counters,
+        # and the error leaves the state of the step before it (also inside a replayed graph).
+        self.net_opt.guard = self.lat_opt.guard = ops.batch_index_guard(latent_codes.device)
+        self._updates = collections.deque(maxlen=4096)     # the sort call number behind every update issued so far
+
+    def _poll_indices(self, synchronise=False):
+        try:
+            ops.check_batch_indices() if synchronise else ops.poll_batch_indices()
+        except IndexError as e:
+            # the host may be several steps ahead of the device: every update issued behind the first bad sort was a no-op on the
+            # device (the guard word is sticky until the host clears it) — take the host-side step counters of exactly those back
+            skipped = sum(1 for s in self._updates if s >= getattr(e, "sort_sequence", 0) > 0)
+            self.net_opt.unstep(skipped)
+            self.lat_opt.unstep(skipped)
+            self._updates.clear()
+            raise
 
     def step_graphed(self, indices):
         """`step` as ONE captured graph launch (single process only): the shape-sorted flow from 8192 points on, the gathered
@@ -209,7 +228,7 @@ class SDFAutoDecoderTrainer(object):
         self._graph_calls += 1
         if self._graph_calls <= 2:
             return self.step(indices)
-        ops.poll_batch_indices()       # the pinned host word an earlier replay's sort kernel may have set
+        self._poll_indices()           # the pinned host word an earlier replay's sort kernel may have set
         if self._graph is None or self._graph_idx.shape != indices.shape:
             self._graph_idx = indices.clone()
             torch.cuda.synchronize()
@@ -247,9 +266,10 @@ class SDFAutoDecoderTrainer(object):
             indices, self.pointcloud_size, shapes, self.points, self.sdf)
         self._sorted_calls += 1
         if self._sorted_calls == 1:
-            ops.check_batch_indices()           # first call: synchronous (a systematically wrong index source fails at once)
+            self._poll_indices(synchronise=True)    # first call: synchronous (a systematically wrong index source fails at once)
         else:
-            ops.poll_batch_indices()            # every later call: no host sync; an out-of-range index raises one step late
+            self._poll_indices()                    # every later call: no host sync; an out-of-range index raises one step late,
+                                                    # behind a guarded (skipped) update
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
         output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
@@ -265,6 +285,7 @@ class SDFAutoDecoderTrainer(object):
         self.lat_bucket.allreduce()
         self.net_opt.step()
         self.lat_opt.step()
+        self._updates.append(ops.batch_sort_sequence(self.latent_codes.device))
         return loss.detach()
 
     def step_gathered(self, indices):

@@ -157,6 +157,11 @@ def test_losses_and_blends(on_cpu):
     LOSS.test_discriminator_clip_weights()
 
 
+@pytest.mark.parametrize("late_polls", [0, 2])
+def test_bad_batch_index_update_is_guarded(on_cpu, late_polls, monkeypatch):
+    LOSS.test_bad_batch_index_leaves_the_state_before_the_bad_batch(False, late_polls, monkeypatch)
+
+
 # ---- modules and training steps (bodies from tests/test_gpu_modules.py: reference-made fixtures + CPU oracle) ----------------
 def test_generator_and_discriminator(on_cpu, golden_modules):
     M.test_generator(golden_modules)

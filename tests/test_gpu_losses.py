@@ -538,6 +538,71 @@ def test_graph_replay_invalidates_weight_packs():
     assert torch.equal(after, expect)
 
 
+@pytest.mark.parametrize("graphed,late_polls", [(False, 0), (True, 0), (False, 2)])
+def test_bad_batch_index_leaves_the_state_before_the_bad_batch(graphed, late_polls, monkeypatch):
+    """train_sdf_autodecoder.py:79 raises an IndexError BEFORE any update.  Here the error is noticed without a host synchronisation,
+    possibly some steps late — but the optimizers are guarded by the device word the sort kernel sets (sg_adam_step_guarded), so when
+    the IndexError arrives, parameters, latent table, both Adam moments and the step counters (host lists, or the device counter
+    inside a replayed graph) are bit-for-bit those of the step before the bad batch; training then continues normally.
+    late_polls: the host's look at the pinned word is made to miss the flag that many times (a host running ahead of the device)."""
+    from shapegan_amd import ops
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+    if graphed and DEV == "cpu":
+        pytest.skip("graph capture needs the GPU")
+    pc, shapes, L, n = 3000, 4, 64, 8192
+    torch.manual_seed(23)
+    pts = torch.rand(shapes * pc, 3, device=DEV) * 2 - 1
+    sdf = torch.rand(shapes * pc, device=DEV) * 0.3 - 0.15
+    net = SDFNet(latent_code_size=L)
+    tr = SDFAutoDecoderTrainer(net, torch.randn(shapes, L, device=DEV) * 1e-2, pts, sdf, pointcloud_size=pc, lr=1e-3,
+                               capturable=graphed)
+    step = tr.step_graphed if graphed else tr.step
+    good = lambda: torch.randint(0, shapes * pc, (n,), device=DEV)
+
+    def state():
+        if DEV != "cpu":
+            torch.cuda.synchronize()
+        out = [p.detach().clone() for p in net.parameters()] + [tr.latent_codes.detach().clone()]
+        for o in (tr.net_opt, tr.lat_opt):
+            out += [o.exp_avg.clone(), o.exp_avg_sq.clone()]
+            out.append(o.step_dev.clone() if graphed else torch.tensor(o.steps))
+        return out
+
+    for _ in range(4):
+        step(good())
+    before, host_steps = state(), list(tr.net_opt.steps)
+    real_poll, misses = ops.poll_batch_indices, [late_polls]
+
+    def poll():
+        if misses[0] > 0 and any(int(w[0][0]) != 0 for w in ops._bad_index_flags.values()):
+            misses[0] -= 1
+            return
+        real_poll()
+    monkeypatch.setattr(ops, "poll_batch_indices", poll)
+    bad = good()
+    bad[n // 3] = shapes * pc + 3
+    raised, calls = False, 0
+    for idx in [bad] + [good() for _ in range(4)]:       # the host is not synchronised: the error may arrive a few calls late
+        calls += 1
+        try:
+            step(idx)
+        except IndexError as e:
+            raised = True
+            assert e.sort_sequence > 0
+            break
+    assert raised, "the out-of-range index was never reported"
+    assert calls > late_polls
+    after = state()
+    for a, b in zip(before, after):
+        assert torch.equal(a, b), "state changed by (or after) the bad batch, %d call(s) before the IndexError" % calls
+    step(good())                                          # the words were cleared: training goes on
+    moved = state()
+    assert not torch.equal(moved[0], before[0])
+    if not graphed:
+        assert tr.net_opt.steps == [s + 1 for s in host_steps]
+
+
 # ---- C-ABI RCCL exchange (SURVEY.md 8b: sg_allreduce_*) -----------------------------------------------------------------------
 def test_native_allreduce_single_rank_stream_order():
     """libshapegan_comm.so on the one GPU of this box: communicator of world size 1 (all a single-GPU box can form), the
