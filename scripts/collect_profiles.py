@@ -17,7 +17,8 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
-             "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json"):
+             "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json",
+             "pytest_gpu.log", "dropin_gpu.log"):
     f = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
@@ -90,6 +91,13 @@ if dom:
 # ---- markdown tables generated from the files above: profiles/README.md and DESIGN.md quote THESE, nothing is typed by hand ------
 def md_tables():
     L = ["<!-- generated by scripts/collect_profiles.py %s from the files named in each heading; do not edit -->" % tag, ""]
+    for name, what in (("_pytest_gpu.log", "`python -m pytest tests -q -m gpu` on the GPU box"),
+                       ("_dropin_gpu.log", "`SHAPEGAN_REFERENCE_DIR=<scratch copy of the five reference scripts> python -m pytest "
+                                           "tests/test_dropin.py -v` on the GPU box")):
+        f = os.path.join(dst, tag + name)
+        if os.path.exists(f):
+            tail = [ln.strip() for ln in open(f).read().splitlines() if " passed" in ln or " failed" in ln or " error" in ln]
+            L += ["### `%s%s` (%s)" % (tag, name, what), "", tail[-1].strip("= ") if tail else "(no summary line)", ""]
     bl = os.path.join(dst, tag + "_bench_line.json")
     if os.path.exists(bl):
         d = json.loads([ln for ln in open(bl).read().splitlines() if ln.startswith("{")][-1])
