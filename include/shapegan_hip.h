@@ -55,6 +55,10 @@ int sg_conv3d_k4s2p1_fwd(const float* x, const float* w, const float* bias, floa
 int sg_conv3d_k4s2p1_fwd_keep(const float* x, const float* w, const float* bias, float* y, int batch, int Cin, int Cin_total,
                               int Cx, int Cout, int ID, int IH, int IW, int act, float slope, void* workspace,
                               size_t workspace_bytes, int weights_unchanged, hipStream_t stream);
+/* 0: the call {kind, dims[8]} (as in sg_conv3d_k4s2p1_pack_images) with a workspace of workspace_bytes is not served by a kernel
+ * with a kept weight image.  Otherwise a number that is equal for two calls exactly when they read the same image: callers key their
+ * kept images on it instead of on the full shape (the batch size does not enter the LDS-halo kernels' images).  Host code only. */
+long long sg_conv3d_k4s2p1_image_layout(int kind, const int* dims, size_t workspace_bytes);
 int sg_conv3d_k4s2p1_pack_images(int n, const int* kinds, const float* const* weights, void* const* workspaces,
                                  const size_t* workspace_bytes, const int* dims, int* served, hipStream_t stream);
 /* testing / tuning: force one forward implementation (0 = gather implicit GEMM, 1 = LDS-halo implicit GEMM) */

@@ -55,6 +55,17 @@ if mode == "mfma":
         ops.conv_wgrad_raw(y16, x32, 1)
         ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2)
         ops.conv_dgrad_raw(y16[:64].contiguous(), w1, None, 1)
+elif mode == "sdfstep":
+    # six 200 000-point / latent-256 auto-decoder steps alone (scripts/kernel_pmc.sh sdfnet ...)
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+    pc, shapes, lat = 200000, 64, 256
+    pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1
+    sdf = torch.rand(shapes * pc, device="cuda") * 0.2 - 0.1
+    tr = SDFAutoDecoderTrainer(SDFNet(latent_code_size=lat), torch.randn(shapes, lat, device="cuda") * 1e-2, pts, sdf, pointcloud_size=pc)
+    idx = torch.randint(0, shapes * pc, (200000,), device="cuda")
+    for _ in range(6):
+        tr.step(idx)
 elif mode == "hbm":
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer

@@ -780,6 +780,39 @@ int sg_conv3d_k4s2p1_pack_images(int n, const int* kinds, const float* const* we
     return SG_OK;
 }
 
+// What the kept image of a call looks like, as one number: 0 if the call {kind, dims} (as in sg_conv3d_k4s2p1_pack_images) on a
+// workspace of `workspace_bytes` is not served by a kernel with a kept image; otherwise a value that is equal for two calls exactly
+// when they read the SAME image (same packed form, row-tile count, channel counts and place in the workspace).  The batch size and
+// the grid do not enter the image of the LDS-halo kernels: the critic's images serve its 128-sample update passes and the 64-sample
+// pass of the generator update alike (a caller keying its images on the full shape rebuilt them at every change of the batch size).
+// Pure host code (the planning half of the calls themselves).
+long long sg_conv3d_k4s2p1_image_layout(int kind, const int* dims, size_t workspace_bytes) {
+    if (!dims || (kind != 0 && kind != 1)) return 0;
+    const int batch = dims[0], Cin = dims[1], Cin_total = dims[2], Cx = dims[3], Cout = dims[4];
+    if (batch <= 0 || Cin <= 1 || Cin > Cin_total || Cin > Cx || Cout <= 0) return 0;
+    ConvGeom g;
+    if (make_geom(g, dims[5], dims[6], dims[7], Cx, Cout)) return 0;
+    if ((long)batch * g.O3() >= (1L << 31) || (long)batch * g.I3() >= (1L << 31)) return 0;
+    PackJobs jobs;
+    static const float dummy = 0.f;               // operand pointers are only stored in collect mode, never dereferenced
+    char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);
+    const int rc = kind == 0 ? halo_fwd_try(&dummy, &dummy, nullptr, const_cast<float*>(&dummy), batch, Cin, Cin_total, g, Cout, SG_ACT_NONE,
+                                            0.f, base, workspace_bytes, nullptr, 0, 0, false, &jobs)
+                             : halo_dgrad_try(&dummy, &dummy, nullptr, const_cast<float*>(&dummy), batch, Cin, Cin_total, g, Cout,
+                                              SG_ACT_NONE, 0.f, base, workspace_bytes, nullptr, 0, false, &jobs);
+    if (rc != 1 || jobs.n != 1) return 0;
+    const PackJob& j = jobs.job[0];
+    unsigned long long h = 1469598103934665603ull;                       // FNV-1a over the fields that define the image
+    const long long f[7] = {j.kind + 1, j.Cout, j.Cin_total, j.Cin, j.nt, (long long)(reinterpret_cast<char*>(j.wp) - base), 0x5347};
+    for (long long v : f)
+        for (int b = 0; b < 8; ++b) {
+            h ^= (unsigned long long)(v >> (8 * b)) & 0xffull;
+            h *= 1099511628211ull;
+        }
+    h &= 0x7fffffffffffffffull;
+    return h ? (long long)h : 1;
+}
+
 // testing / tuning: impl 1 forces the LDS-halo dgrad kernel (SG_ERR_ARG if the shape is not eligible)
 int sg_conv3d_k4s2p1_dgrad_impl(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin,
                                 int Cin_total, int Cx, int Cout, int ID, int IH, int IW, int act, float slope,

@@ -28,6 +28,7 @@ SIGNATURES = {
     "sg_conv3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_conv3d_k4s2p1_fwd_keep": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "sg_conv3d_k4s2p1_pack_images": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "sg_conv3d_k4s2p1_image_layout": (ctypes.c_longlong, [_I, _P, _Z]),
     "sg_conv3d_k4s2p1_fwd_impl": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _I, _P]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes": (_Z, [_I, _I]),
     "sg_conv3d_k4s2p1_dgrad_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),
@@ -175,7 +176,8 @@ def check_comm(rc, what=""):
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
     "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-    "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image"}
+    "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
+    "sg_conv3d_k4s2p1_image_layout"}
 CPU_PATH = os.path.join(_HERE, "libshapegan_cpu.so")
 
 _hip = None

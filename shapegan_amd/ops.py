@@ -74,7 +74,22 @@ class _KeptWeightImages(object):
     input-gradient form) with one launch instead of four."""
 
     def __init__(self, cap=64):
-        self.cap, self.entries, self.groups = cap, {}, {}
+        self.cap, self.entries, self.groups, self.layouts = cap, {}, {}, {}
+
+    def _key(self, w, kind, dims, nbytes):
+        """What an image is valid FOR: the library's layout number of the call where a kept image serves it
+        (sg_conv3d_k4s2p1_image_layout: the batch size does not enter the LDS-halo kernels' images, so the critic's images serve its
+        128-sample update passes and the 64-sample pass of the generator update alike), the full call shape otherwise."""
+        if w.device.type != "cuda":
+            return dims
+        q = (kind, dims, int(nbytes))
+        key = self.layouts.get(q)
+        if key is None:
+            if len(self.layouts) > 4096:
+                self.layouts.clear()
+            layout = _lib().sg_conv3d_k4s2p1_image_layout(kind, (ctypes.c_int * 8)(*[int(d) for d in dims]), int(nbytes))
+            key = self.layouts[q] = ("layout", layout) if layout else dims
+        return key
 
     def _ident(self, w, kind):
         return (w.device.index, stream(), w.data_ptr(), kind)
@@ -87,14 +102,15 @@ class _KeptWeightImages(object):
         ID, IH, IW) of the call.  An entry belongs to one tensor OBJECT (weak reference): a new tensor that the allocator places at
         a freed weight's address, with the same version and epoch, is a different weight."""
         ident = self._ident(w, kind)
-        state = self._state(w, shape_key)
         ent = self.entries.pop(ident, None)
         if ent is None or ent[0].numel() < nbytes or ent[2]() is not w:
-            ent = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device), None, weakref.ref(w)]
+            ent = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device), None, weakref.ref(w), None]
+        # (the layout is asked for the workspace the call is really given: an entry sized by an earlier, larger call keeps its size)
+        state = self._state(w, self._key(w, kind, shape_key, ent[0].numel()))
         unchanged = ent[1] == state
         if not unchanged:
             unchanged = self._pack_group(w, kind, ent, shape_key)
-        ent[1] = state
+        ent[1], ent[3] = state, shape_key        # ent[3]: the shapes of the entry's latest call (what a group launch plans with)
         self.entries[ident] = ent            # (re-inserted last: dict order = age)
         while len(self.entries) > self.cap:
             self.entries.pop(next(iter(self.entries)))
@@ -118,7 +134,7 @@ class _KeptWeightImages(object):
                 if e2 is None or e2[2]() is not v or e2[1] is None:
                     continue
                 if e2[1] != self._state(v, e2[1][2]):          # stale, shapes known from its last call
-                    jobs.append((v, k2, e2, e2[1][2]))
+                    jobs.append((v, k2, e2, e2[3]))
         if len(jobs) < 2:
             return False                     # nothing to share the launch with: the call packs its own image as before
         jobs = jobs[:8]
@@ -132,7 +148,7 @@ class _KeptWeightImages(object):
         L.note_device(w)
         check(_lib().sg_conv3d_k4s2p1_pack_images(n, kinds, wptr, wsp, wsb, dims, served, stream()), "conv3d_pack_images")
         for j, ok in zip(jobs[1:], list(served)[1:]):
-            j[2][1] = self._state(j[0], j[3]) if ok else None
+            j[2][1] = self._state(j[0], self._key(j[0], j[1], j[3], j[2][0].numel())) if ok else None
         return bool(served[0])
 
     def register_group(self, weights):

@@ -44,7 +44,8 @@ def test_twin_exports_every_entry_point():
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
             "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-            "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image")
+            "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
+            "sg_conv3d_k4s2p1_image_layout")
 
 
 def test_dispatch_is_by_tensor_device_only(on_cpu):

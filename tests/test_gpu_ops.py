@@ -1,5 +1,7 @@
 """GPU tier: every HIP kernel family against the CPU oracle on the same seeded inputs.
 Tolerance: 1e-4 relative fp32 (BASELINE.json north star); integer/index work bit-exact."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -310,6 +312,56 @@ def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monke
         for (k, p), (_, q) in zip(d.named_parameters(), fresh.named_parameters()):
             assert torch.equal(p.grad, q.grad), "update %d: gradient of %s" % (it, k)
         opt.step()
+
+
+def test_kept_images_serve_another_batch_size(monkeypatch):
+    """The LDS-halo kernels' weight images do not depend on the batch size (sg_conv3d_k4s2p1_image_layout): train_wgan.py's critic
+    runs at 128 samples in its own updates and at 64 in the generator update — the images built for one serve the other, nothing
+    is re-packed until the weights change.  Results must equal a fresh critic's (no kept state) at every pass."""
+    from shapegan_amd import ops, optim
+    from shapegan_amd import lib as L
+    from shapegan_amd.model.gan import Discriminator
+    if DEV != "cuda":
+        pytest.skip("kept images exist on the GPU only")
+    lay = lambda kind, dims: L.load().sg_conv3d_k4s2p1_image_layout(kind, (ctypes.c_int * 8)(*dims), 1 << 28)
+    assert lay(0, (128, 64, 64, 64, 128, 16, 16, 16)) == lay(0, (64, 64, 64, 64, 128, 16, 16, 16)) != 0
+    assert lay(1, (128, 128, 128, 128, 256, 8, 8, 8)) == lay(1, (64, 128, 128, 128, 256, 8, 8, 8)) != 0
+    assert lay(0, (128, 64, 64, 64, 128, 16, 16, 16)) != lay(1, (128, 64, 64, 64, 128, 16, 16, 16))
+    assert lay(0, (128, 64, 64, 64, 128, 16, 16, 16)) != lay(0, (128, 128, 128, 128, 256, 8, 8, 8))
+    assert lay(0, (2, 64, 64, 64, 128, 16, 16, 16)) == 0 and lay(0, (128, 1, 1, 1, 64, 32, 32, 32)) == 0
+    torch.manual_seed(32)
+    d = Discriminator()
+    d.use_sigmoid = False
+    opt = optim.RMSprop(d.parameters(), lr=1e-3)
+    flags, packs = [], []
+    real_get = ops._KEPT.get
+    monkeypatch.setattr(ops._KEPT, "get", lambda w, nb, key, **kw: (lambda r: (flags.append(r[1]), r)[1])(real_get(w, nb, key, **kw)))
+    real_pack = L.load().sg_conv3d_k4s2p1_pack_images
+    monkeypatch.setattr(L.load(), "sg_conv3d_k4s2p1_pack_images", lambda n, *a: (packs.append(n), real_pack(n, *a))[1])
+    changed = True
+    for it, (nb, step) in enumerate(((128, True), (64, False), (128, True), (64, False), (128, False), (64, True), (128, False))):
+        x = (torch.rand(nb, 32, 32, 32) * 2 - 1).cuda().requires_grad_()
+        opt.zero_grad()
+        del flags[:], packs[:]
+        out = d(x)
+        L.backward(out.mean())
+        if it >= 1 and not changed:
+            assert flags and all(flags) and not packs, "pass %d (batch %d, weights unchanged): re-packed (%r, %r)" % (it, nb, flags, packs)
+        if it >= 2 and changed:
+            assert packs == [4], "pass %d: expected one launch for the four stale images, got %r" % (it, packs)
+        fresh = Discriminator()
+        fresh.load_state_dict({k: v.clone() for k, v in d.state_dict().items()})
+        fresh.use_sigmoid = False
+        xf = x.detach().clone().requires_grad_()
+        of = fresh(xf)
+        of.mean().backward()
+        assert torch.equal(out.detach(), of.detach()), "pass %d: outputs differ from a fresh critic's" % it
+        assert torch.equal(x.grad, xf.grad), "pass %d: input gradient" % it
+        for (k, p), (_, q) in zip(d.named_parameters(), fresh.named_parameters()):
+            assert torch.equal(p.grad, q.grad), "pass %d: gradient of %s" % (it, k)
+        changed = step
+        if step:
+            opt.step()
 
 
 @pytest.mark.parametrize("N", [128, 64, 37])
