@@ -321,7 +321,8 @@ def make_wgan(rank):
     trainer = WGANTrainer(generator, critic)
     gen = torch.Generator().manual_seed(1000 + rank)   # per-rank synthetic data (batch axis sharded)
     reals = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(5)]
-    zs = [torch.randn(BATCH, 128, generator=gen).cuda() for _ in range(5)]
+    # (the unit's five critic latent batches are one draw: WGANTrainer.step's grouped generator pass then reads them in place)
+    zs = list(torch.randn(5, BATCH, 128, generator=gen).cuda().unbind(0))
     zg = torch.randn(BATCH, 128, generator=gen).cuda()
     info = {"optimizers": [trainer.c_opt, trainer.g_opt],
             "metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",

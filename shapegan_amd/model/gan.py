@@ -47,7 +47,10 @@ class Generator(SavableModule):
         with every convolution launched once (model/stack.py:run_stack_groups).  Falls back to exactly that loop when the fused
         path does not apply (grad mode, eval mode, CPU tensors of odd shapes, ...)."""
         if (not torch.is_grad_enabled() and self.training and len(zs) > 1 and len({tuple(z.shape) for z in zs}) == 1):
-            x = torch.cat([z.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1)) for z in zs])
+            x = _stacked_view(zs)                  # latent batches drawn as one tensor: no copy
+            if x is None:
+                x = torch.cat([z.reshape((-1, LATENT_CODE_SIZE)) for z in zs])
+            x = x.reshape((-1, LATENT_CODE_SIZE, 1, 1, 1))
             if run_stack_groups(self.layers, x, len(zs), list(outs)):
                 return outs
         for z, o in zip(zs, outs):
@@ -63,6 +66,20 @@ class Generator(SavableModule):
 
     def copy_autoencoder_weights(self, autoencoder):
         raise Exception("Not implemented.")  # as in the reference (model/gan.py:36-40)
+
+
+def _stacked_view(zs):
+    """[len(zs) * B, 128] view of the latent batches if they are consecutive contiguous slices of one tensor (e.g. the rows of one
+    torch.randn(K, B, 128) draw), else None."""
+    z0 = zs[0]
+    if z0.dim() != 2 or not all(z.is_contiguous() and z.dtype == z0.dtype and z.device == z0.device for z in zs):
+        return None
+    step = z0.numel()
+    for i, z in enumerate(zs):
+        if (z.untyped_storage().data_ptr() != z0.untyped_storage().data_ptr()
+                or z.storage_offset() != z0.storage_offset() + i * step):
+            return None
+    return z0.as_strided((len(zs) * z0.shape[0], z0.shape[1]), (z0.shape[1], 1), z0.storage_offset())
 
 
 class Discriminator(SavableModule):

@@ -394,6 +394,12 @@ def test_generator_forward_groups_equals_separate_evaluations(groups, B):
     with torch.no_grad():
         g.forward_groups(zs, [big[i, :B] for i in range(groups)])
     after = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+    # latent batches that are rows of ONE tensor are read in place (model/gan.py:_stacked_view) — same bits as the torch.cat path
+    g.load_state_dict(state)
+    big2 = torch.full((groups, 2 * B, 1, 32, 32, 32), 7.0).to(DEV)
+    with torch.no_grad():
+        g.forward_groups(list(torch.stack(zs).unbind(0)), [big2[i, :B] for i in range(groups)])
+    assert torch.equal(big2, big)
     g.load_state_dict(state)
     with torch.no_grad():
         ref = [g(z).cpu() for z in zs]
