@@ -423,7 +423,9 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         if (!workspace || workspace_bytes < halo_fwd_workspace_bytes(Cin, Cout)) return 0;
         if ((long)g.Cx * 512 * 4 >= (long)kBufRange || (long)Cin * 8 * 1024 >= (long)kBufRange || batch > 65535 * 16) return 0;
         const int mtiles = sg_cdiv(Cout, 64);
-        if (!force && (long)batch * mtiles < 256) return 0;
+        // (one round of workgroups costs ~130 us at 128 -> 256 channels whatever its size; the split-K gather kernel is faster
+        // below ~160 of them: 113 vs 132 us at 32 samples, 195 vs 129 us at 48 — scripts/small_batch_ab2.py, round 4)
+        if (!force && (long)batch * mtiles < 160) return 0;
         float4* wp = (float4*)workspace;
         const int ntile = mtiles * 2;
         const long total = (long)ntile * Cin * 8 * 64;
@@ -463,13 +465,22 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     // copy / weight-load latency) or 4 waves x 2 tiles (variant 1); 64 channels as 4 waves x 1 tile
     // measured (scripts/halo_bench.py of rounds 1-3: git history): 4 waves x 2 tiles wins below ~1024 workgroups, 8 waves x 1 tile above
     int variant = (debug >> 4) & 3;
-    const int rows = (Cout > 64 && ((debug >> 4) & 3) != 3) ? 128 : 64;   // variant 3: 64-row tiles, twice the workgroups
+    int rows = (Cout > 64 && ((debug >> 4) & 3) != 3) ? 128 : 64;   // variant 3: 64-row tiles, twice the workgroups
     const int ntw = g.OW / 8, nth = g.OH / 8;
     const long tiles = (long)batch * g.OD * nth * ntw;
+    // Small grids (round 4, scripts/small_batch_ab2.py; the critics of the hybrid GANs see 16 - 32 samples): a round of <= 256
+    // workgroups costs the same whatever its size (64 -> 128 channels at 16^3: ~125 us with 128-row tiles, ~70 us with 64-row
+    // tiles), so with 128-row tiles at most half a round (W <= 128) or just over one (256 < W <= 384) the 64-row tiles are chosen:
+    // 16 samples 125 -> 71 us (the gather kernel: 104), 40 samples 238 -> 186 us.  Same weight image (row tiles of 32).
+    if (rows == 128 && variant == 0 && !(debug & 128)) {
+        const long w128 = tiles * sg_cdiv(Cout, 128);
+        if (w128 <= 128 || (w128 > 256 && w128 <= 384)) rows = 64;
+    }
     const int mtiles = sg_cdiv(Cout, rows);
-    // auto-dispatch only where it wins (A/B on MI355X, rounds 1-3): enough workgroups to fill the chip;
-    // below that the split-K gather kernel is faster
-    if (!force && tiles * mtiles < 384) return 0;
+    // auto-dispatch only where it wins (A/B on MI355X): from three quarters of a round of workgroups on; below that the
+    // split-K gather kernel is faster (8 samples at 64 -> 128 channels, 16^3: 63 vs 70 us; 12 samples: 103 vs 70 us; with 128-row
+    // tiles, 20 samples = 160 workgroups: 126 vs 156 us)
+    if (!force && tiles * mtiles < (rows == 128 ? 144 : 192)) return 0;
     if (tiles >= (1L << 31)) return 0;
     if (variant == 0) variant = 2;   // 1 = 4 waves x (32 rows x 64 positions), 2 = 8 waves x (32 x 32): measured 143-146 vs 139-143 TF
     size_t lds = (size_t)2 * kCC * kHS * sizeof(float);
@@ -880,7 +891,9 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     const int ntw = mode1 ? 1 : g.OW / 8, nth = mode1 ? 1 : g.OH / 8, ntd = mode1 ? 1 : g.OD / 2;
     const long tiles = mode1 ? (batch + 1) / 2 : (long)batch * ntd * nth * ntw;
     const int mtiles = (Cin + 63) / 64;
-    if (!force && tiles * mtiles * 8 < 512) return 0;
+    // (round 4, scripts/small_batch_ab2.py: the gather form of the input gradient is slow at every size — 256 -> 128 channels at
+    // 4^3: 110 us at 2 .. 16 samples, 145 at 32, against 75 us for one round of this kernel; 128 -> 64 at 8^3: 59 - 75 us against 43)
+    if (!force && tiles * mtiles * 8 < (mode1 ? 16 : 64)) return 0;
     if (tiles >= (1L << 31) || mtiles > 65535) return 0;
     float4* wp = (float4*)workspace;
     if ((long)8 * mtiles * 2 * Cout * 1024 >= (long)kBufRange) return 0;

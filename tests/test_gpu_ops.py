@@ -700,6 +700,9 @@ def test_conv_fwd_halo_kernel(N, Ci, Co, R):
     y_gather = ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=0)
     close(y_halo, ref, what="halo vs oracle")
     close(y_gather, ref, what="gather vs oracle")
+    if R // 2 >= 8:          # both tile heights of the 8x8-position kernel (64-row tiles: chosen for small grids; 128: debug bit 7)
+        close(ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=1, debug=48), ref, what="halo, 64-row tiles")
+        close(ops.conv_fwd_impl_raw(dev(x), dev(w), dev(b), 1, 0.2, impl=1, debug=128), ref, what="halo, 128-row tiles")
 
 
 @pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 32, 16, 8), (1, 64, 32, 16), (2, 128, 64, 8), (1, 40, 48, 8),
