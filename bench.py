@@ -320,7 +320,11 @@ def make_wgan(rank):
              {k: v.detach().cpu().clone() for k, v in critic.state_dict().items()})
     trainer = WGANTrainer(generator, critic)
     gen = torch.Generator().manual_seed(1000 + rank)   # per-rank synthetic data (batch axis sharded)
-    reals = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(5)]
+    # the real batches are resident where the step reads them: the real halves of the trainer's critic batches (the destination an
+    # input pipeline copies its host batches to; the reference's loop reads each batch where `.to(device)` put it, no device copy)
+    reals = trainer.real_slots(BATCH, resolution=32, updates=5, device="cuda")
+    for slot in reals:
+        slot.copy_((torch.rand(BATCH, 1, 32, 32, 32, generator=gen) * 2 - 1))
     # (the unit's five critic latent batches are one draw: WGANTrainer.step's grouped generator pass then reads them in place)
     zs = list(torch.randn(5, BATCH, 128, generator=gen).cuda().unbind(0))
     zg = torch.randn(BATCH, 128, generator=gen).cuda()

@@ -60,11 +60,13 @@ __global__ void __launch_bounds__(256) head_dot_fwd_kernel(const float* __restri
     if (threadIdx.x == 0) y[n] = ((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.f);
 }
 
-// One workgroup per channel c: 256 threads = 16 float4 columns (S = 64 positions of the channel) x 16 sample groups.
-// thread (col, grp) walks the samples n = grp, grp + 16, ...  All of a thread's loads are independent of each other; eight are
-// requested at a time.
+// One workgroup per channel c: 512 threads = 16 float4 columns (S = 64 positions of the channel) x 32 sample groups.
+// thread (col, grp) walks the samples n = grp, grp + 32, ...  All of a thread's loads are independent of each other; four are
+// requested at a time.  (256 workgroups = one per CU at the critic's 256 channels: eight waves per CU instead of four keep twice
+// the loads in flight — the kernel streams 25 MB in ~11 us, bound by latency, not bandwidth.)
 constexpr int kHeadS = 64;
-__global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
+constexpr int kHeadG = 32;     // sample groups
+__global__ void __launch_bounds__(512) head_dot_bwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                            const float* __restrict__ gy, float* __restrict__ gz,
                                                            float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gbz,
                                                            float4* __restrict__ ap, int N, long K, int act, float slope) {
@@ -86,16 +88,16 @@ __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restri
         ap[e] = make_float4(v[0], v[1], v[2], v[3]);
     };
     int n = grp;
-    for (; n + 7 * 16 < N; n += 8 * 16) {
-        f32x4 zv[8];
-        float g[8];
+    for (; n + 3 * kHeadG < N; n += 4 * kHeadG) {
+        f32x4 zv[4];
+        float g[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (long)(n + 16 * u) * K + k0));
-            g[u] = gy[n + 16 * u];
+        for (int u = 0; u < 4; ++u) {
+            zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (long)(n + kHeadG * u) * K + k0));
+            g[u] = gy[n + kHeadG * u];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -103,11 +105,11 @@ __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restri
                 o[j] = g[u] * wv[j] * head_dact(zv[u][j], act, slope);
             }
             az += (o[0] + o[1]) + (o[2] + o[3]);
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(gz + (long)(n + 16 * u) * K + k0));
-            if (ap) pack(o, n + 16 * u);
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(gz + (long)(n + kHeadG * u) * K + k0));
+            if (ap) pack(o, n + kHeadG * u);
         }
     }
-    for (; n < N; n += 16) {
+    for (; n < N; n += kHeadG) {
         const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (long)n * K + k0);
         const float g = gy[n];
         f32x4 o;
@@ -120,20 +122,21 @@ __global__ void __launch_bounds__(256) head_dot_bwd_kernel(const float* __restri
         *reinterpret_cast<f32x4*>(gz + (long)n * K + k0) = o;
         if (ap) pack(o, n);
     }
-    // fixed-order sums over the 16 sample groups (gw) and over everything (gbz)
-    __shared__ f32x4 redw[16][16];
-    __shared__ float redz[256];
+    // fixed-order sums over the sample groups (gw) and over everything (gbz)
+    __shared__ f32x4 redw[kHeadG][16];
+    __shared__ float redz[16 * kHeadG];
     redw[grp][col] = aw;
     redz[threadIdx.x] = az;
     __syncthreads();
     if (grp == 0) {
         f32x4 t = redw[0][col];
 #pragma unroll
-        for (int g2 = 1; g2 < 16; ++g2) t += redw[g2][col];
+        for (int g2 = 1; g2 < kHeadG; ++g2) t += redw[g2][col];
         if (gw) *reinterpret_cast<f32x4*>(gw + k0) = t;
     }
     if (threadIdx.x < 64) {
-        float t = (redz[threadIdx.x] + redz[threadIdx.x + 64]) + (redz[threadIdx.x + 128] + redz[threadIdx.x + 192]);
+        float t = ((redz[threadIdx.x] + redz[threadIdx.x + 64]) + (redz[threadIdx.x + 128] + redz[threadIdx.x + 192])) +
+                  ((redz[threadIdx.x + 256] + redz[threadIdx.x + 320]) + (redz[threadIdx.x + 384] + redz[threadIdx.x + 448]));
         t = sg_wave_sum(t);
         if (threadIdx.x == 0 && gbz) gbz[c] = t;
     }
@@ -168,7 +171,7 @@ int sg_head_dot_bwd(const float* z, const float* w, const float* gy, float* gz, 
     SG_CHECK_ARG(act == SG_ACT_NONE || act == SG_ACT_LEAKY || act == SG_ACT_RELU);
     SG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)gz & 15) == 0 && ((uintptr_t)gw & 15) == 0);
     SG_CHECK_ARG(!gz_image || C % 128 == 0);     // the image has no padded row tiles
-    hipLaunchKernelGGL(head_dot_bwd_kernel, dim3((unsigned)C), dim3(256), 0, stream, z, w, gy, gz, gw, gb, gbz, (float4*)gz_image, N,
+    hipLaunchKernelGGL(head_dot_bwd_kernel, dim3((unsigned)C), dim3(512), 0, stream, z, w, gy, gz, gw, gb, gbz, (float4*)gz_image, N,
                        (long)C * S, act, slope);
     SG_CHECK_LAUNCH();
     return SG_OK;

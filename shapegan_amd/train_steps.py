@@ -36,11 +36,28 @@ class WGANTrainer(object):
         self.g_opt = optim.RMSprop(generator.parameters(), lr=lr)    # :45
         self.c_opt = optim.RMSprop(critic.parameters(), lr=lr, clip=clip)  # :46 + clip_weights :71 fused
         self.g_bucket, self.c_bucket = GradBucket(self.g_opt), GradBucket(self.c_opt)
-        self._batches = None      # `step`: the critic batches whose fake halves one grouped generator pass fills
+        self._batches = None      # the unit's critic batches [updates, n_fake + n_real, 1, R, R, R], kept between units
 
-    def critic_step(self, real, z, both=None):
-        """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw.  `both` (optional): a [n_fake + n_real, 1,
-        R, R, R] batch whose fake half already holds generator(z) (see `step`)."""
+    def _unit_batches(self, updates, n_fake, n_real, res, device):
+        shape = (updates, n_fake + n_real, 1, res, res, res)
+        if self._batches is None or tuple(self._batches.shape) != shape or self._batches.device != torch.device(device):
+            self._batches = torch.empty(shape, dtype=torch.float32, device=device)
+        return self._batches
+
+    def real_slots(self, n_real, n_fake=None, resolution=32, updates=5, device=None):
+        """Where `step` wants the unit's real batches: the real halves of its critic batches, `updates` tensors [n_real, 1, R, R, R].
+        critic(fake) and critic(real) are one pass over a concatenated batch here (see `critic_step`), which costs one device copy
+        of every real batch that the reference does not have (its loader's batch is read where `.to(device)` put it,
+        train_wgan.py:56-66).  An input pipeline that delivers its batches INTO these slots (`slot.copy_(host_batch,
+        non_blocking=True)`) and passes the slots as `reals` gets that copy back: `critic_step` notices the batch is in place."""
+        n_fake = n_real if n_fake is None else n_fake
+        device = device if device is not None else next(self.critic.parameters()).device
+        batches = self._unit_batches(updates, n_fake, n_real, resolution, device)
+        return [batches[g, n_fake:] for g in range(updates)]
+
+    def critic_step(self, real, z, both=None, fake_ready=False):
+        """train_wgan.py:60-71.  `z` [B,128] replaces generator.generate's CPU draw.  `both` (optional): the [n_fake + n_real, 1,
+        R, R, R] batch to use; fake_ready: its fake half already holds generator(z) (see `step`)."""
         self.c_opt.zero_grad()
         # The critic has no batch statistics, so critic(fake) and critic(real) (train_wgan.py:64-66) are one pass over
         # the concatenated batch: same outputs and gradients, half the launches, one weight-gradient reduction.  The generator
@@ -50,10 +67,12 @@ class WGANTrainer(object):
         with torch.no_grad():                      # == generate(...).detach(); BN running stats still update
             if both is None:
                 both = torch.empty((n_fake + n_real, 1, res, res, res), dtype=torch.float32, device=real.device)
+            if not fake_ready:
                 fake = self.generator(z, out=both[:n_fake])
                 if fake.data_ptr() != both.data_ptr():
                     both[:n_fake].copy_(fake)
-            both[n_fake:].copy_(real.reshape(n_real, 1, res, res, res))
+            if not (real.data_ptr() == both[n_fake:].data_ptr() and real.is_contiguous() and real.numel() == both[n_fake:].numel()):
+                both[n_fake:].copy_(real.reshape(n_real, 1, res, res, res))     # (else: delivered in place, `real_slots`)
         out = self.critic(both)
         out_fake, out_real = out[:n_fake], out[n_fake:]
         loss = ops.mean_difference(out, n_fake)        # mean(out_fake) - mean(out_real), one launch
@@ -94,17 +113,18 @@ class WGANTrainer(object):
                 if i == 0:
                     self.generator_step(z_gen)
             return last
-        self.critic_step(reals[0], zs_critic[0])
+        same = same and reals[0].shape == reals[1].shape and zs_critic[0].shape == zs_critic[1].shape
+        n_fake, n_real, res = zs_critic[1].shape[0], reals[1].shape[0], reals[1].shape[-1]
+        batches = self._unit_batches(len(reals), n_fake, n_real, res, reals[1].device) if same else None
+        self.critic_step(reals[0], zs_critic[0], batches[0] if same else None)
         self.generator_step(z_gen)
-        rest, n_fake, n_real, res = len(reals) - 1, zs_critic[1].shape[0], reals[1].shape[0], reals[1].shape[-1]
-        shape = (rest, n_fake + n_real, 1, res, res, res)
-        if self._batches is None or tuple(self._batches.shape) != shape or self._batches.device != reals[1].device:
-            self._batches = torch.empty(shape, dtype=torch.float32, device=reals[1].device)      # kept between units
+        if not same:
+            batches = self._unit_batches(len(reals), n_fake, n_real, res, reals[1].device)
         with torch.no_grad():
-            self.generator.forward_groups(list(zs_critic[1:]), [self._batches[g, :n_fake] for g in range(rest)])
+            self.generator.forward_groups(list(zs_critic[1:]), [batches[g, :n_fake] for g in range(1, len(reals))])
         last = None
-        for g, (real, z) in enumerate(zip(reals[1:], zs_critic[1:])):
-            last = self.critic_step(real, z, self._batches[g])
+        for g, (real, z) in enumerate(zip(reals[1:], zs_critic[1:]), start=1):
+            last = self.critic_step(real, z, batches[g], fake_ready=True)
         return last
 
 

@@ -286,3 +286,4 @@ def test_conv_transpose3d_to_one_channel_with_input_transform_cpu(on_cpu):
 def test_grouped_generator_pass_cpu(on_cpu):
     M.test_generator_forward_groups_equals_separate_evaluations(3, 5)
     M.test_wgan_step_with_grouped_generator_pass_equals_the_updates_one_by_one(n_units=1)
+    M.test_wgan_step_on_real_batches_delivered_into_the_trainers_slots()

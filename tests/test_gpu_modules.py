@@ -381,6 +381,41 @@ def test_wgan_step_with_grouped_generator_pass_equals_the_updates_one_by_one(n_u
             assert float(bad.double().mean()) < 2e-2, "%s: %.3f %% of the entries differ" % (k, 100 * float(bad.double().mean()))
 
 
+def test_wgan_step_on_real_batches_delivered_into_the_trainers_slots():
+    """WGANTrainer.real_slots: the real halves of the unit's critic batches.  A loader that writes its batches there saves the
+    device copy into the concatenated [fake; real] batch; the step must be bit-identical to the one fed ordinary tensors (same
+    kernels on the same values), over two units (the slots are reused, the fake halves are overwritten in between)."""
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
+    gen = torch.Generator().manual_seed(79)
+    B = 8
+    units = [([(torch.rand(B, 32, 32, 32, generator=gen) * 2 - 1) for _ in range(5)],
+              list(torch.randn(5, B, 128, generator=gen).to(DEV).unbind(0)), torch.randn(B, 128, generator=gen).to(DEV))
+             for _ in range(2)]
+
+    def run(in_place):
+        torch.manual_seed(80)
+        g, c = Generator(), Discriminator()
+        tr = WGANTrainer(g, c)
+        for reals, zs, zg in units:
+            if in_place:
+                slots = tr.real_slots(B, device=DEV)
+                assert len(slots) == 5 and slots[0].shape == (B, 1, 32, 32, 32)
+                for slot, r in zip(slots, reals):
+                    slot.copy_(r.reshape(slot.shape))
+                tr.step(slots, zs, zg)
+                for slot, r in zip(slots, reals):
+                    assert torch.equal(slot.cpu(), r.reshape(slot.shape)), "a real batch was overwritten"
+            else:
+                tr.step([r.to(DEV) for r in reals], zs, zg)
+        state = {("g", k): v.detach().cpu().clone() for k, v in g.state_dict().items()}
+        state.update({("c", k): v.detach().cpu().clone() for k, v in c.state_dict().items()})
+        return state
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("groups,B", [(4, 64), (3, 5)])
 def test_generator_forward_groups_equals_separate_evaluations(groups, B):
     """Generator.forward_groups against `groups` separate inference-mode evaluations from the same state: samples (written into
