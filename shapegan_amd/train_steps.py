@@ -40,7 +40,10 @@ class WGANTrainer(object):
 
     def _unit_batches(self, updates, n_fake, n_real, res, device):
         shape = (updates, n_fake + n_real, 1, res, res, res)
-        if self._batches is None or tuple(self._batches.shape) != shape or self._batches.device != torch.device(device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:          # "cuda" names the current device: compare like with like
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._batches is None or tuple(self._batches.shape) != shape or self._batches.device != device:
             self._batches = torch.empty(shape, dtype=torch.float32, device=device)
         return self._batches
 

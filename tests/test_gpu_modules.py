@@ -401,9 +401,11 @@ def test_wgan_step_on_real_batches_delivered_into_the_trainers_slots():
             if in_place:
                 slots = tr.real_slots(B, device=DEV)
                 assert len(slots) == 5 and slots[0].shape == (B, 1, 32, 32, 32)
+                assert tr.real_slots(B, device=DEV)[0].data_ptr() == slots[0].data_ptr()      # the same buffer every time
                 for slot, r in zip(slots, reals):
                     slot.copy_(r.reshape(slot.shape))
                 tr.step(slots, zs, zg)
+                assert tr.real_slots(B, device=DEV)[0].data_ptr() == slots[0].data_ptr()      # ... and the step used it
                 for slot, r in zip(slots, reals):
                     assert torch.equal(slot.cpu(), r.reshape(slot.shape)), "a real batch was overwritten"
             else:
