@@ -81,7 +81,7 @@ class NativeComm(object):
             msg = self.lib.sg_comm_last_error() if rc != 0 else b""
             result["rc"], result["msg"] = rc, (msg or b"").decode()
         if init_timeout is None:
-            init_timeout = float(os.environ.get("SG_COMM_INIT_TIMEOUT", "120"))
+            init_timeout = float(os.environ.get("SG_COMM_INIT_TIMEOUT", "300"))
         th = threading.Thread(target=init, name="sg_allreduce_init", daemon=True)
         th.start()
         th.join(init_timeout)
