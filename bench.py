@@ -2,8 +2,15 @@
 """bench.py — BASELINE.json's headline metric on MI355X: GAN train steps/sec @32^3 voxels (+ SDFNet Mpoints/sec).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W [--config wgan|hybrid_progressive|hybrid_wgan|sdf]      (self-launching)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--config wgan|hybrid_progressive|hybrid_wgan|sdf]
+        bench.py --gpus N --steps K --warmup W [--config ...]                                             (launcher form)
+
+Both multi-GPU forms run the same thing, one process per GPU: without WORLD_SIZE in the environment `--gpus N > 1` makes this
+process the launcher (`self_launch`: N copies of itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free
+MASTER_PORT; rank 0's single JSON line is passed through on stdout, every rank's stderr is prefixed `[rank r]`, the first rank
+that fails stops the others and its exit code is returned) — the reference's one multi-GPU script needs no launcher either
+(train_hybrid_progressive_gan.py:62-68).
 
 Default workload (`--config wgan`, BASELINE configs[1], the configuration the metric is quoted on): one "step" is one pass
 of the train_wgan.py cadence over synthetic data already resident in HBM — five critic updates (generator forward, one
@@ -456,6 +463,64 @@ def replica_digests(optimizers, world):
 WORKLOADS = {"wgan": make_wgan, "hybrid_progressive": make_hybrid_progressive, "hybrid_wgan": make_hybrid_wgan, "sdf": make_sdf}
 
 
+def self_launch(gpus, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: starts N copies of this script, one per GPU, with the environment
+    torch.distributed.run would have given them (rendezvous on 127.0.0.1 and a free port), passes rank 0's stdout (the ONE
+    JSON line) through, prefixes every rank's stderr lines with its rank, and returns the first non-zero exit code after stopping
+    the remaining ranks (by the PIDs started here, never by pattern)."""
+    import socket
+    import subprocess
+    import threading
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs, pumps = [], []
+
+    def pump(stream, sink, prefix):
+        for line in iter(stream.readline, ""):
+            sink.write(prefix + line)
+            sink.flush()
+        stream.close()
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+        p = subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, text=True, bufsize=1,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(p)
+        if r == 0:
+            pumps.append(threading.Thread(target=pump, args=(p.stdout, sys.stdout, ""), daemon=True))
+        pumps.append(threading.Thread(target=pump, args=(p.stderr, sys.stderr, "[rank %d] " % r), daemon=True))
+    for t in pumps:
+        t.start()
+    rc, live = 0, set(range(gpus))
+    try:
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code
+                        print("bench.py launcher: rank %d exited with code %d — stopping ranks %s" % (r, code, sorted(live)),
+                              file=sys.stderr, flush=True)
+                        break
+            time.sleep(0.05)
+    finally:
+        for r in live:                       # only reached with ranks alive after a failure or an interrupt
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    for t in pumps:
+        t.join(timeout=10)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,9 +531,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / SDFNet side measurements")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))        # this process becomes the launcher of N ranks
+
     from shapegan_amd import parallel
     rank, world, local = parallel.init_distributed()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: either run `python bench.py --gpus N` with no WORLD_SIZE in the "
+                 "environment (it launches its own ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`"
+                 % (args.gpus, world))
     torch.cuda.set_device(local % torch.cuda.device_count())
     step, info, wgan_data = WORKLOADS[args.config](rank)
 

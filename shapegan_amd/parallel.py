@@ -8,9 +8,11 @@ identical updates afterwards), inputs are generated/loaded per rank, and the onl
 1/world factor is applied inside the optimizer kernel (grad_scale), not as a separate pass.
 """
 import atexit
+import json
 import os
 import sys
 import threading
+import time
 import weakref
 
 import torch
@@ -48,6 +50,22 @@ def _close_weak(ref):
         comm.close()
 
 
+def _rank_state(rank, world, device):
+    """What this rank knows about itself when a communicator bring-up goes wrong (printed as one JSON object per rank)."""
+    env = {k: v for k, v in os.environ.items()
+           if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "MASTER_", "SG_")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    state = {"rank": rank, "world": world, "device": device, "pid": os.getpid(), "env": env,
+             "torch_distributed": dist.get_backend() if dist.is_initialized() else None}
+    try:
+        state["visible_devices"] = torch.cuda.device_count()
+        state["device_name"] = torch.cuda.get_device_name(device)
+        free, total = torch.cuda.mem_get_info(device)
+        state["hbm_free_gb"], state["hbm_total_gb"] = round(free / 2 ** 30, 1), round(total / 2 ** 30, 1)
+    except Exception as e:       # noqa: BLE001 — a diagnostic must not raise
+        state["device_query_error"] = str(e)
+    return state
+
+
 class NativeComm(object):
     """The C-ABI gradient exchange (include/shapegan_hip.h: sg_allreduce_*, libshapegan_comm.so): an RCCL communicator with
     its own stream; `launch` enqueues an in-place all-reduce(sum) of a contiguous fp32 CUDA tensor ordered after the current
@@ -83,10 +101,18 @@ class NativeComm(object):
         if init_timeout is None:
             init_timeout = float(os.environ.get("SG_COMM_INIT_TIMEOUT", "300"))
         th = threading.Thread(target=init, name="sg_allreduce_init", daemon=True)
+        t0 = time.perf_counter()
         th.start()
         th.join(init_timeout)
+        self.init_seconds = time.perf_counter() - t0
         if th.is_alive():
+            # everything a post-mortem of a first multi-GPU bring-up needs, from THIS rank, before the job dies
+            print("shapegan_amd.parallel: rank %d of %d STILL INSIDE ncclCommInitRank after %.0f s — %s"
+                  % (rank, world, init_timeout, json.dumps(_rank_state(rank, world, device))), file=sys.stderr, flush=True)
             raise CommInitTimeout("shapegan_comm: ncclCommInitRank did not return within %.0f s (rank %d of %d)" % (init_timeout, rank, world))
+        if os.environ.get("SG_COMM_VERBOSE", "1") != "0" and world > 1:
+            print("shapegan_amd.parallel: rank %d of %d: ncclCommInitRank on device %d returned %d after %.2f s"
+                  % (rank, world, device, result["rc"], self.init_seconds), file=sys.stderr, flush=True)
         if result["rc"] != 0:
             raise RuntimeError("shapegan_comm init failed (%d): %s" % (result["rc"], result["msg"]))
         self.handle, self.rank, self.world = handle, rank, world
@@ -204,7 +230,7 @@ def native_comm():
     if _native is None:
         TRANSPORT.update(name="torch-" + dist.get_backend(), reason="fallback: " + reason)
     else:
-        TRANSPORT.update(name="native-rccl", reason="", **_native.info())
+        TRANSPORT.update(name="native-rccl", reason="", comm_init_seconds=round(_native.init_seconds, 3), **_native.info())
     return _native
 
 

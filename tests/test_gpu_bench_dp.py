@@ -28,13 +28,16 @@ def _free_port():
     return port
 
 
-def _run_bench(config, extra_env, steps=2, warmup=1, timeout=900):
-    env = dict(os.environ)
+def _run_bench(config, extra_env, steps=2, warmup=1, timeout=900, plain=False):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update({"SG_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4"})
     env.update(extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
-           "--no-extras", "--config", config]
+    tail = ["bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--no-extras", "--config", config]
+    if plain:      # the driver's N = 1 command shape with N = 2: bench.py launches its own ranks
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, "bench.py --gpus 2 --config %s failed (%d):\n%s\n%s" % (config, res.returncode, res.stdout[-2000:], res.stderr[-4000:])
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -60,6 +63,15 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(config):
     line, _ = _run_bench(config, {})
     comm = _check_line(line, config)
     assert comm["transport"] == "torch-gloo" and comm["reason"] == "backend is not nccl"
+
+
+@pytest.mark.parametrize("config", ["wgan", "hybrid_progressive", "hybrid_wgan", "sdf"])
+def test_bench_plain_command_launches_its_own_ranks(config):
+    """`python bench.py --gpus 2 --config <c>` with no launcher and no WORLD_SIZE: the same line as the torchrun form."""
+    line, err = _run_bench(config, {}, plain=True)
+    comm = _check_line(line, config)
+    assert comm["transport"] == "torch-gloo"
+    assert "[rank 0]" in err or "[rank 1]" in err or err == ""       # rank output, when there is any, carries its rank
 
 
 def test_native_exchange_refuses_two_ranks_on_one_device_loudly_and_uniformly():
