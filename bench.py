@@ -70,10 +70,21 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
+PROFILE_TAGS = ("r05", "r04", "r03", "r02")     # newest committed profile pass first (scripts/profile_round.sh + collect_profiles.py)
+COLD_BYTES = 640 << 20     # > 2 x the 256 MB Infinity Cache: what a rotation of operand sets must cover to be cold
+
+
 def conv_kernel_table():
     """Every conv form of the WGAN step at the shape it runs with in the critic update (fake+real = 128 samples) or the
     generator (64 samples), timed through the C-ABI entry (weight-image packs included).  flop = 2*Cout*Cin*64 per output
-    voxel; bytes = each operand once."""
+    voxel; bytes = each operand once.
+
+    The HBM-bound rows are timed COLD: a replay loop over one set of buffers keeps a working set of 75 - 151 MB inside the 256 MB
+    Infinity Cache and reports a cache rate, not an HBM rate (conv_fwd_c1 44.9 us warm, 54 - 57 us in every rocprof
+    measurement).  Each call of such a row therefore reads the next of K distinct operand sets and writes a fresh output block
+    (the last K results stay alive, so the allocator cannot hand the same block back), K chosen so that the rotation covers
+    > 640 MB; `us_warm` keeps the replay figure next to it, `us_in_step` the average duration of that kernel at that shape inside
+    the profiled training step (`profiles/rNN_wgan_step_timeline.txt`) where the committed profile has it."""
     from shapegan_amd import ops
     nb = 2 * BATCH
     rows = []
@@ -84,11 +95,27 @@ def conv_kernel_table():
         rows.append({"name": name, "kernel": kernel, "bound": "mfma", "flop": flop, "us": round(ms * 1e3, 1),
                      "tflops": round(tf, 1), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
 
-    def hbm(name, kernel, nbytes, flop, fn):
-        ms = event_time_ms(fn, 20)
+    def hbm(name, kernel, nbytes, flop, make, call, in_step=None):
+        """make() -> one operand set; call(set) -> the result tensor."""
+        k = max(4, int(COLD_BYTES // nbytes) + 1)
+        sets = [make() for _ in range(k)]
+        alive = [None] * k
+        state = {"i": 0}
+
+        def cold():
+            i = state["i"] = (state["i"] + 1) % k
+            alive[i] = call(sets[i])
+        ms = event_time_ms(cold, 4 * k)
+        ms_warm = event_time_ms(lambda: call(sets[0]), 20)
         gbs = nbytes / (ms * 1e-3) / 1e9
-        rows.append({"name": name, "kernel": kernel, "bound": "hbm", "bytes": nbytes, "flop": flop, "us": round(ms * 1e3, 1),
-                     "gb_per_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        row = {"name": name, "kernel": kernel, "bound": "hbm", "bytes": nbytes, "flop": flop, "us": round(ms * 1e3, 1),
+               "gb_per_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "timing": "cold: %d operand sets in rotation" % k,
+               "us_warm": round(ms_warm * 1e3, 1)}
+        us_step = step_kernel_us(kernel, in_step)
+        if us_step is not None:
+            row["us_in_step"], row["frac_in_step"] = us_step, round(nbytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        rows.append(row)
+        del sets, alive
 
     x16 = torch.randn(nb, 64, 16, 16, 16, device="cuda")
     w2 = torch.randn(128, 64, 4, 4, 4, device="cuda") * 0.02
@@ -109,27 +136,53 @@ def conv_kernel_table():
     mfma("Conv3d 128->256 input-gradient / ConvT forward, 4^3 -> 8^3, 128 samples", "conv_dgrad_halo_kernel<1>", f3,
          lambda: ops.conv_dgrad_raw(y4, w3, None, 128))
     mfma("Conv3d 128->256 weight-gradient, 128 samples", "conv_wgrad_halo4_kernel", f3, lambda: ops.conv_wgrad_raw(y4, x8, 128))
+    del x16, y8, x8, y4
     # HBM-bound edge layers (one channel on one side)
-    x32 = torch.randn(nb, 1, 32, 32, 32, device="cuda")
     w1 = torch.randn(64, 1, 4, 4, 4, device="cuda") * 0.1
     b1 = torch.zeros(64, device="cuda")
-    y16 = torch.randn(nb, 64, 16, 16, 16, device="cuda")
+    nx, ny = nb * 32768, nb * 64 * 4096
     f1 = 2.0 * 64 * 64 * 4096 * nb
-    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv_fwd_c1_kernel<2,1>", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
-        lambda: ops.conv_fwd_raw(x32, w1, b1, 1, 0.2))
-    hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv_wgrad_c1_kernel<2,0>", 4.0 * (x32.numel() + y16.numel() + w1.numel()), f1,
-        lambda: ops.conv_wgrad_raw(y16, x32, 1))
-    ya = torch.randn(nb, 64, 16, 16, 16, device="cuda")
+    mk_x = lambda: torch.randn(nb, 1, 32, 32, 32, device="cuda")
+    mk_y = lambda n=nb: torch.randn(n, 64, 16, 16, 16, device="cuda")
+    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv_fwd_c1_kernel<2,1>", 4.0 * (nx + ny + w1.numel()), f1,
+        mk_x, lambda x: ops.conv_fwd_raw(x, w1, b1, 1, 0.2), in_step="largest")
+    hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv_wgrad_c1_kernel<2,0>", 4.0 * (nx + ny + w1.numel()), f1,
+        lambda: (mk_y(), mk_x()), lambda s: ops.conv_wgrad_raw(s[0], s[1], 1))
     hbm("Conv3d 1->64 weight + bias gradient through LeakyReLU (the critic's first layer: reads dy and y), 128 samples",
-        "conv_wgrad_c1_kernel<2,LEAKY>", 4.0 * (x32.numel() + 2 * y16.numel() + w1.numel()), f1,
-        lambda: ops.conv_wgrad_act_raw(y16, ya, x32, 1, 0.2))
-    y16g = y16[:BATCH].contiguous()
-    hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "convT_c1_stream_kernel<true,false,true,0>", 4.0 * (y16g.numel() + BATCH * 32768 + w1.numel()),
-        f1 / 2, lambda: ops.conv_dgrad_raw(y16g, w1, None, 1))
+        "conv_wgrad_c1_kernel<2,LEAKY>", 4.0 * (nx + 2 * ny + w1.numel()), f1,
+        lambda: (mk_y(), mk_y(), mk_x()), lambda s: ops.conv_wgrad_act_raw(s[0], s[1], s[2], 1, 0.2), in_step="largest")
+    hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "convT_c1_stream_kernel<true,false,true,0>",
+        4.0 * (ny // 2 + BATCH * 32768 + w1.numel()), f1 / 2, lambda: mk_y(BATCH), lambda y: ops.conv_dgrad_raw(y, w1, None, 1), in_step="smallest")
     return rows
 
 
-PROFILE_TAGS = ("r04", "r03", "r02")     # newest committed profile pass first (scripts/profile_round.sh + collect_profiles.py)
+def step_kernel_us(kernel, which):
+    """Average duration (us) of `kernel`'s launches at the table's shape inside the profiled 5+1 training step of the newest
+    committed `profiles/rNN_wgan_step_timeline.txt` (one line per launch: start, gap, duration, name).  The step runs the
+    one-channel kernels at two batch sizes (128 samples in the critic updates, 64 in the generator update): `which` = "largest" /
+    "smallest" picks the launches within 35 % of the longest / shortest one.  None: the profile has no such kernel (or the step
+    does not run it at the table's shape — the plain one-channel weight gradient only runs at 64 samples there)."""
+    import re
+    if which is None:
+        return None
+    want = kernel.replace(" ", "").replace("LEAKY", "1")
+    for tag in PROFILE_TAGS:
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_wgan_step_timeline.txt")) as fh:
+                lines = fh.read().splitlines()
+        except OSError:
+            continue
+        durs = []
+        for ln in lines:
+            m = re.match(r"\s*[-\d.]+\s+\+\s+[-\d.]+ gap\s+([\d.]+) us\s+(.*)$", ln)
+            if m and m.group(2).replace(" ", "") == want:
+                durs.append(float(m.group(1)))
+        if not durs:
+            continue
+        ref = max(durs) if which == "largest" else min(durs)
+        pick = [d for d in durs if abs(d - ref) <= 0.35 * ref]
+        return round(sum(pick) / len(pick), 1)
+    return None
 
 
 def dominant_kernel(rows):

@@ -761,20 +761,61 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         pin_vgpr(ovoff[tn]);
     }
     const unsigned bvoff = kpar * 16;
+    // Output parities pw = 0 and pw = 1 interleave at 4 bytes in dx: written by two parity passes, every 32-byte sector of dx was
+    // half-written twice and the memory side filled each partial write from HBM (round 4 counters: 268 MB written and 379 MB
+    // fetched for a 134 MB output).  A workgroup that walks both (ppw >= 2: parities 2k and 2k + 1 are consecutive) keeps the
+    // finished values of pw = 0 in registers and completes them with pw = 1 to 8-byte pieces: a row of 8 (4) lanes writes 64
+    // (32) contiguous bytes, half as many store instructions.
+#ifdef SG_DGRAD_NO_PAIR      // ablation build (scripts/ab_build.sh): the 4-byte stores of rounds 1 - 4
+    const bool paired = false;
+#else
+    const bool paired = a.ppw >= 2;
+#endif
+    float keep[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) keep[t][q] = 0.f;
     auto write_parity = [&](int par) __attribute__((always_inline)) {   // dx[n'][ci][2q + p] = act(acc + bias[ci]); acc = 0
         const int pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
-        const unsigned oshift = (unsigned)((pd * a.g.IH + ph) * a.g.IW + pw) * 4u;
+        const unsigned oshift = (unsigned)((pd * a.g.IH + ph) * a.g.IW) * 4u;   // of the (pd, ph, pw = 0) element
         if (nn < a.batch) {
+            if (paired && pw == 0) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);   // scalar part of the channel; the lane adds 4*kpar
-                if (cis < a.Cin) {   // Cin % 8 == 0: the whole 8-channel block is in or out
-                    const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
+                for (int q = 0; q < 16; ++q) {
+                    const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);
+                    const float bv = a.bias && cis < a.Cin ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) {
-                        const float v = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff[tn],
-                                                              (int)((unsigned)cis * (unsigned)I3 * 4u + oshift), 0);
+                    for (int tn = 0; tn < 2; ++tn) keep[tn][q] = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
+                }
+            } else if (paired) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);   // scalar part of the channel; the lane adds 4*kpar
+                    if (cis < a.Cin) {   // Cin % 8 == 0: the whole 8-channel block is in or out
+                        const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) {
+                            u32x2 v;
+                            v.x = __builtin_bit_cast(unsigned, keep[tn][q]);
+                            v.y = __builtin_bit_cast(unsigned, sg_apply_act(acc[tn][q] + bv, a.act, a.slope));
+                            __builtin_amdgcn_raw_buffer_store_b64(v, ores, (int)ovoff[tn], (int)((unsigned)cis * (unsigned)I3 * 4u + oshift), 0);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);
+                    if (cis < a.Cin) {
+                        const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) {
+                            const float v = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff[tn],
+                                                                  (int)((unsigned)cis * (unsigned)I3 * 4u + oshift + 4u * pw), 0);
+                        }
                     }
                 }
             }

@@ -382,6 +382,23 @@ def param_epoch_of(*tensors):
     return param_epoch_of_ptrs([t.data_ptr() for t in tensors])
 
 
+def writers_known(*tensors):
+    """True when every tensor lives in a registered flat parameter buffer (shapegan_amd.optim): then everything that writes it is
+    ours and announces itself — the optimizer's step, clip_weights, load_state_dict, broadcast_parameters and graph replays all
+    move a parameter epoch.  A weight outside such a buffer may be written through `.data` (the reference's own idiom:
+    `parameter.data.clamp_(...)`, model/gan.py:67-69; EMA copies; manual loading), which moves neither `tensor._version` nor an
+    epoch — images derived from it must not be reused.  A `.data` writer of a flat-buffer parameter calls
+    `ops.invalidate_weight_images()` (INTEGRATION.md)."""
+    for t in tensors:
+        a = t.data_ptr()
+        for r in _PARAM_RANGES:
+            if r[0] <= a < r[1]:
+                break
+        else:
+            return False
+    return True
+
+
 # ---- gradient destinations ---------------------------------------------------------------------------------------------
 # A flat-buffer optimizer (shapegan_amd.optim) registers, per parameter, the slice of its flat gradient buffer that
 # belongs to it.  In a plain backward (no create_graph) the weight-gradient kernels write straight into that slice and hand

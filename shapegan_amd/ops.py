@@ -38,7 +38,7 @@ def conv_fwd_raw(x, w, bias, act=ACT_NONE, slope=0.0, keep=False):
     y = torch.empty((N, Co, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
     lib = _lib()
     nb = lib.sg_conv3d_k4s2p1_fwd_workspace_bytes(N, Cx, Co, D // 2, H // 2, W // 2)
-    if keep and Cx > 1 and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if keep and Cx > 1 and x.is_cuda and L.writers_known(w) and not torch.cuda.is_current_stream_capturing():
         ws, unchanged = _KEPT.get(w, nb, (N, Cx, Ct, Cx, Co, D, H, W), kind=0)
         check(lib.sg_conv3d_k4s2p1_fwd_keep(ptr(x), ptr(w), ptr(bias), ptr(y), N, Cx, Ct, Cx, Co, D, H, W, act, slope, ptr(ws),
                                             ws.numel(), int(unchanged), stream()), "conv3d_fwd_keep")
@@ -160,6 +160,14 @@ class _KeptWeightImages(object):
 _KEPT = _KeptWeightImages()
 
 
+def invalidate_weight_images():
+    """For code that writes parameters behind the library's back — `p.data.mul_(...)`, `p.data.copy_(...)` on a parameter that
+    lives in a shapegan_amd.optim flat buffer (such writes move neither `tensor._version` nor a parameter epoch): every image
+    derived from any weight (kept conv images, the SDFNet pack) is rebuilt at its next use.  Parameters outside a flat buffer
+    (stock torch.optim, the reference's scripts) need no call: their images are rebuilt on every call."""
+    L.bump_param_epoch()
+
+
 def register_pack_group(weights):
     """Declares conv weights that change together (the parameters of one network): their kept images are rebuilt in one launch."""
     _KEPT.register_group(list(weights))
@@ -183,7 +191,7 @@ def conv_dgrad_raw(dy, w, bias, cin, act=ACT_NONE, slope=0.0, keep=False, out=No
     lib = _lib()
     nb = lib.sg_conv3d_k4s2p1_dgrad_workspace_bytes_for(N, cin, Co, OD, OH, OW)
     # (one-channel layers pack nothing; a graph under capture must contain its own packing launch: its replays see new weights)
-    if keep and cin > 1 and dy.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if keep and cin > 1 and dy.is_cuda and L.writers_known(w) and not torch.cuda.is_current_stream_capturing():
         ws, unchanged = _KEPT.get(w, nb, (N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW), kind=1)
         check(lib.sg_conv3d_k4s2p1_dgrad_keep(ptr(dy), ptr(w), ptr(bias), ptr(dx), N, cin, Ct, cin, Co, 2 * OD, 2 * OH, 2 * OW,
                                               act, slope, ptr(ws), ws.numel(), int(unchanged), stream()), "conv3d_dgrad_keep")
@@ -898,7 +906,8 @@ class _PackCache(object):
         ptrs = [p.data_ptr() for p in params]
         key = (kin_used, latent, L.param_epoch_of_ptrs(ptrs)) + tuple(ptrs) + tuple(p._version for p in params)
         entry = self.entries.get(dev)
-        if entry is None or entry[0] != key:
+        # (parameters outside a flat optimizer buffer can be written through `.data` without a trace: never reuse their image)
+        if entry is None or entry[0] != key or not L.writers_known(*params):
             lib = _lib()
             n = lib.sg_sdfnet_packed_floats(kin_used)
             packed = torch.empty(n, dtype=torch.float32, device=dev)

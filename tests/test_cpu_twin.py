@@ -81,6 +81,10 @@ def test_conv_wgrad_act_fallback(on_cpu, monkeypatch):
     OPS.test_conv_wgrad_act_falls_back_when_scratch_exceeds_cap(monkeypatch)
 
 
+def test_data_writes_are_seen(on_cpu, monkeypatch):
+    OPS.test_a_write_through_data_is_never_served_a_stale_weight_image(monkeypatch)
+
+
 def test_from_sdf_zero_channels(on_cpu):
     OPS.test_conv_from_sdf_zero_channels()
 

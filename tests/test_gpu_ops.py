@@ -148,16 +148,84 @@ def test_conv_transpose_keeps_its_weight_image_until_the_weight_changes(monkeypa
         assert flags[-1] is True and torch.equal(y6.detach(), y5)
     # a different weight at a recycled address is not mistaken for the old one
     w1 = torch.nn.Parameter(torch.randn(128, 64, 4, 4, 4).cuda() * 0.03)
+    opt1 = optim.RMSprop([w1], lr=0.05)                    # (images are kept for flat-buffer parameters only)
     x = torch.randn(2, 128, 8, 8, 8).cuda()
     with torch.no_grad():
         ops.conv_transpose3d_k4s2p1(x, w1, None)
         addr = w1.data_ptr()
-        del w1
+        del w1, opt1
         w2 = torch.nn.Parameter(torch.randn(128, 64, 4, 4, 4).cuda() * 0.03)
+        opt2 = optim.RMSprop([w2], lr=0.05)
+        del flags[:]
         y = ops.conv_transpose3d_k4s2p1(x, w2, None)
     if w2.data_ptr() == addr:
-        assert flags[-1] is False
+        assert flags == [False]
     close(y, F.conv_transpose3d(x.cpu(), w2.detach().cpu(), None, stride=2, padding=1), what="convT, recycled address")
+    del opt2
+
+
+def test_a_write_through_data_is_never_served_a_stale_weight_image(monkeypatch):
+    """`p.data.mul_()` / `p.data.clamp_()` (the reference's own clip_weights idiom, model/gan.py:67-69) move neither
+    `tensor._version` nor a parameter epoch.  Images are therefore kept only for parameters that live in a shapegan_amd.optim flat
+    buffer (every writer of those announces itself); any other weight is packed on every call — and a `.data` writer of a
+    flat-buffer parameter calls ops.invalidate_weight_images()."""
+    from shapegan_amd import ops, optim
+    from shapegan_amd.model.gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    calls = []
+    real_get = ops._KEPT.get
+    monkeypatch.setattr(ops._KEPT, "get", lambda *a, **kw: (calls.append(1), real_get(*a, **kw))[1])
+    torch.manual_seed(5)
+    x = torch.randn(4, 128, 8, 8, 8)
+    # (a) a bare parameter, no flat buffer: both convolution directions see the new values at once, nothing is kept
+    wt = torch.nn.Parameter((torch.randn(128, 64, 4, 4, 4) * 0.03).cuda())
+    wc = torch.nn.Parameter((torch.randn(64, 128, 4, 4, 4) * 0.03).cuda())
+    with torch.no_grad():
+        y1 = ops.conv_transpose3d_k4s2p1(x.cuda(), wt, None)
+        c1 = ops.conv3d_k4s2p1(x.cuda(), wc, None)
+        wt.data.mul_(0.5)
+        wc.data.mul_(0.5)
+        assert wt._version == 0                                        # the write left no trace ...
+        y2 = ops.conv_transpose3d_k4s2p1(x.cuda(), wt, None)
+        c2 = ops.conv3d_k4s2p1(x.cuda(), wc, None)
+    assert not calls
+    close(y2, F.conv_transpose3d(x, wt.detach().cpu(), None, stride=2, padding=1), what="convT after p.data.mul_")   # ... and is seen
+    close(c2, F.conv3d(x, wc.detach().cpu(), None, stride=2, padding=1), what="conv after p.data.mul_")
+    close(y2, 0.5 * y1, what="convT halves")
+    close(c2, 0.5 * c1, what="conv halves")
+    # (b) the reference's clip_weights body on a critic that no flat optimizer owns (stock torch.optim in the scripts)
+    d = Discriminator()
+    d.use_sigmoid = False
+    v = (torch.rand(8, 32, 32, 32) * 2 - 1).cuda()
+    with torch.no_grad():
+        d(v)
+        for p in d.parameters():
+            p.data.clamp_(-0.01, 0.01)
+        got = d(v)
+        fresh = Discriminator()
+        fresh.load_state_dict({k: t.clone() for k, t in d.state_dict().items()})
+        fresh.use_sigmoid = False
+        assert torch.equal(got, fresh(v))
+    # (c) a flat-buffer parameter: kept — a `.data` writer says so
+    opt = optim.RMSprop([wt], lr=0.05)
+    with torch.no_grad():
+        ops.conv_transpose3d_k4s2p1(x.cuda(), wt, None)
+        assert calls or DEV != "cuda"
+        wt.data.mul_(2.0)
+        ops.invalidate_weight_images()
+        y3 = ops.conv_transpose3d_k4s2p1(x.cuda(), wt, None)
+    close(y3, F.conv_transpose3d(x, wt.detach().cpu(), None, stride=2, padding=1), what="convT after invalidate_weight_images")
+    del opt
+    # (d) the SDFNet pack follows the same rule
+    net = SDFNet()
+    pts = (torch.rand(4096, 3) * 2 - 1).cuda()
+    z = torch.randn(4096, 128).cuda() * 0.1
+    with torch.no_grad():
+        s1 = net(pts, z)
+        net.layers2[6].weight.data.mul_(0.25)
+        s2 = net(pts, z)
+    close(torch.atanh(s2.clamp(-0.999, 0.999)).cpu() - net.layers2[6].bias.detach().cpu(),
+          0.25 * (torch.atanh(s1.clamp(-0.999, 0.999)).cpu() - net.layers2[6].bias.detach().cpu()), what="SDFNet after p.data.mul_", rtol=2e-3)
 
 
 @pytest.mark.parametrize("N,Co,O,act", [(16, 64, 16, 1), (17, 24, 16, 2), (128, 64, 16, 1)])
