@@ -284,6 +284,77 @@ def sdfnet_numbers():
     return out
 
 
+def _count_launches(fn):
+    """GPU kernel launches of one call of fn() as the torch profiler's device-side activity sees them (None if it cannot trace)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        n = sum(1 for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA") and "memcpy" not in e.name.lower()
+                and "memset" not in e.name.lower())
+        return n or None
+    except Exception:       # noqa: BLE001 — a diagnostic column, never a reason to lose the line
+        return None
+
+
+def dropin_loop_numbers(steps=10, warmup=3):
+    """What the reference's OWN loop achieves on the drop-in surface: the body of train_wgan.py:60-84 over the
+    module-level API only — `generator.generate()` (latents drawn on the CPU and moved, model/gan.py:31-34), two `critic(...)`
+    calls per update, `loss.backward()` through the autograd engine, stock `torch.optim.RMSprop`, `critic.clip_weights()`, the
+    three `.item()` reads of the generator update — on the same modules the headline trains, at batch 64, five critic updates and
+    one generator update per step.  `WGANTrainer.step` (the headline) is the same arithmetic with the step-level fusions a
+    script cannot express through that surface; the ratio is reported so that nobody mistakes one for the other."""
+    from shapegan_amd.model.gan import Discriminator, Generator
+    torch.manual_seed(0)
+    generator, critic = Generator(), Discriminator()
+    critic.use_sigmoid = False
+    g_opt = torch.optim.RMSprop(generator.parameters(), lr=0.00005)
+    c_opt = torch.optim.RMSprop(critic.parameters(), lr=0.00005)
+    gen = torch.Generator().manual_seed(1000)
+    host = [(torch.rand(BATCH, 32, 32, 32, generator=gen) * 2 - 1) for _ in range(5)]      # what a DataLoader hands the loop
+    resident = [b.cuda() for b in host]
+    logged = []
+
+    def unit(batches, to_device):
+        for batch_index, batch in enumerate(batches):
+            generator.zero_grad()
+            critic.zero_grad()
+            fake_sample = generator.generate(sample_size=batch.shape[0]).detach()
+            fake_out = critic(fake_sample)
+            valid_out = critic(batch.cuda() if to_device else batch)
+            critic_loss = torch.mean(fake_out) - torch.mean(valid_out)
+            critic_loss.backward()
+            c_opt.step()
+            critic.clip_weights(0.01)
+            if batch_index % 5 == 0:
+                generator.zero_grad()
+                critic.zero_grad()
+                fake_out = critic(generator.generate(sample_size=BATCH))
+                generator_loss = -torch.mean(fake_out)
+                generator_loss.backward()
+                g_opt.step()
+                del logged[:]
+                logged.extend((torch.mean(fake_out).item(), torch.mean(valid_out).item()))
+
+    out = {"what": "train_wgan.py:60-84 restated over the module-level surface only (generate(), two critic calls, autograd, stock "
+                   "torch.optim.RMSprop, clip_weights, .item() logging), batch 64, 5 critic + 1 generator updates per step"}
+    for key, batches, to_device in (("resident_batches", resident, False), ("host_batches_copied_in_the_loop", host, True)):
+        for _ in range(warmup):
+            unit(batches, to_device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            unit(batches, to_device)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"steps_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3)}
+    out["launches_per_step"] = _count_launches(lambda: unit(resident, False))
+    return out
+
+
 class _ReferenceWGAN(object):
     """train_wgan.py:37-46,60-84 on the REFERENCE's OWN module classes (model.gan.Generator / Discriminator imported from the
     reference checkout by oracle/ref_import.py), stock torch.optim.RMSprop, on the CPU — BASELINE.md section 2's baseline.  Only
@@ -644,6 +715,10 @@ def main():
                 line["roofline"], line["kernels"] = roofline_and_kernels()
                 line["sdfnet"] = sdfnet_numbers()
                 line["other_configs"] = other_configs()
+                line["dropin_loop"] = dropin_loop_numbers()
+                line["dropin_loop"]["trainer_step_launches_per_step"] = _count_launches(step)
+                for k in ("resident_batches", "host_batches_copied_in_the_loop"):
+                    line["dropin_loop"][k]["fraction_of_trainer_step"] = round(line["dropin_loop"][k]["steps_per_s"] / line["value"], 4)
             if world == 1 and not args.no_cpu_baseline:
                 reals, zs, zg, (g_state, c_state) = wgan_data
                 line["cpu_baseline"] = cpu_baseline(reals, zs, zg, g_state, c_state)

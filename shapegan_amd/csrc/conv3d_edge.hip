@@ -77,6 +77,9 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
 //  * every wave walks a contiguous run of tiles (consecutive 128-byte lines of each channel row, the patch rows of the next
 //    tile already in L1);
 //  * bias + LeakyReLU as max(t, slope t) on 2-wide packed adds / multiplies.
+#ifndef SG_FWDC1_ABL
+#define SG_FWDC1_ABL 0   // ablation builds only (scripts/ab_build.sh): 1 no global stores, 2 no MFMAs, 4 no patch loads
+#endif
 template <int NT, int ACT>   // NT: column tiles of 32 output channels (1 or 2); ACT: 0 none, 1 LeakyReLU, 2 any (sg_apply_act)
 __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
     constexpr int kWL = 65;   // LDS row stride of the weight tile: lane = channel row -> 32 distinct banks per fragment read
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
             const int i = sl - 8;
             const int row = 8 * i + (lane >> 3);
             const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * kTL + 4 * (lane & 7));
-            buf_store4(yres, row < a.Cout ? yprev : kBufOutside, (unsigned)(8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
+            buf_store4(yres, row < a.Cout && !(SG_FWDC1_ABL & 1) ? yprev : kBufOutside, (unsigned)(8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
         }
     };
     auto tile_mfma = [&](auto with_epilogue, const float (&c0)[16], const float (&c1)[16]) __attribute__((always_inline)) {
@@ -215,10 +218,15 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
             for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
+            if (SG_FWDC1_ABL & 2) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[g], wfr[nt][g][0], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt][g] += c0[g] * wfr[nt][g][0] + c1[g] * wfr[nt][g][1];
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[g], wfr[nt][g][1], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[g], wfr[nt][g][0], acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[g], wfr[nt][g][1], acc[nt], 0, 0, 0);
+            }
             if (decltype(with_epilogue)::value) {
                 __builtin_amdgcn_sched_barrier(0);
                 epilogue_slice(g);
@@ -237,7 +245,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
         TileLane Ln;
         unsigned yn[1];
         lane_offsets(tcur + 1 < t_end ? tcur + 1 : tcur, Ln, yn);
-        if (tcur + 1 >= t_end) Ln.o0 = Ln.o1 = kBufOutside;
+        if (tcur + 1 >= t_end || (SG_FWDC1_ABL & 4)) Ln.o0 = Ln.o1 = kBufOutside;
         load_patch(Ln, n0, n1);
         yprev = yoff[0];       // where tile tcur's output goes (its epilogue runs during tile tcur + 1)
         L = Ln;

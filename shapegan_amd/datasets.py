@@ -73,8 +73,8 @@ class VoxelDataset(object):
             ops.voxel_prepare(data, self.clamp, self._divisor())
         return ResidentVoxels(data)
 
-    def stream(self, batch_size, device="cuda", shuffle=True, drop_last=False):
-        return VoxelStream(self, batch_size, device, shuffle, drop_last)
+    def stream(self, batch_size, device="cuda", shuffle=True, drop_last=False, into=None):
+        return VoxelStream(self, batch_size, device, shuffle, drop_last, into)
 
 
 def loader_index_order(n, shuffle=True):
@@ -101,24 +101,32 @@ class ResidentVoxels(object):
     def __len__(self):
         return self.data.shape[0]
 
-    def batches(self, batch_size, shuffle=True, drop_last=False):
+    def batches(self, batch_size, shuffle=True, drop_last=False, into=None):
+        """into: destination tensors (e.g. `WGANTrainer.real_slots(batch_size)`), used round-robin: batch k is gathered straight
+        into into[k % len(into)] and THAT tensor is yielded (reshaped views of it keep its storage), so a trainer whose critic
+        batch owns the slot finds its real half in place — no device copy between the loader and the step (train_wgan.py:56-66
+        reads the loader's batch where `.to(device)` put it).  A short last batch is yielded as a fresh tensor."""
         order = loader_index_order(len(self), shuffle).to(self.data.device)
         n = len(self)
         stop = n - n % batch_size if drop_last else n
-        for start in range(0, stop, batch_size):
+        for k, start in enumerate(range(0, stop, batch_size)):
             idx = order[start:min(start + batch_size, n)]
+            dst = into[k % len(into)] if into and idx.numel() == batch_size else None
             with torch.no_grad():
-                batch = ops.gather_rows(self.rows, idx)
-            yield batch.reshape((idx.numel(),) + tuple(self.data.shape[1:]))
+                batch = ops.gather_rows(self.rows, idx, out=dst)
+            yield batch if dst is not None else batch.reshape((idx.numel(),) + tuple(self.data.shape[1:]))
 
 
 class VoxelStream(object):
     """Streaming variant for sets that should not live in HBM: a reader thread fills pinned buffers one batch ahead,
     the copy runs on a side stream, clamp / rescale on the device; the consumer waits on an event only."""
 
-    def __init__(self, dataset, batch_size, device="cuda", shuffle=True, drop_last=False):
+    def __init__(self, dataset, batch_size, device="cuda", shuffle=True, drop_last=False, into=None):
+        """into: destination tensors used round-robin (see ResidentVoxels.batches): the async H2D copy of batch k lands in
+        into[k % len(into)], clamp / rescale run in place there.  Give at least as many slots as batches are alive at once (a
+        WGANTrainer unit: five)."""
         self.dataset, self.batch_size, self.device = dataset, batch_size, torch.device(device)
-        self.shuffle, self.drop_last = shuffle, drop_last
+        self.shuffle, self.drop_last, self.into = shuffle, drop_last, into
         shape = tuple(np.load(dataset.files[0]).shape)
         self.pinned = [torch.empty((batch_size,) + shape, dtype=torch.float32).pin_memory() for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
@@ -147,8 +155,15 @@ class VoxelStream(object):
                     free[slot ^ 1].synchronize()
                 reader = threading.Thread(target=self._fill, args=(slot ^ 1, chunks[k + 1]))
                 reader.start()
+            dst = self.into[k % len(self.into)] if self.into and len(names) == self.batch_size else None
+            if dst is not None:      # the slot's previous batch may still be read by kernels on the consumer's stream
+                self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.copy_stream):
-                batch = self.pinned[slot][:len(names)].to(self.device, non_blocking=True)
+                if dst is not None:
+                    batch = dst
+                    batch.view(self.pinned[slot].shape).copy_(self.pinned[slot], non_blocking=True)
+                else:
+                    batch = self.pinned[slot][:len(names)].to(self.device, non_blocking=True)
                 if ds.clamp is not None:
                     ops.voxel_prepare(batch, ds.clamp, ds._divisor())
                 done = torch.cuda.Event()

@@ -1241,8 +1241,19 @@ class GatherRows(Function):
         return tg, None
 
 
-def gather_rows(table, idx):
-    return GatherRows.apply(table, idx)
+def gather_rows(table, idx, out=None):
+    """table[idx].  out: where to write the rows (no-grad data movement only — e.g. a loader delivering a batch into a trainer's
+    slot): a contiguous fp32 tensor of idx.numel() * table.shape[1] elements on the table's device."""
+    if out is None:
+        return GatherRows.apply(table, idx)
+    table = f32c(table)
+    n, width = idx.numel(), table.shape[1]
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * width or out.device != table.device:
+        raise RuntimeError("gather_rows: `out` must be a contiguous fp32 tensor of %d x %d elements on %s" % (n, width, table.device))
+    if idx.dtype != torch.int64 or not idx.is_contiguous():
+        idx = idx.to(torch.int64).contiguous()
+    check(_lib().sg_gather_rows(ptr(table), ptr(idx), ptr(out), n, width, stream()), "gather_rows")
+    return out
 
 
 _bad_index_flags = {}

@@ -255,6 +255,10 @@ def test_two_threads_drive_two_modules_concurrently(on_cpu):
             assert torch.equal(got[k][0], serial[k][0]) and torch.equal(got[k][1], serial[k][1]), k
 
 
+def test_wgan_headline_step_at_cpu_size(on_cpu):
+    FULL.test_wgan_headline_step_vs_oracle(batch=4)
+
+
 def test_config3_and_config4_step_checks_at_cpu_size(on_cpu):
     """The bodies of the BASELINE-size configs[3] / configs[4] oracle checks (tests/test_gpu_fullsize.py) at sizes the twin
     finishes in seconds: iteration 1 (16^3) with fade-in, batch 3; hybrid WGAN at batch 1."""

@@ -129,6 +129,63 @@ def test_wgan_batch64_update_vs_oracle():
             check_against_oracles(v, o32.G[k], o64.G[k], k)
 
 
+def test_wgan_headline_step_vs_oracle(batch=64):
+    """The exact code path bench.py's headline times: ONE full 5 + 1 `WGANTrainer.step` at batch 64 with the
+    shipped defaults — real batches delivered into `real_slots`, the unit's latents as rows of one tensor, the generator
+    evaluations of critic updates 2..5 as one grouped pass, the inference generator's last BatchNorm folded into the final ConvT —
+    against `WGANOracle.step` (train_wgan.py:60-84 restated on torch CPU ops) in fp32 AND fp64 from the same state and inputs.
+    Compared after the whole unit (six optimizer updates deep): the last critic update's loss and 2 x 64 scores and its
+    gradients by the fp64-truth criterion of test_wgan_batch64_update_vs_oracle; the generator's BatchNorm running statistics and
+    batch counters after its six evaluations; and every parameter's total movement over the unit, which RMSprop makes
+    sign-like (|step| ~ 10 lr on the first update whatever the gradient's size): an entry counts as deviating when it is further
+    from the fp64 oracle than 0.5 % of the tensor's typical movement, and the native path may deviate on at most three times the
+    fraction of entries on which the fp32 oracle — the reference's own arithmetic — deviates, plus 0.1 %."""
+    from test_gpu_modules import check_against_oracles
+    from shapegan_amd.model import stack
+    from shapegan_amd.model.gan import Discriminator, Generator
+    from shapegan_amd.train_steps import WGANTrainer
+    assert stack.FUSE_BN_INTO_LAST_CONV_TRANSPOSE is True         # the shipped default is what is under test
+    torch.manual_seed(0)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    g, c = Generator(), Discriminator()
+    g0, c0 = _state64(g), _state64(c)
+    o32, o64 = O.WGANOracle(_state(g), _state(c)), O.WGANOracle(g0, c0)
+    tr = WGANTrainer(g, c)
+    gen = torch.Generator().manual_seed(1000)
+    reals_host = [torch.rand(batch, 32, 32, 32, generator=gen) * 2 - 1 for _ in range(5)]
+    zs_host = torch.randn(5, batch, 128, generator=gen)
+    zg = torch.randn(batch, 128, generator=gen)
+    slots = tr.real_slots(batch, resolution=32, updates=5)
+    for slot, r in zip(slots, reals_host):
+        slot.copy_(r.reshape(batch, 1, 32, 32, 32))
+    zs = list(zs_host.cuda().unbind(0))
+    loss, out_fake, out_real = tr.step(slots, zs, zg.cuda())
+    assert g.layers[1].num_batches_tracked.item() == 6            # five critic updates + the generator update evaluated it
+    r32 = o32.step(reals_host, list(zs_host.unbind(0)), zg)
+    r64 = o64.step([r.double() for r in reals_host], list(zs_host.double().unbind(0)), zg.double())
+    # the fifth critic update, five critic steps and one generator step behind the common start
+    noise = abs(r32[0].item() - r64[0].item())
+    assert abs(loss.item() - r64[0].item()) <= RTOL * abs(r64[0].item()) + 4 * noise + 1e-7
+    check_against_oracles(out_fake, r32[1], r64[1], "critic(fake), update 5")
+    check_against_oracles(out_real, r32[2], r64[2], "critic(real), update 5")
+    gscale = max(float(v.grad.abs().mean()) for v in o64.C.values() if v.requires_grad)
+    for k, p in c.named_parameters():
+        check_against_oracles(p.grad, o32.C[k].grad, o64.C[k].grad, "critic grad, update 5: " + k, gscale=gscale, max_frac=3e-3)
+    for k, v in g.state_dict().items():
+        if "running_" in k:
+            check_against_oracles(v, o32.G[k], o64.G[k], k)
+        elif "num_batches_tracked" in k:
+            assert int(v) == int(o32.G[k])
+    for name, mod, start, ora32, ora64 in (("generator", g, g0, o32.G, o64.G), ("critic", c, c0, o32.C, o64.C)):
+        for k, p in mod.named_parameters():
+            d = p.detach().double().cpu() - start[k]
+            d32, d64 = ora32[k].detach().double() - start[k], ora64[k].detach() - start[k]
+            unit = 5e-3 * max(float(d64.abs().mean()), 1e-12)
+            f_native, f_ref = float(((d - d64).abs() > unit).double().mean()), float(((d32 - d64).abs() > unit).double().mean())
+            assert f_native <= 3 * f_ref + 1e-3, "%s %s: %.3f %% of the entries moved differently from the fp64 oracle (fp32 oracle: %.3f %%)" % (
+                name, k, 100 * f_native, 100 * f_ref)
+
+
 def test_sdf_autodecoder_200k_L256_step_vs_oracle():
     """BASELINE configs[2]: one auto-decoder step (train_sdf_autodecoder.py:77-91) at 200 000 points, latent 256, through the
     shape-sorted data flow, against SDFAutoDecoderOracle in fp32 AND fp64: loss, network gradients, dense latent-table gradient,
