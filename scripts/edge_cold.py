@@ -43,7 +43,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 w1 = torch.randn(64, 1, 4, 4, 4, device="cuda") * 0.1
 b1 = torch.zeros(64, device="cuda")
 out = {"lib": os.path.basename(os.environ.get("SHAPEGAN_HIP_LIB", "default"))}
-for nb in (128, 64):
+for nb in ((128, 64, 16) if what != 'all' else (128, 64)):
     mk_x = lambda: torch.randn(nb, 1, 32, 32, 32, device="cuda")
     mk_y = lambda: torch.randn(nb, 64, 16, 16, 16, device="cuda")
     nx, ny = nb * 32768, nb * 64 * 4096

@@ -277,6 +277,218 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_kernel(EdgeFwdArgs a) {
     for (int sl = 0; sl < 16; ++sl) epilogue_slice(sl);
 }
 
+// ---- forward, LDS-staged grid (round 5) -------------------------------------------------------------------------------------
+// conv_fwd_c1_kernel gathers its A operand (the patch values of 32 positions) with 32 dword buffer loads per tile that can only be
+// issued one tile ahead (two register sets): its ablations (scripts/ab_build.sh -DSG_FWDC1_ABL=.., cold operands) add up — loads
+// alone 25 us, + MFMAs 43, + stores 60 us at 128 samples for a 27 us matrix-pipe floor: nothing overlaps, every tile waits out an
+// HBM latency.  Here a workgroup owns UNITS of 256 consecutive output positions (BH output rows of one output plane); the
+// 4 x (2 BH + 2) input rows a unit needs are copied into LDS by 16-byte coalesced loads issued a whole unit (8 tiles) ahead —
+// rows / planes in the zero padding are out-of-range offsets, i.e. arrive as zeros — and the A operand of a tile is 16 LDS reads
+// of two consecutive floats per lane (immediate offsets for (kd, kh)).  Everything else — B fragments in registers, the epilogue of
+// tile t - 1 sliced between the MFMA groups of tile t, whole-line stores through a wave-private LDS tile — is the scheme above.
+template <int IWT>
+struct FwdLds {
+    static constexpr int OWT = IWT / 2, BH = 256 / OWT, R = 2 * BH + 2, RS = IWT + 8, PLANE = R * RS, BUF = 4 * PLANE;
+    static constexpr int PW = IWT / 4, PIECES = 4 * R * PW, NP = (PIECES + 255) / 256;
+    static constexpr int TILE_ROWS = IWT == 32 ? 4 : 2;     // input rows between consecutive tiles of a unit
+};
+struct EdgeFwdLdsArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int OD, OH, IH, Cout, Cy, Cin_total;
+    long x_sample;
+    int units, units_per_wg, blocks_per_plane;   // blocks_per_plane = OH / BH
+    FastDiv dbpp, dOD;
+    int act;
+    float slope;
+};
+
+template <int NT, int ACT, int IWT>
+__global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) {
+    using G = FwdLds<IWT>;
+    constexpr int kWL = 65, kTL = 36;
+    __shared__ __attribute__((aligned(16))) float xs[2 * G::BUF];
+    __shared__ __attribute__((aligned(16))) float tl[4][32 * kTL];          // one staging tile of 32 channels per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh2 = lane >> 5;
+    int u = blockIdx.x * a.units_per_wg;
+    const int u_end = min(a.units, u + a.units_per_wg);
+    if (u >= u_end) return;
+    // ---- weights -> B fragments (through xs, which is not in use yet) ----
+    {
+        float* wl = xs;
+        const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.w);
+        f32x4 wv[NT * 2];
+#pragma unroll
+        for (int i = 0; i < NT * 2; ++i) {
+            const int e4 = tid + 256 * i, co = e4 >> 4, t4 = e4 & 15;
+            wv[i] = buf_load4v(wres, co < a.Cout ? (unsigned)(((long)co * a.Cin_total * 64 + t4 * 4) * 4) : kBufOutside, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 2; ++i) {
+            const int e4 = tid + 256 * i, co = e4 >> 4, t4 = e4 & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wl[co * kWL + t4 * 4 + j] = wv[i][j];
+        }
+    }
+    __syncthreads();
+    // lane half 0 owns the taps kw = 0, 1, lane half 1 the taps kw = 2, 3: two consecutive floats of the staged row
+    float wfr[NT][16][2], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + r;
+        bl[nt] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            wfr[nt][g][0] = xs[co * kWL + g * 4 + 2 * kh2];
+            wfr[nt][g][1] = xs[co * kWL + g * 4 + 2 * kh2 + 1];
+        }
+    }
+    __syncthreads();
+    // the pad columns (w = -1 and w = IW) of every staged row stay zero for the whole kernel
+    for (int e = tid; e < 2 * 4 * G::R * 2; e += 256) {
+        const int row = e >> 1;
+        xs[row * G::RS + ((e & 1) ? 4 + IWT : 3)] = 0.f;
+    }
+    // ---- staging bookkeeping: piece e = tid + 256 f is 16 bytes of staged row (plane p, row rr) ----
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x - ((long)a.IH * IWT + IWT));    // (see conv_fwd_c1_kernel: offsets stay >= 0)
+    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.y);
+    // one word per piece: byte offset inside the unit's box (< 2^26) | padding classes in bits 26..30: 1 plane 0 (padding when
+    // od = 0), 2 plane 3 (od = OD - 1), 4 row 0 (first row block), 8 row R - 1 (last row block), 16 not a piece at all
+    unsigned pword[G::NP];
+    lds_f32x4* pdst[G::NP];
+#pragma unroll
+    for (int f = 0; f < G::NP; ++f) {
+        const int e = tid + 256 * f;
+        const int p = e / (G::R * G::PW), rem = e - p * (G::R * G::PW), rr = rem / G::PW, c4 = rem - rr * G::PW;
+        const unsigned cls = e >= G::PIECES ? 16u : ((p == 0 ? 1u : 0u) | (p == 3 ? 2u : 0u) | (rr == 0 ? 4u : 0u) | (rr == G::R - 1 ? 8u : 0u));
+        pword[f] = (unsigned)(((p * a.IH + rr) * IWT + 4 * c4) * 4) | (cls << 26);
+        pdst[f] = (lds_f32x4*)((lds_float*)xs + (e >= G::PIECES ? 0 : p * G::PLANE + rr * G::RS + 4 + 4 * c4));
+    }
+    const unsigned O3 = (unsigned)(a.OD * a.OH * G::OWT);
+    f32x4 sv[G::NP];
+    unsigned ybase = 0;       // byte offset of the unit's first output position in channel row 0 of its sample
+    auto stage_issue = [&](int uu, bool real) __attribute__((always_inline)) {
+        uint32_t q, ohb, n, od;
+        a.dbpp.divmod((uint32_t)uu, q, ohb);
+        a.dOD.divmod(q, n, od);
+        const unsigned mask = 0x03ffffffu | ((16u | (od == 0 ? 1u : 0u) | ((int)od == a.OD - 1 ? 2u : 0u) | (ohb == 0 ? 4u : 0u) |
+                                              ((int)ohb == a.blocks_per_plane - 1 ? 8u : 0u)) << 26);
+        const unsigned sbase = (unsigned)(((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * ohb * G::BH) * IWT) * 4);
+#pragma unroll
+        for (int f = 0; f < G::NP; ++f) {
+            const unsigned t = pword[f] & mask;
+            sv[f] = buf_load4v(xres, (!real || (t >> 26)) ? kBufOutside : t, sbase);
+        }
+    };
+    auto stage_write = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < G::NP; ++f)
+            if (f + 1 < G::NP || tid < G::PIECES - 256 * (G::NP - 1)) pdst[f][buf * (G::BUF / 4)] = sv[f];
+    };
+    auto unit_ybase = [&](int uu) __attribute__((always_inline)) {
+        uint32_t q, ohb, n, od;
+        a.dbpp.divmod((uint32_t)uu, q, ohb);
+        a.dOD.divmod(q, n, od);
+        return (unsigned)(((long)n * a.Cy * O3 + ((long)od * a.OH + ohb * G::BH) * G::OWT) * 4);
+    };
+    // A-operand address of this lane inside a staged buffer for tile 2 wave + j: immediate (kd, kh, j) offsets are added at the reads
+    const int oh_in = IWT == 32 ? 2 * (r >> 4) : 0, ow = IWT == 32 ? (r & 15) : r;
+    const lds_float* const abase = (const lds_float*)xs + (2 * wave * G::TILE_ROWS + oh_in) * G::RS + 3 + 2 * ow + 2 * kh2;
+    const unsigned ylane = (unsigned)(((lane >> 3) * O3 + 64 * wave + 4 * (lane & 7)) * 4);   // row (lane >> 3), tile 2 wave, 16 bytes
+    float* const tw = tl[wave];
+
+    float pv[NT][16];
+    unsigned yprev = kBufOutside;
+    // epilogue of the previous tile in 16 slices: [nt = 0: 4 x registers -> LDS, 4 x LDS -> 8 channel rows of 128 B] [nt = 1: the same]
+    auto epilogue_slice = [&](int sl) __attribute__((always_inline)) {
+        const int nt = sl >> 3, k = sl & 7;
+        if (nt >= NT) return;
+        if (k < 4) {
+            f32x4 v = {pv[nt][4 * k], pv[nt][4 * k + 1], pv[nt][4 * k + 2], pv[nt][4 * k + 3]};
+            v = v + bl[nt];
+            if (ACT == 1) {
+                const f32x4 sv2 = v * a.slope;
+                v = __builtin_elementwise_max(v, sv2);
+            } else if (ACT == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = sg_apply_act(v[i], a.act, a.slope);
+            }
+            *reinterpret_cast<f32x4*>(tw + r * kTL + 8 * k + 4 * kh2) = v;
+        } else {
+            const int i = k - 4;
+            const int row = nt * 32 + 8 * i + (lane >> 3);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + (8 * i + (lane >> 3)) * kTL + 4 * (lane & 7));
+            buf_store4(yres, row < a.Cout ? yprev : kBufOutside, (unsigned)(nt * 32 + 8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto tile = [&](auto with_epilogue, int buf, int j) __attribute__((always_inline)) {
+        const lds_float* ap = abase + buf * G::BUF + j * G::TILE_ROWS * G::RS;
+        // operand values two groups ahead of their MFMAs (an LDS read is ~100 cycles, a group of 2 NT MFMAs 128 NT cycles)
+        float ca[3], cb[3];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            ca[g] = ap[(g >> 2) * G::PLANE + (g & 3) * G::RS];
+            cb[g] = ap[(g >> 2) * G::PLANE + (g & 3) * G::RS + 1];
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 2 < 16) {
+                ca[(g + 2) % 3] = ap[((g + 2) >> 2) * G::PLANE + ((g + 2) & 3) * G::RS];
+                cb[(g + 2) % 3] = ap[((g + 2) >> 2) * G::PLANE + ((g + 2) & 3) * G::RS + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[g % 3], wfr[nt][g][0], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[g % 3], wfr[nt][g][1], acc[nt], 0, 0, 0);
+            if (decltype(with_epilogue)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue_slice(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pv[nt][q] = acc[nt][q];
+    };
+
+    stage_issue(u, true);
+    stage_write(0);
+    __syncthreads();
+    int buf = 0;
+    ybase = unit_ybase(u);
+    // first unit: its first tile has no epilogue to carry
+    stage_issue(u + 1, u + 1 < u_end);
+    tile(IntTag<0>(), buf, 0);
+    yprev = ybase + ylane;
+    tile(IntTag<1>(), buf, 1);
+    yprev = ybase + ylane + 128u;
+    stage_write(buf ^ 1);
+    __syncthreads();
+    for (++u; u < u_end; ++u) {
+        buf ^= 1;
+        ybase = unit_ybase(u);
+        stage_issue(u + 1, u + 1 < u_end);     // (unconditional: out-of-range offsets behind the last unit, see the vmcnt note above)
+        tile(IntTag<1>(), buf, 0);
+        yprev = ybase + ylane;
+        tile(IntTag<1>(), buf, 1);
+        yprev = ybase + ylane + 128u;
+        stage_write(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) epilogue_slice(sl);
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
 constexpr int kEdgePartial = 4096 + 64;   // floats per workgroup partial
 struct EdgeWgradArgs {
@@ -1064,6 +1276,41 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.dOH = FastDiv((uint32_t)g.OH);
     a.act = act;
     a.slope = slope;
+    // round 5: the LDS-staged form for 32- / 64-wide grids (the critic's first layer, the progressive discriminator's 64^3 stage)
+    {
+        static const char* env = getenv("SG_FWD_C1_LDS");
+        const int bh = g.IW == 32 ? 16 : 8;
+        if ((g.IW == 32 || g.IW == 64) && g.OH % bh == 0 && !(env && atoi(env) == 0)) {
+            EdgeFwdLdsArgs l;
+            l.x = x;
+            l.w = w;
+            l.bias = bias;
+            l.y = y;
+            l.OD = g.OD;
+            l.OH = g.OH;
+            l.IH = g.IH;
+            l.Cout = Cout;
+            l.Cy = g.Cy;
+            l.Cin_total = Cin_total;
+            l.x_sample = (long)g.Cx * g.I3();
+            l.blocks_per_plane = g.OH / bh;
+            l.units = batch * g.OD * l.blocks_per_plane;
+            int lwgs = l.units < 512 ? l.units : 512;
+            l.units_per_wg = (l.units + lwgs - 1) / lwgs;
+            lwgs = (l.units + l.units_per_wg - 1) / l.units_per_wg;
+            l.dbpp = FastDiv((uint32_t)l.blocks_per_plane);
+            l.dOD = FastDiv((uint32_t)g.OD);
+            l.act = act;
+            l.slope = slope;
+#define SG_FWD_L(NT_, ACT_, IW_) hipLaunchKernelGGL((conv_fwd_c1_lds_kernel<NT_, ACT_, IW_>), dim3(lwgs), dim3(256), 0, stream, l)
+#define SG_FWD_LA(NT_, IW_) do { if (actk == 0) SG_FWD_L(NT_, 0, IW_); else if (actk == 1) SG_FWD_L(NT_, 1, IW_); else SG_FWD_L(NT_, 2, IW_); } while (0)
+            if (g.IW == 32) { if (Cout > 32) SG_FWD_LA(2, 32); else SG_FWD_LA(1, 32); }
+            else            { if (Cout > 32) SG_FWD_LA(2, 64); else SG_FWD_LA(1, 64); }
+#undef SG_FWD_LA
+#undef SG_FWD_L
+            return 1;
+        }
+    }
     int wgs = (a.total_tiles + 3) / 4;
     if (wgs > 512) wgs = 512;
     {

@@ -305,6 +305,7 @@ class GradBucket(object):
         self.armed = False
         check = False
         if world_size() > 1:
+            self._check_previous_header()     # what the LAST exchange's summed header said, before entering another collective
             f = self.opt.f
             check = self._stage_pattern()
             h = f.header_len
@@ -325,15 +326,19 @@ class GradBucket(object):
         self.wait()
         if check:
             self._check_pattern()
+        elif world_size() > 1:
+            self._snapshot_header()
 
     def _stage_pattern(self):
         """Writes "this rank has a gradient for parameter i" into the header that travels with the head slice.  A parameter
         without a gradient is skipped by step() (torch.optim semantics); if another rank HAS a gradient for it, that rank would
         step it with the summed gradient and the replicas would diverge silently.  The summed header says whether the
-        ranks agree: every entry must come back as 0 or world_size.  Steady state costs one tiny device copy per exchange; the
-        header is read back (a host synchronisation) only when THIS rank's pattern differs from its previous exchange — the first
-        step and, e.g., a progressive-GAN stage switch — which is when a disagreement can begin; the rank whose pattern changed
-        is the one that raises."""
+        ranks agree: every entry must come back as 0 or world_size.  Steady state costs one tiny device copy per exchange and one
+        asynchronous copy of the summed header to pinned host memory.  The rank whose OWN pattern differs from its previous
+        exchange — the first step and, e.g., a progressive-GAN stage switch — reads the header back at once (a host
+        synchronisation) and raises; every OTHER rank finds the same disagreement in its snapshot at the start of its next
+        finish(), before it enters another collective (otherwise the ranks that did not change never look, and block
+        for ever in the next all-reduce once the raising rank is gone)."""
         f = self.opt.f
         pattern = tuple(p.grad is not None for p in f.params)
         changed = pattern != self._pattern
@@ -345,15 +350,40 @@ class GradBucket(object):
         f.header.copy_(self._pattern_dev)
         return changed
 
+    def _snapshot_header(self):
+        """The summed header of the exchange that just completed, on its way to the host without blocking it."""
+        f = self.opt.f
+        if f.header.is_cuda:
+            if getattr(self, "_header_host", None) is None:
+                self._header_host = torch.empty(f.header_len, dtype=torch.float32).pin_memory()
+                self._header_event = torch.cuda.Event()
+            self._header_host.copy_(f.header, non_blocking=True)
+            self._header_event.record()
+        else:
+            self._header_host = f.header.clone()
+            self._header_event = None
+        self._header_pending = True
+
+    def _check_previous_header(self):
+        if getattr(self, "_header_pending", False):
+            self._header_pending = False
+            if self._header_event is not None:
+                self._header_event.synchronize()       # recorded a whole step ago
+            self._validate(self._header_host[:len(self.opt.f.params)].tolist(), late=True)
+
     def _check_pattern(self):
         f = self.opt.f
-        got = f.header[:len(f.params)].cpu().tolist()
+        self._validate(f.header[:len(f.params)].cpu().tolist(), late=False)
+
+    def _validate(self, got, late):
         w = float(world_size())
         bad = [i for i, v in enumerate(got) if v != 0.0 and v != w]
         if bad:
             raise RuntimeError("GradBucket: the ranks disagree on which parameters have a gradient (parameter indices %s: %s of %d "
                                "ranks have one); a rank without it would skip the update the others apply and the replicas "
-                               "would diverge" % (bad[:8], [int(got[i]) for i in bad[:8]], int(w)))
+                               "would diverge%s" % (bad[:8], [int(got[i]) for i in bad[:8]], int(w),
+                                                    " — found in the header of the PREVIOUS exchange: that update has been "
+                                                    "applied on this rank" if late else ""))
 
     def _exchange(self, t):
         """In-place SUM of a slice of the flat gradient buffer across ranks, asynchronous w.r.t. the compute stream."""
@@ -391,3 +421,27 @@ def broadcast_parameters(module, src=0):
         # (kept ConvTranspose images, the SDFNet pack) would keep serving the pre-broadcast weights on the non-source ranks
         from . import lib as L
         L.bump_param_epoch()
+
+
+def save_checkpoint(module, epoch=None, src=0):
+    """`SavableModule.save(epoch)` under process-per-GPU data parallelism: rank `src` writes the file, everybody waits for it.
+
+    Which replica a checkpoint carries: parameters are bit-identical on every rank (same start, same all-reduced gradient, same
+    update), so any rank's would do.  BatchNorm running statistics are NOT — every rank normalises its own shard and updates its
+    own buffers (DataParallel semantics) — and the file carries those of rank `src` = 0: exactly what the reference's
+    `nn.DataParallel` leaves in the module it wraps (train_hybrid_progressive_gan.py:62-68; replica 0 shares its buffers with the
+    wrapped module, the other replicas' updates are dropped with the replicas).  Training-mode forwards never read them; an
+    evaluation after `load_checkpoint` sees the same statistics on every rank."""
+    if world_size() == 1 or dist.get_rank() == src:
+        module.save(epoch=epoch)
+    if world_size() > 1:
+        dist.barrier()
+
+
+def load_checkpoint(module, epoch=None, src=0):
+    """`SavableModule.load(epoch)` under process-per-GPU data parallelism: rank `src` reads the file and broadcasts parameters AND
+    buffers (ranks need not see the same file system, and nobody reads a file another rank is still writing); every rank ends
+    up bit-identical to the file and with its derived weight images invalidated."""
+    if world_size() == 1 or dist.get_rank() == src:
+        module.load(epoch=epoch)
+    broadcast_parameters(module, src=src)

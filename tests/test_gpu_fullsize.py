@@ -139,7 +139,8 @@ def test_wgan_headline_step_vs_oracle(batch=64):
     batch counters after its six evaluations; and every parameter's total movement over the unit, which RMSprop makes
     sign-like (|step| ~ 10 lr on the first update whatever the gradient's size): an entry counts as deviating when it is further
     from the fp64 oracle than 0.5 % of the tensor's typical movement, and the native path may deviate on at most three times the
-    fraction of entries on which the fp32 oracle — the reference's own arithmetic — deviates, plus 0.1 %."""
+    fraction of entries on which the fp32 oracle — the reference's own arithmetic — deviates, plus 0.1 % (or four entries of a small
+    tensor: a gradient at the 1e-8 level of RMSprop's eps moves its entry by anything between 0 and 10 lr)."""
     from test_gpu_modules import check_against_oracles
     from shapegan_amd.model import stack
     from shapegan_amd.model.gan import Discriminator, Generator
@@ -182,7 +183,7 @@ def test_wgan_headline_step_vs_oracle(batch=64):
             d32, d64 = ora32[k].detach().double() - start[k], ora64[k].detach() - start[k]
             unit = 5e-3 * max(float(d64.abs().mean()), 1e-12)
             f_native, f_ref = float(((d - d64).abs() > unit).double().mean()), float(((d32 - d64).abs() > unit).double().mean())
-            assert f_native <= 3 * f_ref + 1e-3, "%s %s: %.3f %% of the entries moved differently from the fp64 oracle (fp32 oracle: %.3f %%)" % (
+            assert f_native <= 3 * f_ref + max(1e-3, 4.0 / d.numel()), "%s %s: %.3f %% of the entries moved differently from the fp64 oracle (fp32 oracle: %.3f %%)" % (
                 name, k, 100 * f_native, 100 * f_ref)
 
 
