@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
 #pragma unroll
         for (int f = 0; f < G::NP; ++f) {
             const unsigned t = pword[f] & mask;
-            sv[f] = buf_load4v(xres, (!real || (t >> 26)) ? kBufOutside : t, sbase);
+            sv[f] = buf_load4v(xres, (!real || (t >> 26) || (SG_FWDC1_ABL & 4)) ? kBufOutside : t, sbase);
         }
     };
     auto stage_write = [&](int buf) __attribute__((always_inline)) {
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
             const int i = k - 4;
             const int row = nt * 32 + 8 * i + (lane >> 3);
             const f32x4 v = *reinterpret_cast<const f32x4*>(tw + (8 * i + (lane >> 3)) * kTL + 4 * (lane & 7));
-            buf_store4(yres, row < a.Cout ? yprev : kBufOutside, (unsigned)(nt * 32 + 8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
+            buf_store4(yres, row < a.Cout && !(SG_FWDC1_ABL & 1) ? yprev : kBufOutside, (unsigned)(nt * 32 + 8 * i) * O3 * 4u, v[0], v[1], v[2], v[3]);
         }
     };
     auto tile = [&](auto with_epilogue, int buf, int j) __attribute__((always_inline)) {
@@ -445,10 +445,15 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
                 cb[(g + 2) % 3] = ap[((g + 2) >> 2) * G::PLANE + ((g + 2) & 3) * G::RS + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (SG_FWDC1_ABL & 2) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[g % 3], wfr[nt][g][0], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt][g] += ca[g % 3] * wfr[nt][g][0] + cb[g % 3] * wfr[nt][g][1];
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[g % 3], wfr[nt][g][1], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[g % 3], wfr[nt][g][0], acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[g % 3], wfr[nt][g][1], acc[nt], 0, 0, 0);
+            }
             if (decltype(with_epilogue)::value) {
                 __builtin_amdgcn_sched_barrier(0);
                 epilogue_slice(g);

@@ -159,6 +159,32 @@ def run_stack(modules, x, training, out=None):
     return x
 
 
+def _shape_after(plan, shape):
+    """Shape of the tensor that leaves the last producer of `plan` ([(producer, BatchNorm3d, act), ...]; BatchNorm and activations
+    keep shapes) for an input of `shape`; None if a producer cannot take it."""
+    for m, _, _ in plan:
+        if isinstance(m, nn.Linear):
+            if shape[-1] != m.in_features:
+                return None
+            shape = shape[:-1] + (m.out_features,)
+            continue
+        if len(shape) != 5 or shape[1] != m.in_channels:
+            return None
+        k, st, pd = m.kernel_size, m.stride, m.padding
+        if isinstance(m, nn.ConvTranspose3d):
+            if tuple(m.output_padding) != (0, 0, 0) or tuple(m.dilation) != (1, 1, 1):
+                return None
+            sp = tuple((shape[2 + i] - 1) * st[i] - 2 * pd[i] + k[i] for i in range(3))
+        else:
+            if tuple(m.dilation) != (1, 1, 1):
+                return None
+            sp = tuple((shape[2 + i] + 2 * pd[i] - k[i]) // st[i] + 1 for i in range(3))
+        if min(sp) < 1:
+            return None
+        shape = (shape[0], m.out_channels) + sp
+    return shape
+
+
 def run_stack_groups(modules, x, groups, outs):
     """`groups` independent evaluations of a generator / decoder stack in ONE pass, WITHOUT grad mode and with batch statistics:
     x [groups * B, ...] holds the groups' inputs one after the other; every BatchNorm3d normalises each group with that group's own
@@ -191,13 +217,19 @@ def run_stack_groups(modules, x, groups, outs):
     a_in = plan[-1][2]
     if a_in[0] not in (ACT_LEAKY, ACT_RELU) or not (0.0 <= a_in[1] <= 1.0):
         return False
+    # the last layer must be served by sg_convT3d_k4s2p1_to1_pre at the shape its input WILL have: decided from the plan before
+    # anything is launched — a refusal behind the grouped BatchNorms would come with their running buffers already updated for
+    # every group, while refusing here lets the caller fall back to one evaluation per group
+    shape = _shape_after(plan, tuple(x.shape))
+    if shape is None or len(shape) != 5 or last.weight.shape[1] != 1 or not ops.convT_to1_pre_eligible(*shape):
+        return False
     for k, (m, bn, a) in enumerate(plan):
         x = _producer(m, x, ACT_NONE, 0.0)
         if k + 1 < len(plan):
             x = ops.bn_train_fwd_grouped_raw(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
                                              bn.momentum, a[0], a[1], groups)
-    if not ops.convT_to1_pre_served(x, last.weight):
-        raise RuntimeError("run_stack_groups: the last layer's shape is not served by sg_convT3d_k4s2p1_to1_pre")
+    if tuple(x.shape) != shape:
+        raise RuntimeError("run_stack_groups: planned %s, got %s" % (shape, tuple(x.shape)))
     bn = plan[-1][1]
     scale, shift = ops.bn_train_stats_affine(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
                                              bn.momentum, groups)

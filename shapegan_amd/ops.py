@@ -576,6 +576,11 @@ def conv_transpose3d_k4s2p1(x, w, b, act=ACT_NONE, slope=0.0, out=None):
     return ConvDgrad.apply(x, w, b, w.shape[1], act, slope, True)
 
 
+def convT_to1_pre_eligible(N, C, D, H, W):
+    """The same question for a shape alone (model/stack.py plans a grouped pass before launching anything)."""
+    return bool(_lib().sg_convT3d_k4s2p1_to1_pre_eligible(int(N), int(C), int(D), int(H), int(W)))
+
+
 def convT_to1_pre_served(x, w):
     """Whether sg_convT3d_k4s2p1_to1_pre takes ConvTranspose3d(C -> 1) on x [N,C,D,H,W] (weight [C,1,4,4,4])."""
     return (w.shape[1] == 1 and x.dim() == 5 and
@@ -1256,14 +1261,71 @@ def gather_rows(table, idx, out=None):
     return out
 
 
-_bad_index_flags = {}
+class BadIndexWords(object):
+    """The out-of-range-batch-index state of ONE consumer of sdf_batch_sort (a trainer): a host word in PINNED HOST memory
+    (device-accessible under unified addressing: the sort kernel touches it only on error, the host reads it with a plain load — no
+    copy, no launch, no synchronisation per step, nothing to capture), a device word that guarded optimizer kernels read
+    (`optim.Adam.guard`), and the number of the latest sort call that used them.  Both words are sticky and set together; they
+    carry the number of the FIRST bad sort call.  Every trainer owns a pair (with one pair per device a second trainer —
+    or a step that does not go through the sort — had its updates dropped by the other one's bad batch without being counted, and
+    whoever polled first cleared the other's error); `default_bad_index_words(dev)` serves direct callers of ops.sdf_batch_sort."""
+
+    def __init__(self, dev):
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        self.flag = torch.zeros(1, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.flag = self.flag.pin_memory()
+        self.guard = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seq = 0
+        _all_bad_index_words.add(self)
+
+    def next_seq(self):
+        self.seq = self.seq % 0x7fffffff + 1        # this call's number (never 0)
+        return self.seq
+
+    def pending(self):
+        return int(self.flag[0]) != 0
+
+    def raise_if_bad(self, synchronise_first=False, synchronise_before_raise=False):
+        capturing = self.dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if synchronise_first and self.dev.type == "cuda" and not capturing:
+            torch.cuda.synchronize(self.dev)
+        if not self.pending():
+            return
+        if synchronise_before_raise and self.dev.type == "cuda" and not capturing:
+            torch.cuda.synchronize(self.dev)
+        err = IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
+        err.sort_sequence = int(self.flag[0])
+        self.flag[0] = 0
+        if not capturing:
+            self.guard.zero_()
+        raise err
 
 
-def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf):
+import weakref as _weakref  # noqa: E402
+_all_bad_index_words = _weakref.WeakSet()
+_bad_index_flags = {}          # device -> the default pair of that device
+
+
+def default_bad_index_words(dev):
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    words = _bad_index_flags.get(dev)
+    if words is None:
+        words = _bad_index_flags[dev] = BadIndexWords(dev)
+    return words
+
+
+def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf, words=None):
     """The auto-decoder batch grouped by shape in one stable counting sort (train_sdf_autodecoder.py:78-85): returns
     points[indices] ([N,3]), sdf[indices] ([N]), the shape id of every entry (int32 [N]), the run bounds of every shape
     (int64 [shapes+1]) and the run lengths (float32 [shapes]) — all in shape order; no host synchronisation.  An index
-    outside the tables raises at the next `check_batch_indices()` (the reference raises an IndexError)."""
+    outside the tables sets `words` (a BadIndexWords; default: the device's shared pair) and raises at the owner's next check
+    (`words.raise_if_bad()` / `check_batch_indices()`; the reference raises an IndexError at once)."""
     lib = _lib()
     if shapes > sdf_batch_sort_max_shapes():
         raise RuntimeError("sdf_batch_sort: %d shapes (at most %d)" % (shapes, sdf_batch_sort_max_shapes()))
@@ -1279,58 +1341,27 @@ def sdf_batch_sort(indices, pointcloud_size, shapes, points, sdf):
     out_shape = torch.empty(n, dtype=torch.int32, device=dev)
     seg_off = torch.empty(shapes + 1, dtype=torch.int64, device=dev)
     counts = torch.empty(shapes, dtype=torch.float32, device=dev)
-    flag, guard = _bad_index_words(dev)
-    seq = _sort_sequence[guard.device] = _sort_sequence.get(guard.device, 0) % 0x7fffffff + 1     # this call's number (never 0)
+    words = default_bad_index_words(dev) if words is None else words
+    seq = words.next_seq()
     ws = workspace("sdf_batch_sort", lib.sg_sdf_batch_sort_workspace_bytes(n, shapes), dev)
     check(lib.sg_sdf_batch_sort(ptr(indices), n, pointcloud_size, shapes, ptr(points), ptr(sdf), ptr(out_points), ptr(out_sdf),
-                                ptr(out_shape), ptr(seg_off), ptr(counts), flag.data_ptr(), ptr(guard), seq, ptr(ws), ws.numel(),
-                                stream()), "sdf_batch_sort")
+                                ptr(out_shape), ptr(seg_off), ptr(counts), words.flag.data_ptr(), ptr(words.guard), seq, ptr(ws),
+                                ws.numel(), stream()), "sdf_batch_sort")
     return out_points, out_sdf, out_shape, seg_off, counts
 
 
-_sort_sequence = {}
-
-
 def batch_sort_sequence(dev):
-    """The number of the latest sdf_batch_sort call on `dev` (1, 2, …; 0 before the first).  The IndexError of a bad batch carries
-    the number of the FIRST call that saw one (`.sort_sequence`)."""
-    return _sort_sequence.get(_bad_index_words(dev)[1].device, 0)
-
-
-def _bad_index_words(dev):
-    """(host word, device word) of `dev`, both sticky and set together by the sort kernel when an index is out of range.
-    The host word lives in PINNED HOST memory (device-accessible under unified addressing): the kernel touches it only on error and
-    the host reads it with a plain load — no copy, no launch, no synchronisation per step, nothing to capture.  The device word is
-    what guarded optimizer kernels read (`batch_index_guard`)."""
-    dev = torch.device(dev)
-    if dev.type == "cuda" and dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    words = _bad_index_flags.get(dev)
-    if words is None:
-        flag = torch.zeros(1, dtype=torch.int32)
-        if dev.type == "cuda":
-            flag = flag.pin_memory()
-        words = _bad_index_flags[dev] = (flag, torch.zeros(1, dtype=torch.int32, device=dev))
-    return words
+    """The number of the latest sdf_batch_sort call on `dev`'s default words (1, 2, …; 0 before the first).  The IndexError of a bad
+    batch carries the number of the FIRST call that saw one (`.sort_sequence`)."""
+    return default_bad_index_words(dev).seq
 
 
 def batch_index_guard(dev):
-    """The device word of `dev` that is non-zero from the moment a sort kernel met an out-of-range batch index until the host has
-    raised for it.  optim.Adam(…).guard = this tensor makes the update of such a batch a no-op (sg_adam_step_guarded): the reference
-    raises its IndexError before any update (train_sdf_autodecoder.py:79), here the error surfaces one step late but the state it
-    leaves behind is the one before the bad batch."""
-    return _bad_index_words(dev)[1]
-
-
-def _raise_bad_index(dev, words, synchronise):
-    if synchronise and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-        torch.cuda.synchronize(dev)
-    err = IndexError("sdf_batch_sort: a batch index was outside [0, shapes * pointcloud_size)")
-    err.sort_sequence = int(words[0][0])
-    words[0][0] = 0
-    if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-        words[1].zero_()
-    raise err
+    """The device word of `dev`'s default pair: non-zero from the moment a sort kernel met an out-of-range batch index until the
+    host has raised for it.  optim.Adam(…).guard = such a tensor makes the update of that batch a no-op (sg_adam_step_guarded): the
+    reference raises its IndexError before any update (train_sdf_autodecoder.py:79), here the error surfaces one step late but the
+    state it leaves behind is the one before the bad batch.  (Trainers own a pair each: BadIndexWords.)"""
+    return default_bad_index_words(dev).guard
 
 
 def sdf_batch_sort_max_shapes():
@@ -1338,22 +1369,18 @@ def sdf_batch_sort_max_shapes():
 
 
 def check_batch_indices():
-    """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables."""
-    for dev, words in _bad_index_flags.items():
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        if int(words[0][0]) != 0:
-            _raise_bad_index(dev, words, False)
+    """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables (every live pair)."""
+    for words in list(_all_bad_index_words):
+        words.raise_if_bad(synchronise_first=True)
 
 
 def poll_batch_indices():
-    """The same check without a synchronisation, for use on EVERY step: a plain read of the pinned host word the sort kernels set.
+    """The same check without a synchronisation, for use on EVERY step: a plain read of the pinned host words the sort kernels set.
     An out-of-range index is reported as soon as the kernel that saw it has run — in practice at the next step (the reference
-    raises at once; the batch in question was computed on clamped rows, and an optimizer guarded by `batch_index_guard` did not
+    raises at once; the batch in question was computed on clamped rows, and an optimizer guarded by the pair's device word did not
     apply it).  Costs nothing on the device and is safe inside a stream capture (there is nothing to record)."""
-    for dev, words in _bad_index_flags.items():
-        if int(words[0][0]) != 0:
-            _raise_bad_index(dev, words, True)
+    for words in list(_all_bad_index_words):
+        words.raise_if_bad(synchronise_before_raise=True)
 
 
 # --------------------------------------------------------------------------------------------------------------

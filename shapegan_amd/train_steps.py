@@ -224,12 +224,14 @@ class SDFAutoDecoderTrainer(object):
         # noticed without a host synchronisation, one step late (`_poll_indices`) — so both optimizers are guarded by the device
         # word the sort kernel sets in the same stream: the bad batch's update is a no-op on parameters, moments and step counters,
         # and the error leaves the state of the step before it (also inside a replayed graph).
-        self.net_opt.guard = self.lat_opt.guard = ops.batch_index_guard(latent_codes.device)
+        # The pair of words is THIS trainer's (ops.BadIndexWords): another trainer on the same device neither skips nor clears it.
+        self._words = ops.BadIndexWords(latent_codes.device)
+        self.net_opt.guard = self.lat_opt.guard = self._words.guard
         self._updates = collections.deque(maxlen=4096)     # the sort call number behind every update issued so far
 
     def _poll_indices(self, synchronise=False):
         try:
-            ops.check_batch_indices() if synchronise else ops.poll_batch_indices()
+            self._words.raise_if_bad(synchronise_first=synchronise, synchronise_before_raise=True)
         except IndexError as e:
             # the host may be several steps ahead of the device: every update issued behind the first bad sort was a no-op on the
             # device (the guard word is sticky until the host clears it) — take the host-side step counters of exactly those back
@@ -286,7 +288,7 @@ class SDFAutoDecoderTrainer(object):
         (ops.sdf_batch_sort: keys, gathers of points / sdf, run bounds and counts; no host round trip)."""
         shapes = self.latent_codes.shape[0]
         batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
-            indices, self.pointcloud_size, shapes, self.points, self.sdf)
+            indices, self.pointcloud_size, shapes, self.points, self.sdf, words=self._words)
         self._sorted_calls += 1
         if self._sorted_calls == 1:
             self._poll_indices(synchronise=True)    # first call: synchronous (a systematically wrong index source fails at once)
@@ -308,12 +310,15 @@ class SDFAutoDecoderTrainer(object):
         self.lat_bucket.allreduce()
         self.net_opt.step()
         self.lat_opt.step()
-        self._updates.append(ops.batch_sort_sequence(self.latent_codes.device))
+        self._updates.append(self._words.seq)
         return loss.detach()
 
     def step_gathered(self, indices):
         """The same step through the reference's data flow (materialised latent_codes[model_indices], per-point
         latent kernel mode) — kept for A/B and parity."""
+        # a sorted step's bad batch may still be pending on the device: this update would then be a guarded no-op too — it is polled
+        # for and counted like the sorted ones (ADVICE r4: mixed batch sizes around the 8192-point threshold)
+        self._poll_indices()
         model_indices = torch.div(indices, self.pointcloud_size, rounding_mode='floor')
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
@@ -330,6 +335,7 @@ class SDFAutoDecoderTrainer(object):
         self.lat_bucket.allreduce()
         self.net_opt.step()
         self.lat_opt.step()
+        self._updates.append(self._words.seq)
         return loss.detach()
 
 

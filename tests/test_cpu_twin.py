@@ -168,6 +168,10 @@ def test_bad_batch_index_update_is_guarded(on_cpu, late_polls, monkeypatch):
 
 
 # ---- modules and training steps (bodies from tests/test_gpu_modules.py: reference-made fixtures + CPU oracle) ----------------
+def test_bad_index_words_per_trainer(on_cpu):
+    LOSS.test_bad_batch_index_words_belong_to_one_trainer()
+
+
 def test_generator_and_discriminator(on_cpu, golden_modules):
     M.test_generator(golden_modules)
     M.test_generator_writes_into_a_given_tensor_without_grad_mode()

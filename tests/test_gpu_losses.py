@@ -572,14 +572,14 @@ def test_bad_batch_index_leaves_the_state_before_the_bad_batch(graphed, late_pol
     for _ in range(4):
         step(good())
     before, host_steps = state(), list(tr.net_opt.steps)
-    real_poll, misses = ops.poll_batch_indices, [late_polls]
+    real_poll, misses = tr._words.raise_if_bad, [late_polls]
 
-    def poll():
-        if misses[0] > 0 and any(int(w[0][0]) != 0 for w in ops._bad_index_flags.values()):
+    def poll(**kw):
+        if misses[0] > 0 and tr._words.pending():
             misses[0] -= 1
             return
-        real_poll()
-    monkeypatch.setattr(ops, "poll_batch_indices", poll)
+        real_poll(**kw)
+    monkeypatch.setattr(tr._words, "raise_if_bad", poll)
     bad = good()
     bad[n // 3] = shapes * pc + 3
     raised, calls = False, 0
@@ -601,6 +601,54 @@ def test_bad_batch_index_leaves_the_state_before_the_bad_batch(graphed, late_pol
     assert not torch.equal(moved[0], before[0])
     if not graphed:
         assert tr.net_opt.steps == [s + 1 for s in host_steps]
+
+
+def test_bad_batch_index_words_belong_to_one_trainer():
+    """the bad-index words used to be one pair per DEVICE.  A second trainer on the same device then had its updates
+    no-op'd by the first one's bad batch without its host counters knowing, and whoever polled first cleared the other's error; a
+    gathered step (below the 8192-point threshold) behind a bad sorted batch was dropped on the device but not counted.  Each
+    trainer owns its pair now: B trains on undisturbed while A's error is pending, A's IndexError arrives at A — also when A's next
+    step is a gathered one — with A's state bit-for-bit that of the step before the bad batch."""
+    from shapegan_amd.model.sdf_net import SDFNet
+    from shapegan_amd.train_steps import SDFAutoDecoderTrainer
+    pc, shapes, L, n = 3000, 4, 64, 8192
+    torch.manual_seed(29)
+    pts = torch.rand(shapes * pc, 3, device=DEV) * 2 - 1
+    sdf = torch.rand(shapes * pc, device=DEV) * 0.3 - 0.15
+
+    def make():
+        return SDFAutoDecoderTrainer(SDFNet(latent_code_size=L), torch.randn(shapes, L, device=DEV) * 1e-2, pts, sdf,
+                                     pointcloud_size=pc, lr=1e-3)
+    A, B = make(), make()
+    assert A._words is not B._words and A.net_opt.guard.data_ptr() != B.net_opt.guard.data_ptr()
+    good = lambda k=n: torch.randint(0, shapes * pc, (k,), device=DEV)
+
+    def state(tr):
+        if DEV != "cpu":
+            torch.cuda.synchronize()
+        return [p.detach().clone() for p in tr.net.parameters()] + [tr.latent_codes.detach().clone(), torch.tensor(tr.net_opt.steps)]
+    for _ in range(3):
+        A.step(good())
+        B.step(good())
+    a0, b0 = state(A), state(B)
+    bad = good()
+    bad[7] = -1
+    raised = False
+    try:
+        A.step(bad)                              # GPU: noticed late (no synchronisation on this path); the synchronous twin: at once
+    except IndexError:
+        raised = True
+    B.step(good())                               # B is not A: its update is applied and counted, nothing raises
+    b1 = state(B)
+    assert not torch.equal(b1[0], b0[0]) and torch.equal(b1[-1], b0[-1] + 1)
+    if not raised:
+        with pytest.raises(IndexError):
+            A.step(good(500))                    # a GATHERED step: polls A's words first
+    for x, y in zip(a0, state(A)):
+        assert torch.equal(x, y), "A's state is not that of the step before its bad batch"
+    B.step(good())                               # B never sees A's error
+    A.step(good(500))                            # and A goes on
+    assert torch.equal(state(A)[-1], a0[-1] + 1) and torch.equal(state(B)[-1], b0[-1] + 2)
 
 
 # ---- C-ABI RCCL exchange (SURVEY.md 8b: sg_allreduce_*) -----------------------------------------------------------------------

@@ -551,3 +551,23 @@ def test_autograd_grad_returns_ordinary_tensors_not_flat_slices():
     d(x * 0.25).mean().backward()                 # a plain backward: ordinary tensors, copied in on demand by step() / the exchange
     assert all(not (lo <= p.grad.data_ptr() < hi) for p in d.parameters())
     opt.step()
+
+
+def test_grouped_generator_pass_refuses_an_unserved_last_layer_before_touching_batchnorm_buffers():
+    """run_stack_groups decided "is the last ConvTranspose3d(C -> 1) served" AFTER the producers and the grouped
+    BatchNorms had run — a generator variant with C > 64 crashed with its running statistics already advanced for every group.  The
+    shape is planned from the module attributes and refused before anything is launched; the caller then evaluates group by
+    group."""
+    import torch.nn as nn
+    from shapegan_amd.model import stack
+    torch.manual_seed(0)
+    layers = nn.Sequential(nn.ConvTranspose3d(8, 96, 4, 2, 1), nn.BatchNorm3d(96), nn.LeakyReLU(0.2),
+                           nn.ConvTranspose3d(96, 1, 4, 2, 1), nn.Tanh())
+    assert stack._shape_after([(layers[0], layers[1], (1, 0.2))], (6, 8, 4, 4, 4)) == (6, 96, 8, 8, 8)
+    gen = nn.Sequential(nn.ConvTranspose3d(128, 256, 4, 1), nn.BatchNorm3d(256), nn.LeakyReLU(0.2), nn.ConvTranspose3d(256, 128, 4, 2, 1))
+    assert stack._shape_after([(gen[0], gen[1], None), (gen[3], None, None)], (5, 128, 1, 1, 1)) == (5, 128, 8, 8, 8)
+    x = torch.randn(6, 8, 4, 4, 4)
+    outs = [torch.empty(2, 1, 16, 16, 16) for _ in range(3)]
+    with torch.no_grad():
+        assert stack.run_stack_groups(layers, x, 3, outs) is False       # 96 channels: not served by sg_convT3d_k4s2p1_to1_pre
+    assert int(layers[1].num_batches_tracked) == 0 and torch.equal(layers[1].running_mean, torch.zeros(96))
