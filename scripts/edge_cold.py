@@ -43,7 +43,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 w1 = torch.randn(64, 1, 4, 4, 4, device="cuda") * 0.1
 b1 = torch.zeros(64, device="cuda")
 out = {"lib": os.path.basename(os.environ.get("SHAPEGAN_HIP_LIB", "default"))}
-for nb in ((128, 64, 16) if what != 'all' else (128, 64)):
+for nb in (() if what == 'convT' else (128, 64, 16) if what != 'all' else (128, 64)):
     mk_x = lambda: torch.randn(nb, 1, 32, 32, 32, device="cuda")
     mk_y = lambda: torch.randn(nb, 64, 16, 16, 16, device="cuda")
     nx, ny = nb * 32768, nb * 64 * 4096
@@ -52,4 +52,8 @@ for nb in ((128, 64, 16) if what != 'all' else (128, 64)):
         out["wgrad_%d" % nb] = both(4.0 * (nx + ny), lambda: (mk_y(), mk_x()), lambda s: ops.conv_wgrad_raw(s[0], s[1], 1))
         out["wgrad_act_%d" % nb] = both(4.0 * (nx + 2 * ny), lambda: (mk_y(), mk_y(), mk_x()), lambda s: ops.conv_wgrad_act_raw(s[0], s[1], s[2], 1, 0.2))
         out["convT_%d" % nb] = both(4.0 * (nx + ny), mk_y, lambda y: ops.conv_dgrad_raw(y, w1, None, 1))
+if what == "convT":
+    for nb in (256, 64, 32, 16):
+        mk_y = lambda: torch.randn(nb, 64, 16, 16, 16, device="cuda")
+        out["convT_%d" % nb] = both(4.0 * (nb * 32768 + nb * 64 * 4096), mk_y, lambda y: ops.conv_dgrad_raw(y, w1, None, 1))
 print(json.dumps(out))

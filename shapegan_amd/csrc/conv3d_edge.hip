@@ -316,6 +316,39 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
     int u = blockIdx.x * a.units_per_wg;
     const int u_end = min(a.units, u + a.units_per_wg);
     if (u >= u_end) return;
+    // ---- staging bookkeeping: piece e = tid + 256 f is 16 bytes of staged row (plane p, row rr) ----
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x - ((long)a.IH * IWT + IWT));    // (see conv_fwd_c1_kernel: offsets stay >= 0)
+    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.y);
+    // one word per piece: byte offset inside the unit's box (< 2^26) | padding classes in bits 26..30: 1 plane 0 (padding when
+    // od = 0), 2 plane 3 (od = OD - 1), 4 row 0 (first row block), 8 row R - 1 (last row block), 16 not a piece at all
+    unsigned pword[G::NP];
+    lds_f32x4* pdst[G::NP];
+#pragma unroll
+    for (int f = 0; f < G::NP; ++f) {
+        const int e = tid + 256 * f;
+        const int p = e / (G::R * G::PW), rem = e - p * (G::R * G::PW), rr = rem / G::PW, c4 = rem - rr * G::PW;
+        const unsigned cls = e >= G::PIECES ? 16u : ((p == 0 ? 1u : 0u) | (p == 3 ? 2u : 0u) | (rr == 0 ? 4u : 0u) | (rr == G::R - 1 ? 8u : 0u));
+        pword[f] = (unsigned)(((p * a.IH + rr) * IWT + 4 * c4) * 4) | (cls << 26);
+        pdst[f] = (lds_f32x4*)((lds_float*)xs + (e >= G::PIECES ? 0 : p * G::PLANE + rr * G::RS + 4 + 4 * c4));
+    }
+    const unsigned O3 = (unsigned)(a.OD * a.OH * G::OWT);
+    f32x4 sv[G::NP];
+    unsigned ybase = 0;       // byte offset of the unit's first output position in channel row 0 of its sample
+    auto stage_issue = [&](int uu, bool real) __attribute__((always_inline)) {
+        uint32_t q, ohb, n, od;
+        a.dbpp.divmod((uint32_t)uu, q, ohb);
+        a.dOD.divmod(q, n, od);
+        const unsigned mask = 0x03ffffffu | ((16u | (od == 0 ? 1u : 0u) | ((int)od == a.OD - 1 ? 2u : 0u) | (ohb == 0 ? 4u : 0u) |
+                                              ((int)ohb == a.blocks_per_plane - 1 ? 8u : 0u)) << 26);
+        const unsigned sbase = (unsigned)(((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * ohb * G::BH) * IWT) * 4);
+#pragma unroll
+        for (int f = 0; f < G::NP; ++f) {
+            const unsigned t = pword[f] & mask;
+            sv[f] = buf_load4v(xres, (!real || (t >> 26) || (SG_FWDC1_ABL & 4)) ? kBufOutside : t, sbase);
+        }
+    };
+    // the first unit's rows are requested before anything else: their HBM latency passes under the weight staging below
+    stage_issue(u, true);
     // ---- weights -> B fragments (through xs, which is not in use yet) ----
     {
         float* wl = xs;
@@ -352,37 +385,6 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
         const int row = e >> 1;
         xs[row * G::RS + ((e & 1) ? 4 + IWT : 3)] = 0.f;
     }
-    // ---- staging bookkeeping: piece e = tid + 256 f is 16 bytes of staged row (plane p, row rr) ----
-    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x - ((long)a.IH * IWT + IWT));    // (see conv_fwd_c1_kernel: offsets stay >= 0)
-    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.y);
-    // one word per piece: byte offset inside the unit's box (< 2^26) | padding classes in bits 26..30: 1 plane 0 (padding when
-    // od = 0), 2 plane 3 (od = OD - 1), 4 row 0 (first row block), 8 row R - 1 (last row block), 16 not a piece at all
-    unsigned pword[G::NP];
-    lds_f32x4* pdst[G::NP];
-#pragma unroll
-    for (int f = 0; f < G::NP; ++f) {
-        const int e = tid + 256 * f;
-        const int p = e / (G::R * G::PW), rem = e - p * (G::R * G::PW), rr = rem / G::PW, c4 = rem - rr * G::PW;
-        const unsigned cls = e >= G::PIECES ? 16u : ((p == 0 ? 1u : 0u) | (p == 3 ? 2u : 0u) | (rr == 0 ? 4u : 0u) | (rr == G::R - 1 ? 8u : 0u));
-        pword[f] = (unsigned)(((p * a.IH + rr) * IWT + 4 * c4) * 4) | (cls << 26);
-        pdst[f] = (lds_f32x4*)((lds_float*)xs + (e >= G::PIECES ? 0 : p * G::PLANE + rr * G::RS + 4 + 4 * c4));
-    }
-    const unsigned O3 = (unsigned)(a.OD * a.OH * G::OWT);
-    f32x4 sv[G::NP];
-    unsigned ybase = 0;       // byte offset of the unit's first output position in channel row 0 of its sample
-    auto stage_issue = [&](int uu, bool real) __attribute__((always_inline)) {
-        uint32_t q, ohb, n, od;
-        a.dbpp.divmod((uint32_t)uu, q, ohb);
-        a.dOD.divmod(q, n, od);
-        const unsigned mask = 0x03ffffffu | ((16u | (od == 0 ? 1u : 0u) | ((int)od == a.OD - 1 ? 2u : 0u) | (ohb == 0 ? 4u : 0u) |
-                                              ((int)ohb == a.blocks_per_plane - 1 ? 8u : 0u)) << 26);
-        const unsigned sbase = (unsigned)(((long)n * a.x_sample + ((long)(2 * od) * a.IH + 2 * ohb * G::BH) * IWT) * 4);
-#pragma unroll
-        for (int f = 0; f < G::NP; ++f) {
-            const unsigned t = pword[f] & mask;
-            sv[f] = buf_load4v(xres, (!real || (t >> 26) || (SG_FWDC1_ABL & 4)) ? kBufOutside : t, sbase);
-        }
-    };
     auto stage_write = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < G::NP; ++f)
@@ -466,7 +468,6 @@ __global__ void __launch_bounds__(256) conv_fwd_c1_lds_kernel(EdgeFwdLdsArgs a) 
             for (int q = 0; q < 16; ++q) pv[nt][q] = acc[nt][q];
     };
 
-    stage_issue(u, true);
     stage_write(0);
     __syncthreads();
     int buf = 0;
@@ -1035,6 +1036,7 @@ struct ConvTStreamArgs {
     long dx_sample;
     int batch, act;
     float slope;
+    int splits;              // 1, or 2: the input planes of a (sample, pd, ph) are walked by two workgroups, [0, OD/2) and [OD/2 - 1, OD)
 };
 
 // ALLCH: Cout == 64 (sixteen full k-steps, no channel clamps); FULL: P2 == 256 (every wave owns two whole position tiles).
@@ -1051,9 +1053,14 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     const int i16 = lane & 15, kq = lane >> 4;
     // XCD-aware decode: workgroup b runs on XCD b % 8; the four workgroups of a sample are neighbours in dispatch order on one XCD
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int n = (j >> 2) * 8 + xcd, pd = (j >> 1) & 1, ph = j & 1;
+    // Plane split (round 5): at batch 64 the grid is 256 workgroups — ONE per CU, two waves per SIMD — and the plane walk is a
+    // latency chain (prefetch distance one plane): with two workgroups per (sample, pd, ph) the CU holds two such chains.  The
+    // second one starts one plane early (plane OD/2 - 1 again: only for its carried sum, nothing is stored for it).
+    const int sub = a.splits == 2 ? (j & 7) : (j & 3), half = sub >> 2;
+    const int n = (a.splits == 2 ? (j >> 3) : (j >> 2)) * 8 + xcd, pd = (sub >> 1) & 1, ph = sub & 1;
     if (n >= a.batch) return;     // (the whole workgroup)
     const int P2 = a.P2, OW = a.OW, OH = a.OH, OD = a.OD;
+    const int qs = a.splits == 2 && half ? OD / 2 - 1 : 0, qe = a.splits == 2 && !half ? OD / 2 : OD;   // planes [qs, qe)
     // Positions are handled in blocks of 32 (one per wave): lane (i16, kq) loads TWO consecutive positions 2 i16, 2 i16 + 1 of
     // channel 4 s + kq with one 8-byte load — a wave instruction covers one whole 128-byte line of each of four channel rows (with
     // 4-byte loads it touched eight half lines for the same data and the texture addresser, not the matrix pipe, paced the plane)
@@ -1073,7 +1080,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     // one k-step of a plane's A fragments (both MFMA tiles of the block); behind the last plane nothing is fetched (out-of-range
     // scalar offset)
     auto load_step = [&](int qd, int s, float (&dst)[2][16]) __attribute__((always_inline)) {
-        const unsigned pshift = qd < OD ? (unsigned)(qd * P2) * 4u : kBufOutside;
+        const unsigned pshift = qd < qe ? (unsigned)(qd * P2) * 4u : kBufOutside;
         // (bit_cast the WHOLE result of the builtin: component access on its own vector type narrows the load to one dword)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x2 v;
@@ -1089,7 +1096,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     };
     float A0[2][16], A1[2][16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) load_step(0, s, A0);
+    for (int s = 0; s < 16; ++s) load_step(qs, s, A0);
     // B fragments: column i16 = tap (g2 = cur / far, khi = same row / neighbour row, kw), k row kq = channel 4 s + kq
     // (requested after plane 0's A fragments below have been: one memory round trip for both)
     const int g2 = i16 >> 3, khi = (i16 >> 2) & 1, kw = i16 & 3;
@@ -1174,7 +1181,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
             }
             eval = v;
         } else {
-            const bool skip = pd == 1 && p == 0;
+            const bool skip = p == qs && (pd == 1 || qs > 0);    // nothing complete yet at the first plane of a walk
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, eval), ores, (int)(skip ? kBufOutside : ovoff),
                                                   (int)((unsigned)(2 * p - pd) * oplane), 0);
         }
@@ -1222,18 +1229,19 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
                 *(__attribute__((address_space(3))) f32x4v*)(buf + i16 * stride + wave * 32 + t * 16 + 4 * kq) = c4[t];
         }
     };
-    plane(0, IntTag<0>(), A0, A1);
-    int qd = 1;
-    for (; qd + 1 < OD; qd += 2) {
+    plane(qs, IntTag<0>(), A0, A1);
+    int qd = qs + 1;
+    // (buffer parity = plane parity; the register sets alternate from the walk's first plane)
+    for (; qd + 1 < qe; qd += 2) {
         plane(qd, IntTag<1>(), A1, A0);
         plane(qd + 1, IntTag<1>(), A0, A1);
     }
-    if (qd < OD) plane(qd, IntTag<1>(), A1, A0);
+    if (qd < qe) plane(qd, IntTag<1>(), A1, A0);
     // the last plane's epilogue, and for d-parity 1 the output plane 2 OD - 1 (cur taps of the last plane alone)
     __syncthreads();
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) epilogue_slice(OD - 1, sl);
-    if (pd == 1) {
+    for (int sl = 0; sl < 3; ++sl) epilogue_slice(qe - 1, sl);
+    if (pd == 1 && qe == OD) {
         float v = carry + b0;
         v = EPI == SG_ACT_NONE ? v : sg_apply_act(v, a.act, a.slope);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff, (int)((unsigned)(2 * OD - 1) * oplane), 0);
@@ -1426,7 +1434,11 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     f.out_group_stride = samples_per_group > 0 ? out_group_stride : (long)batch * f.dx_sample;
     const int nblocks = (f.P2 + 31) / 32;
     const size_t lds = (size_t)2 * 16 * (nblocks * 32 + 4) * sizeof(float);
-    const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4);
+    // two walks per (sample, pd, ph) while one walk each would leave CUs with a single workgroup (<= 1.5 per CU)
+    static const char* split_env = getenv("SG_CONVT_SPLIT");
+    f.splits = (g.OD >= 8 && g.OD % 2 == 0 && (long)((batch + 7) / 8 * 8) * 4 <= 384) ? 2 : 1;
+    if (split_env) f.splits = atoi(split_env) == 2 && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
+    const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4 * f.splits);
 #define SG_CONVT_STREAM(ALL_, PRE_, FULL_, EPI_) \
     hipLaunchKernelGGL((convT_c1_stream_kernel<ALL_, PRE_, FULL_, EPI_>), dim3(wgs), dim3(512), lds, stream, f)
 #define SG_CONVT_STREAM_EPI(ALL_, PRE_, FULL_)                          \
@@ -1455,7 +1467,8 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
     static const bool stream_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 16);
     // (the streaming kernel runs four workgroups per sample for the whole depth of the grid: below ~48 samples it leaves CUs
     // idle and the one-workgroup-per-plane kernel is faster — 17.8 vs 22.6 us at 32 samples, 32.0 vs 22.7 at 64, 114 vs 92 at 256)
-    if (!stream_off && g.OH * g.OW <= 256 && (force || (long)batch * O3 >= 512) && batch >= 48 &&
+    static const int stream_min_batch = getenv("SG_CONVT_MIN_BATCH") ? atoi(getenv("SG_CONVT_MIN_BATCH")) : 48;
+    if (!stream_off && g.OH * g.OW <= 256 && (force || (long)batch * O3 >= 512) && batch >= stream_min_batch &&
         edge_dgrad_stream_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, stream, nullptr, nullptr, 0, 0.f, 0, 0) == 1)
         return 1;
     // fused kernel: a whole (OH x OW) plane of the four tap groups fits in LDS
