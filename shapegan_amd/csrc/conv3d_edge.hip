@@ -1404,7 +1404,7 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
 // the input transform act_in(dy * in_scale[c] + in_shift[c]) folded into the loads (in_act: none / LeakyReLU / ReLU).
 int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                           const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
-                          const float* in_shift, int in_act, float in_slope, int samples_per_group, long out_group_stride) {
+                          const float* in_shift, int in_act, float in_slope, int samples_per_group, long out_group_stride, int force_split) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64 || g.OH * g.OW > 256 || (size_t)g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
     const bool pre = in_scale != nullptr;
@@ -1434,10 +1434,13 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     f.out_group_stride = samples_per_group > 0 ? out_group_stride : (long)batch * f.dx_sample;
     const int nblocks = (f.P2 + 31) / 32;
     const size_t lds = (size_t)2 * 16 * (nblocks * 32 + 4) * sizeof(float);
-    // two walks per (sample, pd, ph) while one walk each would leave CUs with a single workgroup (<= 1.5 per CU)
-    static const char* split_env = getenv("SG_CONVT_SPLIT");
-    f.splits = (g.OD >= 8 && g.OD % 2 == 0 && (long)((batch + 7) / 8 * 8) * 4 <= 384) ? 2 : 1;
-    if (split_env) f.splits = atoi(split_env) == 2 && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
+    // Two walks per (sample, pd, ph) — measured in round 5 and NOT the default: at 64 samples (256 -> 512 workgroups) the cold time
+    // went from 27.7 to 31.5 us, i.e. the plane walk is not a latency chain that a second workgroup per CU would hide (the four
+    // workgroups of a sample already pull every input line through L2 four times; a second walk adds a recomputed plane to that);
+    // only at 32 samples does it win (18.4 us against 25.6 unsplit and 19.4 - 20.9 for the per-plane kernel that serves < 48
+    // samples).  SG_CONVT_SPLIT=2 turns it on for A/B; tests/test_gpu_ops.py runs both forms.
+    const char* split_env = getenv("SG_CONVT_SPLIT");      // (read per call: the parity test toggles it)
+    f.splits = (force_split == 2 || (split_env && atoi(split_env) == 2)) && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
     const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4 * f.splits);
 #define SG_CONVT_STREAM(ALL_, PRE_, FULL_, EPI_) \
     hipLaunchKernelGGL((convT_c1_stream_kernel<ALL_, PRE_, FULL_, EPI_>), dim3(wgs), dim3(512), lds, stream, f)

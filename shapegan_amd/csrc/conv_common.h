@@ -113,6 +113,7 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
 
 int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                           const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
-                          const float* in_shift, int in_act, float in_slope, int samples_per_group = 0, long out_group_stride = 0);
+                          const float* in_shift, int in_act, float in_slope, int samples_per_group = 0, long out_group_stride = 0,
+                          int force_split = 0);
 
 }  // namespace sg

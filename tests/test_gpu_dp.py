@@ -169,3 +169,48 @@ def test_hybrid_progressive_discriminator_step_world2(tmp_path):
 def test_sdf_autodecoder_sorted_step_world2(tmp_path):
     mp.spawn(_sdf_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     check_sdf(tmp_path)
+
+
+def test_nn_dataparallel_of_the_shells_on_a_duplicated_device():
+    """with device_count() > 1 the unmodified train_hybrid_progressive_gan.py wraps both modules in
+    nn.DataParallel (:62-68) — replicate() makes shallow copies whose parameters are broadcast copies, parallel_apply drives them from
+    one thread per device.  The one GPU of a test box stands in for two (device_ids=[0, 0]: two replicas, two threads, one device):
+    outputs equal the unwrapped module's, and the gradients that the reduce-add brings back to the wrapped module equal the plain
+    backward's.  What this exercises in the shells: no state keyed on the module object survives into a replica (kept weight images
+    are not taken for the replicas' broadcast weights — nobody announces writes to them —, the SDFNet pack is rebuilt per call),
+    and two host threads inside the library at once on one device."""
+    import torch.nn as nn
+    from shapegan_amd.model.progressive_gan import Discriminator
+    from shapegan_amd.model.sdf_net import SDFNet
+    torch.manual_seed(12)
+    net = SDFNet()
+    pts = (torch.rand(8192, 3, device="cuda") * 2 - 1)
+    lat = torch.randn(8192, 128, device="cuda") * 0.1
+    want = net(pts, lat)
+    want.square().mean().backward()
+    ref_grads = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    try:
+        dp = nn.DataParallel(net, device_ids=[0, 0])
+        got = dp(pts, lat)
+    except (RuntimeError, AssertionError) as e:           # a torch build that refuses a repeated device id
+        pytest.skip("nn.DataParallel on a duplicated device is not possible here: %s" % e)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7)
+    got.square().mean().backward()
+    for p, r in zip(net.parameters(), ref_grads):
+        torch.testing.assert_close(p.grad, r, rtol=1e-4, atol=1e-6 * float(r.abs().max() + 1e-30))
+    disc = Discriminator().cuda()
+    disc.set_iteration(2)
+    x = (torch.rand(8, 32, 32, 32, device="cuda") * 2 - 1).requires_grad_()
+    want = disc(x)
+    want.mean().backward()
+    ref_x, ref_grads = x.grad.clone(), [None if p.grad is None else p.grad.clone() for p in disc.parameters()]
+    disc.zero_grad()
+    x.grad = None
+    got = nn.DataParallel(disc, device_ids=[0, 0])(x)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    got.mean().backward()
+    torch.testing.assert_close(x.grad, ref_x, rtol=1e-4, atol=1e-7)
+    for p, r in zip(disc.parameters(), ref_grads):
+        if r is not None:
+            torch.testing.assert_close(p.grad, r, rtol=1e-4, atol=1e-6 * float(r.abs().max() + 1e-30))

@@ -341,6 +341,21 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
         with torch.no_grad():
             got2 = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0, out=out[:N])
         assert got2.data_ptr() == out.data_ptr() and torch.equal(got2, got.detach()) and bool((out[N] == 7.0).all())
+    # the opt-in two-walk form (SG_CONVT_SPLIT=2: the planes of a (sample, pd, ph) split over two workgroups, the second one
+    # recomputing the plane in front of its half for the carried sum): the same sums in the same order, bit for bit
+    if DEV == "cuda":
+        import os
+        for N, C, R in ((9, 64, 16), (5, 24, 6), (3, 7, 4), (50, 64, 8)):
+            torch.manual_seed(N + R)
+            x, w, b = dev(torch.randn(N, C, R, R, R)), dev(torch.randn(C, 1, 4, 4, 4) / (C * 8) ** 0.5), dev(torch.randn(1))
+            scale, shift = dev(torch.randn(C)), dev(torch.randn(C) * 0.3)
+            one = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
+            os.environ["SG_CONVT_SPLIT"] = "2"
+            try:
+                two = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
+            finally:
+                del os.environ["SG_CONVT_SPLIT"]
+            assert torch.equal(one, two), "two-walk form differs at N=%d C=%d R=%d" % (N, C, R)
 
 
 def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monkeypatch):
