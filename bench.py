@@ -144,7 +144,7 @@ def conv_kernel_table():
     f1 = 2.0 * 64 * 64 * 4096 * nb
     mk_x = lambda: torch.randn(nb, 1, 32, 32, 32, device="cuda")
     mk_y = lambda n=nb: torch.randn(n, 64, 16, 16, 16, device="cuda")
-    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv_fwd_c1_kernel<2,1>", 4.0 * (nx + ny + w1.numel()), f1,
+    hbm("Conv3d 1->64 forward, 32^3 -> 16^3, 128 samples", "conv_fwd_c1_lds_kernel<2,1,32>", 4.0 * (nx + ny + w1.numel()), f1,
         mk_x, lambda x: ops.conv_fwd_raw(x, w1, b1, 1, 0.2), in_step="largest")
     hbm("Conv3d 1->64 weight-gradient, 128 samples", "conv_wgrad_c1_kernel<2,0>", 4.0 * (nx + ny + w1.numel()), f1,
         lambda: (mk_y(), mk_x()), lambda s: ops.conv_wgrad_raw(s[0], s[1], 1))
@@ -258,7 +258,10 @@ def sdfnet_numbers():
     out = {"fwd_mpoints_per_s": round(n_fwd / ms_fwd / 1e3, 2),
            "fwd_tflops_algorithmic": round(n_fwd * alg / (ms_fwd * 1e-3) / 1e12, 2),
            "fwd_tflops_executed": round(n_fwd * exe / (ms_fwd * 1e-3) / 1e12, 2),
-           "fwd_frac_of_f32_mfma_peak_algorithmic": round(n_fwd * alg / (ms_fwd * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+           # (the algorithmic count includes the latent columns of layers1.0 / layers2.0 that the per-shape fold never multiplies:
+           # against the reference's FLOP count the kernel is this factor "faster" than its executed rate — a speed-up of the data
+           # flow, not a fraction of the matrix peak)
+           "speedup_from_latent_fold": round(alg / exe, 4),
            "fwd_frac_of_f32_mfma_peak_executed": round(n_fwd * exe / (ms_fwd * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     pc, shapes = 200000, 64
     pts = torch.rand(shapes * pc, 3, device="cuda") * 2 - 1

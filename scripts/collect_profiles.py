@@ -18,7 +18,8 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
              "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json",
-             "pytest_gpu.log", "dropin_gpu.log"):
+             "pytest_gpu.log", "dropin_gpu.log", "write_pattern.jsonl", "edge_kernels_cold.json", "fwd_c1_ablation.json",
+             "dgrad_paired_stores.json"):
     f = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
@@ -84,7 +85,9 @@ dom = [r for r in rows if dom_name and dom_name.replace(" ", "") in r["kernel"].
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_read_bytes"] + dom[0]["hbm_write_bytes"],
                "read": dom[0]["hbm_read_bytes"], "write": dom[0]["hbm_write_bytes"],
-               "note": "median over the launches of two WGAN steps (shapes of 64 / 128 / 256 samples mixed)"},
+               "note": "median launch of two WGAN steps = the critic's 128-sample shape ([128,128,8^3] -> [128,64,16^3]: 134 MB of output, "
+                       "35.6 MB of operands); the step also runs the kernel at 64 and 256 samples.  Per-shape figures: "
+                       "<tag>_dgrad_paired_stores.json"},
               open(os.path.join(dst, tag + "_dominant_kernel_hbm.json"), "w"), indent=1)
 
 
@@ -120,12 +123,25 @@ def md_tables():
         if cb:
             L += ["| cpu_baseline | %.3f %s on %d of %d host threads, kind `%s` |" % (cb["value"], cb["unit"], cb["cores"],
                                                                                     cb.get("host_cores", 0), cb["kind"])]
-        L += ["", "| conv form (`kernels`) | kernel | us | rate | fraction of its roofline |", "|---|---|---|---|---|"]
+        L += ["", "| conv form (`kernels`) | kernel | us | rate | fraction of its roofline | us warm (replay on one buffer set) | us inside the profiled step |",
+              "|---|---|---|---|---|---|---|"]
         for k in d["kernels"]:
             rate = "%.1f TFLOP/s" % k["tflops"] if k["bound"] == "mfma" else "%.0f GB/s" % k["gb_per_s"]
-            L += ["| %s | `%s` | %.1f | %s | %.3f (%s) |" % (k["name"], k["kernel"], k["us"], rate, k["frac"],
-                                                           "fp32 MFMA 157.3 TF" if k["bound"] == "mfma" else "HBM 8 TB/s")]
+            L += ["| %s | `%s` | %.1f%s | %s | %.3f (%s) | %s | %s |" % (
+                k["name"], k["kernel"], k["us"], " (cold)" if k.get("timing", "").startswith("cold") else "", rate, k["frac"],
+                "fp32 MFMA 157.3 TF" if k["bound"] == "mfma" else "HBM 8 TB/s", k.get("us_warm", ""), k.get("us_in_step", ""))]
         L += [""]
+        dl = d.get("dropin_loop")
+        if dl:
+            L += ["`dropin_loop` (%s):" % dl["what"], "",
+                  "| loop | steps/s | ms per step | fraction of `WGANTrainer.step` | kernel launches per step |", "|---|---|---|---|---|",
+                  "| `WGANTrainer.step` (the headline) | %.2f | %.3f | 1 | %s |" % (d["value"], d["ms_per_step"], dl.get("trainer_step_launches_per_step")),
+                  "| module-level loop, batches resident on the device | %.2f | %.3f | %.3f | %s |" % (
+                      dl["resident_batches"]["steps_per_s"], dl["resident_batches"]["ms_per_step"],
+                      dl["resident_batches"].get("fraction_of_trainer_step", 0), dl.get("launches_per_step")),
+                  "| module-level loop, pageable host batches copied in the loop (`batch.to(device)`) | %.2f | %.3f | %.3f | |" % (
+                      dl["host_batches_copied_in_the_loop"]["steps_per_s"], dl["host_batches_copied_in_the_loop"]["ms_per_step"],
+                      dl["host_batches_copied_in_the_loop"].get("fraction_of_trainer_step", 0)), ""]
     b2 = os.path.join(dst, tag + "_bench_line_2ranks_gloo_one_gpu.json")
     if os.path.exists(b2):
         lines = [ln for ln in open(b2).read().splitlines() if ln.startswith("{")]
@@ -180,6 +196,49 @@ def md_tables():
         L += ["### `%s_edge_kernels_by_batch.json` (`python scripts/edge_ab.py`: one-channel kernels, us per launch)" % tag, "",
               "| entry | " + " | ".join(k for k in d if k != "lib") + " |", "|---|" + "---|" * (len(d) - 1),
               "| us | " + " | ".join(str(v) for k, v in d.items() if k != "lib") + " |", ""]
+    f = os.path.join(dst, tag + "_edge_kernels_cold.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_edge_kernels_cold.json` (`python scripts/edge_cold.py all`: every call on the next of K operand sets, > 640 MB in rotation)" % tag, "",
+              "| kernel @ samples | cold us | warm us | cold fraction of 8 TB/s |", "|---|---|---|---|"]
+        for k, v in d.items():
+            if isinstance(v, dict):
+                L += ["| %s | %.1f | %.1f | %.3f |" % (k, v["cold_us"], v["warm_us"], v["cold_frac_8TBs"])]
+        L += [""]
+    f = os.path.join(dst, tag + "_fwd_c1_ablation.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_fwd_c1_ablation.json` (Conv3d(1 -> 64) forward, 32^3 -> 16^3: what each part of the kernel costs, cold us)" % tag, "",
+              "| build | 128 samples | 64 samples | 16 samples |", "|---|---|---|---|"]
+        for k, v in d.items():
+            L += ["| %s | %.1f | %.1f | %.1f |" % (k, v["fwd_128"]["cold_us"], v["fwd_64"]["cold_us"], v["fwd_16"]["cold_us"])]
+        L += [""]
+    f = os.path.join(dst, tag + "_write_pattern.jsonl")
+    if os.path.exists(f):
+        rows_ = [json.loads(ln) for ln in open(f) if ln.startswith("{")]
+        names = {0: "the forward's pattern: a wave writes 128 B to each of 64 rows 16 KB apart", 1: "512 B runs, a wave per 64 rows",
+                 2: "512 B runs, a wave per 16 rows", 3: "plain fill (1 KB per wave instruction)"}
+        L += ["### `%s_write_pattern.jsonl` (`scripts/micro/write_pattern`: 134 MB written with nothing else going on)" % tag, "",
+              "| workgroups | pattern | cold us | TB/s | warm us |", "|---|---|---|---|---|"]
+        cold = {(r["grid"], r["mode"]): r for r in rows_ if "us" in r}
+        warm = {(r["grid"], r["mode"]): r for r in rows_ if "warm_us" in r}
+        for (g_, m_), r in sorted(cold.items()):
+            if r["us"] > 10:
+                L += ["| %d | %s | %.1f | %.2f | %.1f |" % (g_, names.get(m_, m_), r["us"], r["tb_per_s"], warm.get((g_, m_), {}).get("warm_us", 0))]
+        L += [""]
+    f = os.path.join(dst, tag + "_dgrad_paired_stores.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_dgrad_paired_stores.json` (`conv_dgrad_halo_kernel`: 8-byte (pw0, pw1) stores against the 4-byte stores of rounds 1-4)" % tag, "",
+              "| kernel, grid | build | written MB | fetched MB (x2) | MFMA busy |", "|---|---|---|---|---|"]
+        for v in ("paired", "unpaired"):
+            for k, r in d[v].items():
+                if k != "time" and "written_MB" in r:
+                    L += ["| %s | %s | %.1f | %.1f | %s |" % (k, v, r["written_MB"], r["fetched_MB_x2"], r.get("mfma_busy", ""))]
+        L += ["", "| shape | paired us | unpaired us |", "|---|---|---|"]
+        for k in d["paired"]["time"]:
+            L += ["| %s | %.1f | %.1f |" % (k, d["paired"]["time"][k]["us"], d["unpaired"]["time"].get(k, {}).get("us", 0))]
+        L += ["", d.get("note", ""), ""]
     f = os.path.join(dst, tag + "_cpu_baseline_reference_vs_port.json")
     if os.path.exists(f):
         d = json.load(open(f))
