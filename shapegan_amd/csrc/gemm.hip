@@ -9,6 +9,8 @@
 // A, B, C are addressed through element strides; each operand must have one unit stride (either
 // along its row or along k) so that staging loads coalesce.  j is the lane axis of the MFMA C/D
 // fragment: pick j as the contiguous axis of C.
+#include <stdlib.h>
+
 #include "mfma_tile.h"
 #include "../../include/shapegan_hip.h"
 
@@ -366,6 +368,284 @@ static void gemm_nt_plan(int M, int N, long K, int& nsplit, long& kchunk, int ba
     nsplit = (int)((K + kchunk - 1) / kchunk);
 }
 
+// ================================================================================================================
+// gemm128_kernel (round 5): the data movement of gemm_nt_bigk_kernel for sg_gemm's large dense products — the Linear layers of the
+// PointNet GAN family run at 196 608 x 256 x 256 (model/point_sdf_net.py:50-119: forward x W^T, input gradient g W, weight gradient
+// g^T x), where the generic 16-k skeleton of mfma_tile.h (4-byte staging, two barriers and a fragment-read phase per k-tile) sat at
+// 0.63 - 0.68 of the matrix peak and took 69 % of the family's kernel time (profiles/r05_point_gan_kernel_stats.csv).
+//   C(i, j) = epilogue( sum_k A(i, k) B(k, j) )       128 x 128 tile per workgroup, 32 k per stage, 16-byte loads, one barrier per stage
+// Each operand is either k-major (element (row, k) at p[row * ld + k]: the 16-byte piece is 4 consecutive k of one row and goes to LDS
+// as it is, [k / 4][row][4]) or row-major (element at p[k * ld + row]: a thread loads the pieces of 4 consecutive k for the same 4
+// rows — a wave instruction covers 512 contiguous bytes of one k — transposes the 4 x 4 block in registers and writes the same LDS
+// layout).  Fragment reads, MFMA loop and the XCD-aware tile order are those of gemm_nt_bigk_kernel.  Requirements of the fast path
+// (sg_gemm checks them and keeps the skeleton otherwise): 16-byte aligned bases and leading dimensions; for a row-major operand its
+// row count is a multiple of 4.
+struct Gemm128Args {
+    const float* A;
+    const float* B;
+    long lda, ldb;
+    int M, N;
+    long K, kchunk;
+    int nsplit;
+};
+
+template <bool AK, bool BK, class EPI>
+__global__ void __launch_bounds__(256) gemm128_kernel(Gemm128Args a, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A | B][8][kNtChunk]
+    lds_float* const sl = (lds_float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kh = lane >> 5;
+    const int tiles_n = (a.N + 127) >> 7, tiles = tiles_n * ((a.M + 127) >> 7);
+    // K splits are spread over the XCDs, the tiles of one split are consecutive workgroups of one XCD (they share operand slices)
+    const int xcd = blockIdx.x & 7, qx = blockIdx.x >> 3;
+    const int sz = a.nsplit > 1 ? (qx / tiles) * 8 + xcd : 0;
+    const int tile = a.nsplit > 1 ? qx % tiles : (int)blockIdx.x;
+    if (sz >= a.nsplit || tile >= tiles) return;
+    // (without a K split consecutive workgroups walk a tile COLUMN: they share the 128 x K slice of B, the small operand of a Linear)
+    const int i0 = a.nsplit > 1 ? (tile / tiles_n) * 128 : (tile % ((a.M + 127) >> 7)) * 128;
+    const int j0 = a.nsplit > 1 ? (tile % tiles_n) * 128 : (tile / ((a.M + 127) >> 7)) * 128;
+    const long kbeg = (long)sz * a.kchunk, kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const int nstage = (int)((kend - kbeg + kNtKC - 1) / kNtKC);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // ---- copy roles ----
+    // k-major operand: thread -> (row inside a 32-row pass, piece kq of the stage's 128-byte row segment), 4 passes
+    // row-major operand: thread -> (k chunk c of the stage, row piece rq): loads k = 4 c .. 4 c + 3 for rows 4 rq .. 4 rq + 3
+    const int rowl = tid >> 3, kq = tid & 7, cc = tid >> 5, rq = tid & 31;
+    const __amdgpu_buffer_rsrc_t ares =
+        AK ? make_rsrc_bytes(a.A + (long)i0 * a.lda + kbeg, ((long)(a.M - 1 - i0) * a.lda + (a.K - kbeg)) * 4)
+           : make_rsrc_bytes(a.A + kbeg * a.lda + i0, ((a.K - 1 - kbeg) * a.lda + (a.M - i0)) * 4);
+    const __amdgpu_buffer_rsrc_t bres =
+        BK ? make_rsrc_bytes(a.B + (long)j0 * a.ldb + kbeg, ((long)(a.N - 1 - j0) * a.ldb + (a.K - kbeg)) * 4)
+           : make_rsrc_bytes(a.B + kbeg * a.ldb + j0, ((a.K - 1 - kbeg) * a.ldb + (a.N - j0)) * 4);
+    unsigned avoff[4], bvoff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (AK) avoff[p] = i0 + p * 32 + rowl < a.M ? (unsigned)(((long)rowl * a.lda + 4 * kq) * 4) : kBufOutside;
+        else avoff[p] = i0 + 4 * rq < a.M ? (unsigned)(((long)(4 * cc + p) * a.lda + 4 * rq) * 4) : kBufOutside;
+        if (BK) bvoff[p] = j0 + p * 32 + rowl < a.N ? (unsigned)(((long)rowl * a.ldb + 4 * kq) * 4) : kBufOutside;
+        else bvoff[p] = j0 + 4 * rq < a.N ? (unsigned)(((long)(4 * cc + p) * a.ldb + 4 * rq) * 4) : kBufOutside;
+    }
+    const unsigned pass_a = (unsigned)(32 * a.lda * 4), pass_b = (unsigned)(32 * a.ldb * 4);
+    const unsigned stage_a = AK ? (unsigned)(kNtKC * 4) : (unsigned)(kNtKC * a.lda * 4);
+    const unsigned stage_b = BK ? (unsigned)(kNtKC * 4) : (unsigned)(kNtKC * a.ldb * 4);
+    lds_float* const adst = AK ? sl + kq * kNtChunk + rowl * 4 : sl + cc * kNtChunk + rq * 16;
+    lds_float* const bdst = (BK ? sl + kq * kNtChunk + rowl * 4 : sl + cc * kNtChunk + rq * 16) + kNtOp;
+    const lds_float* afrag = sl + kh * kNtChunk + (wm * 64 + r) * 4;
+    const lds_float* bfrag = sl + kNtOp + kh * kNtChunk + (wn * 64 + r) * 4;
+
+    f32x4 ra[4], rb[4];   // pieces in flight (two stages ahead)
+    auto issue = [&](int s) __attribute__((always_inline)) {   // (a stage past the end re-reads the last one: never committed)
+        const int sc = s < nstage ? s : nstage - 1;
+        // row-major pieces of k >= kend are whole loads beyond the K range: out of range through the scalar offset
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (AK) ra[p] = buf_load4v(ares, avoff[p], (unsigned)sc * stage_a + (unsigned)p * pass_a);
+            else ra[p] = buf_load4v(ares, kbeg + (long)sc * kNtKC + 4 * cc + p < kend ? avoff[p] : kBufOutside, (unsigned)sc * stage_a);
+            if (BK) rb[p] = buf_load4v(bres, bvoff[p], (unsigned)sc * stage_b + (unsigned)p * pass_b);
+            else rb[p] = buf_load4v(bres, kbeg + (long)sc * kNtKC + 4 * cc + p < kend ? bvoff[p] : kBufOutside, (unsigned)sc * stage_b);
+        }
+    };
+    auto mask_tail = [&](int s) __attribute__((always_inline)) {   // k-major pieces: zero the k >= kend part of the last stage
+        const long k = kbeg + (long)s * kNtKC + 4 * kq;
+        if (k + 4 > kend) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j >= kend) {
+                        if (AK) ra[p][j] = 0.f;
+                        if (BK) rb[p][j] = 0.f;
+                    }
+            }
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        if (AK) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(lds_f32x4*)(adst + buf * 2 * kNtOp + p * 128) = ra[p];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};     // row 4 rq + e, k = 4 cc .. 4 cc + 3
+                *(lds_f32x4*)(adst + buf * 2 * kNtOp + e * 4) = t;
+            }
+        }
+        if (BK) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(lds_f32x4*)(bdst + buf * 2 * kNtOp + p * 128) = rb[p];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
+                *(lds_f32x4*)(bdst + buf * 2 * kNtOp + e * 4) = t;
+            }
+        }
+    };
+
+    if (nstage > 0) {
+        issue(0);
+        if (nstage == 1) mask_tail(0);
+        commit(0);
+        issue(1);
+        __syncthreads();
+        auto stage = [&](auto tag, int s) __attribute__((always_inline)) {
+            constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+            if (s + 1 == nstage - 1) mask_tail(s + 1);   // the pieces in registers belong to stage s + 1
+            commit(NXT);
+            issue(s + 2);
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + t * 128);
+                fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + t * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ca[2], cb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ca[t] = fa[t];
+                    cb[t] = fb[t];
+                }
+                if (g + 1 < 4) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                        fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a0 = ca[0][j], a1 = ca[1][j], b0 = cb[0][j], b1 = cb[1][j];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int s = 0; s + 1 < nstage; s += 2) {
+            stage(IntTag<0>(), s);
+            stage(IntTag<1>(), s + 1);
+        }
+        if (nstage & 1) stage(IntTag<0>(), nstage - 1);
+    }
+    // (a split's partial image is addressed through blockIdx.z by EpiWorkspace: the launcher puts the split there too — see below)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int j = j0 + wn * 64 + tj * 32 + r;
+        if (j >= a.N) continue;
+        const typename EPI::Col c = epi.col(j, sz);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = i0 + wm * 64 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (i < a.M) epi.store(c, i, j, acc[ti][tj][q]);
+            }
+    }
+}
+
+// the two epilogues of gemm128_kernel: the product itself through sg_gemm's GemmEpi, or a split's partial image
+struct Gemm128Direct {
+    GemmEpi e;
+    typedef GemmEpi::Col Col;
+    __device__ Col col(int j, int) const { return e.col(j); }
+    __device__ void store(const Col& c, int i, int j, float v) const { e.store(c, i, j, v); }
+};
+struct Gemm128Partial {
+    float* ws;
+    int M, N;
+    struct Col {
+        long off;
+    };
+    __device__ Col col(int j, int split) const { return Col{(long)split * M * N + j}; }
+    __device__ void store(const Col& c, int i, int j, float v) const { ws[c.off + (long)i * N] = v; }
+};
+
+// Returns 1 if the product was launched here, 0 if the shape / layout is left to the skeleton.
+static int gemm128_try(const float* A, long sai, long sak, const float* B, long sbk, long sbj, const GemmEpi& epi, int M, int N,
+                       int K, float* ws, size_t ws_bytes, hipStream_t stream) {
+    static const bool off = getenv("SG_GEMM128") && atoi(getenv("SG_GEMM128")) == 0;
+    const bool ak = sak == 1 && sai != 1, bk = sbk == 1 && sbj != 1;      // (a degenerate dimension keeps the skeleton)
+    if (off || (!ak && sai != 1) || (!bk && sbj != 1) || (!ak && bk)) return 0;
+    const long lda = ak ? sai : sak, ldb = bk ? sbj : sbk;
+    if (M < 128 || N < 128 || K < 64 || (long)M * N < (1L << 16)) return 0;
+    if ((lda & 3) || (ldb & 3) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return 0;
+    if ((!ak && (M & 3)) || (!bk && (N & 3))) return 0;
+    // 32-bit byte offsets inside a workgroup's window: 128 rows (k-major) or one K chunk of rows (row-major) of an operand
+    const long tiles = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
+    long s = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
+    const long maxs = K / (8 * kNtKC) > 0 ? K / (8 * kNtKC) : 1;
+    if (s > maxs) s = maxs;
+    if (s > 128) s = 128;
+    if (s > 1 && (!ws || ws_bytes < (size_t)s * M * N * sizeof(float))) s = ws ? (long)(ws_bytes / ((size_t)M * N * sizeof(float))) : 1;
+    if (s < 1) s = 1;
+    if (tiles * s < 128) return 0;                                          // too small to fill the chip either way
+    Gemm128Args g;
+    g.A = A;
+    g.B = B;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.kchunk = ((K + s - 1) / s + kNtKC - 1) / kNtKC * kNtKC;
+    g.nsplit = (int)((K + g.kchunk - 1) / g.kchunk);
+    const long win_a = ak ? 128 * lda + g.kchunk : g.kchunk * lda + 128, win_b = bk ? 128 * ldb + g.kchunk : g.kchunk * ldb + 128;
+    if (win_a * 4 >= (long)kBufRange || win_b * 4 >= (long)kBufRange) return 0;
+    const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
+    const unsigned wgs = g.nsplit > 1 ? (unsigned)((g.nsplit + 7) / 8 * 8 * tiles) : (unsigned)tiles;
+#define SG_G128(AK_, BK_)                                                                                                         \
+    do {                                                                                                                         \
+        static SgPerDeviceOnce once_d, once_p;                                                                                  \
+        if (g.nsplit == 1) {                                                                                                     \
+            if (once_d.begin()) {                                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<AK_, BK_, Gemm128Direct>),                \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+                once_d.end();                                                                                                    \
+            }                                                                                                                    \
+            hipLaunchKernelGGL((gemm128_kernel<AK_, BK_, Gemm128Direct>), dim3(wgs), dim3(256), lds, stream, g, Gemm128Direct{epi}); \
+        } else {                                                                                                                 \
+            if (once_p.begin()) {                                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<AK_, BK_, Gemm128Partial>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+                once_p.end();                                                                                                    \
+            }                                                                                                                    \
+            hipLaunchKernelGGL((gemm128_kernel<AK_, BK_, Gemm128Partial>), dim3(wgs), dim3(256), lds, stream, g,                 \
+                               Gemm128Partial{ws, M, N});                                                                        \
+        }                                                                                                                        \
+    } while (0)
+    if (ak && bk) SG_G128(true, true);
+    else if (ak && !bk) SG_G128(true, false);
+    else SG_G128(false, false);
+#undef SG_G128
+    if (g.nsplit > 1) {
+        if (g.nsplit >= 32 && (long)M * N <= (1L << 18)) {
+            hipLaunchKernelGGL((splitk_finalize_deep_kernel<GemmEpi>), dim3((unsigned)(((long)M * N + 63) / 64)), dim3(256), 0, stream,
+                               (const float*)ws, epi, M, N, g.nsplit);
+        } else {
+            const long fb = (long)M * ((N + 1023) >> 10);
+            hipLaunchKernelGGL((splitk_finalize_kernel<GemmEpi>), dim3((unsigned)fb), dim3(256), 0, stream, (const float*)ws, epi, M, N,
+                               g.nsplit);
+        }
+    }
+    return 1;
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -383,6 +663,10 @@ int sg_gemm(const float* A, long sai, long sak, const float* B, long sbk, long s
     SG_CHECK_ARG(sbk == 1 || sbj == 1);
     GemmEpi epi{C, sci, scj, bias_i, bias_j, bias_j_shift, act, slope};
     float* ws = (float*)workspace;
+    if (gemm128_try(A, sai, sak, B, sbk, sbj, epi, M, N, K, ws, workspace_bytes, stream) == 1) {
+        SG_CHECK_LAUNCH();
+        return SG_OK;
+    }
     // prefer the k-contiguous form when a dimension is degenerate (both strides legal)
     const bool a_kfast = (sak == 1);
     const bool b_kfast = (sbk == 1);

@@ -536,7 +536,11 @@ def test_conv_linearity_and_adjoint_full_size():
 
 # ---- GEMM / Linear / 1^3<->4^3 convs --------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(64, 128, 256), (4, 128, 256), (16, 128, 16384), (64, 1, 16384), (5, 7, 3),
-                                   (200, 300, 130), (64, 16384, 128)])
+                                   (200, 300, 130), (64, 16384, 128),
+                                   # shapes that take gemm128_kernel (round 5): the PointNet GAN's Linear layers at many points —
+                                   # forward k-major x k-major, input gradient k-major x row-major, weight gradient row-major x
+                                   # row-major with a K split; ragged row counts, a K that ends inside a stage
+                                   (20000, 256, 256), (16388, 384, 320), (40004, 128, 100)])
 def test_linear_fwd_bwd(M, N, K):
     from shapegan_amd import ops
     from shapegan_amd.lib import ACT_LEAKY
