@@ -31,7 +31,11 @@ Rank 0 prints ONE JSON line (schema in the task contract).  At N=1 with the defa
                   executed FLOP rates,
   `other_configs` BASELINE configs[2] / [3] / [4] on the same GPU (a few timed steps each: value, ms per step, the SDFNet share),
   `cpu_baseline`  the same step on the host cores — the reference's own modules where the checkout exists (`kind: "reference"`),
-                  else the CPU restatement (`kind: "port"`, `reference_present: false`) — and the GPU-vs-oracle loss agreement.
+                  else the CPU restatement (`kind: "port"`, `reference_present: false`) — and the GPU-vs-oracle loss agreement;
+                  `value` = ALL host cores, filled with concurrent 32-thread replicas of the step (one process stops scaling at
+                  ~32 threads), `single_process` = one of them alone,
+  `dropin_loop`   what the reference's own loop body (train_wgan.py:60-84 over the module-level surface: generate(), two critic
+                  calls, stock torch.optim, clip_weights, .item()) reaches on the same modules, next to `WGANTrainer.step`.
 With N > 1 the line carries `comm`: what exchanged the gradients (`native-rccl`: the C-ABI exchange, ranks / RCCL version read
 back from the communicator; `torch-nccl`: torch.distributed, with the reason) and the all-reduced bytes per step.
 """
@@ -397,6 +401,50 @@ class _ReferenceWGAN(object):
                 self.generator_step(zg)
 
 
+def _cpu_replica_main(argv):
+    """`python bench.py --cpu-replica <state file> <steps> <threads> <index>`: one replica of the CPU baseline (no GPU, no
+    shapegan_amd): loads state and inputs, pins itself to its core set, runs `steps` 5+1 steps, prints its elapsed seconds."""
+    path, steps, threads, index = argv[0], int(argv[1]), int(argv[2]), int(argv[3])
+    try:
+        os.sched_setaffinity(0, range(index * threads, (index + 1) * threads))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(threads)
+    from oracle import ref_import
+    from oracle import torch_oracle as O
+    d = torch.load(path)
+    orc = _ReferenceWGAN(ref_import.load(), d["g"], d["c"]) if ref_import.available() else O.WGANOracle(d["g"], d["c"])
+    orc.critic_step(d["reals"][0], d["zs"][0])          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.step(d["reals"], d["zs"], d["zg"])
+    print(json.dumps({"elapsed": time.perf_counter() - t0, "steps": steps}), flush=True)
+
+
+def _cpu_replicas(replicas, threads, steps, reals, zs, zg, g_state, c_state):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "state.pt")
+        torch.save({"g": g_state, "c": c_state, "reals": reals, "zs": zs, "zg": zg}, path)
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-replica", path, str(steps), str(threads), str(i)],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(replicas)]
+        times = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=600)
+                lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+                if p.returncode == 0 and lines:
+                    times.append(json.loads(lines[-1])["elapsed"])
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if len(times) != replicas:
+        return None        # a replica failed: keep the single-process figure
+    return {"replicas": replicas, "threads_each": threads, "steps_each": steps, "slowest_s": round(max(times), 3),
+            "fastest_s": round(min(times), 3), "steps_per_s": replicas * steps / max(times)}
+
+
 def cpu_baseline(reals, zs, zg, g_state, c_state):
     """The same 5+1 step on the host cores, plus the agreement of the GPU path with it on the first critic update.  Where the
     reference checkout is present the step runs on the reference's own modules (`kind: "reference"`); on a box without it — the
@@ -434,10 +482,19 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
     for _ in range(nsteps):
         orc.step(reals, zs, zg)
     dt = time.perf_counter() - t0
-    return {"value": round(nsteps / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": kind,
-            "reference_present": have_ref, "host_cores": os.cpu_count(),
-            "sample": "%d full 5+1 WGAN step(s) at batch 64 after 1 warm-up critic update, %s on torch CPU fp32"
-                      % (nsteps, who),
+    threads = torch.get_num_threads()
+    single = {"value": round(nsteps / dt, 4), "cores": threads}
+    # ALL host cores: one process does not use them — oneDNN's conv3d backward gets slower beyond ~32
+    # threads — so the box's cores are filled with independent replicas of the same step, 32 threads each, pinned to disjoint
+    # core sets (the data-parallel way to use a many-core host); the aggregate over the replicas is the baseline's value
+    replicas = max(1, (os.cpu_count() or threads) // threads)
+    agg = _cpu_replicas(replicas, threads, max(1, nsteps // 2), reals, zs, zg, g_state, c_state) if replicas > 1 else None
+    value, cores = (agg["steps_per_s"], replicas * threads) if agg else (single["value"], threads)
+    return {"value": round(value, 4), "unit": "steps/s", "cores": cores, "kind": kind,
+            "reference_present": have_ref, "host_cores": os.cpu_count(), "single_process": single, "all_cores": agg,
+            "sample": "%d full 5+1 WGAN step(s) at batch 64 after 1 warm-up critic update, %s on torch CPU fp32%s"
+                      % (nsteps, who, "" if not agg else "; value = %d concurrent replicas x %d threads, %d step(s) each, steps summed "
+                         "over the replicas / the slowest replica's time" % (replicas, threads, agg["steps_each"])),
             "why_port": None if have_ref else "the reference checkout (/root/reference) does not exist on this box, so its module "
                         "classes cannot be imported; the port runs the same torch.nn.functional calls from the same state_dict",
             "gpu_vs_oracle": {"critic_scores_max_err_over_mean_abs": rel, "critic_loss_rel_err": loss_rel,
@@ -649,6 +706,8 @@ def self_launch(gpus, argv, script=None):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-replica":
+        return _cpu_replica_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
