@@ -19,7 +19,7 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
 for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
              "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json",
              "pytest_gpu.log", "dropin_gpu.log", "write_pattern.jsonl", "edge_kernels_cold.json", "fwd_c1_ablation.json",
-             "dgrad_paired_stores.json"):
+             "convT_c1_ablation.json", "dgrad_paired_stores.json"):
     f = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
@@ -212,6 +212,16 @@ def md_tables():
               "| build | 128 samples | 64 samples | 16 samples |", "|---|---|---|---|"]
         for k, v in d.items():
             L += ["| %s | %.1f | %.1f | %.1f |" % (k, v["fwd_128"]["cold_us"], v["fwd_64"]["cold_us"], v["fwd_16"]["cold_us"])]
+        L += [""]
+    f = os.path.join(dst, tag + "_convT_c1_ablation.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        L += ["### `%s_convT_c1_ablation.json` (ConvTranspose3d(64 -> 1) forward, 16^3 -> 32^3: `convT_c1_stream_kernel` builds, cold us; below 48 "
+              "samples the per-plane kernel serves the call and the builds do not differ)" % tag, "",
+              "| build | 256 samples | 64 samples | 32 samples | 16 samples |", "|---|---|---|---|---|"]
+        for k, v in d.items():
+            L += ["| %s | %.1f | %.1f | %.1f | %.1f |" % (k, v["convT_256"]["cold_us"], v["convT_64"]["cold_us"], v["convT_32"]["cold_us"],
+                                                       v["convT_16"]["cold_us"])]
         L += [""]
     f = os.path.join(dst, tag + "_write_pattern.jsonl")
     if os.path.exists(f):

@@ -3,6 +3,7 @@
 #   <tag>_write_pattern.jsonl             what the memory side takes when 134 MB are written the way conv_fwd_c1 writes them (cold / warm)
 #   <tag>_edge_kernels_cold.json          the four one-channel kernels timed cold AND warm (scripts/edge_cold.py)
 #   <tag>_fwd_c1_ablation.json            conv_fwd_c1_lds_kernel without stores / MFMAs / staging loads, and the gather form it replaced
+#   <tag>_convT_c1_ablation.json         convT_c1_stream_kernel without plane loads / MFMAs / global stores (cold, 256 .. 16 samples)
 #   <tag>_dgrad_paired_stores.json        conv_dgrad_halo_kernel with 8-byte (pw0, pw1) stores against the 4-byte stores of rounds 1-4:
 #                                         time, WRITE_SIZE, FETCH_SIZE, MFMA busy per shape
 tag=${1:-rXX}
@@ -11,7 +12,17 @@ repo=$(pwd); out=$repo/gpurun_out/prof_$tag; mkdir -p $out
 scripts/micro/write_pattern > $out/${tag}_write_pattern.jsonl 2>/dev/null
 [ -f scripts/_abl/nopair.so ] || bash scripts/ab_build.sh nopair conv3d_halo.hip -DSG_DGRAD_NO_PAIR > /dev/null 2>&1
 for v in 1 2 4 3; do [ -f scripts/_abl/fwdc1_abl$v.so ] || bash scripts/ab_build.sh fwdc1_abl$v conv3d_edge.hip -DSG_FWDC1_ABL=$v > /dev/null 2>&1; done
+for v in 1 2 4 3; do [ -f scripts/_abl/convt_abl$v.so ] || bash scripts/ab_build.sh convt_abl$v conv3d_edge.hip -DSG_CONVT_ABL=$v > /dev/null 2>&1; done
 python scripts/edge_cold.py all > $out/${tag}_edge_kernels_cold.json 2> $out/edge_cold.err
+{
+  echo '{'
+  echo '"shipped": '; python scripts/edge_cold.py convT 2>/dev/null; echo ','
+  echo '"no_plane_loads": '; SHAPEGAN_HIP_LIB=$repo/scripts/_abl/convt_abl1.so python scripts/edge_cold.py convT 2>/dev/null; echo ','
+  echo '"no_mfma": '; SHAPEGAN_HIP_LIB=$repo/scripts/_abl/convt_abl2.so python scripts/edge_cold.py convT 2>/dev/null; echo ','
+  echo '"no_global_stores": '; SHAPEGAN_HIP_LIB=$repo/scripts/_abl/convt_abl4.so python scripts/edge_cold.py convT 2>/dev/null; echo ','
+  echo '"no_plane_loads_no_mfma": '; SHAPEGAN_HIP_LIB=$repo/scripts/_abl/convt_abl3.so python scripts/edge_cold.py convT 2>/dev/null
+  echo '}'
+} > $out/${tag}_convT_c1_ablation.json
 {
   echo '{'
   echo '"lds": '; python scripts/edge_cold.py fwd 2>/dev/null; echo ','
@@ -54,9 +65,10 @@ for v in ("paired", "unpaired"):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE"):
             d["mfma_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
     res[v] = rec
-res["note"] = ("grids: <0> 131072 / 262144 / 524288 threads = 64 / 128 / 256 samples of [N,128,8^3] -> [N,64,16^3] (134 MB of output at 128 "
-               "samples); <1> 32768 .. 131072 = 16 .. 256 samples of [N,256,4^3] -> [N,128,8^3].  paired = this round's library, "
-               "unpaired = the same source built with -DSG_DGRAD_NO_PAIR (the 4-byte stores of rounds 1-4)")
+res["note"] = ("grids: <0> 131072 threads = 64 AND 128 samples of [N,128,8^3] -> [N,64,16^3] (512 workgroups either way, 4 or 8 parities "
+               "each; the median launch is a 128-sample one: 134 MB of output), 262144 = 256 samples; <1> 32768 / 65536 / 131072 = 16-32 / 64 / "
+               "128-256 samples of [N,256,4^3] -> [N,128,8^3].  paired = this round's library, unpaired = the same source built with "
+               "-DSG_DGRAD_NO_PAIR (the 4-byte stores of rounds 1-4)")
 json.dump(res, open(os.path.join(out, tag + "_dgrad_paired_stores.json"), "w"), indent=1)
 PY
-ls -la $out | grep -E "write_pattern|edge_kernels_cold|fwd_c1_ablation|dgrad_paired" 
+ls -la $out | grep -E "write_pattern|edge_kernels_cold|fwd_c1_ablation|convT_c1_ablation|dgrad_paired" 

@@ -1045,6 +1045,9 @@ struct ConvTStreamArgs {
 // `if (more planes) prefetch` it waited for the just-issued loads of plane qd + 1 before the first MFMA of plane qd (ISA listing:
 // vmcnt(31) .. vmcnt(0) instead of vmcnt(63) .. vmcnt(32)), i.e. no overlap at all.  The prefetch behind the last plane is issued
 // anyway with an out-of-range scalar offset (returns zeros without touching memory).
+#ifndef SG_CONVT_ABL
+#define SG_CONVT_ABL 0   // ablation builds only (scripts/ab_build.sh): 1 no plane loads, 2 no MFMAs, 4 no global stores
+#endif
 template <bool ALLCH, bool PRE, bool FULL, int EPI>   // EPI: SG_ACT_NONE, SG_ACT_TANH (inlined, branch-free) or -1 (a.act at run time)
 __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float S[];   // [2 buffers][16 taps][stride]
@@ -1080,7 +1083,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     // one k-step of a plane's A fragments (both MFMA tiles of the block); behind the last plane nothing is fetched (out-of-range
     // scalar offset)
     auto load_step = [&](int qd, int s, float (&dst)[2][16]) __attribute__((always_inline)) {
-        const unsigned pshift = qd < qe ? (unsigned)(qd * P2) * 4u : kBufOutside;
+        const unsigned pshift = qd < qe && !(SG_CONVT_ABL & 1) ? (unsigned)(qd * P2) * 4u : kBufOutside;
         // (bit_cast the WHOLE result of the builtin: component access on its own vector type narrows the load to one dword)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x2 v;
@@ -1181,7 +1184,7 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
             }
             eval = v;
         } else {
-            const bool skip = p == qs && (pd == 1 || qs > 0);    // nothing complete yet at the first plane of a walk
+            const bool skip = (p == qs && (pd == 1 || qs > 0)) || (SG_CONVT_ABL & 4);    // nothing complete yet at the first plane of a walk
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, eval), ores, (int)(skip ? kBufOutside : ovoff),
                                                   (int)((unsigned)(2 * p - pd) * oplane), 0);
         }
@@ -1218,7 +1221,8 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
                     v = fmaf(v, psc[s], psh[s]);
                     v = fmaxf(v, v * a.in_slope);     // LeakyReLU with 0 <= slope <= 1 (ReLU: 0, none: 1) as max(t, slope t)
                 }
-                c4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[s], c4[t], 0, 0, 0);
+                if (SG_CONVT_ABL & 2) c4[t][s & 3] += v * wfr[s];
+                else c4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[s], c4[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
