@@ -68,3 +68,25 @@ def test_a_world_size_that_contradicts_gpus_is_refused_with_both_launch_forms_na
                          env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert res.returncode != 0
     assert "python bench.py --gpus N" in res.stderr and "torch.distributed.run" in res.stderr
+
+
+def test_cpu_baseline_fills_all_cores_with_pinned_replicas(monkeypatch):
+    """bench.py's cpu_baseline: one process stops scaling at ~32 threads, so ALL host cores are filled with
+    concurrent replicas of the same 5 + 1 step; the aggregate is steps summed over the replicas / the slowest replica's time.  Here:
+    two replicas of two threads each on a batch of 2 (the replicas import only torch and oracle/, never the GPU library)."""
+    import torch
+    import torch.nn as nn
+    import shapegan_amd.model.gan as G
+    monkeypatch.setattr(nn.Module, "cuda", lambda self, *a, **k: self)       # CPU tier: the shells' constructors call .cuda()
+    monkeypatch.setattr(G, "default_device", torch.device("cpu"))
+    torch.manual_seed(0)
+    g, c = G.Generator(), G.Discriminator()
+    g_state = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    c_state = {k: v.detach().clone() for k, v in c.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    reals = [torch.rand(2, 32, 32, 32, generator=gen) * 2 - 1 for _ in range(5)]
+    zs = [torch.randn(2, 128, generator=gen) for _ in range(5)]
+    zg = torch.randn(2, 128, generator=gen)
+    agg = bench._cpu_replicas(2, 2, 1, reals, zs, zg, g_state, c_state)
+    assert agg is not None and agg["replicas"] == 2 and agg["steps_each"] == 1
+    assert agg["steps_per_s"] > 0 and abs(agg["steps_per_s"] - 2 * 1 / agg["slowest_s"]) < 1e-2 * agg["steps_per_s"]
