@@ -559,6 +559,197 @@ __global__ void __launch_bounds__(256) gemm128_kernel(Gemm128Args a, EPI epi) {
     }
 }
 
+// gemm128p_kernel: the same tile loop, PERSISTENT over the tiles of a product without a K split.  At K = 256 a tile is only eight
+// stages long, and a workgroup per tile paid two exposed memory round trips (first stage, second stage) and a store burst per
+// 13.6 us of MFMAs: 0.54 of the matrix peak at 196 608 x 256 x 256 where gemm_nt_bigk_kernel (thousands of stages per tile) holds 0.85.
+// Here a workgroup walks tiles b, b + G, b + 2 G, ... (down a tile column: the small operand B stays in L2) as ONE stream of stages:
+// the loads of the next tile's first two stages are in flight while the current tile's last two stages compute, and its 64 result
+// stores per lane drain under the next tile's MFMAs.
+template <bool AK, bool BK>
+__global__ void __launch_bounds__(256, 2) gemm128p_kernel(Gemm128Args a, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A | B][8][kNtChunk]
+    lds_float* const sl = (lds_float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kh = lane >> 5;
+    const int tiles_m = (a.M + 127) >> 7, tiles = tiles_m * ((a.N + 127) >> 7);
+    const int nstage = (int)((a.K + kNtKC - 1) / kNtKC);
+    const int G = gridDim.x;
+    const int n_my = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (n_my == 0 || nstage == 0) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int rowl = tid >> 3, kq = tid & 7, cc = tid >> 5, rq = tid & 31;
+    const unsigned pass_a = (unsigned)(32 * a.lda * 4), pass_b = (unsigned)(32 * a.ldb * 4);
+    const unsigned stage_a = AK ? (unsigned)(kNtKC * 4) : (unsigned)(kNtKC * a.lda * 4);
+    const unsigned stage_b = BK ? (unsigned)(kNtKC * 4) : (unsigned)(kNtKC * a.ldb * 4);
+    // lane offsets inside a tile's window (row validity is added per tile at issue time)
+    unsigned alane[4], blane[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        alane[p] = AK ? (unsigned)(((long)rowl * a.lda + 4 * kq) * 4) : (unsigned)(((long)(4 * cc + p) * a.lda + 4 * rq) * 4);
+        blane[p] = BK ? (unsigned)(((long)rowl * a.ldb + 4 * kq) * 4) : (unsigned)(((long)(4 * cc + p) * a.ldb + 4 * rq) * 4);
+    }
+    lds_float* const adst = AK ? sl + kq * kNtChunk + rowl * 4 : sl + cc * kNtChunk + rq * 16;
+    lds_float* const bdst = (BK ? sl + kq * kNtChunk + rowl * 4 : sl + cc * kNtChunk + rq * 16) + kNtOp;
+    const lds_float* afrag = sl + kh * kNtChunk + (wm * 64 + r) * 4;
+    const lds_float* bfrag = sl + kNtOp + kh * kNtChunk + (wn * 64 + r) * 4;
+
+    // tile `it` of this workgroup: global tile t = blockIdx.x + it * G, walking down a tile column (i fastest)
+    auto origin = [&](int it, int& i0, int& j0) __attribute__((always_inline)) {
+        const int t = (int)blockIdx.x + it * G;
+        i0 = (t % tiles_m) * 128;
+        j0 = (t / tiles_m) * 128;
+    };
+    f32x4 ra[4], rb[4];   // pieces in flight
+    int is_it = 0, is_s = 0;                 // the (tile, stage) the NEXT issue fetches
+    auto issue = [&]() __attribute__((always_inline)) {
+        const bool real = is_it < n_my;
+        int i0, j0;
+        origin(real ? is_it : n_my - 1, i0, j0);
+        const __amdgpu_buffer_rsrc_t ares =
+            AK ? make_rsrc_bytes(a.A + (long)i0 * a.lda, ((long)(a.M - 1 - i0) * a.lda + a.K) * 4)
+               : make_rsrc_bytes(a.A + i0, ((a.K - 1) * a.lda + (a.M - i0)) * 4);
+        const __amdgpu_buffer_rsrc_t bres =
+            BK ? make_rsrc_bytes(a.B + (long)j0 * a.ldb, ((long)(a.N - 1 - j0) * a.ldb + a.K) * 4)
+               : make_rsrc_bytes(a.B + j0, ((a.K - 1) * a.ldb + (a.N - j0)) * 4);
+        const long k0 = (long)is_s * kNtKC;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool aok = real && (AK ? i0 + p * 32 + rowl < a.M : (i0 + 4 * rq < a.M && k0 + 4 * cc + p < a.K));
+            const bool bok = real && (BK ? j0 + p * 32 + rowl < a.N : (j0 + 4 * rq < a.N && k0 + 4 * cc + p < a.K));
+            ra[p] = buf_load4v(ares, aok ? alane[p] : kBufOutside, (unsigned)is_s * stage_a + (AK ? (unsigned)p * pass_a : 0u));
+            rb[p] = buf_load4v(bres, bok ? blane[p] : kBufOutside, (unsigned)is_s * stage_b + (BK ? (unsigned)p * pass_b : 0u));
+        }
+        if (++is_s == nstage) {
+            is_s = 0;
+            ++is_it;
+        }
+    };
+    auto mask_tail = [&](int s) __attribute__((always_inline)) {   // k-major pieces of a tile's last stage: zero k >= K
+        const long k = (long)s * kNtKC + 4 * kq;
+        if (k + 4 > a.K) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j >= a.K) {
+                        if (AK) ra[p][j] = 0.f;
+                        if (BK) rb[p][j] = 0.f;
+                    }
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        if (AK) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(lds_f32x4*)(adst + buf * 2 * kNtOp + p * 128) = ra[p];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+                *(lds_f32x4*)(adst + buf * 2 * kNtOp + e * 4) = t;
+            }
+        }
+        if (BK) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(lds_f32x4*)(bdst + buf * 2 * kNtOp + p * 128) = rb[p];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
+                *(lds_f32x4*)(bdst + buf * 2 * kNtOp + e * 4) = t;
+            }
+        }
+    };
+    const bool ktail = (a.K % kNtKC) != 0 && (AK || BK);
+    int reg_s = 0;                           // stage (inside its tile) of the pieces currently in registers
+    issue();                                 // stage 0 of the first tile
+    if (ktail && nstage == 1) mask_tail(0);
+    commit(0);
+    issue();                                 // the second stage of the stream
+    reg_s = nstage == 1 ? 0 : 1;
+    __syncthreads();
+    auto stage = [&](auto tag) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+        if (ktail && reg_s == nstage - 1) mask_tail(reg_s);
+        commit(NXT);                         // (behind the last stage of the stream: clamped pieces into a buffer nobody reads)
+        issue();
+        reg_s = reg_s + 1 == nstage ? 0 : reg_s + 1;
+        f32x4 fa[2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + t * 128);
+            fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + t * 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 ca[2], cb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ca[t] = fa[t];
+                cb[t] = fb[t];
+            }
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = *(const lds_f32x4*)(afrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                    fb[t] = *(const lds_f32x4*)(bfrag + CUR * 2 * kNtOp + (g + 1) * 2 * kNtChunk + t * 128);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = ca[0][j], a1 = ca[1][j], b0 = cb[0][j], b1 = cb[1][j];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    // (an even stage count per tile: the buffer parity is the same at every tile's first stage — sg_gemm's dispatch guarantees it)
+    for (int it = 0; it < n_my; ++it) {
+        for (int s2 = 0; s2 < nstage; s2 += 2) {
+            stage(IntTag<0>());
+            stage(IntTag<1>());
+        }
+        // the tile is complete: its results leave while the next tile's first stages (already requested) arrive
+        {
+            int i0, j0;
+            origin(it, i0, j0);
+            // raw buffer stores: the resource starts at C(i0, j0) and ENDS with row M - 1, so rows beyond M are out of range by
+            // themselves; a lane keeps one offset per column tile (4 kh rows down, its column), everything else is scalar
+            const __amdgpu_buffer_rsrc_t cres = make_rsrc_bytes(epi.c + (long)i0 * epi.sci + j0, ((long)(a.M - 1 - i0) * epi.sci + (a.N - j0)) * 4);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int jl = wn * 64 + tj * 32 + r;
+                const bool jok = j0 + jl < a.N;
+                const float bj = epi.bias_j && jok ? epi.bias_j[(j0 + jl) >> epi.bias_j_shift] : 0.f;
+                const unsigned voff = jok ? (unsigned)(((long)(4 * kh) * epi.sci + jl) * 4) : kBufOutside;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const unsigned soff = (unsigned)(((long)(wm * 64 + ti * 32 + (q & 3) + 8 * (q >> 2)) * epi.sci) * 4);
+                        const float v = sg_apply_act(acc[ti][tj][q] + bj, epi.act, epi.slope);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cres, (int)voff, (int)soff, 0);
+                        acc[ti][tj][q] = 0.f;
+                    }
+            }
+        }
+    }
+}
+
 // the two epilogues of gemm128_kernel: the product itself through sg_gemm's GemmEpi, or a split's partial image
 struct Gemm128Direct {
     GemmEpi e;
@@ -608,11 +799,26 @@ static int gemm128_try(const float* A, long sai, long sak, const float* B, long 
     const long win_a = ak ? 128 * lda + g.kchunk : g.kchunk * lda + 128, win_b = bk ? 128 * ldb + g.kchunk : g.kchunk * ldb + 128;
     if (win_a * 4 >= (long)kBufRange || win_b * 4 >= (long)kBufRange) return 0;
     const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
+    // a product without a K split and with more tiles than resident workgroups runs persistently (SG_GEMM128=2: one workgroup per tile)
+    static const bool persist_off = getenv("SG_GEMM128") && atoi(getenv("SG_GEMM128")) == 2;
+    // (its epilogue writes rows of C through one 32-bit-offset window per tile: unit column stride, no per-row bias, 128 rows of C
+    // below 2 GiB; its operand windows span the whole K range)
+    const bool persistent = !persist_off && tiles > 512 && ((K + kNtKC - 1) / kNtKC) % 2 == 0 && epi.scj == 1 && !epi.bias_i && 128 * epi.sci * 4 < (long)kBufRange &&
+                            (ak ? 128 * lda + K : (long)K * lda + 128) * 4 < (long)kBufRange &&
+                            (bk ? 128 * ldb + K : (long)K * ldb + 128) * 4 < (long)kBufRange;
     const unsigned wgs = g.nsplit > 1 ? (unsigned)((g.nsplit + 7) / 8 * 8 * tiles) : (unsigned)tiles;
 #define SG_G128(AK_, BK_)                                                                                                         \
     do {                                                                                                                         \
         static SgPerDeviceOnce once_d, once_p;                                                                                  \
-        if (g.nsplit == 1) {                                                                                                     \
+        if (g.nsplit == 1 && persistent) {                                                                                       \
+            static SgPerDeviceOnce once_pp;                                                                                      \
+            if (once_pp.begin()) {                                                                                               \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128p_kernel<AK_, BK_>),                              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+                once_pp.end();                                                                                                   \
+            }                                                                                                                    \
+            hipLaunchKernelGGL((gemm128p_kernel<AK_, BK_>), dim3(tiles < 512 ? (unsigned)tiles : 512u), dim3(256), lds, stream, g, epi); \
+        } else if (g.nsplit == 1) {                                                                                              \
             if (once_d.begin()) {                                                                                                \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<AK_, BK_, Gemm128Direct>),                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \

@@ -540,7 +540,9 @@ def test_conv_linearity_and_adjoint_full_size():
                                    # shapes that take gemm128_kernel (round 5): the PointNet GAN's Linear layers at many points —
                                    # forward k-major x k-major, input gradient k-major x row-major, weight gradient row-major x
                                    # row-major with a K split; ragged row counts, a K that ends inside a stage
-                                   (20000, 256, 256), (16388, 384, 320), (40004, 128, 100)])
+                                   (20000, 256, 256), (16388, 384, 320), (40004, 128, 100),
+                                   # more than 512 tiles: the persistent form (gemm128p_kernel) for forward and input gradient
+                                   (70004, 256, 128)])
 def test_linear_fwd_bwd(M, N, K):
     from shapegan_amd import ops
     from shapegan_amd.lib import ACT_LEAKY
@@ -557,6 +559,26 @@ def test_linear_fwd_bwd(M, N, K):
     close(xg.grad, xr.grad, what="linear dx")
     close(wg.grad, wr.grad, what="linear dw")
     close(bg.grad, br.grad, what="linear db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(70004, 256, 128), (66000, 384, 64), (131072, 128, 320)])
+def test_gemm128_persistent_all_layouts(M, N, K):
+    """gemm128p_kernel (a workgroup walks tiles as one stream of stages, > 512 tiles, even stage count) in its three operand layouts,
+    with a per-column bias and LeakyReLU in the epilogue, against torch in fp64; ragged last row tile."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ACT_LEAKY
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K)
+    b = torch.randn(N, K) / K ** 0.5
+    bias = torch.randn(N)
+    ref = F.leaky_relu(a.double() @ b.double().t() + bias.double(), 0.2).float()
+    got = ops.gemm_raw(dev(a), False, dev(b), True, bias_j=dev(bias), act=ACT_LEAKY, slope=0.2)                 # k-major x k-major
+    close(got, ref, what="A [M,K] x B [N,K]^T")
+    got = ops.gemm_raw(dev(a), False, dev(b.t().contiguous()), False, bias_j=dev(bias), act=ACT_LEAKY, slope=0.2)   # k-major x row-major
+    close(got, ref, what="A [M,K] x B [K,N]")
+    got = ops.gemm_raw(dev(a.t().contiguous()), True, dev(b.t().contiguous()), False, bias_j=dev(bias), act=ACT_LEAKY, slope=0.2)
+    close(got, ref, what="A [K,M]^T x B [K,N]")                                                                   # row-major x row-major
 
 
 def test_gemm_double_backward():
