@@ -610,27 +610,42 @@ __global__ void __launch_bounds__(256, 2) gemm128p_kernel(Gemm128Args a, GemmEpi
     };
     f32x4 ra[4], rb[4];   // pieces in flight
     int is_it = 0, is_s = 0;                 // the (tile, stage) the NEXT issue fetches
-    auto issue = [&]() __attribute__((always_inline)) {
-        const bool real = is_it < n_my;
+    // operand windows and row validity of the tile being fetched: rebuilt when the fetch cursor enters a tile, not per stage (the
+    // 64-bit scalar arithmetic of two resources and a tile decode per issue was 190 SALU instructions per stage and wave)
+    __amdgpu_buffer_rsrc_t ares, bres;
+    unsigned aoff[4], boff[4];
+    bool is_real = true;
+    auto enter_tile = [&]() __attribute__((always_inline)) {
+        is_real = is_it < n_my;
         int i0, j0;
-        origin(real ? is_it : n_my - 1, i0, j0);
-        const __amdgpu_buffer_rsrc_t ares =
-            AK ? make_rsrc_bytes(a.A + (long)i0 * a.lda, ((long)(a.M - 1 - i0) * a.lda + a.K) * 4)
-               : make_rsrc_bytes(a.A + i0, ((a.K - 1) * a.lda + (a.M - i0)) * 4);
-        const __amdgpu_buffer_rsrc_t bres =
-            BK ? make_rsrc_bytes(a.B + (long)j0 * a.ldb, ((long)(a.N - 1 - j0) * a.ldb + a.K) * 4)
-               : make_rsrc_bytes(a.B + j0, ((a.K - 1) * a.ldb + (a.N - j0)) * 4);
+        origin(is_real ? is_it : n_my - 1, i0, j0);
+        ares = AK ? make_rsrc_bytes(a.A + (long)i0 * a.lda, ((long)(a.M - 1 - i0) * a.lda + a.K) * 4)
+                  : make_rsrc_bytes(a.A + i0, ((a.K - 1) * a.lda + (a.M - i0)) * 4);
+        bres = BK ? make_rsrc_bytes(a.B + (long)j0 * a.ldb, ((long)(a.N - 1 - j0) * a.ldb + a.K) * 4)
+                  : make_rsrc_bytes(a.B + j0, ((a.K - 1) * a.ldb + (a.N - j0)) * 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool aok = is_real && (AK ? i0 + p * 32 + rowl < a.M : i0 + 4 * rq < a.M);
+            const bool bok = is_real && (BK ? j0 + p * 32 + rowl < a.N : j0 + 4 * rq < a.N);
+            aoff[p] = aok ? alane[p] : kBufOutside;
+            boff[p] = bok ? blane[p] : kBufOutside;
+        }
+    };
+    enter_tile();
+    auto issue = [&]() __attribute__((always_inline)) {
         const long k0 = (long)is_s * kNtKC;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const bool aok = real && (AK ? i0 + p * 32 + rowl < a.M : (i0 + 4 * rq < a.M && k0 + 4 * cc + p < a.K));
-            const bool bok = real && (BK ? j0 + p * 32 + rowl < a.N : (j0 + 4 * rq < a.N && k0 + 4 * cc + p < a.K));
-            ra[p] = buf_load4v(ares, aok ? alane[p] : kBufOutside, (unsigned)is_s * stage_a + (AK ? (unsigned)p * pass_a : 0u));
-            rb[p] = buf_load4v(bres, bok ? blane[p] : kBufOutside, (unsigned)is_s * stage_b + (BK ? (unsigned)p * pass_b : 0u));
+            // (a row-major piece is ONE k: beyond K it is a whole load out of range)
+            const unsigned ao = AK || k0 + 4 * cc + p < a.K ? aoff[p] : kBufOutside;
+            const unsigned bo = BK || k0 + 4 * cc + p < a.K ? boff[p] : kBufOutside;
+            ra[p] = buf_load4v(ares, ao, (unsigned)is_s * stage_a + (AK ? (unsigned)p * pass_a : 0u));
+            rb[p] = buf_load4v(bres, bo, (unsigned)is_s * stage_b + (BK ? (unsigned)p * pass_b : 0u));
         }
         if (++is_s == nstage) {
             is_s = 0;
             ++is_it;
+            enter_tile();
         }
     };
     auto mask_tail = [&](int s) __attribute__((always_inline)) {   // k-major pieces of a tile's last stage: zero k >= K
@@ -736,12 +751,17 @@ __global__ void __launch_bounds__(256, 2) gemm128p_kernel(Gemm128Args a, GemmEpi
                 const bool jok = j0 + jl < a.N;
                 const float bj = epi.bias_j && jok ? epi.bias_j[(j0 + jl) >> epi.bias_j_shift] : 0.f;
                 const unsigned voff = jok ? (unsigned)(((long)(4 * kh) * epi.sci + jl) * 4) : kBufOutside;
+                const unsigned row4 = (unsigned)epi.sci * 4u;          // bytes per row of C (the window is below 2 GiB)
+                const unsigned sbase = (unsigned)(wm * 64) * row4;
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const unsigned soff = (unsigned)(((long)(wm * 64 + ti * 32 + (q & 3) + 8 * (q >> 2)) * epi.sci) * 4);
-                        const float v = sg_apply_act(acc[ti][tj][q] + bj, epi.act, epi.slope);
+                        const unsigned soff = sbase + (unsigned)(ti * 32 + (q & 3) + 8 * (q >> 2)) * row4;
+                        float v = acc[ti][tj][q] + bj;
+                        if (epi.act == SG_ACT_LEAKY) v = v > 0.f ? v : v * epi.slope;       // (uniform: the common cases stay branch-free)
+                        else if (epi.act == SG_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (epi.act != SG_ACT_NONE) v = sg_apply_act(v, epi.act, epi.slope);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cres, (int)voff, (int)soff, 0);
                         acc[ti][tj][q] = 0.f;
                     }
