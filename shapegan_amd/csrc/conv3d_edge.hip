@@ -1046,7 +1046,8 @@ struct ConvTStreamArgs {
 // vmcnt(31) .. vmcnt(0) instead of vmcnt(63) .. vmcnt(32)), i.e. no overlap at all.  The prefetch behind the last plane is issued
 // anyway with an out-of-range scalar offset (returns zeros without touching memory).
 #ifndef SG_CONVT_ABL
-#define SG_CONVT_ABL 0   // ablation builds only (scripts/ab_build.sh): 1 no plane loads, 2 no MFMAs, 4 no global stores
+#define SG_CONVT_ABL 0   // ablation builds only (scripts/ab_build.sh): 1 no plane loads, 2 no MFMAs, 4 no global stores,
+                         // 8 no gather epilogue, 16 no LDS tile writes, 32 no per-plane barrier, 64 no load instructions at all
 #endif
 template <bool ALLCH, bool PRE, bool FULL, int EPI>   // EPI: SG_ACT_NONE, SG_ACT_TANH (inlined, branch-free) or -1 (a.act at run time)
 __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs a) {
@@ -1199,15 +1200,15 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
         f32x4v c4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            load_step(qd + 1, s, nxt);
-            if (decltype(with_epi)::value) {
+            if (!(SG_CONVT_ABL & 64)) load_step(qd + 1, s, nxt);
+            if (decltype(with_epi)::value && !(SG_CONVT_ABL & 8)) {
                 // The barrier that publishes plane qd - 1's tap rows sits HERE, one MFMA pair into plane qd, not behind the LDS
                 // writes at the end of plane qd - 1: the drain of that plane's last MFMAs, the write latency and the arrival
                 // skew of the eight waves then pass under this plane's first MFMAs (counters with the barrier at the end of the
                 // plane: matrix pipe 51 % busy, 30 % of the wave cycles parked).  Safe with two buffers: a wave writes buffer b
                 // again only at the end of the plane after next, behind a barrier every reader of b has passed.
                 if (s == 1) {
-                    __syncthreads();
+                    if (!(SG_CONVT_ABL & 32)) __syncthreads();
                     epilogue_slice(qd - 1, 0);
                 }
                 if (s == 5) epilogue_slice(qd - 1, 1);
@@ -1227,10 +1228,12 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
             __builtin_amdgcn_sched_barrier(0);
         }
         // column i16 = tap row, fragment rows r = 4 kq + (0..3) of tile j = positions 2 r + j of the block: slots j * 16 + r
-        if (FULL || block_on) {
+        if ((FULL || block_on) && !(SG_CONVT_ABL & 16)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 *(__attribute__((address_space(3))) f32x4v*)(buf + i16 * stride + wave * 32 + t * 16 + 4 * kq) = c4[t];
+        } else if (SG_CONVT_ABL & 16) {
+            asm volatile("" ::"v"(c4[0]), "v"(c4[1]));       // (keep the accumulators alive)
         }
     };
     plane(qs, IntTag<0>(), A0, A1);
