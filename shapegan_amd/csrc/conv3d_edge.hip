@@ -1255,6 +1255,240 @@ __global__ void __launch_bounds__(512, 2) convT_c1_stream_kernel(ConvTStreamArgs
     }
 }
 
+// convT_c1_stream2_kernel (round 5): the same plane walk with BOTH h parities in one workgroup.  The ablations of the kernel above
+// (profiles/r05_convT_c1_ablation.json) show its load stream — 16 eight-byte load instructions per wave and plane, the same 64 KB
+// plane pulled through the texture addresser by each of the four (pd, ph) workgroups of a sample — NOT hiding under the MFMAs: 102 us
+// at 256 samples, 61 without the load instructions, 55 for the MFMAs alone.  Here a workgroup owns (sample, pd): every A fragment it
+// loads feeds the 16 taps of ph = 0 AND the 16 taps of ph = 1 (two B-fragment sets, 32 tap rows in LDS), a thread gathers one output of
+// each h parity per plane: half the load instructions and half the L2 traffic per output, one barrier per plane for twice the outputs.
+template <bool ALLCH, bool PRE, bool FULL, int EPI>
+__global__ void __launch_bounds__(512, 1) convT_c1_stream2_kernel(ConvTStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [2 buffers][2 ph][16 taps][stride]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    // XCD-aware decode: workgroup b runs on XCD b % 8; the four workgroups of a sample are neighbours in dispatch order on one XCD
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // Plane split (round 5): at batch 64 the grid is 256 workgroups — ONE per CU, two waves per SIMD — and the plane walk is a
+    // latency chain (prefetch distance one plane): with two workgroups per (sample, pd, ph) the CU holds two such chains.  The
+    // second one starts one plane early (plane OD/2 - 1 again: only for its carried sum, nothing is stored for it).
+    const int sub = a.splits == 2 ? (j & 3) : (j & 1), half = sub >> 1;
+    const int n = (a.splits == 2 ? (j >> 2) : (j >> 1)) * 8 + xcd, pd = sub & 1;
+    if (n >= a.batch) return;     // (the whole workgroup)
+    const int P2 = a.P2, OW = a.OW, OH = a.OH, OD = a.OD;
+    const int qs = a.splits == 2 && half ? OD / 2 - 1 : 0, qe = a.splits == 2 && !half ? OD / 2 : OD;   // planes [qs, qe)
+    // Positions are handled in blocks of 32 (one per wave): lane (i16, kq) loads TWO consecutive positions 2 i16, 2 i16 + 1 of
+    // channel 4 s + kq with one 8-byte load — a wave instruction covers one whole 128-byte line of each of four channel rows (with
+    // 4-byte loads it touched eight half lines for the same data and the texture addresser, not the matrix pipe, paced the plane)
+    // — and the two components feed two MFMAs whose row r is position 2 r + j of the block.  The tap rows are stored in that
+    // permuted order, [block][j][r], and the gather indexes them accordingly.
+    const int nblocks = (P2 + 31) >> 5;                // <= 8
+    const int stride = nblocks * 32 + 4;               // floats per tap row
+    lds_float* const Sl = (lds_float*)S;
+    const int nks = ALLCH ? 16 : (a.Cout + 3) >> 2;    // k-steps of 4 channels
+
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc_bytes(a.dy + (long)n * a.Cy * OD * P2, (long)a.Cy * OD * P2 * 4);
+    const unsigned chan = (unsigned)(OD * P2) * 4u;     // bytes between channels of a sample
+    // lane offset of the wave's block at plane 0 (out of range beyond the plane)
+    const bool block_on = wave < nblocks;
+    const int p0 = wave * 32 + 2 * i16;
+    const unsigned voff = (block_on && p0 < P2) ? (unsigned)p0 * 4u + (unsigned)kq * chan : kBufOutside;
+    // one k-step of a plane's A fragments (both MFMA tiles of the block); behind the last plane nothing is fetched (out-of-range
+    // scalar offset)
+    auto load_step = [&](int qd, int s, float (&dst)[2][16]) __attribute__((always_inline)) {
+        const unsigned pshift = qd < qe ? (unsigned)(qd * P2) * 4u : kBufOutside;
+        // (bit_cast the WHOLE result of the builtin: component access on its own vector type narrows the load to one dword)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v;
+        if (ALLCH) {
+            v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dres, (int)voff, (int)((unsigned)(4 * s) * chan + pshift), 0));
+        } else {   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight is zero
+            const int co = min(4 * s + kq, a.Cout - 1);
+            const unsigned off = voff == kBufOutside ? kBufOutside : voff - (unsigned)kq * chan + (unsigned)co * chan;
+            v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dres, (int)(s < nks ? off : kBufOutside), (int)pshift, 0));
+        }
+        dst[0][s] = v.x;
+        dst[1][s] = v.y;
+    };
+    float A0[2][16], A1[2][16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) load_step(qs, s, A0);
+    // B fragments: column i16 = tap (g2 = cur / far, khi = same row / neighbour row, kw), k row kq = channel 4 s + kq
+    // (requested after plane 0's A fragments below have been: one memory round trip for both)
+    const int g2 = i16 >> 3, khi = (i16 >> 2) & 1, kw = i16 & 3;
+    const int kd = g2 == 0 ? (pd == 0 ? 1 : 2) : (pd == 0 ? 3 : 0);
+    const int khp[2] = {khi == 0 ? 1 : 3, khi == 0 ? 2 : 0};     // kh of this tap column for ph = 0 / 1
+    float wfr[2][16], psc[PRE ? 16 : 1], psh[PRE ? 16 : 1];
+    {
+        // branch-free: channels beyond Cout carry an out-of-range offset (weight, scale and shift read as 0)
+        const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.w);
+        const long grow = (long)(n / a.spg) * a.Cout;     // this sample's group row of the input transform
+        const __amdgpu_buffer_rsrc_t sres = make_rsrc(PRE ? a.in_scale + grow : a.w), hres = make_rsrc(PRE ? a.in_shift + grow : a.w);
+        const unsigned wtap0 = (unsigned)(kd * 16 + khp[0] * 4 + kw) * 4u, wtap1 = (unsigned)(kd * 16 + khp[1] * 4 + kw) * 4u;
+        const unsigned wrow = (unsigned)a.Cin_total * 256u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int co = 4 * s + kq;
+            const bool have = s < nks && co < a.Cout;
+            wfr[0][s] = buf_load(wres, have ? (unsigned)co * wrow + wtap0 : kBufOutside, 0);
+            wfr[1][s] = buf_load(wres, have ? (unsigned)co * wrow + wtap1 : kBufOutside, 0);
+            if (PRE) {
+                psc[s] = buf_load(sres, have ? (unsigned)co * 4u : kBufOutside, 0);
+                psh[s] = buf_load(hres, have ? (unsigned)co * 4u : kBufOutside, 0);
+            }
+        }
+    }
+    // gather role of this thread: output (qh, qw, pw) of the plane pair row 2 qh + ph
+    const int q = tid >> 1, pw = tid & 1;
+    const int qh = q / OW, qw = q - qh * OW;
+    const bool gather_on = q < P2;
+    // the four (khi, kwi) taps of a group: row qh (+ dh for khi 1), column qw (+ dw for kwi 1); per h parity
+    const int dw = pw == 0 ? -1 : 1;
+    const int kw_same = pw == 0 ? 1 : 2, kw_nb = pw == 0 ? 3 : 0;
+    const bool col_nb = (unsigned)(qw + dw) < (unsigned)OW;
+    const int qc = gather_on ? q : 0;
+    const int qcol = col_nb ? dw : 0;
+    auto slot = [](int pos) { return (pos & ~31) + (pos & 1) * 16 + ((pos & 31) >> 1); };   // position -> index in a tap row
+    int goff[2][4];
+    float gmul[2][4];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const int dh = ph == 0 ? -1 : 1;
+        const bool row_nb = (unsigned)(qh + dh) < (unsigned)OH;
+        const int qrow = row_nb ? dh * OW : 0;
+        const int base = ph * 16 * stride;                 // this parity's 16 tap rows
+        goff[ph][0] = base + (0 * 4 + kw_same) * stride + slot(qc);
+        goff[ph][1] = base + (0 * 4 + kw_nb) * stride + slot(qc + qcol);
+        goff[ph][2] = base + (1 * 4 + kw_same) * stride + slot(qc + qrow);
+        goff[ph][3] = base + (1 * 4 + kw_nb) * stride + slot(qc + qrow + qcol);
+        gmul[ph][0] = 1.f;
+        gmul[ph][1] = col_nb ? 1.f : 0.f;
+        gmul[ph][2] = row_nb ? 1.f : 0.f;
+        gmul[ph][3] = (row_nb && col_nb) ? 1.f : 0.f;
+    }
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+    const int IH = 2 * OH, IW = 2 * OW;
+    // outputs leave through a raw buffer on the sample: lane offset = (row 2 qh + ph, column 2 qw + pw), scalar offset = output
+    // plane; a lane / plane with nothing to store carries an out-of-range offset instead of a branch
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)(n / a.spg) * a.out_group_stride + (long)(n % a.spg) * a.dx_sample);
+    const unsigned ovoff = gather_on ? (unsigned)((2 * qh) * IW + 2 * qw + pw) * 4u : kBufOutside;      // row of ph = 0; ph = 1: + IW
+    const unsigned oplane = (unsigned)(IH * IW) * 4u;
+    float carry[2] = {0.f, 0.f};
+    // Epilogue of plane p (its 16 tap rows are in LDS buffer p & 1, behind plane p's barrier): gather, complete one output plane
+    // with the sum carried from plane p - 1, activation, store, carry the other sum.  d-parity 0: output plane 2 p = carried far
+    // taps (kd 3 of plane p - 1) + cur taps (kd 1); d-parity 1: output plane 2 p - 1 = carried cur taps (kd 2 of plane p - 1) + far
+    // taps (kd 0), nothing to store at p = 0.  It is issued in three slices INSIDE plane p + 1's MFMA loop (the matrix pipe runs
+    // 32 cycles per MFMA during which the wave is free to issue LDS / VALU / VMEM work): with the epilogue behind the barrier the
+    // pipe idled a third of every plane (25.4 us at 64 samples).  Everything in it is branch-free — selects on the uniform
+    // parities, the tanh as exp / rcp with a series near 0 — so the loop stays one basic block and the compiler's s_waitcnt
+    // bookkeeping exact.
+    float etc[2][4], etf[2][4], eval[2] = {0.f, 0.f};
+    auto epilogue_slice = [&](int p, int slice) __attribute__((always_inline)) {
+        const lds_float* pb = Sl + (p & 1) * 32 * stride;
+        if (slice == 0) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    etc[ph][g] = pb[goff[ph][g]];
+                    etf[ph][g] = pb[goff[ph][g] + 8 * stride];
+                }
+        } else if (slice == 1) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const float sc = (etc[ph][0] + etc[ph][1] * gmul[ph][1]) + (etc[ph][2] * gmul[ph][2] + etc[ph][3] * gmul[ph][3]);
+                const float sf = (etf[ph][0] + etf[ph][1] * gmul[ph][1]) + (etf[ph][2] * gmul[ph][2] + etf[ph][3] * gmul[ph][3]);
+                const float fin = pd == 0 ? sc : sf, keep = pd == 0 ? sf : sc;
+                float v = carry[ph] + fin + b0;
+                carry[ph] = keep;
+                if (EPI == SG_ACT_TANH) {
+                    const float ax = fabsf(v), x2 = v * v;
+                    const float e = __expf(2.f * ax);
+                    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);                       // |err| ~ 1e-7
+                    const float small = ax * (1.f + x2 * (-0.33333334f + x2 * 0.13333334f));          // |v| < 0.06: rel. err < 1e-8
+                    v = copysignf(ax < 0.06f ? small : big, v);
+                } else if (EPI != SG_ACT_NONE) {
+                    v = sg_apply_act(v, a.act, a.slope);
+                }
+                eval[ph] = v;
+            }
+        } else {
+            const bool skip = (p == qs && (pd == 1 || qs > 0)) || (SG_CONVT_ABL & 4);    // nothing complete yet at the first plane of a walk
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, eval[ph]), ores, (int)(skip ? kBufOutside : ovoff),
+                                                      (int)((unsigned)(2 * p - pd) * oplane + (unsigned)(ph * IW) * 4u), 0);
+        }
+    };
+
+    auto plane = [&](int qd, auto with_epi, float (&cur)[2][16], float (&nxt)[2][16]) __attribute__((always_inline)) {
+        // The loads of plane qd + 1 are issued BETWEEN the MFMAs of plane qd, one k-step (two dword loads) per MFMA pair: all
+        // eight waves of the workgroup run in lockstep (one barrier per plane), so a block of 32 loads per wave up front was a
+        // phase in which the texture addresser worked and the matrix pipe idled (first version: 36.8 us at 64 samples, no better
+        // than one workgroup per plane).
+        lds_float* const buf = Sl + (qd & 1) * 32 * stride;
+        f32x4v c4[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            load_step(qd + 1, s, nxt);
+            if (decltype(with_epi)::value) {
+                // The barrier that publishes plane qd - 1's tap rows sits HERE, one MFMA pair into plane qd, not behind the LDS
+                // writes at the end of plane qd - 1: the drain of that plane's last MFMAs, the write latency and the arrival
+                // skew of the eight waves then pass under this plane's first MFMAs (counters with the barrier at the end of the
+                // plane: matrix pipe 51 % busy, 30 % of the wave cycles parked).  Safe with two buffers: a wave writes buffer b
+                // again only at the end of the plane after next, behind a barrier every reader of b has passed.
+                if (s == 1) {
+                    __syncthreads();
+                    epilogue_slice(qd - 1, 0);
+                }
+                if (s == 5) epilogue_slice(qd - 1, 1);
+                if (s == 9) epilogue_slice(qd - 1, 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v = cur[t][s];
+                if (PRE) {
+                    v = fmaf(v, psc[s], psh[s]);
+                    v = fmaxf(v, v * a.in_slope);     // LeakyReLU with 0 <= slope <= 1 (ReLU: 0, none: 1) as max(t, slope t)
+                }
+                c4[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[0][s], c4[t][0], 0, 0, 0);
+                c4[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[1][s], c4[t][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // column i16 = tap row, fragment rows r = 4 kq + (0..3) of tile j = positions 2 r + j of the block: slots j * 16 + r
+        if (FULL || block_on) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+                    *(__attribute__((address_space(3))) f32x4v*)(buf + (ph * 16 + i16) * stride + wave * 32 + t * 16 + 4 * kq) = c4[t][ph];
+        }
+    };
+    plane(qs, IntTag<0>(), A0, A1);
+    int qd = qs + 1;
+    // (buffer parity = plane parity; the register sets alternate from the walk's first plane)
+    for (; qd + 1 < qe; qd += 2) {
+        plane(qd, IntTag<1>(), A1, A0);
+        plane(qd + 1, IntTag<1>(), A0, A1);
+    }
+    if (qd < qe) plane(qd, IntTag<1>(), A1, A0);
+    // the last plane's epilogue, and for d-parity 1 the output plane 2 OD - 1 (cur taps of the last plane alone)
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) epilogue_slice(qe - 1, sl);
+    if (pd == 1 && qe == OD) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float v = carry[ph] + b0;
+            v = EPI == SG_ACT_NONE ? v : sg_apply_act(v, a.act, a.slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff,
+                                                  (int)((unsigned)(2 * OD - 1) * oplane + (unsigned)(ph * IW) * 4u), 0);
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 size_t edge_fwd_workspace_bytes(int, int, int, int) { return 0; }   // the forward reads the grid in place
 size_t edge_wgrad_workspace_bytes(int, int, int, int) { return (size_t)512 * kEdgePartial * sizeof(float); }   // partial tiles
@@ -1440,13 +1674,54 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     f.spg = samples_per_group > 0 ? samples_per_group : batch;
     f.out_group_stride = samples_per_group > 0 ? out_group_stride : (long)batch * f.dx_sample;
     const int nblocks = (f.P2 + 31) / 32;
+    // Both h parities per workgroup (convT_c1_stream2_kernel, round 5): half the plane loads per output.  Workgroups = samples x 2
+    // (x 2 plane walks while that leaves CUs without one).  SG_CONVT_BOTH=0: the one-parity kernel (A/B).
+    // Measured (cold): 256 samples 100.5 -> 86.8 us; 64 samples 27.5 - 31.5 -> 25.9 us with two plane walks (the one-parity kernel
+    // fills the chip with twice the workgroups there and is as fast warm): taken from 192 samples on — the grouped generator pass of
+    // WGANTrainer.step runs at 256 —; SG_CONVT_BOTH=1 / 0 forces it on / off (read per call: the parity test toggles it).
+    const char* both_env = getenv("SG_CONVT_BOTH");
+    const char* split_env = getenv("SG_CONVT_SPLIT");      // (read per call: the parity test toggles it)
+    const long base_wgs = (long)((batch + 7) / 8 * 8) * 2;
+    const bool both = both_env ? atoi(both_env) != 0 : base_wgs >= 384;
+    if (both) {
+        f.splits = (force_split == 2 || (split_env && atoi(split_env) == 2) || (!split_env && base_wgs < 256)) && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
+        const size_t lds2 = (size_t)2 * 32 * (nblocks * 32 + 4) * sizeof(float);
+        const unsigned wgs2 = (unsigned)(base_wgs * f.splits);
+        static SgPerDeviceOnce once2;
+        if (once2.begin()) {      // 66.5 KB of dynamic LDS: the attribute, once per device, for every instantiation that may be launched
+#define SG_ATTR2(ALL_, PRE_, FULL_, EPI_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_stream2_kernel<ALL_, PRE_, FULL_, EPI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 260 * 4)
+#define SG_ATTR2E(ALL_, PRE_, FULL_) do { SG_ATTR2(ALL_, PRE_, FULL_, SG_ACT_TANH); SG_ATTR2(ALL_, PRE_, FULL_, SG_ACT_NONE); SG_ATTR2(ALL_, PRE_, FULL_, -1); } while (0)
+            SG_ATTR2E(true, true, true);
+            SG_ATTR2E(true, false, true);
+            SG_ATTR2E(false, true, false);
+            SG_ATTR2E(false, false, false);
+#undef SG_ATTR2E
+#undef SG_ATTR2
+            once2.end();
+        }
+#define SG_CONVT_STREAM2(ALL_, PRE_, FULL_, EPI_) \
+    hipLaunchKernelGGL((convT_c1_stream2_kernel<ALL_, PRE_, FULL_, EPI_>), dim3(wgs2), dim3(512), lds2, stream, f)
+#define SG_CONVT_STREAM2_EPI(ALL_, PRE_, FULL_)                          \
+    do {                                                                 \
+        if (act == SG_ACT_TANH) SG_CONVT_STREAM2(ALL_, PRE_, FULL_, SG_ACT_TANH); \
+        else if (act == SG_ACT_NONE) SG_CONVT_STREAM2(ALL_, PRE_, FULL_, SG_ACT_NONE); \
+        else SG_CONVT_STREAM2(ALL_, PRE_, FULL_, -1);                     \
+    } while (0)
+        if (Cout == 64 && f.P2 == 256) {
+            if (pre) SG_CONVT_STREAM2_EPI(true, true, true); else SG_CONVT_STREAM2_EPI(true, false, true);
+        } else {
+            if (pre) SG_CONVT_STREAM2_EPI(false, true, false); else SG_CONVT_STREAM2_EPI(false, false, false);
+        }
+#undef SG_CONVT_STREAM2_EPI
+#undef SG_CONVT_STREAM2
+        return 1;
+    }
     const size_t lds = (size_t)2 * 16 * (nblocks * 32 + 4) * sizeof(float);
     // Two walks per (sample, pd, ph) — measured in round 5 and NOT the default: at 64 samples (256 -> 512 workgroups) the cold time
     // went from 27.7 to 31.5 us, i.e. the plane walk is not a latency chain that a second workgroup per CU would hide (the four
     // workgroups of a sample already pull every input line through L2 four times; a second walk adds a recomputed plane to that);
     // only at 32 samples does it win (18.4 us against 25.6 unsplit and 19.4 - 20.9 for the per-plane kernel that serves < 48
     // samples).  SG_CONVT_SPLIT=2 turns it on for A/B; tests/test_gpu_ops.py runs both forms.
-    const char* split_env = getenv("SG_CONVT_SPLIT");      // (read per call: the parity test toggles it)
     f.splits = (force_split == 2 || (split_env && atoi(split_env) == 2)) && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
     const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4 * f.splits);
 #define SG_CONVT_STREAM(ALL_, PRE_, FULL_, EPI_) \

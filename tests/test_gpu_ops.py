@@ -356,6 +356,24 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
             finally:
                 del os.environ["SG_CONVT_SPLIT"]
             assert torch.equal(one, two), "two-walk form differs at N=%d C=%d R=%d" % (N, C, R)
+            # convT_c1_stream2_kernel (both h parities per workgroup; the default from 192 samples on) at any batch size, with one
+            # and with two plane walks: the same sums in the same order
+            for split in ("1", "2"):
+                os.environ["SG_CONVT_BOTH"], os.environ["SG_CONVT_SPLIT"] = "1", split
+                try:
+                    both = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
+                finally:
+                    del os.environ["SG_CONVT_BOTH"], os.environ["SG_CONVT_SPLIT"]
+                assert torch.equal(one, both), "both-parity form (split %s) differs at N=%d C=%d R=%d" % (split, N, C, R)
+        x = dev(torch.randn(200, 64, 16, 16, 16))                       # 200 samples: the default path takes it
+        w, b = dev(torch.randn(64, 1, 4, 4, 4) / 23.0), dev(torch.randn(1))
+        got = ops.conv_transpose3d_k4s2p1(x, w, b, ACT_TANH, 0.0)
+        os.environ["SG_CONVT_BOTH"] = "0"
+        try:
+            ref1 = ops.conv_transpose3d_k4s2p1(x, w, b, ACT_TANH, 0.0)
+        finally:
+            del os.environ["SG_CONVT_BOTH"]
+        assert torch.equal(got, ref1)
 
 
 def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monkeypatch):
