@@ -580,7 +580,7 @@ def test_linear_fwd_bwd(M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(70004, 256, 128), (66000, 384, 64), (131072, 128, 320)])
+@pytest.mark.parametrize("M,N,K", [(70004, 256, 128), (66000, 384, 64), (131072, 128, 320), (70004, 256, 100)])     # (K = 100: a tile's last stage ends inside a 16-byte piece)
 def test_gemm128_persistent_all_layouts(M, N, K):
     """gemm128p_kernel (a workgroup walks tiles as one stream of stages, > 512 tiles, even stage count) in its three operand layouts,
     with a per-column bias and LeakyReLU in the epilogue, against torch in fp64; ragged last row tile."""
