@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 6
+#define SG_ABI_VERSION 7
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 
@@ -226,7 +226,7 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
                   int latent_size, const float* packed, int kin_used, const float* zb1, const float* zb5,
                   long points_per_shape, const int* shape_index, float* out, float* acts, long ldn, long N,
                   hipStream_t stream);
-/* Point tiles of the backward = columns of bias_partials: tile t covers the points [sg_sdfnet_bwd_tile_start(N, t),
+/* Point tiles of the backward = rows of bias_partials: tile t covers the points [sg_sdfnet_bwd_tile_start(N, t),
  * sg_sdfnet_bwd_tile_start(N, t + 1)).  With tiles = ceil(N / 64), rem = tiles % 512, full = tiles - rem: 64 points per tile,
  * except for the last, partly filled round of workgroups (512 = two per CU):
  *   256 < rem <= 384: 64-point tiles up to full + 256 (one more per CU), the points after them in 32-point tiles;
@@ -234,11 +234,14 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
  * A pure function of N: the layout does not depend on the device. */
 long sg_sdfnet_bwd_blocks(long N);
 long sg_sdfnet_bwd_tile_start(long N, long t);
-/* bias_partials (optional): [7*256][blocks] per-tile row sums of dZ1..dZ7 (sum each row: bias gradients).  With `points`
- * (the xyz of the batch, as given to sg_sdfnet_fwd) it is [14*256][blocks]: rows 7*256.. = sum_p dz8[p] H7[row][p] (the
- * layers2.6 weight gradient), rows (8+c)*256.. / (11+c)*256.. = sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns
- * of the layers1.0 / layers2.0 weight gradients) — partial sums the kernel has the operands in registers for, instead of three
- * more passes over the [256][N] images. */
+/* bias_partials (optional): TILE-MAJOR [blocks][SG_SDFNET_PARTIAL_ROW] (ABI 7; it was [14*256][blocks]: 3 584 scattered 4-byte
+ * writes per tile).  Row t holds the sums over the points of tile t: floats [256 b, 256 b + 256), b = 0..6: the row sums of
+ * dZ_{b+1} (sum over the tiles: bias gradients); float 14*256: the sum of dz8 (the layers2.6 bias gradient).  With `points` (the
+ * xyz of the batch, as given to sg_sdfnet_fwd) also b = 7: sum_p dz8[p] H7[row][p] (the layers2.6 weight gradient) and b = 8+c /
+ * 11+c: sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns of the layers1.0 / layers2.0 weight gradients) — sums the
+ * kernel has the operands on chip for, instead of three more passes over the [256][N] images.  sg_sdfnet_bwd_finish reduces
+ * them. */
+#define SG_SDFNET_PARTIAL_ROW 3616 /* 14 * 256 + 32 */
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
                   long N, hipStream_t stream);
@@ -248,11 +251,20 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
  * (NULL, NULL to skip) and the latent gradient gz [nshapes][L] (NULL to skip); nshapes <= 6144. */
 int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
                              const float* W5, float* dW1, float* dW5, float* gz, hipStream_t stream);
-/* t1[256][nseg], t5[256][nseg]: sums of dZ1 / dZ5 over every segment [seg_off[s], seg_off[s+1]) of points (per-shape sums: the
- * latent-table gradient and the latent columns of the layers1.0 / layers2.0 weight gradients of the shape-sorted auto-decoder
- * step, train_sdf_autodecoder.py:80-91 backward), taken from `dz` and the `bias_partials` of the same sg_sdfnet_bwd call. */
-int sg_sdfnet_segsum(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
-                     float* t5, hipStream_t stream);
+/* Everything that is derived from the bias_partials of ONE sg_sdfnet_bwd call, in one launch (replaces five: the segment sums,
+ * two multi-row sums and the two-stage sum of dz8 of train_sdf_autodecoder.py:80-91's backward):
+ *   bias_grads[0..6] (256 floats each; NULL: skip all column sums), b8_grad[1], and with `extended` (sg_sdfnet_bwd was given
+ *   `points`) w8_grad[256] and the three point columns of dW1 / dW5: element (row, c) at w1_cols[row * w1_ld + c] / w5_cols[...];
+ *   nseg > 0: t1[256][nseg], t5[256][nseg] = sums of dZ1 / dZ5 over every segment [seg_off[s], seg_off[s+1]) of points (per-shape
+ *   sums: the latent-table gradient and the latent columns of the layers1.0 / layers2.0 weight gradients of the shape-sorted step),
+ *   interior tiles from the partials, the cut tiles from `dz`.
+ * Deterministic (two-level column sums, added in split order by whichever block finishes last).  `tickets`: 16 unsigned, zero
+ * before the first call; every call leaves them zero (one buffer per stream of concurrent calls). */
+size_t sg_sdfnet_bwd_finish_workspace_bytes(long N);
+int sg_sdfnet_bwd_finish(const float* dz, const float* bias_partials, long ldn, long N, int extended, float* const* bias_grads,
+                         float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
+                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
+                         unsigned* tickets, hipStream_t stream);
 
 /* ---- K8/K9/K10/K11: blends, reductions, latent-table rows, optimizers ------------------------------------------
  * reference: fade-in / GP lerp (model/progressive_gan.py:50, train_hybrid_progressive_gan.py:105), batch means

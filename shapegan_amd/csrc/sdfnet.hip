@@ -123,7 +123,7 @@ static SdfPackLayout make_layout(int KU) {
 // fixed lane offset, k-group in the scalar offset), the B fragments of k-group sq+1 are read from LDS (immediate offsets
 // from one running address) while the 4*NT MFMAs of group sq run; sched_barriers keep the loads where they are issued.
 // One VALU instruction (the LDS address step) per 4*NT MFMAs.
-template <int NT, int RING = 4>
+template <int NT, int RING = 4, int TS = 32>   // TS: floats between the column tiles of a row (32: one [K][ld] tile; else one tile per chain)
 __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __restrict__ wp, int nsq,
                                          const float* __restrict__ Bs, int ld, int lane) {
     const int r = lane & 31, kh = lane >> 5;
@@ -141,14 +141,14 @@ __device__ __forceinline__ void mlp_gemm(f32x16 (&acc)[NT], const float4* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[j][t] = bp[j * 2 * ld + t * 32];
+        for (int t = 0; t < NT; ++t) b[j][t] = bp[j * 2 * ld + t * TS];
     auto group = [&](float4 a, int sq) __attribute__((always_inline)) {
         // B of the next group (the last group re-reads its own: no branch)
         const lds_float* nb = bp + (sq < last ? 8 * ld : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bn[j][t] = nb[j * 2 * ld + t * 32];
+            for (int t = 0; t < NT; ++t) bn[j][t] = nb[j * 2 * ld + t * TS];
         bp = nb;
         __builtin_amdgcn_sched_barrier(0);
         const float av[4] = {a.x, a.y, a.z, a.w};
@@ -501,9 +501,9 @@ struct SdfBwdArgs {
     const float* acts;   // [7][256][ldn]
     float* dz;           // [7][256][ldn]  dZ1..dZ7
     float* dz8;          // [N]
-    float* bsum;         // optional [7*256][nblk]: per-workgroup row sums of dZ1..dZ7 (bias-gradient partials); with `points`
-                         // [14*256][nblk]: + rows 7*256.. : sum_p dz8[p] H7[row][p] (w8 gradient), rows (8+c)*256.. and
-                         // (11+c)*256.. : sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns of dW1 / dW5)
+    float* bsum;         // optional [nblk][kPartRow], tile-major: blocks 0..6 of 256 = row sums of dZ1..dZ7 (bias-gradient partials),
+                         // element 14*256 = the tile's sum of dz8; with `points` also block 7: sum_p dz8[p] H7[row][p] (w8 gradient),
+                         // blocks 8+c / 11+c: sum_p dZ1 / dZ5 [row][p] * xyz_c[p] (the three point columns of dW1 / dW5)
     const float* points; // optional [*,3] (with bsum): the xyz of the points, for the extended partial sums
     long points_period;
     float* dx;           // optional: input gradient, row-major [N][dx_ld] (first KU columns written)
@@ -513,26 +513,93 @@ struct SdfBwdArgs {
     long ldn;
     long N;
     long nbig;           // workgroups [0, nbig): P-point tiles; the rest: kSmallTile points each (sg_sdfnet_bwd_tile_start)
-    long nblk;           // all workgroups = columns of bsum
+    long nblk;           // all workgroups = rows of bsum
 };
 
-// Backward-data chain for one tile of P points.  G[256][P] holds dH_l; the X-gradient tile DX[KUr][P+1]
-// accumulates W5i^T dZ5 + W1^T dZ1 (only when a.dx != nullptr).
-// P = 64: 64.3 KB of LDS and <= 128 VGPRs, so two workgroups (16 waves) share a CU and one's mask / write-back phases
-// overlap the other's MFMA phases; P = 128 fills the LDS with one workgroup.
-template <int P>
-__device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long p0) {
-    constexpr int NT = P / 32;
+// ---------------------------------------------------------------------------------------------------------------------------
+// The backward-data chain of one tile as TWO SKEWED 32-POINT CHAINS per workgroup (round 6).
+//
+// dZ_l = dH_l * (H_l > 0), dH_{l-1} = W_l^T dZ_l on the matrix pipe (transposed packs); each wave owns rows [32 wave, 32 wave + 32) of
+// every dH_l in MFMA fragment layout.  The points of a tile are independent all the way down the chain, so its two 32-point
+// column tiles (chain A = points 0..31, chain B = points 32..63) need not move in lock-step.  Rounds 1 - 5 ran a layer as GEMM ->
+// barrier -> epilogue (ReLU' select, LDS write-back, dZ image stores, DPP row sums) -> barrier with no MFMA during the epilogue
+// (MFMA busy 0.77; git history has that form).  Here chain B lags half a layer behind chain A:
+//
+//     phase 1 of image i:   GEMM_A(i) reads G_A(i+1)   ||   epilogue_B(i+1) writes G_B(i+1)      barrier
+//     phase 2 of image i:   GEMM_B(i) reads G_B(i+1)   ||   epilogue_A(i)   writes G_A(i)        barrier
+//
+// so every phase of every wave is a 128-MFMA GEMM with one sixteenth of the other chain's epilogue between the MFMAs of every
+// second k-group.  Still two barriers per layer; a chain's tile is never written while its GEMM reads it.  The weight ring runs
+// on from one GEMM into the next (chain A and chain B of an image read the same pack).  dz / dz8 / dx and the sign words keep
+// their layouts; a tile is still 64 or 32 points (sg_sdfnet_bwd_tile_start).
+//
+// Row sums (bias-gradient partials, the point columns of dW1 / dW5): 80 - 320 DPP operations and 16 - 64 one-lane stores per wave
+// and layer in the old form.  Now a thread owns 16 points of one row of a chain's LDS tile (row pitch 36 floats: the b128 reads
+// of a wave's 32 rows x 2 halves hit every bank once) while that tile is the B operand of the next GEMM — in eight pieces
+// between that GEMM's MFMAs —, adds chain B's share half a layer later and stores one value per row and tile.  The partial
+// sums are TILE-MAJOR, [tiles][kPartRow]: a tile's 14 x 256 sums are 14 KB of contiguous stores (the old row-major
+// [14*256][tiles] matrix took 3 584 scattered 4-byte writes per tile — as many memory transactions as the dZ images).
+constexpr int kLdg = 36;
+constexpr int kPartRow = SG_SDFNET_PARTIAL_ROW;   // 14 * 256 row sums + the tile's sum of dz8 (+ padding)
+static_assert(kPartRow >= 14 * kH + 1, "partial row");
+
+template <int RING, int NSQ, bool HAS_NEXT, class Slice>
+__device__ __forceinline__ void chain_gemm(f32x16& acc, WRing<RING>& w, const __amdgpu_buffer_rsrc_t next,
+                                           const float* __restrict__ Bs, int lane, Slice slice) {
+    static_assert(NSQ % RING == 0 && NSQ >= 2 * RING, "ring and GEMM length");
+    const int r = lane & 31, kh = lane >> 5;
+    const unsigned wvoff = lane * 16;
+    const lds_float* bp = (const lds_float*)Bs + kh * kLdg + r;
+    float b[4], bn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = bp[j * 2 * kLdg];
+#pragma unroll
+    for (int sq = 0; sq < NSQ; ++sq) {
+        const float4 a4 = w.ar[sq % RING];
+        if (sq + RING < NSQ)
+            w.ar[sq % RING] = buf_load4(w.res, wvoff, (unsigned)(sq + RING) * 1024u);
+        else if (HAS_NEXT)
+            w.ar[sq % RING] = buf_load4(next, wvoff, (unsigned)(sq + RING - NSQ) * 1024u);
+        const lds_float* nb = bp + (sq + 1 < NSQ ? 8 * kLdg : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = nb[j * 2 * kLdg];
+        bp = nb;
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[1], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slice(sq);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = bn[j];
+    }
+    if (HAS_NEXT) w.res = next;
+}
+
+#ifdef SG_ABL_NOBAR
+#define SG_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SG_PHASE_BARRIER() __syncthreads()
+#endif
+template <bool DUAL>
+__device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long p0) {
+    constexpr int NH = DUAL ? 2 : 1;
+    constexpr int P = NH * 32;
+    constexpr int RING = SG_BWD_RING;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;            // [256][P]
-    float* dz8s = Gs + kH * P;   // [P]
-    float* xs = dz8s + P;        // [3][P] xyz of the tile (only with a.points)
+    float* const G0 = smem;                  // chain A: dZ of points p0 .. p0+31, [256][kLdg]
+    float* const G1 = smem + kH * kLdg;      // chain B: points p0+32 .. p0+63
+    float* const dz8s = smem + 2 * kH * kLdg;   // [64]
+    float* const xs = dz8s + 64;                 // [3][64] xyz of the tile (only with a.points)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
     const float4* pk = reinterpret_cast<const float4*>(a.packed);
     const int KUr = a.lay.KUr;
-    const int nxt = KUr / 32;  // X row tiles
+    const int nxt = KUr / 32;
 
     if (tid < P) {
         const long gp = p0 + tid;
@@ -545,237 +612,259 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
         dz8s[tid] = v;
     }
     const bool ext = a.bsum && a.points;
-    if (ext && tid >= 64 && tid < 64 + 3 * P) {   // (P = 64: threads 64..255)
+    if (ext && tid >= 64 && tid < 64 + 3 * P) {
         const int e = tid - 64, c = e / P, pp = e - c * P;
         const long gp = p0 + pp;
         float v = 0.f;
         if (gp < a.N) v = a.points[(a.points_period > 0 ? gp % a.points_period : gp) * 3 + c];
-        xs[c * P + pp] = v;
+        xs[c * 64 + pp] = v;
     }
     __syncthreads();
+    if (a.bsum && tid < 64) {       // the tile's share of the layers2.6 bias gradient: sum of dz8 (element 14 * 256 of its partial row)
+        const float t8 = sg_wave_sum(tid < P ? dz8s[tid] : 0.f);
+        if (tid == 0) a.bsum[(long)blockIdx.x * kPartRow + 14 * kH] = t8;
+    }
 
-    f32x16 acc[NT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-    };
-    // Each wave owns rows [32 wave, 32 wave + 32) of every dH_l in MFMA fragment layout (row = frag_row(q, kh), point =
-    // t*32 + r).  The ReLU mask, the dZ_l write-back and the bias-gradient partial sums happen right there in the GEMM
-    // epilogue: H_l is prefetched in the same layout while the GEMM runs (one lane offset + scalar offsets: buffer loads),
-    // so there is no separate pass over the LDS tile and its HBM latency is off the critical path.
-    // Addressing: the resource base of a layer image is the wave's own row block at the tile's first point (a scalar), the lane
-    // adds (4 kh) rows + its point, the fragment row goes into the scalar offset: lane offset + scalar offset < 124 ldn + 256
-    // bytes, inside the 2 GiB window for up to 16 M points per call (checked by the host).
+    f32x16 acc[NH];
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 32;
-    bool pok[NT];
+    bool pok[NH];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) pok[t] = p0 + t * 32 + r < a.N;
+    for (int h = 0; h < NH; ++h) pok[h] = p0 + h * 32 + r < a.N;
     const unsigned khoff = (unsigned)(4L * kh * a.ldn * 4);
-    // Loads of H_l for points beyond N (the ragged last tile) are redirected to the tile's first point: their values are
-    // masked out below, but the ADDRESS must stay inside the tensor — an image that ends at the end of a mapped segment put the
-    // stray reads on an unmapped page, and the faulting wave then retried forever (seen as a hang that depended on where the
-    // caching allocator happened to place `acts`).  Stores of such lanes get an out-of-range offset: the hardware drops them,
-    // so the epilogue has no exec-mask branches.
-    unsigned hload[NT], zstore[NT];
+    // (addresses of lanes beyond N: loads go to the tile's first point, stores out of range — see the form above)
+    unsigned hload[NH], zstore[NH], mload[NH];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        hload[t] = pok[t] ? khoff + (unsigned)(t * 32 + r) * 4u : khoff;
-        zstore[t] = pok[t] ? khoff + (unsigned)(t * 32 + r) * 4u : kBufOutside;
+    for (int h = 0; h < NH; ++h) {
+        hload[h] = pok[h] ? khoff + (unsigned)(h * 32 + r) * 4u : khoff;
+        zstore[h] = pok[h] ? khoff + (unsigned)(h * 32 + r) * 4u : kBufOutside;
+        mload[h] = (unsigned)((long)kh * a.ldn * 2) + (pok[h] ? (unsigned)(h * 32 + r) * 2u : 0u);
     }
     auto layer_rsrc = [&](const float* image, int layer) __attribute__((always_inline)) {
         return make_rsrc(image + ((long)layer * kH + wrow) * a.ldn + p0);
     };
-    // ReLU'(H_l) for the layers below the last one comes from the forward's 16-bit sign words (one 2-byte load per column tile
-    // instead of 16 dword loads): bit q of mk[t] <-> row frag_row(q, kh), point t*32 + r
-    unsigned mk[NT];
-    // this wave's mask row of the layer about to be processed (walks down one layer = 16 rows per step: a running scalar, so
-    // that the six bases are not all computed — and kept in SGPRs — up front)
-    const unsigned short* mkrow = sdf_mask_base(a.acts, a.ldn) + ((long)5 * 16 + (wrow >> 4)) * a.ldn + p0;
-    auto load_mask = [&](int layer) __attribute__((always_inline)) {
-        // the resource starts at this wave's (layer, group 2 wave + kh) row and the tile's first point: the lane offset is just
-        // its point (lanes beyond N read the tile's first point; their bits are masked by pok)
-        const __amdgpu_buffer_rsrc_t mres = make_rsrc(mkrow);
-        mkrow -= 16 * a.ldn;
-        asm volatile("" : "+s"(mkrow));
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
+    auto load_mask = [&](int layer, int h) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t mres =
+            make_rsrc(sdf_mask_base(a.acts, a.ldn) + ((long)layer * 16 + (wrow >> 4)) * a.ldn + p0);
+        const unsigned m = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(mres, (int)mload[h], 0, 0);
 #ifdef SG_ABL_NOLOAD
-            mk[t] = 0xffffu;
+        return 0xffffu;
 #else
-            mk[t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(mres, (int)(((hload[t] - khoff) >> 1) + (khoff >> 3)), 0, 0);
+        return pok[h] ? m : 0u;
 #endif
     };
-    float hf[16][NT];
-    auto load_h = [&](int layer) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t hres = layer_rsrc(a.acts, layer);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#ifdef SG_ABL_NOLOAD
-                hf[q][t] = 1.f;
-#else
-                hf[q][t] = buf_load(hres, hload[t], (unsigned)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4));
-#endif
-    };
-    // Row sums over the 32 points a half-wave holds, on the VALU's DPP path (quad swaps, half-row mirror, row mirror, then
-    // lane 15 of the even rows broadcast into the odd rows): no LDS traffic and no dependent ds_bpermute round trips, so the 16
-    // rows of an epilogue pipeline freely.  Lanes 16..31 / 48..63 end up with the totals of lanes 0..31 / 32..63; lanes 31 and 63
-    // store (every other lane carries an out-of-range offset).
+    // this lane's element q of a chain's tile: row wave*32 + frag_row(q, kh), point r
+    lds_float* const gw[2] = {(lds_float*)G0 + (wave * 32 + 4 * kh) * kLdg + r, (lds_float*)G1 + (wave * 32 + 4 * kh) * kLdg + r};
+    auto rowoff = [](int q) { return (q & 3) + 8 * (q >> 2); };
+
+    // ---- the w8 gradient partial and dZ7 = (w8 (x) dz8) * (H7 > 0), both chains at once (once per tile) ----
     auto dpp_add = [&](float v, auto ctrl, auto rowmask) __attribute__((always_inline)) {
         return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
                                                                          decltype(rowmask)::value, 0xf, false));
     };
     auto half_sum = [&](float v) __attribute__((always_inline)) {
-        v = dpp_add(v, IntTag<0xB1>(), IntTag<0xf>());    // quad_perm [1,0,3,2]
-        v = dpp_add(v, IntTag<0x4E>(), IntTag<0xf>());    // quad_perm [2,3,0,1]
-        v = dpp_add(v, IntTag<0x141>(), IntTag<0xf>());   // row_half_mirror
-        v = dpp_add(v, IntTag<0x140>(), IntTag<0xf>());   // row_mirror
-        return dpp_add(v, IntTag<0x142>(), IntTag<0xa>());   // row_bcast15 into rows 1 and 3
+        v = dpp_add(v, IntTag<0xB1>(), IntTag<0xf>());
+        v = dpp_add(v, IntTag<0x4E>(), IntTag<0xf>());
+        v = dpp_add(v, IntTag<0x141>(), IntTag<0xf>());
+        v = dpp_add(v, IntTag<0x140>(), IntTag<0xf>());
+        return dpp_add(v, IntTag<0x142>(), IntTag<0xa>());
     };
-    const unsigned bsoff = r == 31 ? (unsigned)((4L * kh * a.nblk + blockIdx.x) * 4) : kBufOutside;
-    // partial-sum block `blk` (0..6: dZ1..dZ7, 7: w8, 8..10 / 11..13: point columns): [256][nblk], this wave's rows from wrow
-    auto partial_rsrc = [&](int blk) __attribute__((always_inline)) {
-        return make_rsrc(a.bsum + ((long)blk * kH + wrow) * a.nblk);
+    WRing<RING> wr;
+    auto pack_rsrc = [&](long toff) __attribute__((always_inline)) {
+        const unsigned long long wq = (unsigned long long)(pk + (toff >> 2) + (long)wave * (kH / 8) * 64);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wq), hi = __builtin_amdgcn_readfirstlane((unsigned)(wq >> 32));
+        return make_rsrc((const void*)(((unsigned long long)hi << 32) | lo));
     };
-    auto row_partial = [&](float v, __amdgpu_buffer_rsrc_t res, int q) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(v)), res, (int)bsoff,
-                                              (int)(((q & 3) + 8 * (q >> 2)) * a.nblk * 4), 0);
-    };
-    // dZ_l = acc * (H_l > 0): to the LDS tile (B operand of the next GEMM), to the dz image, row sums to bsum
-    // XC: -1, or the block of extended partial rows (8: dW1 point columns, 11: dW5 point columns) this layer feeds
-    auto mask_store = [&](int layer, auto xtag, auto bits_tag) __attribute__((always_inline)) {
-        constexpr int XC = decltype(xtag)::value;
-        constexpr bool BITS = decltype(bits_tag)::value != 0;    // ReLU' from the sign words (mk) instead of the fp32 image (hf)
-        const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, layer);
-        const __amdgpu_buffer_rsrc_t bres = partial_rsrc(a.bsum ? layer : 0);
+    {
+        float hf[16][NH];
+        const __amdgpu_buffer_rsrc_t hres = layer_rsrc(a.acts, 6);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) hf[q][h] = buf_load(hres, hload[h], (unsigned)(rowoff(q) * a.ldn * 4));
+        // (the first weight ring behind the H7 loads: its wait then covers them)
+        wring_start(wr, pk + (a.lay.T7 >> 2) + (long)wave * (kH / 8) * 64, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* w8 = a.packed + a.lay.W8;
+        const unsigned bsoff = r == 31 ? (unsigned)(4 * kh * 4) : kBufOutside;
+        const __amdgpu_buffer_rsrc_t w8res = make_rsrc(a.bsum + (long)blockIdx.x * kPartRow + (ext ? 7 : 0) * kH + wrow);
+        const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, 6);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = wave * 32 + frag_row(q, kh);
-            float rs = 0.f;
+            const float wv = w8[wave * 32 + frag_row(q, kh)];
+            float s8 = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float g;
-                if (BITS) {
-                    // bit q of the sign word; lanes beyond N had their word cleared
-                    // (toolchain note, hipcc ROCm 7.2: forming the result as `bit_cast<int>(acc[t][q]) & -(bit q)` — two VALU
-                    // instructions, no compare — compiled to ANDs that all read element 0 of the accumulator vector; caught
-                    // by the parity tests, kept as a select)
-                    g = ((mk[t] >> q) & 1u) ? acc[t][q] : 0.f;
-                } else {
-                    g = (pok[t] && hf[q][t] > 0.f) ? acc[t][q] : 0.f;
-                }
-                Gs[row * P + t * 32 + r] = g;
-#ifndef SG_ABL_NOSTORE
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[t],
-                                                      (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
-#endif
-                rs += g;
+            for (int h = 0; h < NH; ++h) {
+                const float d8 = dz8s[h * 32 + r];
+                const bool on = pok[h] && hf[q][h] > 0.f;
+                const float g = on ? wv * d8 : 0.f;
+                s8 = fmaf(pok[h] ? hf[q][h] : 0.f, d8, s8);
+                gw[h][rowoff(q) * kLdg] = g;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[h],
+                                                      (int)(rowoff(q) * a.ldn * 4), 0);
             }
-            if (a.bsum) row_partial(rs, bres, q);
+            if (ext)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(s8)), w8res, (int)bsoff,
+                                                      (int)(rowoff(q) * 4), 0);
         }
-        if (XC >= 0 && ext) {
-            // point columns: a second, short pass over the rows this wave has just written to LDS (same wave, LDS operations
-            // are in order: no barrier), so that the products do not lengthen the register lifetimes of the loop above
-            float xv[3][NT];
+    }
+    __syncthreads();
+
+    // ---- row sums of a chain's tile from LDS: thread (row = tid / 2, 16-point half = tid % 2) ----
+    const int srow = tid >> 1, ssub = tid & 1;
+    float rs[4];
+    auto rowsum_pass = [&](const float* G, int h, bool xc) __attribute__((always_inline)) {
+        const lds_f32x4* gp = (const lds_f32x4*)((const lds_float*)G + srow * kLdg + ssub * 16);
+        f32x4 v[4];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 4; ++i) v[i] = gp[i];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) xv[c][t] = xs[c * P + t * 32 + r];
-            const __amdgpu_buffer_rsrc_t xres[3] = {partial_rsrc(XC), partial_rsrc(XC + 1), partial_rsrc(XC + 2)};
+        for (int i = 0; i < 4; ++i) rs[0] += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        if (xc) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = wave * 32 + frag_row(q, kh);
-                float gq[NT];
+            for (int c = 0; c < 3; ++c) {
+                const lds_f32x4* xp = (const lds_f32x4*)((const lds_float*)xs + c * 64 + h * 32 + ssub * 16);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) gq[t] = Gs[row * P + t * 32 + r];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) v = fmaf(gq[t], xv[c][t], v);
-                    row_partial(v, xres[c], q);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 x = xp[i];
+                    rs[1 + c] = fmaf(v[i].x, x.x, fmaf(v[i].y, x.y, fmaf(v[i].z, x.z, fmaf(v[i].w, x.w, rs[1 + c]))));
                 }
+            }
+        }
+    };
+    // the same pass cut into eight pieces that ride between the MFMAs of a GEMM (k-groups 1, 3, ... 15: a quarter of the row is
+    // requested in one piece and added in the next), so that nothing but the first B fragments stands between a barrier and the
+    // first MFMA of a phase (the pass in front of the GEMM cost 64 us of 1304 at 200 000 points)
+    f32x4 rq[4];
+    auto rowsum_slice = [&](const float* G, int h, bool xc, int sq) __attribute__((always_inline)) {
+        if ((sq & 1) == 0 || sq >= 16) return;
+        const int i = sq >> 2;
+        if ((sq & 3) == 1) {
+            rq[0] = ((const lds_f32x4*)((const lds_float*)G + srow * kLdg + ssub * 16))[i];
+            if (xc) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rq[1 + c] = ((const lds_f32x4*)((const lds_float*)xs + c * 64 + h * 32 + ssub * 16))[i];
+            }
+        } else {
+            rs[0] += (rq[0].x + rq[0].y) + (rq[0].z + rq[0].w);
+            if (xc) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    rs[1 + c] = fmaf(rq[0].x, rq[1 + c].x, fmaf(rq[0].y, rq[1 + c].y, fmaf(rq[0].z, rq[1 + c].z, fmaf(rq[0].w, rq[1 + c].w, rs[1 + c]))));
+            }
+        }
+    };
+    auto rowsum_clear = [&]() __attribute__((always_inline)) { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; };
+    // both 16-point halves of a row -> partial block `blk` (and the three point-column blocks xblk..xblk+2 behind it)
+    auto rowsum_store = [&](int blk, int xblk) __attribute__((always_inline)) {
+        const int n = xblk >= 0 ? 4 : 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+                const float t = dpp_add(rs[i], IntTag<0xB1>(), IntTag<0xf>());
+                if (ssub == 0) a.bsum[(long)blockIdx.x * kPartRow + (i == 0 ? blk : xblk + i - 1) * kH + srow] = t;
             }
         }
     };
 
-    // dZ7 = (w8 (x) dz8) * (H7 > 0): the outer product is formed directly in fragment layout
-    load_h(6);
-    {
-        const float* w8 = a.packed + a.lay.W8;
-        const __amdgpu_buffer_rsrc_t w8res = partial_rsrc(ext ? 7 : 0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float wv = w8[wave * 32 + frag_row(q, kh)];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t][q] = wv * dz8s[t * 32 + r];
-            if (ext) {   // w8 gradient partial: sum_p dz8[p] * H7[row][p]  (H7 = relu output, already in registers)
-                float s8 = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) s8 = fmaf(pok[t] ? hf[q][t] : 0.f, dz8s[t * 32 + r], s8);
-                row_partial(s8, w8res, q);
-            }
-        }
-    }
-    // the weight ring of the next GEMM is started before the stores of each epilogue (see WRing)
-    WRing<SG_BWD_RING> wr;
-    auto wtile_t = [&](long toff) { return pk + (toff >> 2) + (long)wave * (kH / 8) * 64; };
-    wring_start(wr, wtile_t(a.lay.T7), lane);
-    __builtin_amdgcn_sched_barrier(0);
-    mask_store(6, IntTag<-1>(), IntTag<0>());      // (H7 itself is in registers: the w8 gradient above needs its values)
-    __syncthreads();
-    // dZ_layer+1 (LDS) -> dZ_layer; tnext: transposed pack of the following step (-1: none)
-    // (whether a next step exists is a COMPILE-TIME tag: as a run-time test of the pack offset it was a branch around the ring start,
-    // and at the join behind it the compiler — s_waitcnt vmcnt counts in issue order, a join takes the path with the fewest
-    // younger loads — waited vmcnt(0) for the mask word: i.e. for the ring loads it had just issued, a full weight-fetch latency
-    // in front of every epilogue, which is exactly what starting the ring early was meant to hide)
-    auto back_step = [&](int layer, long tnext, auto xtag, auto has_next) __attribute__((always_inline)) {
-        zero_acc();
-#ifdef SG_SDF_NO_MASK   // A/B build (scripts/ab_build.sh): ReLU' from the fp32 images, as before round 3
-        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_h(layer); });
-        __syncthreads();
-        if (decltype(has_next)::value) wring_start(wr, wtile_t(tnext), lane);
-        __builtin_amdgcn_sched_barrier(0);
-        mask_store(layer, xtag, IntTag<0>());
-#else
-        mlp_gemm_ring<NT, SG_BWD_RING, kH / 8>(acc, wr, Gs, P, lane, [&]() __attribute__((always_inline)) { load_mask(layer); });
-        __syncthreads();   // every wave is done reading the tile
-        if (decltype(has_next)::value) wring_start(wr, wtile_t(tnext), lane);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mk[t] = pok[t] ? mk[t] : 0u;
-        mask_store(layer, xtag, IntTag<1>());
+    // ---- epilogue of chain h for image `layer`, element q: dZ = acc * ReLU'(H) -> LDS tile, dz image ----
+    unsigned mk[NH];
+    auto epi_q = [&](int h, int q, const __amdgpu_buffer_rsrc_t zres) __attribute__((always_inline)) {
+        const float g = ((mk[h] >> q) & 1u) ? acc[h][q] : 0.f;
+        gw[h][rowoff(q) * kLdg] = g;
+#ifndef SG_ABL_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[h], (int)(rowoff(q) * a.ldn * 4), 0);
 #endif
+    };
+    auto zero = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[h][q] = 0.f;
+    };
+#ifdef SG_ABL_NOSUM
+    const bool sums = false;
+#else
+    const bool sums = a.bsum != nullptr;
+#endif
+
+    // image i: GEMMs with pack `toff`; `tnext`: the pack of image i - 1 (HAS_NEXT); xprev: the point-column block of image i + 1
+    auto step = [&](auto itag, long toff, long tnext, auto has_next, auto xprev_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(itag)::value;
+        constexpr bool HAS_NEXT = decltype(has_next)::value != 0;
+        constexpr int XPREV = decltype(xprev_tag)::value;
+        const bool xc = XPREV >= 0 && ext;
+        // ---- phase 1: GEMM_A(i) || epilogue_B(i + 1) ----
+        if (sums) rowsum_clear();
+        const unsigned mka = load_mask(i, 0);
+        zero(0);
+        if (DUAL) {
+            const __amdgpu_buffer_rsrc_t zprev = layer_rsrc(a.dz, i + 1);
+            chain_gemm<RING, kH / 8, true>(acc[0], wr, pack_rsrc(toff), G0, lane, [&](int sq) __attribute__((always_inline)) {
+                if (i < 5 && (sq & 1) == 0) epi_q(NH - 1, sq >> 1, zprev);
+                if (sums) rowsum_slice(G0, 0, xc, sq);
+            });
+        } else {
+            chain_gemm<RING, kH / 8, HAS_NEXT>(acc[0], wr, pack_rsrc(HAS_NEXT ? tnext : toff), G0, lane,
+                                              [&](int sq) __attribute__((always_inline)) {
+                                                  if (sums) rowsum_slice(G0, 0, xc, sq);
+                                              });
+        }
+        mk[0] = mka;
+        SG_PHASE_BARRIER();
+        const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, i);
+        if (DUAL) {
+            // ---- phase 2: GEMM_B(i) || epilogue_A(i) ----
+            const unsigned mkb = load_mask(i, NH - 1);
+            zero(NH - 1);
+            chain_gemm<RING, kH / 8, HAS_NEXT>(acc[NH - 1], wr, pack_rsrc(HAS_NEXT ? tnext : toff), G1, lane,
+                                              [&](int sq) __attribute__((always_inline)) {
+                                                  if ((sq & 1) == 0) epi_q(0, sq >> 1, zres);
+                                                  if (sums) {
+                                                      rowsum_slice(G1, 1, xc, sq);
+                                                      if (sq == 17) rowsum_store(i + 1, xc ? XPREV : -1);
+                                                  }
+                                              });
+            mk[NH - 1] = mkb;
+        } else {
+            if (sums) rowsum_store(i + 1, xc ? XPREV : -1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) epi_q(0, q, zres);
+        }
         __syncthreads();
     };
-    back_step(5, a.lay.T6, IntTag<-1>(), IntTag<1>());    // dH6 -> dZ6
-    back_step(4, a.lay.T5x, IntTag<11>(), IntTag<1>());   // dZ5 (+ point columns of dW5)
-    back_step(3, a.lay.T4, IntTag<-1>(), IntTag<1>());    // dZ4
-    back_step(2, a.lay.T3, IntTag<-1>(), IntTag<1>());    // dZ3
-    back_step(1, a.lay.T2, IntTag<-1>(), IntTag<1>());    // dZ2
-    back_step(0, -1, IntTag<8>(), IntTag<0>());           // dZ1 (+ point columns of dW1)
-    // (element indexing of the dX part below)
-    constexpr int HE = kH * P / 512;      // elements per thread: rows (tid / P) + i * (512 / P), point tid % P
-    constexpr int RSTEP = 512 / P;
-    const int mrow = tid / P, mp = tid % P;
-    const long mgp = p0 + mp;
-    const bool mok = mgp < a.N;
-    const long moff = mok ? (long)mrow * a.ldn + mgp : 0;   // element 0 of this thread inside a layer's [256][ldn] image
-    const long mstride = (long)RSTEP * a.ldn;
+    step(IntTag<5>(), a.lay.T7, a.lay.T6, IntTag<1>(), IntTag<-1>());
+    step(IntTag<4>(), a.lay.T6, a.lay.T5x, IntTag<1>(), IntTag<-1>());
+    step(IntTag<3>(), a.lay.T5x, a.lay.T4, IntTag<1>(), IntTag<11>());     // (sums of image 4 = dZ5: + point columns of dW5)
+    step(IntTag<2>(), a.lay.T4, a.lay.T3, IntTag<1>(), IntTag<-1>());
+    step(IntTag<1>(), a.lay.T3, a.lay.T2, IntTag<1>(), IntTag<-1>());
+    step(IntTag<0>(), a.lay.T2, -1, IntTag<0>(), IntTag<-1>());
+    // ---- tail: epilogue_B(0), then the sums of image 0 = dZ1 (+ point columns of dW1) ----
+    if (DUAL) {
+        const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) epi_q(NH - 1, q, zres);
+        __syncthreads();
+    }
+    if (sums) {
+        rowsum_clear();
+        rowsum_pass(G0, 0, ext);
+        if (DUAL) rowsum_pass(G1, 1, ext);
+        rowsum_store(0, ext ? 8 : -1);
+    }
+
     // ---- input gradient dX = W1^T dZ1 + W5[:,256:]^T dZ5 (rows = input features, 32-row tiles round-robin over waves) ----
-    // G holds dZ1 now; the dZ5 tile is read back from the dz image this workgroup wrote (L2-hot).  Accumulating both
-    // products in registers and writing dx once needs neither LDS nor a read-modify-write.
+    // The chains' tiles hold dZ1 now; the dZ5 tile is read back from the dz image this workgroup wrote (L2-hot).
     if (a.dx) {
-        auto reload = [&](int layer) {  // G <- dZ_{layer+1} tile
-            const float* z = a.dz + (long)layer * kH * a.ldn + moff;
+        constexpr int HE = kH * P / 512;
+        constexpr int RSTEP = 512 / P;
+        const int mrow = tid / P, mp = tid % P;
+        // (scalar row base + one 32-bit lane offset per thread: points beyond N carry an out-of-range offset and read 0)
+        const unsigned rvoff = p0 + mp < a.N ? (unsigned)(((long)mrow * a.ldn + mp) * 4) : kBufOutside;
+        float* const gdst = (mp < 32 ? G0 : G1) + mrow * kLdg + (mp & 31);
+        auto reload = [&](int layer) {
             __syncthreads();
 #pragma unroll 8
             for (int i = 0; i < HE; ++i) {
-                const float v = z[mok ? i * mstride : 0];
-                Gs[tid + i * 512] = mok ? v : 0.f;
+                const __amdgpu_buffer_rsrc_t zr = make_rsrc(a.dz + ((long)layer * kH + i * RSTEP) * a.ldn + p0);
+                gdst[i * RSTEP * kLdg] = buf_load(zr, rvoff, 0);
             }
             __syncthreads();
         };
@@ -783,20 +872,21 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
             const int xt = pass * 8 + wave;
             const bool mine = xt < nxt;
             if (pass > 0) reload(0);
-            zero_acc();
-            if (mine) mlp_gemm<NT>(acc, pk + (a.lay.T1 >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) zero(h);
+            if (mine) mlp_gemm<NH, 4, kH * kLdg>(acc, pk + (a.lay.T1 >> 2) + (long)xt * (kH / 8) * 64, kH / 8, G0, kLdg, lane);
             reload(4);
             if (mine) {
-                mlp_gemm<NT>(acc, pk + (a.lay.T5i >> 2) + (long)xt * (kH / 8) * 64, kH / 8, Gs, P, lane);
+                mlp_gemm<NH, 4, kH * kLdg>(acc, pk + (a.lay.T5i >> 2) + (long)xt * (kH / 8) * 64, kH / 8, G0, kLdg, lane);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const long gp = p0 + t * 32 + r;
+                for (int h = 0; h < NH; ++h) {
+                    const long gp = p0 + h * 32 + r;
                     if (gp < a.N) {
                         float* d = a.dx + gp * a.dx_ld;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
                             const int row = xt * 32 + frag_row(q, kh);
-                            if (row < a.lay.KU) d[row] = acc[t][q];
+                            if (row < a.lay.KU) d[row] = acc[h][q];
                         }
                     }
                 }
@@ -806,45 +896,149 @@ __device__ __forceinline__ void sdfnet_bwd_tile(const SdfBwdArgs& a, const long 
 }
 
 template <int P>
-__global__ void __launch_bounds__(512, (P == 64 ? 4 : 2)) sdfnet_bwd_kernel(SdfBwdArgs a) {
+__global__ void __launch_bounds__(512, 4) sdfnet_bwd_kernel(SdfBwdArgs a) {
+    static_assert(P == 64, "two 32-point chains per workgroup");
     const long b = blockIdx.x;
     if (b < a.nbig)
-        sdfnet_bwd_tile<P>(a, b * P);
+        sdfnet_bwd_tile2<true>(a, b * P);
     else
-        sdfnet_bwd_tile<kSmallTile>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+        sdfnet_bwd_tile2<false>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
 }
 
-// t[which][row][s] = sum over the points of segment s of dZ_layer[row][.] (which 0: dZ1, 1: dZ5): the per-shape sums behind
-// the latent-table gradient and the latent columns of dW1 / dW5.  The fused backward has already reduced every row over every
-// tile (bias partials), so a segment costs its interior tiles' partials plus the points of the (at most two) tiles its ends cut:
-// 3 loads per lane instead of a pass over the two [256][N] images.  One wave per (row, segment).
-__global__ void __launch_bounds__(256) sdfnet_segsum_kernel(const float* __restrict__ dz, const float* __restrict__ bsum,
-                                                            long ldn, long nbig, long nblk, const int64_t* __restrict__ off,
-                                                            long S, float* __restrict__ t1, float* __restrict__ t5) {
-    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= (long)kH * S) return;
-    const int layer = blockIdx.y ? 4 : 0;
-    const long row = pair / S, sg = pair - row * S;
-    const long beg = off[sg], end = off[sg + 1];
-    const int lane = threadIdx.x & 63;
-    const long edge = nbig * 64;   // first point of the small tiles
-    // first tile that starts at or after beg / last tile boundary at or before end
-    const long ta = beg <= edge ? (beg + 63) / 64 : nbig + (beg - edge + kSmallTile - 1) / kSmallTile;
-    const long tb = end <= edge ? end / 64 : nbig + (end - edge) / kSmallTile;
-    auto start = [&](long t) { return t <= nbig ? t * 64 : edge + (t - nbig) * kSmallTile; };
-    const float* p = dz + ((long)layer * kH + row) * ldn;
-    float acc = 0.f;
-    if (ta >= tb) {
-        for (long e = beg + lane; e < end; e += 64) acc += p[e];
-    } else {
-        const long head = start(ta), tail = start(tb);
-        for (long e = beg + lane; e < head; e += 64) acc += p[e];
-        const float* q = bsum + ((long)layer * kH + row) * nblk;
-        for (long t = ta + lane; t < tb; t += 64) acc += q[t];
-        for (long e = tail + lane; e < end; e += 64) acc += p[e];
+// ---- everything that is derived from the tile partials of one backward, in ONE launch (round 6; it replaces sdfnet_segsum +
+// two rowsum_multi + the two-stage sum of dz8 = five launches of the auto-decoder step) ------------------------------------------
+//   column sums over the tiles:  group g = 0..6 -> bias gradient of dZ_{g+1}; 7 -> w8 gradient; 8..10 / 11..13 -> point columns
+//                                of dW1 / dW5 (written with the matrices' row strides); 14 -> b8 gradient (one value)
+//   segment sums:                t[which][row][s] = sum over the points of segment s of dZ_layer[row][.] (which 0: dZ1, 1: dZ5),
+//                                the per-shape sums behind the latent-table gradient and the latent columns of dW1 / dW5: the
+//                                interior tiles of a shape's run come from the partials, only the (at most two) tiles its ends
+//                                cut are read from the images.
+// Column sums are two-level and deterministic: block (g, split) adds its range of tiles (thread = (tile phase, column): coalesced
+// 1 KB rows), parks 256 values in the workspace and takes a ticket; the block that draws the last ticket of its group adds the
+// splits IN SPLIT ORDER and writes the destination — the arrival order decides who does the addition, never its order.  The
+// tickets are left at zero for the next launch.
+struct SdfFinishArgs {
+    const float* part;     // [nblk][kPartRow]
+    const float* dz;       // [7][256][ldn]
+    long ldn, nblk, nbig;
+    int ngroups;           // 15, or 7 + 1 (bias groups and the dz8 group) without the extended blocks
+    int extended;
+    int nsplit;
+    long tiles_per_split;
+    float* dst[15];
+    long dst_stride[15];
+    float* ws;             // [nsplit][15 * 256]
+    unsigned* tickets;     // [16], zero
+    const int64_t* seg_off;
+    long S;
+    float* t1;
+    float* t5;
+    long ncol_blocks;      // ngroups * nsplit
+};
+__global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
+    __shared__ float red[4][kH];
+    __shared__ float edge[kH];
+    __shared__ int last;
+    const int tid = threadIdx.x, phase = tid >> 8, col = tid & 255;
+    if ((long)blockIdx.x < a.ncol_blocks) {
+        const int gi = blockIdx.x / a.nsplit, sp = blockIdx.x - gi * a.nsplit;
+        const int g = (a.extended || gi < 7) ? gi : 14;     // (without the extended blocks: groups 0..6 and 14)
+        const long t0 = sp * a.tiles_per_split;
+        const long t1 = t0 + a.tiles_per_split < a.nblk ? t0 + a.tiles_per_split : a.nblk;
+        const bool on = g < 14 || col == 0;
+        const float* src = a.part + (g < 14 ? g * kH + col : 14 * kH);
+        float acc = 0.f;
+        if (on) {
+            long t = t0 + phase;
+            for (; t + 28 < t1; t += 32) {       // eight loads in flight per thread
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(t + 4 * u) * kPartRow];
+                acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; t < t1; t += 4) acc += src[t * kPartRow];
+        }
+        red[phase][col] = acc;
+        __syncthreads();
+        if (phase == 0) a.ws[((long)sp * 15 + g) * kH + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        __syncthreads();      // (every wave's stores have been acknowledged by this XCD's L2: s_waitcnt vmcnt(0) in front of the barrier)
+        if (tid == 0) {
+            // ONE release per block: a device-scope fence writes this XCD's L2 back (the eight L2s are not coherent with each
+            // other) — executed by all 16 waves of all 960 blocks of a 200 000-point launch it was 300 us of a 330 us kernel
+            __threadfence();
+            last = atomicAdd(&a.tickets[g], 1u) == (unsigned)(a.nsplit - 1);
+        }
+        __syncthreads();
+        if (last) {
+            // (the loads below are device-scope atomic loads: they are served coherently, no acquire fence needed)
+            // the splits in split order, whoever adds them: thread (phase, col) takes splits phase, phase + 4, ... (all its loads
+            // in flight together), the four phase sums are combined in a fixed order
+            float s = 0.f;
+            if (on) {
+                int q = phase;
+                for (; q + 12 < a.nsplit; q += 16) {
+                    const float v0 = __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float v1 = __hip_atomic_load(&a.ws[((long)(q + 4) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float v2 = __hip_atomic_load(&a.ws[((long)(q + 8) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float v3 = __hip_atomic_load(&a.ws[((long)(q + 12) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s += (v0 + v1) + (v2 + v3);
+                }
+                for (; q < a.nsplit; q += 4)
+                    s += __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();      // (red[] of the first level has been read by phase 0 above: behind the barriers in between)
+            red[phase][col] = s;
+            __syncthreads();
+            if (phase == 0 && on) a.dst[g][(long)col * a.dst_stride[g]] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+            if (tid == 0) a.tickets[g] = 0u;
+        }
+        return;
     }
-    acc = sg_wave_sum(acc);
-    if (lane == 0) (blockIdx.y ? t5 : t1)[pair] = acc;
+    // ---- segment sums: block = (segment, which) ----
+    const long sb = (long)blockIdx.x - a.ncol_blocks;
+    const long sg = sb >> 1;
+    const int which = (int)(sb & 1);
+    const int layer = which ? 4 : 0;
+    const long beg = a.seg_off[sg], end = a.seg_off[sg + 1];
+    const long edge0 = a.nbig * 64;   // first point of the small tiles
+    // first tile that starts at or after beg / last tile boundary at or before end
+    const long ta = beg <= edge0 ? (beg + 63) / 64 : a.nbig + (beg - edge0 + kSmallTile - 1) / kSmallTile;
+    const long tb = end <= edge0 ? end / 64 : a.nbig + (end - edge0) / kSmallTile;
+    auto start = [&](long t) { return t <= a.nbig ? t * 64 : edge0 + (t - a.nbig) * kSmallTile; };
+    const bool interior = ta < tb;
+    const long head = interior ? start(ta) : end, tail = interior ? start(tb) : end;
+    // interior tiles from the partials: thread = (tile phase, row)
+    float acc = 0.f;
+    if (interior) {
+        const float* src = a.part + layer * kH + col;
+        long t = ta + phase;
+        for (; t + 12 < tb; t += 16) {
+            const float v0 = src[t * kPartRow], v1 = src[(t + 4) * kPartRow], v2 = src[(t + 8) * kPartRow], v3 = src[(t + 12) * kPartRow];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; t < tb; t += 4) acc += src[t * kPartRow];
+    }
+    red[phase][col] = acc;
+    // the cut tiles from the image: wave w takes rows 16 w .. 16 w + 15, lanes walk the points ([beg, head) and [tail, end) are
+    // shorter than a tile each; a run without an interior tile is walked whole)
+    const int lane = tid & 63, wave = tid >> 6;
+    // ([beg, head) is shorter than two tiles even for a run without an interior tile, [tail, end) shorter than one: three
+    // loads per lane and row, all 48 of a wave's 16 rows requested before the first sum)
+    float ev[16];
+    const long x0 = beg + lane, x1 = beg + 64 + lane, x2 = tail + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float* p = a.dz + ((long)layer * kH + wave * 16 + j) * a.ldn;
+        const float v0 = x0 < head ? p[x0] : 0.f, v1 = x1 < head ? p[x1] : 0.f, v2 = x2 < end ? p[x2] : 0.f;
+        ev[j] = (v0 + v1) + v2;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float e = sg_wave_sum(ev[j]);
+        if (lane == 0) edge[wave * 16 + j] = e;
+    }
+    __syncthreads();
+    if (phase == 0) (which ? a.t5 : a.t1)[(long)col * a.S + sg] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + edge[col];
 }
 
 // ---- backward of the per-shape latent fold (the latent columns of layers1.0 / layers2.0 enter the forward as per-shape bias rows) ----
@@ -937,11 +1131,12 @@ static TilePlan tile_plan(long N, int P, long slots) {
     if (full == 0 || rem == 0 || 4 * rem > 3 * slots) return TilePlan{tiles, 0};
     return TilePlan{full, (N - full * P + kSmallTile - 1) / kSmallTile};
 }
+constexpr int kFinishMaxSplit = 32;
 constexpr long kFwdSlots = kCUs;       // one workgroup per CU (LDS)
 constexpr long kBwdSlots = 2 * kCUs;   // two per CU
 
 static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P + 7 * kH) * sizeof(float); }
-static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)kH * P + 4 * P) * sizeof(float); }
+static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)2 * kH * kLdg + 4 * 64) * sizeof(float); }   // two chains [256][kLdg] + dz8 + xyz
 
 template <class K>
 static int set_lds(K kern, size_t bytes) {
@@ -1136,14 +1331,67 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
     return SG_OK;
 }
 
-// Per-segment sums of dZ1 and dZ5 (t1, t5: [256][nseg]) from the images and the tile partials of the same sg_sdfnet_bwd call
-// (bias_partials as written there: rows [0, 7*256) x sg_sdfnet_bwd_blocks(N) columns).
-int sg_sdfnet_segsum(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
-                     float* t5, hipStream_t stream) {
-    SG_CHECK_ARG(dz && bias_partials && seg_off && t1 && t5 && N > 0 && ldn >= N && nseg > 0);
+// The sums derived from one sg_sdfnet_bwd call's partials, one launch (see sdfnet_finish_kernel): bias gradients of the seven
+// hidden layers (bias_grads[0..6], 256 floats each), and with `extended` (the call was given `points`) the layers2.6 weight
+// gradient w8_grad[256] and the three point columns of dW1 / dW5 (w1_cols / w5_cols: element (row, c) at [row * ld + c]);
+// b8_grad[1] = sum of dz8; optionally (seg_off != NULL) the per-segment sums t1 / t5 [256][nseg] of dZ1 / dZ5.
+size_t sg_sdfnet_bwd_finish_workspace_bytes(long N) { return (size_t)kFinishMaxSplit * 15 * kH * sizeof(float); }
+
+int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long N, int extended, float* const* bias_grads,
+                         float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
+                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
+                         unsigned* tickets, hipStream_t stream) {
+    SG_CHECK_ARG(dz && partials && N > 0 && ldn >= N && workspace && tickets && nseg >= 0);
+    SG_CHECK_ARG(!bias_grads || b8_grad);
+    SG_CHECK_ARG(!extended || !bias_grads || (w8_grad && w1_cols && w5_cols));
+    SG_CHECK_ARG(nseg == 0 || (seg_off && t1 && t5));
     const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
-    hipLaunchKernelGGL(sdfnet_segsum_kernel, dim3((unsigned)(((long)kH * nseg + 3) / 4), 2), dim3(256), 0, stream, dz,
-                       bias_partials, ldn, tp.nbig, tp.nbig + tp.nsmall, seg_off, nseg, t1, t5);
+    SdfFinishArgs a;
+    a.part = partials;
+    a.dz = dz;
+    a.ldn = ldn;
+    a.nblk = tp.nbig + tp.nsmall;
+    a.nbig = tp.nbig;
+    a.extended = extended ? 1 : 0;
+    a.ngroups = bias_grads ? (extended ? 15 : 8) : 0;
+    // a split adds about 64 tiles (16 per thread, eight loads in flight), at most kFinishMaxSplit splits: every block ends in
+    // a device-scope release (an L2 write-back), so few, longer blocks
+    long nsplit = (a.nblk + 63) / 64;
+    if (nsplit > kFinishMaxSplit) nsplit = kFinishMaxSplit;
+    if (nsplit < 1) nsplit = 1;
+    a.nsplit = (int)nsplit;
+    a.tiles_per_split = (a.nblk + nsplit - 1) / nsplit;
+    if (workspace_bytes < (size_t)nsplit * 15 * kH * sizeof(float)) SG_FAIL(SG_ERR_WORKSPACE, "sg_sdfnet_bwd_finish: workspace too small");
+    for (int g = 0; g < 15; ++g) {
+        a.dst[g] = nullptr;
+        a.dst_stride[g] = 1;
+    }
+    if (bias_grads) {
+        for (int g = 0; g < 7; ++g) {
+            SG_CHECK_ARG(bias_grads[g] != nullptr);
+            a.dst[g] = bias_grads[g];
+        }
+        a.dst[14] = b8_grad;
+        if (extended) {
+            a.dst[7] = w8_grad;
+            for (int c = 0; c < 3; ++c) {
+                a.dst[8 + c] = w1_cols + c;
+                a.dst_stride[8 + c] = w1_ld;
+                a.dst[11 + c] = w5_cols + c;
+                a.dst_stride[11 + c] = w5_ld;
+            }
+        }
+    }
+    a.ws = static_cast<float*>(workspace);
+    a.tickets = tickets;
+    a.seg_off = seg_off;
+    a.S = nseg;
+    a.t1 = t1;
+    a.t5 = t5;
+    a.ncol_blocks = (long)a.ngroups * a.nsplit;
+    const long blocks = a.ncol_blocks + 2 * nseg;
+    if (blocks == 0) return SG_OK;
+    hipLaunchKernelGGL(sdfnet_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

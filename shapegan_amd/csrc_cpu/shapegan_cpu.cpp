@@ -21,6 +21,7 @@
 
 typedef void* hipStream_t_;
 #define SG_OK 0
+#define SG_SDFNET_PARTIAL_ROW (14 * 256 + 32)   // include/shapegan_hip.h (the twin does not include the HIP header)
 #define SG_ERR_ARG (-1)
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
 
@@ -697,12 +698,14 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
         }
     }
     if (bias_partials) {
+        // tile-major partial rows (header: SG_SDFNET_PARTIAL_ROW): 14 blocks of 256 row sums + the tile's sum of dz8
         const long nblk = sdf_bwd_tiles(N);
         const long nrows = points ? 14 * 256 : 7 * 256;
 #pragma omp parallel for schedule(static)
-        for (long r = 0; r < nrows; ++r) {
-            for (long t = 0; t < nblk; ++t) {
-                const long p0 = sdf_bwd_tile_start(N, t), p1 = sdf_bwd_tile_start(N, t + 1);
+        for (long t = 0; t < nblk; ++t) {
+            const long p0 = sdf_bwd_tile_start(N, t), p1 = sdf_bwd_tile_start(N, t + 1);
+            float* prow = bias_partials + t * SG_SDFNET_PARTIAL_ROW;
+            for (long r = 0; r < nrows; ++r) {
                 double s = 0;
                 if (r < 7 * 256) {
                     for (long p = p0; p < p1; ++p) s += dz[r * ldn + p];
@@ -717,8 +720,11 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
                         s += (double)dz[(layer * 256 + row) * ldn + p] * points[pi * 3 + c];
                     }
                 }
-                bias_partials[r * nblk + t] = (float)s;
+                prow[r] = (float)s;
             }
+            double s8 = 0;
+            for (long p = p0; p < p1; ++p) s8 += dz8[p];
+            prow[14 * 256] = (float)s8;
         }
     }
     return SG_OK;
@@ -753,10 +759,35 @@ int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes,
     }
     return SG_OK;
 }
-// per-segment sums of dZ1 / dZ5 (header: sg_sdfnet_segsum), straight from the images
-int sg_sdfnet_segsum_cpu(const float* dz, const float* bias_partials, long ldn, long N, const int64_t* seg_off, long nseg, float* t1,
-                         float* t5, void*) {
-    CPU_CHECK(dz && bias_partials && seg_off && t1 && t5 && N > 0 && ldn >= N && nseg > 0);
+// the sums derived from one backward's partials (header: sg_sdfnet_bwd_finish): column sums over the tiles, segment sums
+// straight from the images
+int sg_sdfnet_bwd_finish_cpu(const float* dz, const float* bias_partials, long ldn, long N, int extended, float* const* bias_grads,
+                             float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
+                             const int64_t* seg_off, long nseg, float* t1, float* t5, void*, size_t, unsigned*, void*) {
+    CPU_CHECK(dz && bias_partials && N > 0 && ldn >= N && nseg >= 0 && (!bias_grads || b8_grad));
+    CPU_CHECK(!extended || !bias_grads || (w8_grad && w1_cols && w5_cols));
+    CPU_CHECK(nseg == 0 || (seg_off && t1 && t5));
+    const long nblk = sdf_bwd_tiles(N);
+    if (bias_grads) {
+        const int ngroups = extended ? 14 : 7;
+#pragma omp parallel for schedule(static)
+        for (long e = 0; e < (long)ngroups * 256; ++e) {
+            const long g = e / 256, row = e % 256;
+            double s = 0;
+            for (long t = 0; t < nblk; ++t) s += bias_partials[t * SG_SDFNET_PARTIAL_ROW + e];
+            if (g < 7)
+                bias_grads[g][row] = (float)s;
+            else if (g == 7)
+                w8_grad[row] = (float)s;
+            else if (g < 11)
+                w1_cols[row * w1_ld + (g - 8)] = (float)s;
+            else
+                w5_cols[row * w5_ld + (g - 11)] = (float)s;
+        }
+        double s8 = 0;
+        for (long t = 0; t < nblk; ++t) s8 += bias_partials[t * SG_SDFNET_PARTIAL_ROW + 14 * 256];
+        b8_grad[0] = (float)s8;
+    }
 #pragma omp parallel for schedule(static)
     for (long pair = 0; pair < 256 * nseg; ++pair) {
         const long row = pair / nseg, sgm = pair % nseg;

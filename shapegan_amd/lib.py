@@ -69,7 +69,8 @@ SIGNATURES = {
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
     "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P]),
-    "sg_sdfnet_segsum": (c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _P]),
+    "sg_sdfnet_bwd_finish_workspace_bytes": (_Z, [_L]),
+    "sg_sdfnet_bwd_finish": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _Z, _P, _P]),
     "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
     "sg_axpby": (c_int, [_P, _P, _P, _L, _F, _F, _P]),
     "sg_reduce_workspace_bytes": (_Z, []),
@@ -197,7 +198,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 6:
+        if lib.sg_abi_version() != 7:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip
@@ -319,6 +320,23 @@ def workspace(name, nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
+    return buf
+
+
+_tickets = {}
+
+
+def tickets(name, device, count=16):
+    """`count` zeroed 32-bit words, cached per (device, stream, name): the arrival counters of kernels that finish their
+    reduction in the last workgroup to arrive.  Zeroed once; every such kernel leaves them zero."""
+    if device.type != "cuda":
+        key = ("cpu", threading.get_ident(), name)
+    else:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
+    buf = _tickets.get(key)
+    if buf is None or buf.numel() < count:
+        buf = torch.zeros(count, dtype=torch.int32, device=device)
+        _tickets[key] = buf
     return buf
 
 

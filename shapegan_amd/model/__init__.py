@@ -56,7 +56,13 @@ class SavableModule(nn.Module):
         return checkpoint_file(self.filename if filename is None else filename, epoch)
 
     def load(self, epoch=None):
-        state = torch.load(self.get_filename(epoch=epoch))
+        # map_location: a file written from cuda:0 must not allocate on cuda:0 when rank r loads it onto cuda:r (process-per-GPU
+        # DP); load_state_dict copies into the parameters where they live either way
+        try:
+            target = self.device
+        except StopIteration:
+            target = None
+        state = torch.load(self.get_filename(epoch=epoch), map_location=target)
         self.load_state_dict(state, strict=False)
         from ..lib import bump_param_epoch
         bump_param_epoch()   # packed weight images derived from the old values are stale now

@@ -923,9 +923,18 @@ class _PackCache(object):
         return entry[1]
 
 
-def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None):
+_PART_ROW = 14 * _H + 32      # SG_SDFNET_PARTIAL_ROW: floats per tile of the backward's partial sums
+
+
+def _sdf_partials(N, extended, dev):
+    """[tiles][_PART_ROW] partial sums of one fused backward (include/shapegan_hip.h: bias_partials), tile-major."""
+    return torch.empty((_lib().sg_sdfnet_bwd_blocks(N), _PART_ROW), dtype=torch.float32, device=dev)
+
+
+def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None, extended=False, seg=None):
     """Weight/bias gradients from the saved dZ_l / H_l images.  x_parts: list of (tensor [N,w], col_offset, w)
-    blocks of the per-point input X that are materialised row-major (points, and latents in per-point mode)."""
+    blocks of the per-point input X that are materialised row-major (points, and latents in per-point mode).
+    seg: (seg_off, S, t1, t5) — the per-segment sums of dZ1 / dZ5 come out of the same finishing launch."""
     lib = _lib()
     dev = dz.device
     grads = [None] * 16
@@ -939,35 +948,35 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
         gemm_raw(dz, False, rows, False, out=out, a_off=layer_dz * _H * ldn, M=_H, N=width, K=N, lda=ldn,
                  ldb=rows.shape[1], ldc=ldc, c_off=c_off)
 
-    # bias gradients: [7*256][nblk] partial row sums from the fused backward -> one short reduction for all seven layers,
-    # each layer's 256 sums written where that parameter's gradient lives.  With the extended partials ([14*256][nblk],
-    # sg_sdfnet_bwd given the points) the same launch also finishes the layers2.6 weight gradient.
-    bias_idx = (1, 3, 5, 7, 9, 11, 13)                       # parameter index of the bias of dZ layer 0..6
-    bouts = [_param_grad_out(ctx_params[pi], (_H,), dev) for pi in bias_idx]
-    extended = bsum is not None and bsum.shape[0] == 14 * _H
-    w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
-    if bsum is not None:
-        nblk = bsum.shape[1]
-        dsts = bouts + ([w8] if extended else [])
-        arr = (ctypes.c_void_p * len(dsts))(*[ptr(t) for t in dsts])
-        check(lib.sg_rowsum_multi(ptr(bsum), arr, None, len(dsts), _H, nblk, nblk, stream()), "rowsum_multi")
-    else:
-        for layer_dz, out in enumerate(bouts):
-            check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
-
-    def bgrad(layer_dz):
-        return bouts[layer_dz]
-
     # layers1.0 / layers2.0 take X; pieces not materialised per point are filled by the caller afterwards
     # (every column of both is written: points / latent columns below or by the caller, the hidden block by the batch)
     w1 = _param_grad_out(ctx_params[0], (_H, kin_total), dev)
     w5 = _param_grad_out(ctx_params[8], (_H, _H + kin_total), dev)
-    if extended:
-        # the three point columns of both: column sums of the kernel's partials, written with the matrices' row strides
-        nblk = bsum.shape[1]
-        cols = (ctypes.c_void_p * 6)(*([ptr(w1) + 4 * c for c in range(3)] + [ptr(w5) + 4 * (_H + c) for c in range(3)]))
-        strides = (ctypes.c_long * 6)(*([kin_total] * 3 + [_H + kin_total] * 3))
-        check(lib.sg_rowsum_multi(ptr(bsum) + 4 * 8 * _H * nblk, cols, strides, 6, _H, nblk, nblk, stream()), "rowsum_multi")
+    # bias gradients: [tiles][_PART_ROW] partial sums from the fused backward -> ONE finishing launch (sg_sdfnet_bwd_finish):
+    # the seven bias gradients, the layers2.6 bias gradient (sum of dz8) and, with the extended partials (sg_sdfnet_bwd given
+    # the points), the layers2.6 weight gradient and the three point columns of dW1 / dW5 — each written where that
+    # parameter's gradient lives — and the per-segment sums of the shape-sorted step.
+    bias_idx = (1, 3, 5, 7, 9, 11, 13)                       # parameter index of the bias of dZ layer 0..6
+    bouts = [_param_grad_out(ctx_params[pi], (_H,), dev) for pi in bias_idx]
+    w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
+    b8 = _param_grad_out(ctx_params[15], (1,), dev)
+    if bsum is not None:
+        arr = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
+        ws = workspace("sdf_finish", lib.sg_sdfnet_bwd_finish_workspace_bytes(N), dev)
+        seg_off, S, t1, t5 = seg if seg is not None else (None, 0, None, None)
+        check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), ldn, N, 1 if extended else 0, arr, ptr(w8), ptr(b8), ptr(w1),
+                                       kin_total, ptr(w5) + 4 * _H if extended else None, _H + kin_total, ptr(seg_off), S,
+                                       ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
+              "sdfnet_bwd_finish")
+    else:
+        for layer_dz, out in enumerate(bouts):
+            check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
+        rws = workspace("reduce", lib.sg_reduce_workspace_bytes(), dev)
+        check(lib.sg_reduce_sum(ptr(dz8), ptr(b8), N, 1.0, ptr(rws), rws.numel(), stream()), "reduce_sum")
+
+    def bgrad(layer_dz):
+        return bouts[layer_dz]
+
     for rows, off, width in x_parts:
         if extended and off == 0 and width == 3:
             continue
@@ -991,12 +1000,9 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
     for i, (pi, (ldz, _)) in enumerate(zip((2, 4, 6, 10, 12), pairs[1:])):
         grads[pi] = hidden[i]
         grads[pi + 1] = bgrad(ldz)
-    # layers2.6: W8 [1,256] (from the partials when extended), b8 [1] (two-stage sum of dz8)
+    # layers2.6: W8 [1,256] (from the partials when extended), b8 [1] (from the partials, or a two-stage sum of dz8)
     if not extended:
         gemm_raw(dz8, False, acts, True, out=w8, b_off=6 * _H * ldn, M=1, N=_H, K=N, lda=N, ldb=ldn, ldc=_H)
-    b8 = _param_grad_out(ctx_params[15], (1,), dev)
-    rws = workspace("reduce", lib.sg_reduce_workspace_bytes(), dev)
-    check(lib.sg_reduce_sum(ptr(dz8), ptr(b8), N, 1.0, ptr(rws), rws.numel(), stream()), "reduce_sum")
     grads[14], grads[15] = w8, b8
     return grads
 
@@ -1041,13 +1047,13 @@ class SDFNetPoints(Function):
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((N, kin), dtype=torch.float32, device=dev) if need_x else None
         need_p = any(ctx.needs_input_grad[4:])
-        bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        bsum = _sdf_partials(N, True, dev) if need_p else None
         check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
                                 0, ptr(dx), kin, ptr(packed), kin, N, N, stream()), "sdfnet_bwd")
         grads = [None] * 16
         if need_p:
             grads = _sdf_param_grads(params, ctx.needs_input_grad[4:], dz, dz8, acts, N, N,
-                                     [(points, 0, 3), (latent, 3, Lz)], kin, bsum)
+                                     [(points, 0, 3), (latent, 3, Lz)], kin, bsum, extended=True)
         gp = dx[:, :3] if ctx.needs_input_grad[1] else None
         gl = dx[:, 3:] if ctx.needs_input_grad[2] else None
         return (None, gp, gl, None) + tuple(grads)
@@ -1108,12 +1114,15 @@ class SDFNetShapes(Function):
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         need_p = any(ctx.needs_input_grad[7:])
-        bsum = torch.empty((14 * _H, lib.sg_sdfnet_bwd_blocks(N)), dtype=torch.float32, device=dev) if need_p else None
+        need_z = ctx.needs_input_grad[2]
+        # (the tile partials are also what the per-shape sums of a shape-sorted batch are assembled from)
+        want_partials = need_p or (need_z and ctx.seg_off is not None)
+        bsum = _sdf_partials(N, need_p, dev) if want_partials else None
         check(lib.sg_sdfnet_bwd(ptr(gout), ptr(out), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(points) if need_p else None,
                                 0, ptr(dx), 3, ptr(packed), 3, N, N, stream()), "sdfnet_bwd")
-        need_z = ctx.needs_input_grad[2]
         grads = [None] * 16
         gz = None
+        seg = None
         if need_p or need_z:
             # per-shape sums of dZ1 / dZ5: T[o, s] = sum_{p in shape s} dZ[o, p]   (each shape's points are contiguous)
             t1 = torch.empty((_H, S), dtype=torch.float32, device=dev)
@@ -1121,16 +1130,18 @@ class SDFNetShapes(Function):
             if ctx.seg_off is None:
                 check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
                 check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
-            elif bsum is not None:
-                # interior tiles of a segment come from the backward's own per-tile partials: no pass over the images
-                check(lib.sg_sdfnet_segsum(ptr(dz), ptr(bsum), N, N, ptr(ctx.seg_off), S, ptr(t1), ptr(t5), stream()),
-                      "sdfnet_segsum")
+            elif need_p:
+                # interior tiles of a segment come from the backward's own per-tile partials, in the launch that also finishes
+                # the bias gradients (sg_sdfnet_bwd_finish inside _sdf_param_grads): no pass over the images
+                seg = (ctx.seg_off, S, t1, t5)
             else:
-                check(lib.sg_segsum(ptr(dz), ptr(t1), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
-                check(lib.sg_segsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H, N, ptr(ctx.seg_off), S, stream()), "segsum")
+                ws = workspace("sdf_finish", lib.sg_sdfnet_bwd_finish_workspace_bytes(N), dev)
+                check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), N, N, 0, None, None, None, None, 0, None, 0, ptr(ctx.seg_off), S,
+                                               ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
+                      "sdfnet_bwd_finish")
         if need_p:
             grads = _sdf_param_grads(params, ctx.needs_input_grad[7:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
-                                     bsum)
+                                     bsum, extended=True, seg=seg)
         if (need_p or need_z) and S <= _FOLD_MAX_SHAPES:
             # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
             # latent gradient gz = T1^T W1[:, 3:] + T5^T W5[:, 259:]

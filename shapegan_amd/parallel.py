@@ -307,7 +307,14 @@ class GradBucket(object):
         if world_size() > 1:
             self._check_previous_header()     # what the LAST exchange's summed header said, before entering another collective
             f = self.opt.f
-            check = self._stage_pattern()
+            first = self._pattern is None
+            # Only the FIRST exchange of a bucket is validated synchronously: every rank is at its first exchange at the same
+            # program point, so every rank reads the same summed header and raises (or not) together.  A pattern that changes
+            # later on ONE rank must not make that rank raise alone — with two buckets per trainer the others would already be
+            # inside the next bucket's collective, which the raising rank never joins.  Every rank finds such a
+            # disagreement in the snapshot of the summed header at the top of this bucket's NEXT finish(): identical data on
+            # every rank, identical decision at the identical program point, nobody is left behind in a collective.
+            check = self._stage_pattern() and first
             h = f.header_len
             if getattr(self, "tail_done", False):
                 a, _ = self.tail
@@ -334,11 +341,12 @@ class GradBucket(object):
         without a gradient is skipped by step() (torch.optim semantics); if another rank HAS a gradient for it, that rank would
         step it with the summed gradient and the replicas would diverge silently.  The summed header says whether the
         ranks agree: every entry must come back as 0 or world_size.  Steady state costs one tiny device copy per exchange and one
-        asynchronous copy of the summed header to pinned host memory.  The rank whose OWN pattern differs from its previous
-        exchange — the first step and, e.g., a progressive-GAN stage switch — reads the header back at once (a host
-        synchronisation) and raises; every OTHER rank finds the same disagreement in its snapshot at the start of its next
-        finish(), before it enters another collective (otherwise the ranks that did not change never look, and block
-        for ever in the next all-reduce once the raising rank is gone)."""
+        asynchronous copy of the summed header to pinned host memory.  The first exchange is read back at once (a host
+        synchronisation on every rank, at the same program point); from then on EVERY rank — also the one whose own pattern
+        just changed, e.g. at a progressive-GAN stage switch — validates the snapshot of the summed header at the start of this
+        bucket's next finish(), before it enters another collective: the decision is taken from identical data at an identical
+        program point on all ranks, so they raise together whatever other buckets' collectives lie in between.
+        Returns whether this rank's pattern differs from its previous exchange."""
         f = self.opt.f
         pattern = tuple(p.grad is not None for p in f.params)
         changed = pattern != self._pattern
@@ -423,6 +431,24 @@ def broadcast_parameters(module, src=0):
         L.bump_param_epoch()
 
 
+def _on_src_then_tell_everyone(action, src, what):
+    """Runs `action` on rank `src` only and broadcasts whether it worked BEFORE anybody enters the payload collective: a missing
+    file or a full disk on `src` raises on every rank instead of leaving the others inside a broadcast / barrier that `src`
+    never joins."""
+    status, error = [None], None
+    if dist.get_rank() == src:
+        try:
+            action()
+        except Exception as e:       # noqa: BLE001 — reported on every rank below
+            error = e
+            status = ["%s: %s" % (type(e).__name__, e)]
+    dist.broadcast_object_list(status, src=src)
+    if status[0] is not None:
+        if error is not None:
+            raise error
+        raise RuntimeError("%s failed on rank %d: %s" % (what, src, status[0]))
+
+
 def save_checkpoint(module, epoch=None, src=0):
     """`SavableModule.save(epoch)` under process-per-GPU data parallelism: rank `src` writes the file, everybody waits for it.
 
@@ -432,16 +458,18 @@ def save_checkpoint(module, epoch=None, src=0):
     `nn.DataParallel` leaves in the module it wraps (train_hybrid_progressive_gan.py:62-68; replica 0 shares its buffers with the
     wrapped module, the other replicas' updates are dropped with the replicas).  Training-mode forwards never read them; an
     evaluation after `load_checkpoint` sees the same statistics on every rank."""
-    if world_size() == 1 or dist.get_rank() == src:
+    if world_size() == 1:
         module.save(epoch=epoch)
-    if world_size() > 1:
-        dist.barrier()
+        return
+    _on_src_then_tell_everyone(lambda: module.save(epoch=epoch), src, "save_checkpoint")
 
 
 def load_checkpoint(module, epoch=None, src=0):
     """`SavableModule.load(epoch)` under process-per-GPU data parallelism: rank `src` reads the file and broadcasts parameters AND
     buffers (ranks need not see the same file system, and nobody reads a file another rank is still writing); every rank ends
     up bit-identical to the file and with its derived weight images invalidated."""
-    if world_size() == 1 or dist.get_rank() == src:
+    if world_size() == 1:
         module.load(epoch=epoch)
+        return
+    _on_src_then_tell_everyone(lambda: module.load(epoch=epoch), src, "load_checkpoint")
     broadcast_parameters(module, src=src)
