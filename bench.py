@@ -541,9 +541,21 @@ def cpu_baseline(reals, zs, zg, g_state, c_state):
 
 
 # ---- workloads -----------------------------------------------------------------------------------------------------------
-def make_wgan(rank):
+def _local_batch(global_batch, world, strong, what):
+    """Per-GPU share of one step.  weak: every GPU runs the reference's own batch (SURVEY 8e's headline); strong: the reference's
+    batch is split over the GPUs (the batch axis shards, every loss is a batch mean: averaged shard gradients = the full-batch
+    gradient up to summation order)."""
+    if not strong or world == 1:
+        return global_batch
+    if global_batch % world:
+        sys.exit("bench.py --scaling strong: %s batch %d does not split over %d GPUs" % (what, global_batch, world))
+    return global_batch // world
+
+
+def make_wgan(rank, world=1, strong=False):
     from shapegan_amd.model.gan import Discriminator, Generator
     from shapegan_amd.train_steps import WGANTrainer
+    B = _local_batch(BATCH, world, strong, "train_wgan.py")
     torch.manual_seed(0)                        # identical replicas on every rank
     generator, critic = Generator(), Discriminator()
     state = ({k: v.detach().cpu().clone() for k, v in generator.state_dict().items()},
@@ -552,28 +564,28 @@ def make_wgan(rank):
     gen = torch.Generator().manual_seed(1000 + rank)   # per-rank synthetic data (batch axis sharded)
     # the real batches are resident where the step reads them: the real halves of the trainer's critic batches (the destination an
     # input pipeline copies its host batches to; the reference's loop reads each batch where `.to(device)` put it, no device copy)
-    reals = trainer.real_slots(BATCH, resolution=32, updates=5, device="cuda")
+    reals = trainer.real_slots(B, resolution=32, updates=5, device="cuda")
     for slot in reals:
-        slot.copy_((torch.rand(BATCH, 1, 32, 32, 32, generator=gen) * 2 - 1))
+        slot.copy_((torch.rand(B, 1, 32, 32, 32, generator=gen) * 2 - 1))
     # (the unit's five critic latent batches are one draw: WGANTrainer.step's grouped generator pass then reads them in place)
-    zs = list(torch.randn(5, BATCH, 128, generator=gen).cuda().unbind(0))
-    zg = torch.randn(BATCH, 128, generator=gen).cuda()
+    zs = list(torch.randn(5, B, 128, generator=gen).cuda().unbind(0))
+    zg = torch.randn(B, 128, generator=gen).cuda()
     info = {"optimizers": [trainer.c_opt, trainer.g_opt],
             "metric": "GAN train steps/sec @32^3 voxels (train_wgan.py 5 critic + 1 generator updates, batch 64/GPU)",
-            "unit": "steps/s", "units_per_step": 1.0,
+            "unit": "steps/s", "units_per_step": 1.0 / (world if strong else 1),
             "workload": "train_wgan.py 32^3 voxel WGAN, fp32, batch=64 synthetic SDF grids (BASELINE configs[1])",
-            "batch": BATCH, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
+            "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
             "allreduce_bytes_per_step": 4 * (5 * trainer.c_opt.f.total + trainer.g_opt.f.total)}
     return (lambda: trainer.step(reals, zs, zg)), info, (reals, zs, zg, state)
 
 
-def make_hybrid_progressive(rank):
+def make_hybrid_progressive(rank, world=1, strong=False):
     from shapegan_amd.model.progressive_gan import Discriminator
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import HybridProgressiveGANTrainer
     from shapegan_amd.util import get_voxel_coordinates
     torch.manual_seed(0)
-    R, B = 64, 16
+    R, B = 64, _local_batch(16, world, strong, "train_hybrid_progressive_gan.py")
     g, d = SDFNet(), Discriminator().cuda()
     d.set_iteration(3)
     tr = HybridProgressiveGANTrainer(g, d, torch.tensor(get_voxel_coordinates(R)).cuda(), R)
@@ -588,7 +600,7 @@ def make_hybrid_progressive(rank):
             tr.discriminator_step(real, z, alpha)
     info = {"optimizers": [tr.d_opt, tr.g_opt],
             "metric": "hybrid progressive WGAN-GP train steps/sec @64^3 (1 generator + 5 discriminator updates, batch 16/GPU)",
-            "unit": "steps/s", "units_per_step": 1.0,
+            "unit": "steps/s", "units_per_step": 1.0 / (world if strong else 1),
             "workload": "train_hybrid_progressive_gan.py iteration=3 (64^3), SDFNet generator + progressive 3D-CNN discriminator, "
                         "WGAN-GP double backward, fp32, batch=16 (BASELINE configs[3])",
             "batch": B, "extra": {"discriminator_updates_per_step": 5, "generator_updates_per_step": 1},
@@ -597,13 +609,13 @@ def make_hybrid_progressive(rank):
     return step, info, None
 
 
-def make_hybrid_wgan(rank):
+def make_hybrid_wgan(rank, world=1, strong=False):
     from shapegan_amd.model.gan import Discriminator
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import HybridWGANTrainer
     from shapegan_amd.util import get_voxel_coordinates
     torch.manual_seed(0)
-    B = 8
+    B = _local_batch(8, world, strong, "train_hybrid_wgan.py")
     tr = HybridWGANTrainer(SDFNet(), Discriminator(), torch.tensor(get_voxel_coordinates(32)).cuda())
     gen = torch.Generator().manual_seed(1000 + rank)
     reals = [(torch.rand(B, 32, 32, 32, generator=gen) * 0.2 - 0.1).cuda() for _ in range(5)]
@@ -616,7 +628,7 @@ def make_hybrid_wgan(rank):
                 tr.generator_step(zs[5])
     info = {"optimizers": [tr.c_opt, tr.g_opt],
             "metric": "hybrid WGAN train steps/sec @32^3 (5 critic + 1 generator updates, batch 8/GPU)", "unit": "steps/s",
-            "units_per_step": 1.0,
+            "units_per_step": 1.0 / (world if strong else 1),
             "workload": "train_hybrid_wgan.py, SDFNet generator sampled to 32^3 + 3D-CNN critic, fp32, batch=8 (BASELINE configs[4])",
             "batch": B, "extra": {"critic_updates_per_step": 5, "generator_updates_per_step": 1},
             "allreduce_bytes_per_step": 4 * (5 * tr.c_opt.f.total + tr.g_opt.f.total),
@@ -624,11 +636,12 @@ def make_hybrid_wgan(rank):
     return step, info, None
 
 
-def make_sdf(rank):
+def make_sdf(rank, world=1, strong=False):
     from shapegan_amd.model.sdf_net import SDFNet
     from shapegan_amd.train_steps import SDFAutoDecoderTrainer
     torch.manual_seed(0)
-    pc, shapes, lat, npts = 200000, 64, 256, 200000
+    pc, shapes, lat = 200000, 64, 256
+    npts = _local_batch(200000, world, strong, "train_sdf_autodecoder.py")
     gen = torch.Generator().manual_seed(1000 + rank)
     pts = (torch.rand(shapes * pc, 3, generator=gen) * 2 - 1).cuda()
     sdf = (torch.rand(shapes * pc, generator=gen) * 0.2 - 0.1).cuda()
@@ -752,6 +765,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="wgan")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the headline): every GPU runs the reference's own batch; strong: the reference's batch is "
+                         "split over the GPUs (64 -> 64/N samples, 16 -> 16/N shapes, 200 000 -> 200 000/N points per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / SDFNet side measurements")
     args = ap.parse_args()
@@ -766,7 +782,8 @@ def main():
                  "environment (it launches its own ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`"
                  % (args.gpus, world))
     torch.cuda.set_device(local % torch.cuda.device_count())
-    step, info, wgan_data = WORKLOADS[args.config](rank)
+    strong = args.scaling == "strong"
+    step, info, wgan_data = WORKLOADS[args.config](rank, world, strong)
 
     def sync():
         if world > 1:
@@ -780,25 +797,36 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if world > 1:
+        parallel.EXPOSED.enable()      # event pairs around every wait for a gradient exchange (two event records each)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    digests = None
+    digests, exposed = None, None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
         digests = replica_digests(info["optimizers"], world)      # after the timed region
+        stream_ms, host_ms, waits = parallel.EXPOSED.totals()
+        e = torch.tensor([stream_ms, host_ms], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.MAX)
+        exposed = (float(e[0].item()), float(e[1].item()), waits)
 
     if rank == 0:
-        config = {"workload": info["workload"], "global_batch": info["batch"] * world, "parallelism": "dp%d" % world}
+        config = {"workload": info["workload"], "global_batch": info["batch"] * world, "per_gpu_batch": info["batch"],
+                  "parallelism": "dp%d" % world}
         config.update(info["extra"])
+        # weak: every GPU does the reference's step -> N steps' worth of units per step time; strong: the N GPUs share ONE
+        # reference step (a rank's units_per_step is then 1/N of a step, or its 1/N share of the points)
+        units = world * args.steps * info["units_per_step"]
         line = {
-            "metric": info["metric"], "value": round(world * args.steps * info["units_per_step"] / elapsed, 4),
+            "metric": info["metric"] if not strong else info["metric"].replace("/GPU", " GLOBAL, split over the GPUs"),
+            "value": round(units / elapsed, 4),
             "unit": info["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config,
         }
         if world > 1:
@@ -806,6 +834,17 @@ def main():
             line["comm"] = dict(parallel.TRANSPORT, transport=parallel.TRANSPORT["name"], world=world,
                                 allreduce_bytes_per_step=info.get("allreduce_bytes_per_step"))
             line["comm"].pop("name", None)
+            # what the overlap did NOT hide: how long the compute stream stood still at the buckets' waits (max over ranks), and
+            # how long the host sat in the wait calls (a gloo exchange blocks the host; RCCL only enqueues)
+            line["comm"]["exposed_ms_per_step"] = round(exposed[0] / args.steps, 4)
+            line["comm"]["host_wait_ms_per_step"] = round(exposed[1] / args.steps, 4)
+            line["comm"]["exchanges_waited_per_step"] = round(exposed[2] / args.steps, 2)
+            from shapegan_amd import lib as sglib
+            try:
+                sglib.load_comm()
+                line["comm"].update({k: v for k, v in sglib.COMM_INFO.items()})
+            except RuntimeError as e:       # noqa: BLE001 — a diagnostic field
+                line["comm"]["rccl_bind_error"] = str(e)
             line["comm"]["replicas_bit_identical"] = all(d == digests[0] for d in digests)
             line["comm"]["parameter_digests_rank0"] = digests[0]
         if args.config == "wgan":

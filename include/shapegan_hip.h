@@ -245,6 +245,11 @@ long sg_sdfnet_bwd_tile_start(long N, long t);
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
                   long N, hipStream_t stream);
+/* Per-shape mode: the latent fold zb1[s][o] = b1[o] + sum_k z[s][k] W1[o][3+k], zb5[s][o] = b5[o] + sum_k z[s][k] W5[o][259+k]
+ * (W1 [256][3+L], W5 [256][259+L]: the reference multiplies these columns with the tiled latents of every point,
+ * model/sdf_net.py:27,41,57-59), both [nshapes][256] outputs in one launch, accumulated in double and rounded once. */
+int sg_sdfnet_shape_bias(const float* z, long nshapes, int latent, const float* W1, const float* b1, const float* W5, const float* b5,
+                         float* zb1, float* zb5, hipStream_t stream);
 /* Per-shape mode: backward of the latent fold zb1[s][o] = b1[o] + sum_k z[s][k] W1[o][3+k], zb5[s][o] = b5[o] + sum_k z[s][k] W5[o][259+k]
  * (the latent columns of layers1.0 / layers2.0, model/sdf_net.py:27,41, enter sg_sdfnet_fwd as bias rows) from the per-shape sums
  * t1 / t5 [256][nshapes] of dZ1 / dZ5, in one launch: the latent columns of dW1 [256][3+L] / dW5 [256][259+L] written in place
@@ -377,6 +382,13 @@ int sg_loss_deepsdf_fwd(const float* out, const float* target, long n, const flo
                         double denom, float* loss, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_loss_deepsdf_bwd(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
                         double denom, const float* gloss, float* dout, float* dz, hipStream_t stream);
+/* The same loss AND its gradient for an upstream gradient of exactly 1 (dout_unit[n], dz_unit[rows][L]; either may be NULL) in
+ * ONE launch: the loss is the root of the trainer's backward (train_sdf_autodecoder.py:88-89).  Bit-identical to
+ * sg_loss_deepsdf_fwd / sg_loss_deepsdf_bwd with gloss = 1; the workgroup that arrives last runs the finishing wave.
+ * `ticket`: one unsigned, zero before the first call, left zero. */
+int sg_loss_deepsdf_fused(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                          double denom, float* loss, float* dout_unit, float* dz_unit, void* workspace, size_t workspace_bytes,
+                          unsigned* ticket, hipStream_t stream);
 /* voxel_difference, train_autoencoder.py:50-52: count[0] = #{e : (a[e] * b[e]) < 0} with the product rounded to fp32 as the
  * reference's `(input * target) < 0` does (a product that underflows to -0, or a NaN, does not count).  Integer arithmetic
  * throughout: bit-exact.  The caller divides by n (`torch.sum(wrong_signs).item() / wrong_signs.nelement()`). */
@@ -445,6 +457,12 @@ int sg_scatter_max_gather(const float* x, const int* arg, float* out, long N, lo
  * unique id (sg_allreduce_unique_id) and distributes it out of band (a file, MPI, torch.distributed's store). */
 typedef struct sg_comm sg_comm;
 const char* sg_comm_last_error(void);
+/* libshapegan_comm.so does not link RCCL: sg_comm_bind opens the RCCL the host process names (NULL: "librccl.so.1" by the loader's
+ * search order) — for a PyTorch process the one torch.distributed's nccl backend has mapped, so that both live in one RCCL
+ * instance — and must be called before any sg_allreduce_* entry.  sg_comm_versions: the NCCL_VERSION_CODE of the header the
+ * library was compiled against and the version the bound library reports; a different major version is refused by sg_comm_bind. */
+int sg_comm_bind(const char* librccl_path);
+int sg_comm_versions(int* header_version, int* runtime_version);
 size_t sg_allreduce_unique_id_bytes(void);
 int sg_allreduce_unique_id(void* id_out, size_t bytes);
 int sg_allreduce_init(sg_comm** comm, int rank, int world, const void* unique_id, size_t id_bytes, int device);

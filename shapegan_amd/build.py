@@ -91,12 +91,14 @@ COMM_LIB = os.path.join(HERE, "libshapegan_comm.so")
 
 
 def build_comm(force=False, verbose=True):
-    """libshapegan_comm.so: the RCCL gradient exchange of the C ABI (csrc/comm.cpp), linked against the ROCm RCCL."""
+    """libshapegan_comm.so: the RCCL gradient exchange of the C ABI (csrc/comm.cpp); RCCL itself is bound at run time."""
     src = os.path.join(CSRC, "comm.cpp")
     if not (force or _stale(COMM_LIB, [src, HEADERS[-1]])):
         return COMM_LIB
-    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", COMM_LIB, "-L/opt/rocm/lib", "-lrccl",
-           "-lamdhip64"]
+    # host code only: g++, no -lrccl (RCCL is bound at run time, csrc/comm.cpp) and no RUNPATH into the toolchain's ROCm — the HIP
+    # runtime it needs is the one the host process (PyTorch) has already mapped
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", src, "-o", COMM_LIB, "-L/opt/rocm/lib", "-lamdhip64", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

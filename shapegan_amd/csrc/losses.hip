@@ -277,6 +277,57 @@ __global__ void __launch_bounds__(256) deepsdf_bwd_kernel(const float* __restric
     }
 }
 
+// The same loss as ONE launch (round 6): the pass of deepsdf_fwd_kernel also writes the gradient for an upstream gradient of
+// exactly 1 — the loss is the root of the trainer's backward, as with sg_loss_mean_split_fwd — and the workgroup that arrives
+// last runs the finishing wave of deepsdf_final_kernel (the same sums in the same order: bit-identical loss; the gradients are
+// those of deepsdf_bwd_kernel with gloss = 1, bit for bit).  One device-scope release per workgroup, by one thread.
+__global__ void __launch_bounds__(256) deepsdf_fused_kernel(const float* __restrict__ o, const float* __restrict__ t, long n,
+                                                            int nb1, const float* __restrict__ x, const float* __restrict__ roww,
+                                                            long m, int L, double* __restrict__ partial, float* __restrict__ d_o,
+                                                            float* __restrict__ dx, float inv_n, float scale2g, double scale1,
+                                                            double scale2, float* __restrict__ out, unsigned* __restrict__ ticket) {
+    __shared__ double red[4];
+    __shared__ int last;
+    double s = 0;
+    const int b = blockIdx.x;
+    const int nb2 = gridDim.x - nb1;
+    if (b < nb1) {
+        for (long e = (long)b * 256 + threadIdx.x; e < n; e += (long)nb1 * 256) {
+            const float d = o[e] - t[e];
+            s += (double)fabsf(d);
+            if (d_o) d_o[e] = inv_n * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+    } else {
+        for (long e = (long)(b - nb1) * 256 + threadIdx.x; e < m; e += (long)nb2 * 256) {
+            const float v = x[e];
+            const float w = roww ? roww[e / L] : 1.f;
+            s += (double)(roww ? w * v * v : v * v);
+            if (dx) dx[e] = w * scale2g * v;
+        }
+    }
+    s = sg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[b < nb1 ? b : kRedBlocks + (b - nb1)] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+        double s1 = 0, s2 = 0;
+        for (int i = threadIdx.x; i < nb1; i += 64) s1 += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < nb2; i += 64)
+            s2 += __hip_atomic_load(&partial[kRedBlocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 = sg_wave_sum_d(s1);
+        s2 = sg_wave_sum_d(s2);
+        if (threadIdx.x == 0) {
+            out[0] = (float)(s1 * scale1) + (float)(s2 * scale2);
+            ticket[0] = 0u;
+        }
+    }
+}
+
 // ---- gradient penalty ----------------------------------------------------------------------------------------------
 // one workgroup per sample row: norm_b = ||g_b||_2
 __global__ void __launch_bounds__(256) row_norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long M) {
@@ -597,6 +648,19 @@ int sg_loss_deepsdf_fwd(const float* out, const float* target, long n, const flo
                        (double*)workspace);
     hipLaunchKernelGGL(deepsdf_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, loss, nb1, nb2,
                        1.0 / (double)n, 1.0 / denom);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_loss_deepsdf_fused(const float* out, const float* target, long n, const float* z, const float* row_weight, long rows, int L,
+                          double denom, float* loss, float* dout_unit, float* dz_unit, void* workspace, size_t workspace_bytes,
+                          unsigned* ticket, hipStream_t stream) {
+    SG_CHECK_ARG(out && target && z && loss && ticket && n > 0 && rows > 0 && L > 0 && denom > 0);
+    SG_CHECK_WS();
+    const long m = rows * L;
+    const int nb1 = red_grid(n), nb2 = red_grid(m);
+    hipLaunchKernelGGL(deepsdf_fused_kernel, dim3(nb1 + nb2), dim3(256), 0, stream, out, target, n, nb1, z, row_weight, m, L,
+                       (double*)workspace, dout_unit, dz_unit, (float)(1.0 / (double)n), (float)(2.0 / denom), 1.0 / (double)n,
+                       1.0 / denom, loss, ticket);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

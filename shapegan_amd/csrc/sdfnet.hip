@@ -45,13 +45,29 @@ struct PackDesc {
     int nsq;      // padded cols / 8
     long dst_off;
 };
+struct PackVectors {     // the seven bias vectors, b8 and w8 (blockIdx.y == descs.n of the pack launch)
+    const float* b[8];
+    const float* w8;
+    long dst_b, dst_w8;  // offsets into the packed buffer
+};
 struct PackDescs {
     PackDesc d[16];
     int n;
+    PackVectors v;
 };
 
 // dst[((t*nsq + sq)*64 + lane)*4 + j] = M(t*32 + (lane&31), (sq*4 + j)*2 + (lane>>5))
+// (row blockIdx.y == descs.n: the bias vectors and w8 — one launch instead of two, round 6)
 __global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float* __restrict__ dst) {
+    if ((int)blockIdx.y == descs.n) {
+        if (blockIdx.x != 0) return;
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) dst[descs.v.dst_b + l * kH + t] = descs.v.b[l][t];
+        dst[descs.v.dst_b + 7 * kH + t] = (t == 0) ? descs.v.b[7][0] : 0.f;
+        dst[descs.v.dst_w8 + t] = descs.v.w8[t];
+        return;
+    }
     const PackDesc d = descs.d[blockIdx.y];
     const long total = (long)d.ntiles * d.nsq * 256;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -64,18 +80,6 @@ __global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float
         const int c = (sq * 4 + j) * 2 + (lane >> 5);
         dst[d.dst_off + e] = (r < d.R && c < d.C) ? d.src[(long)r * d.rs + (long)c * d.cs] : 0.f;
     }
-}
-
-__global__ void __launch_bounds__(256) copy_vectors_kernel(const float* b1, const float* b2, const float* b3,
-                                                           const float* b4, const float* b5, const float* b6,
-                                                           const float* b7, const float* b8, const float* w8,
-                                                           float* __restrict__ dst_b, float* __restrict__ dst_w8) {
-    const int t = threadIdx.x;
-    const float* bs[7] = {b1, b2, b3, b4, b5, b6, b7};
-#pragma unroll
-    for (int l = 0; l < 7; ++l) dst_b[l * kH + t] = bs[l][t];
-    dst_b[7 * kH + t] = (t == 0) ? b8[0] : 0.f;
-    dst_w8[t] = w8[t];
 }
 
 struct SdfPackLayout {
@@ -927,7 +931,7 @@ struct SdfFinishArgs {
     long tiles_per_split;
     float* dst[15];
     long dst_stride[15];
-    float* ws;             // [nsplit][15 * 256]
+    double* ws;            // [nsplit][15 * 256]
     unsigned* tickets;     // [16], zero
     const int64_t* seg_off;
     long S;
@@ -936,8 +940,8 @@ struct SdfFinishArgs {
     long ncol_blocks;      // ngroups * nsplit
 };
 __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
-    __shared__ float red[4][kH];
-    __shared__ float edge[kH];
+    __shared__ double red[4][kH];     // (sums over tiles in double: a sum that cancels to rounding level must not pick up the
+    __shared__ float edge[kH];        //  noise of a thousand fp32 partial additions on top of the tiles' own)
     __shared__ int last;
     const int tid = threadIdx.x, phase = tid >> 8, col = tid & 255;
     if ((long)blockIdx.x < a.ncol_blocks) {
@@ -947,20 +951,20 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
         const long t1 = t0 + a.tiles_per_split < a.nblk ? t0 + a.tiles_per_split : a.nblk;
         const bool on = g < 14 || col == 0;
         const float* src = a.part + (g < 14 ? g * kH + col : 14 * kH);
-        float acc = 0.f;
+        double acc = 0;
         if (on) {
             long t = t0 + phase;
             for (; t + 28 < t1; t += 32) {       // eight loads in flight per thread
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = src[(t + 4 * u) * kPartRow];
-                acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                acc += (((double)v[0] + v[1]) + ((double)v[2] + v[3])) + (((double)v[4] + v[5]) + ((double)v[6] + v[7]));
             }
             for (; t < t1; t += 4) acc += src[t * kPartRow];
         }
         red[phase][col] = acc;
         __syncthreads();
-        if (phase == 0) a.ws[((long)sp * 15 + g) * kH + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (phase == 0) a.ws[((long)sp * 15 + g) * kH + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);   // (a double)
         __syncthreads();      // (every wave's stores have been acknowledged by this XCD's L2: s_waitcnt vmcnt(0) in front of the barrier)
         if (tid == 0) {
             // ONE release per block: a device-scope fence writes this XCD's L2 back (the eight L2s are not coherent with each
@@ -973,14 +977,14 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
             // (the loads below are device-scope atomic loads: they are served coherently, no acquire fence needed)
             // the splits in split order, whoever adds them: thread (phase, col) takes splits phase, phase + 4, ... (all its loads
             // in flight together), the four phase sums are combined in a fixed order
-            float s = 0.f;
+            double s = 0;
             if (on) {
                 int q = phase;
                 for (; q + 12 < a.nsplit; q += 16) {
-                    const float v0 = __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float v1 = __hip_atomic_load(&a.ws[((long)(q + 4) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float v2 = __hip_atomic_load(&a.ws[((long)(q + 8) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float v3 = __hip_atomic_load(&a.ws[((long)(q + 12) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v0 = __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v1 = __hip_atomic_load(&a.ws[((long)(q + 4) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v2 = __hip_atomic_load(&a.ws[((long)(q + 8) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v3 = __hip_atomic_load(&a.ws[((long)(q + 12) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s += (v0 + v1) + (v2 + v3);
                 }
                 for (; q < a.nsplit; q += 4)
@@ -989,7 +993,7 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
             __syncthreads();      // (red[] of the first level has been read by phase 0 above: behind the barriers in between)
             red[phase][col] = s;
             __syncthreads();
-            if (phase == 0 && on) a.dst[g][(long)col * a.dst_stride[g]] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+            if (phase == 0 && on) a.dst[g][(long)col * a.dst_stride[g]] = (float)((red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
             if (tid == 0) a.tickets[g] = 0u;
         }
         return;
@@ -1008,13 +1012,13 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
     const bool interior = ta < tb;
     const long head = interior ? start(ta) : end, tail = interior ? start(tb) : end;
     // interior tiles from the partials: thread = (tile phase, row)
-    float acc = 0.f;
+    double acc = 0;
     if (interior) {
         const float* src = a.part + layer * kH + col;
         long t = ta + phase;
         for (; t + 12 < tb; t += 16) {
             const float v0 = src[t * kPartRow], v1 = src[(t + 4) * kPartRow], v2 = src[(t + 8) * kPartRow], v3 = src[(t + 12) * kPartRow];
-            acc += (v0 + v1) + (v2 + v3);
+            acc += ((double)v0 + v1) + ((double)v2 + v3);
         }
         for (; t < tb; t += 4) acc += src[t * kPartRow];
     }
@@ -1038,7 +1042,39 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
         if (lane == 0) edge[wave * 16 + j] = e;
     }
     __syncthreads();
-    if (phase == 0) (which ? a.t5 : a.t1)[(long)col * a.S + sg] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + edge[col];
+    if (phase == 0) (which ? a.t5 : a.t1)[(long)col * a.S + sg] = (float)(((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + (double)edge[col]);
+}
+
+// ---- the per-shape latent fold itself, both matrices in one launch (round 6; it was two sg_gemm calls = 2 - 4 launches) ----
+//   zb1[s][o] = b1[o] + sum_k z[s][k] W1[o][3 + k]        zb5[s][o] = b5[o] + sum_k z[s][k] W5[o][259 + k]
+// A [S, L] x [L, 256] product of a few MFLOP: workgroup = 16 shapes x 16 outputs of one matrix, K in chunks of 64 through LDS,
+// accumulated in DOUBLE and rounded once — the value does not depend on a tile or split-K plan, and it is the correctly rounded
+// sum up to the last bit.
+__global__ void __launch_bounds__(256) shape_fold_kernel(const float* __restrict__ z, int S, int L, const float* __restrict__ W1,
+                                                         const float* __restrict__ W5, const float* __restrict__ b1,
+                                                         const float* __restrict__ b5, float* __restrict__ zb1,
+                                                         float* __restrict__ zb5) {
+    __shared__ float zs[16][65];
+    __shared__ float ws[16][65];
+    const int which = blockIdx.z;
+    const float* W = which ? W5 + kH + 3 : W1 + 3;
+    const long ldw = which ? kH + 3 + L : 3 + L;
+    const int s0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, sl = tid >> 4, ol = tid & 15;
+    double acc = 0;
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 6) + 4 * i, k = tid & 63;
+            zs[r][k] = (s0 + r < S && k0 + k < L) ? z[(long)(s0 + r) * L + k0 + k] : 0.f;
+            ws[r][k] = k0 + k < L ? W[(long)(o0 + r) * ldw + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) acc = fma((double)zs[sl][k], (double)ws[ol][k], acc);
+    }
+    if (s0 + sl < S) ((which ? zb5 : zb1) + (long)(s0 + sl) * kH)[o0 + ol] = (float)(acc + (double)(which ? b5 : b1)[o0 + ol]);
 }
 
 // ---- backward of the per-shape latent fold (the latent columns of layers1.0 / layers2.0 enter the forward as per-shape bias rows) ----
@@ -1191,9 +1227,11 @@ int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* 
     add(W6, 1, kH, kH, kH, kH, kH, L.T6);
     add(W7, 1, kH, kH, kH, kH, kH, L.T7);
     D.n = n;
-    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n), dim3(256), 0, stream, D, packed);
-    hipLaunchKernelGGL(copy_vectors_kernel, dim3(1), dim3(256), 0, stream, params[1], params[3], params[5], params[7],
-                       params[9], params[11], params[13], params[15], W8, packed + L.B, packed + L.W8);
+    for (int l = 0; l < 8; ++l) D.v.b[l] = params[2 * l + 1];
+    D.v.w8 = W8;
+    D.v.dst_b = L.B;
+    D.v.dst_w8 = L.W8;
+    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n + 1), dim3(256), 0, stream, D, packed);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -1269,6 +1307,17 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
     return SG_OK;
 }
 
+// Per-shape mode: the latent fold zb1 = b1 + z W1[:, 3:]^T, zb5 = b5 + z W5[:, 259:]^T ([nshapes][256] each) from the latents
+// z [nshapes][latent] and the full layers1.0 / layers2.0 matrices, one launch.
+int sg_sdfnet_shape_bias(const float* z, long nshapes, int latent, const float* W1, const float* b1, const float* W5, const float* b5,
+                         float* zb1, float* zb5, hipStream_t stream) {
+    SG_CHECK_ARG(z && W1 && b1 && W5 && b5 && zb1 && zb5 && nshapes > 0 && latent > 0);
+    hipLaunchKernelGGL(shape_fold_kernel, dim3((unsigned)((nshapes + 15) / 16), 16, 2), dim3(256), 0, stream, z, (int)nshapes, latent,
+                       W1, W5, b1, b5, zb1, zb5);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
 // Per-shape mode: the backward of the latent fold (zb1 = b1 + z W1[:, 3:]^T, zb5 = b5 + z W5[:, 259:]^T) from the per-shape sums
 // t1 / t5 [256][S] of dZ1 / dZ5 (sg_sdfnet_segsum or sg_rowsum): the latent columns of dW1 / dW5 (written in place, row strides of
 // the full matrices; pass NULL to skip) and the latent gradient gz [S][L] (NULL to skip).
@@ -1335,7 +1384,7 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
 // hidden layers (bias_grads[0..6], 256 floats each), and with `extended` (the call was given `points`) the layers2.6 weight
 // gradient w8_grad[256] and the three point columns of dW1 / dW5 (w1_cols / w5_cols: element (row, c) at [row * ld + c]);
 // b8_grad[1] = sum of dz8; optionally (seg_off != NULL) the per-segment sums t1 / t5 [256][nseg] of dZ1 / dZ5.
-size_t sg_sdfnet_bwd_finish_workspace_bytes(long N) { return (size_t)kFinishMaxSplit * 15 * kH * sizeof(float); }
+size_t sg_sdfnet_bwd_finish_workspace_bytes(long N) { return (size_t)kFinishMaxSplit * 15 * kH * sizeof(double); }
 
 int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long N, int extended, float* const* bias_grads,
                          float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
@@ -1361,7 +1410,7 @@ int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long 
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;
     a.tiles_per_split = (a.nblk + nsplit - 1) / nsplit;
-    if (workspace_bytes < (size_t)nsplit * 15 * kH * sizeof(float)) SG_FAIL(SG_ERR_WORKSPACE, "sg_sdfnet_bwd_finish: workspace too small");
+    if (workspace_bytes < (size_t)nsplit * 15 * kH * sizeof(double)) SG_FAIL(SG_ERR_WORKSPACE, "sg_sdfnet_bwd_finish: workspace too small");
     for (int g = 0; g < 15; ++g) {
         a.dst[g] = nullptr;
         a.dst_stride[g] = 1;
@@ -1382,7 +1431,7 @@ int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long 
             }
         }
     }
-    a.ws = static_cast<float*>(workspace);
+    a.ws = static_cast<double*>(workspace);
     a.tickets = tickets;
     a.seg_off = seg_off;
     a.S = nseg;

@@ -729,6 +729,24 @@ int sg_sdfnet_bwd_cpu(const float* dout, const float* out, const float* acts, fl
     }
     return SG_OK;
 }
+// the per-shape latent fold (header: sg_sdfnet_shape_bias)
+int sg_sdfnet_shape_bias_cpu(const float* z, long nshapes, int latent, const float* W1, const float* b1, const float* W5,
+                             const float* b5, float* zb1, float* zb5, void*) {
+    CPU_CHECK(z && W1 && b1 && W5 && b5 && zb1 && zb5 && nshapes > 0 && latent > 0);
+    const long ld1 = 3 + latent, ld5 = 259 + latent;
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < nshapes * 256; ++e) {
+        const long s = e / 256, o = e % 256;
+        double a = b1[o], b = b5[o];
+        for (int k = 0; k < latent; ++k) {
+            a += (double)z[s * latent + k] * W1[o * ld1 + 3 + k];
+            b += (double)z[s * latent + k] * W5[o * ld5 + 259 + k];
+        }
+        zb1[e] = (float)a;
+        zb5[e] = (float)b;
+    }
+    return SG_OK;
+}
 // backward of the per-shape latent fold (header: sg_sdfnet_shape_bias_bwd)
 int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
                                  const float* W5, float* dW1, float* dW5, float* gz, void*) {
@@ -1110,6 +1128,21 @@ int sg_loss_deepsdf_bwd_cpu(const float* o, const float* t, long n, const float*
         d_o[e] = g1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
     }
     for (long e = 0; e < rows * L; ++e) dz[e] = (roww ? roww[e / L] : 1.f) * g2 * z[e];
+    return SG_OK;
+}
+int sg_loss_deepsdf_fused_cpu(const float* o, const float* t, long n, const float* z, const float* roww, long rows, int L, double denom,
+                              float* loss, float* d_o, float* dz, void*, size_t, unsigned*, void*) {
+    CPU_CHECK(o && t && z && loss && n > 0 && rows > 0 && L > 0 && denom > 0);
+    const int rc = sg_loss_deepsdf_fwd_cpu(o, t, n, z, roww, rows, L, denom, loss, nullptr, 0, nullptr);
+    if (rc != SG_OK) return rc;
+    const float g1 = (float)(1.0 / (double)n), g2 = (float)(2.0 / denom);
+    if (d_o)
+        for (long e = 0; e < n; ++e) {
+            const float d = o[e] - t[e];
+            d_o[e] = g1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+    if (dz)
+        for (long e = 0; e < rows * L; ++e) dz[e] = (roww ? roww[e / L] : 1.f) * g2 * z[e];
     return SG_OK;
 }
 int sg_gradient_penalty_fwd_cpu(const float* grad, long B, long M, float weight, float* norms, float* loss, void*) {

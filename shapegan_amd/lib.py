@@ -68,6 +68,7 @@ SIGNATURES = {
     "sg_sdfnet_fwd": (c_int, [_P, _L, _P, _P, _I, _P, _I, _P, _P, _L, _P, _P, _P, _L, _L, _P]),
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
+    "sg_sdfnet_shape_bias": (c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P]),
     "sg_sdfnet_bwd_finish_workspace_bytes": (_Z, [_L]),
     "sg_sdfnet_bwd_finish": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _Z, _P, _P]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "sg_loss_meansq_bwd": (c_int, [_P, _P, _P, _P, _L, _I, _D, _P]),
     "sg_loss_deepsdf_fwd": (c_int, [_P, _P, _L, _P, _P, _L, _I, _D, _P, _P, _Z, _P]),
     "sg_loss_deepsdf_bwd": (c_int, [_P, _P, _L, _P, _P, _L, _I, _D, _P, _P, _P, _P]),
+    "sg_loss_deepsdf_fused": (c_int, [_P, _P, _L, _P, _P, _L, _I, _D, _P, _P, _P, _P, _Z, _P, _P]),
     "sg_count_sign_mismatch": (c_int, [_P, _P, _L, _P, _P, _Z, _P]),
     "sg_gradient_penalty_fwd": (c_int, [_P, _L, _L, _F, _P, _P, _P]),
     "sg_gradient_penalty_bwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
@@ -141,6 +143,8 @@ SIGNATURES = {
 COMM_PATH = os.path.join(_HERE, "libshapegan_comm.so")
 COMM_SIGNATURES = {
     "sg_comm_last_error": (c_char_p, []),
+    "sg_comm_bind": (c_int, [c_char_p]),
+    "sg_comm_versions": (c_int, [_P, _P]),
     "sg_allreduce_unique_id_bytes": (_Z, []),
     "sg_allreduce_unique_id": (c_int, [_P, _Z]),
     "sg_allreduce_init": (c_int, [_P, _I, _I, _P, _Z, _I]),
@@ -152,8 +156,28 @@ COMM_SIGNATURES = {
 _comm = None
 
 
+def rccl_path():
+    """The RCCL of THIS process: the one PyTorch ships and its "nccl" backend maps (torch/lib/librccl.so).  The C-ABI exchange binds
+    the same file, so that both communicators of a rank live in one RCCL instance of one version (the library used to be
+    linked against the ROCm toolchain's librccl with a RUNPATH into /opt/rocm-7.2.0 and took whichever librccl.so.1 the loader
+    found first).  SG_RCCL_PATH overrides; None if torch carries none (the loader's default search is used then)."""
+    override = os.environ.get("SG_RCCL_PATH")
+    if override:
+        return override
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else None
+
+
+COMM_INFO = {}      # what load_comm() bound: {"rccl_path", "rccl_header_version", "rccl_runtime_version"}
+
+
+def _version_string(code):
+    return "%d.%d.%d" % (code // 10000, code // 100 % 100, code % 100) if code >= 10000 else str(code)
+
+
 def load_comm():
-    """Loads libshapegan_comm.so (once).  Raises if it has not been built."""
+    """Loads libshapegan_comm.so (once) and binds it to this process's RCCL (rccl_path()).  Raises if it has not been built, if the
+    RCCL cannot be opened, or if its major version differs from the header the library was compiled against."""
     global _comm
     if _comm is None:
         if not os.path.exists(COMM_PATH):
@@ -163,6 +187,14 @@ def load_comm():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        path = rccl_path()
+        if lib.sg_comm_bind(path.encode() if path else None) != 0:
+            msg = lib.sg_comm_last_error()
+            raise RuntimeError("shapegan_comm: cannot bind RCCL (%s): %s" % (path or "loader default", msg.decode() if msg else "?"))
+        hv, rv = c_int(0), c_int(0)
+        lib.sg_comm_versions(ctypes.byref(hv), ctypes.byref(rv))
+        COMM_INFO.update(rccl_path=path or "librccl.so.1 (loader default)", rccl_header_version=_version_string(hv.value),
+                         rccl_runtime_version=_version_string(rv.value))
         _comm = lib
     return _comm
 

@@ -1081,11 +1081,12 @@ class SDFNetShapes(Function):
         lib = _lib()
         packed = cache.get(params, Lz, 3)
         w1, b1, w5, b5 = f32c(params[0]), params[1], f32c(params[8]), params[9]
-        # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]
-        # (the [S,L] x [L,256] fold stays on sg_gemm: a dedicated one-launch kernel with double accumulation was exact to
-        # 1e-7 but saved only ~10 us, and any change of rounding here re-rolls which ReLU kinks flip in the trajectory tests)
-        zb1 = gemm_raw(z, False, w1, True, bias_j=b1, b_off=3, M=S, N=_H, K=Lz, lda=Lz, ldb=kin_total)
-        zb5 = gemm_raw(z, False, w5, True, bias_j=b5, b_off=_H + 3, M=S, N=_H, K=Lz, lda=Lz, ldb=_H + kin_total)
+        # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]: both folds in one launch,
+        # accumulated in double (round 6: the two sg_gemm calls were 2 - 4 launches and 24 us of the 20 000-point step)
+        zb1 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
+        zb5 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
+        check(lib.sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(w1), ptr(f32c(b1)), ptr(w5), ptr(f32c(b5)), ptr(zb1), ptr(zb5), stream()),
+              "sdfnet_shape_bias")
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
@@ -1718,8 +1719,12 @@ class DeepSDFLoss(Function):
         rw = None if row_weight is None else f32c(row_weight)
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         ws = _loss_ws(out.device)
-        check(_lib().sg_loss_deepsdf_fwd(ptr(out), ptr(target), out.numel(), ptr(z), ptr(rw), rows, width, float(denom),
-                                         ptr(loss), ptr(ws), ws.numel(), stream()), "loss_deepsdf_fwd")
+        # the gradient for an upstream 1 comes out of the same launch (the loss is the root of lib.backward() in the trainer)
+        ctx.d_unit = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        ctx.dz_unit = torch.empty_like(z) if ctx.needs_input_grad[2] else None
+        check(_lib().sg_loss_deepsdf_fused(ptr(out), ptr(target), out.numel(), ptr(z), ptr(rw), rows, width, float(denom),
+                                           ptr(loss), ptr(ctx.d_unit), ptr(ctx.dz_unit), ptr(ws), ws.numel(),
+                                           ptr(L.tickets("deepsdf", out.device)), stream()), "loss_deepsdf_fused")
         ctx.denom = float(denom)
         ctx.save_for_backward(out, target, z, rw)
         return loss
@@ -1728,6 +1733,8 @@ class DeepSDFLoss(Function):
     @once_differentiable
     def backward(ctx, g):
         out, target, z, rw = ctx.saved_tensors
+        if L.is_unit_gradient(g) and (ctx.d_unit is not None or ctx.dz_unit is not None):
+            return ctx.d_unit, None, ctx.dz_unit, None, None
         d, dz = torch.empty_like(out), torch.empty_like(z)
         check(_lib().sg_loss_deepsdf_bwd(ptr(out), ptr(target), out.numel(), ptr(z), ptr(rw), z.shape[0], z.shape[1],
                                          ctx.denom, ptr(f32c(g)), ptr(d), ptr(dz), stream()), "loss_deepsdf_bwd")

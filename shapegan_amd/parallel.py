@@ -230,8 +230,56 @@ def native_comm():
     if _native is None:
         TRANSPORT.update(name="torch-" + dist.get_backend(), reason="fallback: " + reason)
     else:
+        from . import lib as L
         TRANSPORT.update(name="native-rccl", reason="", comm_init_seconds=round(_native.init_seconds, 3), **_native.info())
+        TRANSPORT.update(L.COMM_INFO)     # which RCCL file was bound, header version vs runtime version
     return _native
+
+
+class _ExposedCommTime(object):
+    """How long the COMPUTE stream actually stood still for gradient exchanges (bench.py: comm.exposed_ms_per_step): one event on
+    the compute stream where it reaches a bucket's wait, one right behind the wait — their distance is what the overlap did not
+    hide (0 when the all-reduce had finished before backward did).  Next to it the time the HOST spent inside the wait calls
+    (a gloo exchange blocks the host, an RCCL one only enqueues).  Off unless `enable()`d: two event records per exchange."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pairs = []
+        self.host_s = 0.0
+
+    def enable(self, on=True):
+        self.enabled = bool(on)
+        self.reset()
+
+    def reset(self):
+        self.pairs, self.host_s = [], 0.0
+
+    def begin(self):
+        if not self.enabled:
+            return None
+        a = torch.cuda.Event(enable_timing=True) if torch.cuda.is_available() else None
+        if a is not None:
+            a.record()
+        return (a, time.perf_counter())
+
+    def end(self, probe):
+        if probe is None:
+            return
+        a, t0 = probe
+        self.host_s += time.perf_counter() - t0
+        if a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.pairs.append((a, b))
+
+    def totals(self):
+        """(compute-stream milliseconds, host milliseconds, exchanges waited for) since the last reset; synchronises the device."""
+        if self.pairs:
+            torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.pairs), self.host_s * 1e3, len(self.pairs)
+
+
+EXPOSED = _ExposedCommTime()
 
 
 class GradBucket(object):
@@ -402,11 +450,15 @@ class GradBucket(object):
             self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):
-        if self.native is not None and self.works:
+        if not self.works:
+            return
+        probe = EXPOSED.begin()
+        if self.native is not None:
             self.native.wait()
         for w in self.works:
             if w is not None:
                 w.wait()
+        EXPOSED.end(probe)
         self.works = []
 
     def allreduce(self):

@@ -43,7 +43,9 @@ def check_against_oracles(got, ref32, ref64, what, rtol=RTOL, gscale=0.0, noise_
     assert frac <= allowed, "%s: %.3f%% of elements beyond tol %.3e (max err %.3e, fp32-oracle noise %.3e, scale %.3e)" % (
         what, 100 * frac, tol, float(err.max()), noise, scale)
     if frac > 0:
-        assert float(err.max()) <= outlier_cap * max(float(r64.abs().max()), gscale), what + ": kink outlier too large"
+        # (an outlier is by definition beyond `tol`: where the measured fp32 noise of a quantity already exceeds 5 % of its largest
+        # entry — optimizer steps of parameters whose gradient is at rounding level — the cap is twice the tolerance instead)
+        assert float(err.max()) <= max(outlier_cap * max(float(r64.abs().max()), gscale), 2.0 * tol), what + ": kink outlier too large"
 
 
 def _oracle_grads(sd, ins, forward_oracle, dtype, flips=None):
