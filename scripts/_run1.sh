@@ -1,2 +1,4 @@
-out=gpurun_out/full1; mkdir -p $out
-timeout 2400 python -m pytest tests -q -m gpu -x > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $out/pytest.log
+out=gpurun_out/sdf1; mkdir -p $out
+timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_modules.py tests/test_gpu_losses.py tests/test_gpu_dp.py -x -q -m gpu -k "sdf or hybrid or normals or deepsdf or bad_batch" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
+python scripts/_sdfnum.py 2>/dev/null | grep -E "mpoints|frac|ms_per|\"train|fwd_"
+cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl20 -o t20 -- python $OLDPWD/scripts/sdf_step_prof.py 20000 128 > /dev/null 2>&1; f=$(find /tmp/tl20 -name "*kernel_trace.csv" | head -1); python $OLDPWD/scripts/step_timeline.py $f adam_kernel 2

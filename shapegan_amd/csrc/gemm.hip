@@ -821,9 +821,10 @@ static int gemm128_try(const float* A, long sai, long sak, const float* B, long 
     const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
     // a product without a K split and with more tiles than resident workgroups runs persistently (SG_GEMM128=2: one workgroup per tile)
     static const bool persist_off = getenv("SG_GEMM128") && atoi(getenv("SG_GEMM128")) == 2;
-    // (its epilogue writes rows of C through one 32-bit-offset window per tile: unit column stride, no per-row bias, 128 rows of C
-    // below 2 GiB; its operand windows span the whole K range)
-    const bool persistent = !persist_off && tiles > 512 && ((K + kNtKC - 1) / kNtKC) % 2 == 0 && epi.scj == 1 && !epi.bias_i && 128 * epi.sci * 4 < (long)kBufRange &&
+    // (its epilogue writes rows of C through one 32-bit-offset window per tile that ends with row M - 1: unit column stride, rows
+    // that do not overlap (sci >= N: the window's end is what clips the rows beyond M), no per-row bias, 128 rows of C below 2 GiB;
+    // its operand windows span the whole K range)
+    const bool persistent = !persist_off && tiles > 512 && ((K + kNtKC - 1) / kNtKC) % 2 == 0 && epi.scj == 1 && epi.sci >= N && !epi.bias_i && 128 * epi.sci * 4 < (long)kBufRange &&
                             (ak ? 128 * lda + K : (long)K * lda + 128) * 4 < (long)kBufRange &&
                             (bk ? 128 * ldb + K : (long)K * ldb + 128) * 4 < (long)kBufRange;
     const unsigned wgs = g.nsplit > 1 ? (unsigned)((g.nsplit + 7) / 8 * 8 * tiles) : (unsigned)tiles;

@@ -31,7 +31,12 @@
 #ifndef SG_BWD_RING
 #define SG_BWD_RING 4
 #endif
-#define SG_BWD_TILE 64   // (the tile layout of the partial sums is part of the ABI: include/shapegan_hip.h)
+#define SG_BWD_TILE 64
+// cache policy of the activation / dZ image stores (aux of the raw buffer store: 0 default, 2 = nt: streaming, evict-first in L2 —
+// the images are written once and read by a later kernel, the weight packs every wave streams should keep the L2)
+#ifndef SG_IMG_AUX
+#define SG_IMG_AUX 2
+#endif   // (the tile layout of the partial sums is part of the ABI: include/shapegan_hip.h)
 
 namespace sg {
 
@@ -388,7 +393,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
                 Hs[row * P + t * 32 + r] = v;
                 if (save)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ares, (int)astore[t],
-                                                          (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), 0);
+                                                          (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), SG_IMG_AUX);
             }
         }
         if constexpr (TRAIN) {
@@ -704,7 +709,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
                 s8 = fmaf(pok[h] ? hf[q][h] : 0.f, d8, s8);
                 gw[h][rowoff(q) * kLdg] = g;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[h],
-                                                      (int)(rowoff(q) * a.ldn * 4), 0);
+                                                      (int)(rowoff(q) * a.ldn * 4), SG_IMG_AUX);
             }
             if (ext)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(s8)), w8res, (int)bsoff,
@@ -776,7 +781,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         const float g = ((mk[h] >> q) & 1u) ? acc[h][q] : 0.f;
         gw[h][rowoff(q) * kLdg] = g;
 #ifndef SG_ABL_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[h], (int)(rowoff(q) * a.ldn * 4), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[h], (int)(rowoff(q) * a.ldn * 4), SG_IMG_AUX);
 #endif
     };
     auto zero = [&](int h) __attribute__((always_inline)) {

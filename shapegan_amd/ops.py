@@ -1381,9 +1381,13 @@ def sdf_batch_sort_max_shapes():
 
 
 def check_batch_indices():
-    """Synchronises and raises if any sdf_batch_sort call since the last check saw an index outside its tables (every live pair)."""
-    for words in list(_all_bad_index_words):
-        words.raise_if_bad(synchronise_first=True)
+    """Synchronises (once) and raises if any sdf_batch_sort call on a device's DEFAULT pair of words since the last check saw an index
+    outside its tables.  Pairs a trainer owns (BadIndexWords passed as `words=`) are the trainer's to poll: its handler also takes the
+    host-side Adam counters of the skipped updates back, which a raise from here would bypass."""
+    if torch.cuda.is_available() and any(d.type == "cuda" for d in _bad_index_flags):
+        torch.cuda.synchronize()
+    for words in list(_bad_index_flags.values()):
+        words.raise_if_bad()
 
 
 def poll_batch_indices():
@@ -1391,7 +1395,7 @@ def poll_batch_indices():
     An out-of-range index is reported as soon as the kernel that saw it has run — in practice at the next step (the reference
     raises at once; the batch in question was computed on clamped rows, and an optimizer guarded by the pair's device word did not
     apply it).  Costs nothing on the device and is safe inside a stream capture (there is nothing to record)."""
-    for words in list(_all_bad_index_words):
+    for words in list(_bad_index_flags.values()):       # (the default pairs only: see check_batch_indices)
         words.raise_if_bad(synchronise_before_raise=True)
 
 

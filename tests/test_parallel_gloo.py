@@ -107,20 +107,24 @@ def _pattern_worker(rank, world, port, out_dir):
     parallel.init_distributed(backend="gloo")
     torch.manual_seed(5)
     ps = [torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(5))]
-    opt = optim.Adam(ps, lr=1e-2)
-    bucket = parallel.GradBucket(opt)
+    qs = [torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt, opt2 = optim.Adam(ps, lr=1e-2), optim.Adam(qs, lr=1e-2)
+    bucket, bucket2 = parallel.GradBucket(opt), parallel.GradBucket(opt2)     # two buckets per trainer, as every shipped trainer has
     msgs = []
-    # step 0: every rank has every gradient; step 1: every rank lacks parameter 1 (an unused stage: consistent, fine);
-    # step 2: rank 1 suddenly has one (a data-dependent branch) -> rank 1's pattern changed, it reads the header back and raises
-    # step 3: the rank whose pattern did NOT change finds the disagreement of step 2 in its header snapshot before it enters
-    # another collective (it used to block for ever in that all-reduce once the raising rank was gone)
+    # step 0: every rank has every gradient (the first exchange is validated at once, on every rank);
+    # step 1: every rank lacks parameter 1 (an unused stage: consistent, fine);
+    # step 2: rank 1 suddenly has one (a data-dependent branch).  NOBODY raises yet — the rank whose pattern changed must not leave
+    #         alone: the other rank is about to enter the SECOND bucket's collective of the same step — both finish the step;
+    # step 3: BOTH ranks find the disagreement in the snapshot of step 2's summed header at the top of the first bucket's finish(),
+    #         before they enter another collective, and raise at the same program point.
     for step, missing in enumerate(((), (1,), (1,) if rank == 0 else (), (1,) if rank == 0 else ())):
-        if step == 3 and rank == 1:
-            break                               # this rank raised at step 2 and is gone
         opt.zero_grad()
+        opt2.zero_grad()
         for i, p in enumerate(ps):
             if i not in missing:
                 p.grad = torch.full_like(p, float(rank + 1))
+        for q in qs:
+            q.grad = torch.full_like(q, float(rank + 1))
         try:
             bucket.finish()
             msgs.append("ok")
@@ -129,7 +133,11 @@ def _pattern_worker(rank, world, port, out_dir):
                 assert torch.equal(ps[0].grad, torch.full_like(ps[0], 3.0))        # 1 + 2: the head slice after the header is intact
         except RuntimeError as e:
             msgs.append(str(e))
+            break                               # every rank stops here, at the same call: no collective is left half-entered
+        bucket2.finish()                        # the intervening collective of the same step: both ranks must take part
+        assert torch.equal(qs[0].grad, torch.full_like(qs[0], 3.0))
         opt.step()
+        opt2.step()
     with open(os.path.join(out_dir, "pattern%d.txt" % rank), "w") as fh:
         fh.write("\n".join(msgs))
     # broadcast_parameters is a raw .data write: it must move the parameter epochs
@@ -140,14 +148,15 @@ def _pattern_worker(rank, world, port, out_dir):
 
 
 def test_ranks_disagreeing_on_missing_gradients_is_an_error_not_a_divergence(tmp_path):
-    """a parameter without a gradient is skipped by step(); if the ranks disagree about it the replicas diverge.  The
-    header that rides with the flat gradient exchange makes the rank whose pattern changed raise."""
+    """a parameter without a gradient is skipped by step(); if the ranks disagree about it the replicas diverge.
+    The header that rides with the flat gradient exchange tells every rank; all of them raise at the SAME call — the first bucket's
+    finish() of the next step — also with a second bucket's collective in between, so nobody is left inside a collective."""
     mp.spawn(_pattern_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0 = (tmp_path / "pattern0.txt").read_text().split("\n")
     r1 = (tmp_path / "pattern1.txt").read_text().split("\n")
-    assert r0[:3] == ["ok", "ok", "ok"]                  # rank 0's own pattern did not change at step 2: no read-back, no cost ...
-    assert "disagree on which parameters have a gradient" in r0[3] and "PREVIOUS exchange" in r0[3]     # ... it learns it one step on
-    assert r1[:2] == ["ok", "ok"] and "disagree on which parameters have a gradient" in r1[2] and "[1]" in r1[2]
+    for r in (r0, r1):
+        assert r[:3] == ["ok", "ok", "ok"] and len(r) == 4
+        assert "disagree on which parameters have a gradient" in r[3] and "PREVIOUS exchange" in r[3] and "[1]" in r[3]
 
 
 def _checkpoint_worker(rank, world, port, out_dir):
