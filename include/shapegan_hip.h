@@ -126,6 +126,12 @@ int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW)
 int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
                               const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,
                               float slope, hipStream_t stream);
+/* the same with the kernel form chosen by the caller (tests / tuning; the library reads no environment variable): form 0 = the
+ * dispatch rule, 1 / 2 = one output-row parity per workgroup with one / two plane walks, 3 / 4 = both row parities per workgroup
+ * with one / two plane walks.  Every form computes the same sums in the same order (bit-identical results). */
+int sg_convT3d_k4s2p1_to1_pre_impl(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                   const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                   int act, float slope, int form, hipStream_t stream);
 /* Several independent batches in one pass ("groups" of samples_per_group samples: e.g. the generator evaluations of four
  * consecutive critic updates, train_wgan.py:60-63, whose BatchNorm statistics are per evaluation): sample n takes row n /
  * samples_per_group of in_scale / in_shift ([groups][C]) and is written at y + (n / samples_per_group) * y_group_stride +
@@ -317,6 +323,9 @@ int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* ex
                              float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
                              const int* skip_if_nonzero, hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
+/* clamp of `ntensors` tensors (host arrays of device pointers and element counts) in one launch per 16 tensors:
+ * Discriminator.clip_weights (model/gan.py:67-69) over the module-level surface, eight parameter tensors per critic update */
+int sg_clamp_multi(float* const* tensors, const long* counts, int ntensors, float lo, float hi, hipStream_t stream);
 
 /* ---- K8/K9: loss compositions, gradient-penalty pieces, fade-in blend ---------------------------
  * Each loss is one streaming pass + a finishing wave (deterministic, double partial sums) writing a device scalar;

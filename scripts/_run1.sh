@@ -1,4 +1,14 @@
-out=gpurun_out/sdf1; mkdir -p $out
-timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_modules.py tests/test_gpu_losses.py tests/test_gpu_dp.py -x -q -m gpu -k "sdf or hybrid or normals or deepsdf or bad_batch" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
-python scripts/_sdfnum.py 2>/dev/null | grep -E "mpoints|frac|ms_per|\"train|fwd_"
-cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl20 -o t20 -- python $OLDPWD/scripts/sdf_step_prof.py 20000 128 > /dev/null 2>&1; f=$(find /tmp/tl20 -name "*kernel_trace.csv" | head -1); python $OLDPWD/scripts/step_timeline.py $f adam_kernel 2
+out=gpurun_out/full2; mkdir -p $out
+timeout 2400 python -m pytest tests -q -m gpu -x > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $out/pytest.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
+python - $out <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]+'/bench.json'))
+print(d['value'], d['ms_per_step'])
+for k in d['kernels']: print(k['kernel'], k['us'], k['frac'])
+s=d['sdfnet']
+print('fwd', s['fwd_mpoints_per_s'], s['fwd_frac_of_f32_mfma_peak_executed'])
+for k in ('train_ref_20k_L128','train_ref_20k_L128_eager','train_cfg_200k_L256'): print(k, s[k]['ms_per_step'], s[k]['frac_of_f32_mfma_peak_executed'])
+for k,v in d['other_configs'].items(): print(k, v['value'], v['ms_per_step'])
+print(d['dropin_loop'])
+PY

@@ -512,7 +512,7 @@ extern "C" {
 
 // A/B switch for the edge-layer kernels of conv3d_edge.hip (SG_NO_EDGE=1 restores the previous kernels)
 static bool edge_enabled(int which = 7) {   // SG_NO_EDGE = bit mask: 1 forward, 2 input gradient, 4 weight gradient
-    static const int off = getenv("SG_NO_EDGE") ? atoi(getenv("SG_NO_EDGE")) : 0;
+    constexpr int off = SG_NO_EDGE;
     return (off & which) == 0;
 }
 
@@ -960,10 +960,10 @@ int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW)
     return batch > 0 && C > 0 && C <= 64 && ID > 0 && IH > 0 && IW > 0 && IH * IW <= 256 &&
            (size_t)C * ID * IH * IW * 4 < (size_t)kBufRange && (long)batch * 8 * ID * IH * IW < (1L << 31);
 }
-int sg_convT3d_k4s2p1_to1_pre_grouped(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
-                                      const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
-                                      int act, float slope, int samples_per_group, long y_group_stride, hipStream_t stream) {
-    SG_CHECK_ARG(x && w && y && in_scale && in_shift && samples_per_group > 0 && batch % samples_per_group == 0);
+static int convT_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                         const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                         int act, float slope, int samples_per_group, long y_group_stride, int form, hipStream_t stream) {
+    SG_CHECK_ARG(x && w && y && in_scale && in_shift && samples_per_group > 0 && batch % samples_per_group == 0 && form >= 0 && form <= 4);
     SG_CHECK_ARG(y_group_stride >= (long)samples_per_group * 8 * ID * IH * IW);
     if (!sg_convT3d_k4s2p1_to1_pre_eligible(batch, C, ID, IH, IW))
         SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: shape not served (C <= 64, IH * IW <= 256)");
@@ -971,10 +971,24 @@ int sg_convT3d_k4s2p1_to1_pre_grouped(const float* x, const float* w, const floa
     ConvGeom g;
     if (make_geom(g, 2 * ID, 2 * IH, 2 * IW, 1, C)) SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: bad spatial dims");
     if (edge_dgrad_stream_try(x, w, bias, y, batch, 1, 1, g, C, act, slope, stream, in_scale, in_shift, in_act, in_slope,
-                              samples_per_group, y_group_stride) != 1)
+                              samples_per_group, y_group_stride, form) != 1)
         SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: not served");
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+int sg_convT3d_k4s2p1_to1_pre_grouped(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                      const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                      int act, float slope, int samples_per_group, long y_group_stride, hipStream_t stream) {
+    return convT_to1_pre(x, w, bias, y, in_scale, in_shift, in_act, in_slope, batch, C, ID, IH, IW, act, slope, samples_per_group,
+                         y_group_stride, 0, stream);
+}
+// the same with the kernel form chosen by the caller (tests / tuning): 0 the dispatch rule, 1 / 2 one h parity per workgroup with
+// one / two plane walks, 3 / 4 both h parities per workgroup with one / two plane walks
+int sg_convT3d_k4s2p1_to1_pre_impl(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
+                                   const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
+                                   int act, float slope, int form, hipStream_t stream) {
+    return convT_to1_pre(x, w, bias, y, in_scale, in_shift, in_act, in_slope, batch, C, ID, IH, IW, act, slope, batch,
+                         (long)batch * 8 * ID * IH * IW, form, stream);
 }
 int sg_convT3d_k4s2p1_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
                               const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW, int act,

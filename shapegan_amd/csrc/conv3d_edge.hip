@@ -1532,9 +1532,8 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     a.slope = slope;
     // round 5: the LDS-staged form for 32- / 64-wide grids (the critic's first layer, the progressive discriminator's 64^3 stage)
     {
-        static const char* env = getenv("SG_FWD_C1_LDS");
         const int bh = g.IW == 32 ? 16 : 8;
-        if ((g.IW == 32 || g.IW == 64) && g.OH % bh == 0 && !(env && atoi(env) == 0)) {
+        if (SG_FWD_C1_LDS && (g.IW == 32 || g.IW == 64) && g.OH % bh == 0) {
             EdgeFwdLdsArgs l;
             l.x = x;
             l.w = w;
@@ -1567,14 +1566,6 @@ int edge_fwd_try(const float* x, const float* w, const float* bias, float* y, in
     }
     int wgs = (a.total_tiles + 3) / 4;
     if (wgs > 512) wgs = 512;
-    {
-        const char* dbg = getenv("SG_EDGE_DEBUG");
-        const int d = dbg ? atoi(dbg) : 0;
-        if (d & 1) wgs = wgs > 256 ? 256 : wgs;
-        if (d & 2) (void)hipStreamSynchronize(stream);
-        if (d & 4) wgs = wgs > 128 ? 128 : wgs;
-        if ((d & 8) && (a.total_tiles + 3) / 4 >= 768) wgs = 768;
-    }
 #define SG_FWD_C1(NT_, ACT_) hipLaunchKernelGGL((conv_fwd_c1_kernel<NT_, ACT_>), dim3(wgs), dim3(256), 0, stream, a)
     if (Cout > 32) {
         if (actk == 0) SG_FWD_C1(2, 0); else if (actk == 1) SG_FWD_C1(2, 1); else SG_FWD_C1(2, 2);
@@ -1620,10 +1611,6 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     a.dOH = FastDiv((uint32_t)g.OH);
     int wgs = (a.total_passes + 3) / 4;
     if (wgs > 512) wgs = 512;
-    {
-        const char* dbg = getenv("SG_EDGE_DEBUG");   // tuning: bit 16 -> at most 256 workgroups (half the partial tiles)
-        if (dbg && (atoi(dbg) & 16) && wgs > 256) wgs = 256;
-    }
     const int fuse = y ? act : 0;
 #define SG_LAUNCH_WGRAD_C1(MT, F) hipLaunchKernelGGL((conv_wgrad_c1_kernel<MT, F>), dim3(wgs), dim3(256), 0, stream, a)
     if (Cout > 32) {
@@ -1645,7 +1632,7 @@ int edge_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
 // the input transform act_in(dy * in_scale[c] + in_shift[c]) folded into the loads (in_act: none / LeakyReLU / ReLU).
 int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                           const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
-                          const float* in_shift, int in_act, float in_slope, int samples_per_group, long out_group_stride, int force_split) {
+                          const float* in_shift, int in_act, float in_slope, int samples_per_group, long out_group_stride, int form) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64 || g.OH * g.OW > 256 || (size_t)g.Cy * O3 * 4 >= (size_t)kBufRange) return 0;
     const bool pre = in_scale != nullptr;
@@ -1675,16 +1662,17 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     f.out_group_stride = samples_per_group > 0 ? out_group_stride : (long)batch * f.dx_sample;
     const int nblocks = (f.P2 + 31) / 32;
     // Both h parities per workgroup (convT_c1_stream2_kernel, round 5): half the plane loads per output.  Workgroups = samples x 2
-    // (x 2 plane walks while that leaves CUs without one).  SG_CONVT_BOTH=0: the one-parity kernel (A/B).
+    // (x 2 plane walks while that leaves CUs without one).
     // Measured (cold): 256 samples 100.5 -> 86.8 us; 64 samples 27.5 - 31.5 -> 25.9 us with two plane walks (the one-parity kernel
     // fills the chip with twice the workgroups there and is as fast warm): taken from 192 samples on — the grouped generator pass of
-    // WGANTrainer.step runs at 256 —; SG_CONVT_BOTH=1 / 0 forces it on / off (read per call: the parity test toggles it).
-    const char* both_env = getenv("SG_CONVT_BOTH");
-    const char* split_env = getenv("SG_CONVT_SPLIT");      // (read per call: the parity test toggles it)
+    // WGANTrainer.step runs at 256.
+    // `form` (sg_convT3d_k4s2p1_to1_pre_impl; 0 = this dispatch rule): 1 / 2 = one h parity per workgroup with one / two plane walks,
+    // 3 / 4 = both h parities with one / two walks.  Tests and tuning select a form through the ABI, not through the environment.
     const long base_wgs = (long)((batch + 7) / 8 * 8) * 2;
-    const bool both = both_env ? atoi(both_env) != 0 : base_wgs >= 384;
+    const bool both = form ? form >= 3 : base_wgs >= 384;
+    const bool can_split = g.OD >= 4 && g.OD % 2 == 0;
     if (both) {
-        f.splits = (force_split == 2 || (split_env && atoi(split_env) == 2) || (!split_env && base_wgs < 256)) && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
+        f.splits = (form ? form == 4 : base_wgs < 256) && can_split ? 2 : 1;
         const size_t lds2 = (size_t)2 * 32 * (nblocks * 32 + 4) * sizeof(float);
         const unsigned wgs2 = (unsigned)(base_wgs * f.splits);
         static SgPerDeviceOnce once2;
@@ -1721,8 +1709,8 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     // went from 27.7 to 31.5 us, i.e. the plane walk is not a latency chain that a second workgroup per CU would hide (the four
     // workgroups of a sample already pull every input line through L2 four times; a second walk adds a recomputed plane to that);
     // only at 32 samples does it win (18.4 us against 25.6 unsplit and 19.4 - 20.9 for the per-plane kernel that serves < 48
-    // samples).  SG_CONVT_SPLIT=2 turns it on for A/B; tests/test_gpu_ops.py runs both forms.
-    f.splits = (force_split == 2 || (split_env && atoi(split_env) == 2)) && g.OD >= 4 && g.OD % 2 == 0 ? 2 : 1;
+    // samples).  Form 2 of sg_convT3d_k4s2p1_to1_pre_impl; tests/test_gpu_ops.py runs every form.
+    f.splits = form == 2 && can_split ? 2 : 1;
     const unsigned wgs = (unsigned)((batch + 7) / 8 * 8 * 4 * f.splits);
 #define SG_CONVT_STREAM(ALL_, PRE_, FULL_, EPI_) \
     hipLaunchKernelGGL((convT_c1_stream_kernel<ALL_, PRE_, FULL_, EPI_>), dim3(wgs), dim3(512), lds, stream, f)
@@ -1748,16 +1736,16 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
                    hipStream_t stream, int force) {
     const long O3 = g.O3();
     if (Cin != 1 || Cout > 64) return 0;
-    // plane-streaming kernel (round 4); SG_NO_EDGE bit 16 restores the per-plane fused kernel below (A/B)
-    static const bool stream_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 16);
+    // plane-streaming kernel (round 4); -DSG_NO_EDGE=16 builds restore the per-plane fused kernel below (A/B)
+    constexpr bool stream_off = (SG_NO_EDGE & 16) != 0;
     // (the streaming kernel runs four workgroups per sample for the whole depth of the grid: below ~48 samples it leaves CUs
     // idle and the one-workgroup-per-plane kernel is faster — 17.8 vs 22.6 us at 32 samples, 32.0 vs 22.7 at 64, 114 vs 92 at 256)
-    static const int stream_min_batch = getenv("SG_CONVT_MIN_BATCH") ? atoi(getenv("SG_CONVT_MIN_BATCH")) : 48;
+    constexpr int stream_min_batch = SG_CONVT_MIN_BATCH;
     if (!stream_off && g.OH * g.OW <= 256 && (force || (long)batch * O3 >= 512) && batch >= stream_min_batch &&
         edge_dgrad_stream_try(dy, w, bias, dx, batch, Cin, Cin_total, g, Cout, act, slope, stream, nullptr, nullptr, 0, 0.f, 0, 0) == 1)
         return 1;
     // fused kernel: a whole (OH x OW) plane of the four tap groups fits in LDS
-    static const bool fused_off = getenv("SG_NO_EDGE") && (atoi(getenv("SG_NO_EDGE")) & 8);
+    constexpr bool fused_off = (SG_NO_EDGE & 8) != 0;
     if (!fused_off && g.OH * g.OW <= 256 && (size_t)g.Cy * O3 * 4 < (size_t)kBufRange && (force || (long)batch * O3 >= 512)) {
         ConvTFusedArgs f;
         f.dy = dy;

@@ -114,6 +114,18 @@ int edge_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
 int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, float* dx, int batch, int Cin, int Cin_total,
                           const ConvGeom& g, int Cout, int act, float slope, hipStream_t stream, const float* in_scale,
                           const float* in_shift, int in_act, float in_slope, int samples_per_group = 0, long out_group_stride = 0,
-                          int force_split = 0);
+                          int form = 0);
 
 }  // namespace sg
+
+// ---- tuning switches: COMPILE-TIME constants (scripts/ab_build.sh builds variants with -D...); the product library reads no
+// environment variable and keeps no mutable global state (include/shapegan_hip.h) ----------------------------------------------------
+#ifndef SG_NO_EDGE
+#define SG_NO_EDGE 0            // bits: which one-channel ("edge") kernels are switched off (A/B builds)
+#endif
+#ifndef SG_FWD_C1_LDS
+#define SG_FWD_C1_LDS 1         // the LDS-staged Conv3d(1 -> C) forward at 32- / 64-wide grids (0: the gather form)
+#endif
+#ifndef SG_CONVT_MIN_BATCH
+#define SG_CONVT_MIN_BATCH 48   // the plane-streaming ConvT(C -> 1) from this many samples on
+#endif

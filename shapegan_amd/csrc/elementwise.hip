@@ -162,6 +162,18 @@ __global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, long 
         p[e] = fminf(fmaxf(p[e], lo), hi);
 }
 
+// the same for up to 16 tensors in one launch (Discriminator.clip_weights, model/gan.py:67-69: eight parameter tensors per update):
+// blockIdx.y = tensor
+struct ClampMulti {
+    float* p[16];
+    long n[16];
+};
+__global__ void __launch_bounds__(256) clamp_multi_kernel(ClampMulti t, float lo, float hi) {
+    float* __restrict__ p = t.p[blockIdx.y];
+    const long n = t.n[blockIdx.y];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) p[e] = fminf(fmaxf(p[e], lo), hi);
+}
+
 // out = clamp(x, -c, c) [/ divisor]: VoxelDataset.__getitem__'s clamp_ and /= (datasets.py:19-22), NaN-propagating like
 // torch.clamp, true IEEE division like torch's `/= 0.1` (a reciprocal multiply differs in the last bit)
 __global__ void __launch_bounds__(256) voxel_prepare_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
@@ -306,6 +318,24 @@ int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* ex
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream) {
     SG_CHECK_ARG(p && n > 0);
     hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, n, lo, hi);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_clamp_multi(float* const* tensors, const long* counts, int ntensors, float lo, float hi, hipStream_t stream) {
+    SG_CHECK_ARG(tensors && counts && ntensors > 0);
+    for (int i0 = 0; i0 < ntensors; i0 += 16) {
+        ClampMulti t;
+        const int m = ntensors - i0 < 16 ? ntensors - i0 : 16;
+        long most = 0;
+        for (int i = 0; i < 16; ++i) {
+            const int k = i < m ? i0 + i : i0;
+            SG_CHECK_ARG(tensors[k] != nullptr && counts[k] > 0);
+            t.p[i] = tensors[k];
+            t.n[i] = counts[k];
+            if (i < m && counts[k] > most) most = counts[k];
+        }
+        hipLaunchKernelGGL(clamp_multi_kernel, dim3(ew_grid(most, 2), m), dim3(256), 0, stream, t, lo, hi);
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

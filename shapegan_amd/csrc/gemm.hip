@@ -12,6 +12,9 @@
 #include <stdlib.h>
 
 #include "mfma_tile.h"
+#ifndef SG_GEMM128
+#define SG_GEMM128 1   // sg_gemm's large products: 1 = gemm128 (persistent where eligible), 2 = one workgroup per tile, 0 = the skeleton (A/B builds)
+#endif
 #include "../../include/shapegan_hip.h"
 
 namespace sg {
@@ -790,7 +793,7 @@ struct Gemm128Partial {
 // Returns 1 if the product was launched here, 0 if the shape / layout is left to the skeleton.
 static int gemm128_try(const float* A, long sai, long sak, const float* B, long sbk, long sbj, const GemmEpi& epi, int M, int N,
                        int K, float* ws, size_t ws_bytes, hipStream_t stream) {
-    static const bool off = getenv("SG_GEMM128") && atoi(getenv("SG_GEMM128")) == 0;
+    constexpr bool off = SG_GEMM128 == 0;
     const bool ak = sak == 1 && sai != 1, bk = sbk == 1 && sbj != 1;      // (a degenerate dimension keeps the skeleton)
     if (off || (!ak && sai != 1) || (!bk && sbj != 1) || (!ak && bk)) return 0;
     const long lda = ak ? sai : sak, ldb = bk ? sbj : sbk;
@@ -819,8 +822,8 @@ static int gemm128_try(const float* A, long sai, long sak, const float* B, long 
     const long win_a = ak ? 128 * lda + g.kchunk : g.kchunk * lda + 128, win_b = bk ? 128 * ldb + g.kchunk : g.kchunk * ldb + 128;
     if (win_a * 4 >= (long)kBufRange || win_b * 4 >= (long)kBufRange) return 0;
     const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
-    // a product without a K split and with more tiles than resident workgroups runs persistently (SG_GEMM128=2: one workgroup per tile)
-    static const bool persist_off = getenv("SG_GEMM128") && atoi(getenv("SG_GEMM128")) == 2;
+    // a product without a K split and with more tiles than resident workgroups runs persistently (-DSG_GEMM128=2 builds: one workgroup per tile)
+    constexpr bool persist_off = SG_GEMM128 == 2;
     // (its epilogue writes rows of C through one 32-bit-offset window per tile that ends with row M - 1: unit column stride, rows
     // that do not overlap (sci >= N: the window's end is what clips the rows beyond M), no per-row bias, 128 rows of C below 2 GiB;
     // its operand windows span the whole K range)

@@ -935,6 +935,14 @@ int sg_clamp_cpu(float* p, long n, float lo, float hi, void*) {
     for (long e = 0; e < n; ++e) p[e] = std::min(std::max(p[e], lo), hi);
     return SG_OK;
 }
+int sg_clamp_multi_cpu(float* const* tensors, const long* counts, int ntensors, float lo, float hi, void*) {
+    CPU_CHECK(tensors && counts && ntensors > 0);
+    for (int i = 0; i < ntensors; ++i) {
+        const int rc = sg_clamp_cpu(tensors[i], counts[i], lo, hi, nullptr);
+        if (rc != SG_OK) return rc;
+    }
+    return SG_OK;
+}
 int sg_voxel_prepare_cpu(const float* x, float* out, long n, float c, float divisor, void*) {
     CPU_CHECK(x && out && n > 0 && c >= 0.f);
     for (long e = 0; e < n; ++e) {

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sg_convT3d_k4s2p1_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_to1_pre_eligible": (c_int, [_I, _I, _I, _I, _I]),
     "sg_convT3d_k4s2p1_to1_pre": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "sg_convT3d_k4s2p1_to1_pre_impl": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "sg_convT3d_k4s2p1_to1_pre_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _F, _I, _L, _P]),
     "sg_convT3d_k4s2p1_dgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "sg_convT3d_k4s2p1_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "sg_adam_step_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P, _P]),
     "sg_adam_step_dev_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P, _P]),
     "sg_clamp": (c_int, [_P, _L, _F, _F, _P]),
+    "sg_clamp_multi": (c_int, [_P, _P, _I, _F, _F, _P]),
     "sg_voxel_prepare": (c_int, [_P, _P, _L, _F, _F, _P]),
     "sg_gemm_nt_workspace_bytes": (_Z, [_I, _I, _L]),
     "sg_gemm_nt": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _L, _P, _Z, _P]),

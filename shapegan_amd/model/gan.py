@@ -104,9 +104,13 @@ class Discriminator(SavableModule):
         return run_stack(self.layers, x, self.training).squeeze()
 
     def clip_weights(self, value):
-        """WGAN weight clipping (model/gan.py:67-69) — one clamp launch per parameter tensor, in place on the
-        real storage.  shapegan_amd.optim.RMSprop(clip=value) fuses it into the optimizer step instead."""
+        """WGAN weight clipping (model/gan.py:67-69) — ONE clamp launch for all parameter tensors (sg_clamp_multi; it was one per
+        tensor: eight launches per critic update of the reference's own loop), in place on the real storage.
+        shapegan_amd.optim.RMSprop(clip=value) fuses it into the optimizer step instead."""
+        import ctypes
         lib = ops.L.load()
-        for p in self.parameters():
-            ops.check(lib.sg_clamp(ops.ptr(p.data), p.numel(), -value, value, ops.stream()), "clamp")
+        params = [p.data for p in self.parameters()]
+        ptrs = (ctypes.c_void_p * len(params))(*[ops.ptr(t) for t in params])
+        counts = (ctypes.c_long * len(params))(*[t.numel() for t in params])
+        ops.check(lib.sg_clamp_multi(ptrs, counts, len(params), -value, value, ops.stream()), "clamp_multi")
         ops.L.bump_param_epoch()

@@ -626,11 +626,12 @@ def bn_train_fwd_grouped_raw(x, gamma, beta, running_mean, running_var, num_batc
     return y
 
 
-def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=ACT_NONE, slope=0.0, out=None, outs=None):
+def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=ACT_NONE, slope=0.0, out=None, outs=None, form=0):
     """act(conv_transpose3d_k4s2p1(act_in(x * scale[c] + shift[c]), w) + b) for w [C,1,4,4,4]: the BatchNorm + activation between
     the producing layer and the last transposed convolution ride in this kernel's loads (no autograd).
     outs (with scale / shift [groups, C]): x holds `groups` independent batches; batch g is written to outs[g] (equally spaced
-    contiguous fp32 tensors [N / groups, 1, 2D, 2H, 2W], e.g. the fake halves of consecutive critic batches)."""
+    contiguous fp32 tensors [N / groups, 1, 2D, 2H, 2W], e.g. the fake halves of consecutive critic batches).
+    form (GPU only, tests / tuning): a kernel form of sg_convT3d_k4s2p1_to1_pre_impl instead of the dispatch rule."""
     x, w = f32c(x), f32c(w)
     N, C, D, H, W = x.shape
     if outs is not None:
@@ -654,6 +655,13 @@ def conv_transpose3d_to1_pre_raw(x, scale, shift, in_act, in_slope, w, b, act=AC
         y = out
     else:
         y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if form:
+        args = (ptr(x), ptr(w), ptr(b), ptr(y), ptr(scale), ptr(shift), in_act, in_slope, N, C, D, H, W, act, slope, int(form), stream())
+        L.reset_call_state()      # (an *_impl entry has no twin: it is called on the HIP library directly)
+        if not x.is_cuda:
+            raise RuntimeError("conv_transpose3d_to1_pre: kernel forms exist on the GPU only")
+        check(L._load_hip().sg_convT3d_k4s2p1_to1_pre_impl(*args), "convT3d_to1_pre_impl")
+        return y
     check(_lib().sg_convT3d_k4s2p1_to1_pre(ptr(x), ptr(w), ptr(b), ptr(y), ptr(scale), ptr(shift), in_act, in_slope, N, C, D, H, W,
                                            act, slope, stream()), "convT3d_to1_pre")
     return y

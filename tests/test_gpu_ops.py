@@ -341,39 +341,31 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
         with torch.no_grad():
             got2 = ops.conv_transpose3d_k4s2p1(dev(x), dev(w), dev(b), ACT_TANH, 0.0, out=out[:N])
         assert got2.data_ptr() == out.data_ptr() and torch.equal(got2, got.detach()) and bool((out[N] == 7.0).all())
-    # the opt-in two-walk form (SG_CONVT_SPLIT=2: the planes of a (sample, pd, ph) split over two workgroups, the second one
-    # recomputing the plane in front of its half for the carried sum): the same sums in the same order, bit for bit
+    # the kernel forms of sg_convT3d_k4s2p1_to1_pre_impl (selected through the ABI; the library reads no environment variable):
+    # 1 = one h parity per workgroup, 2 = the same with two plane walks per (sample, pd, ph) (the second workgroup recomputes the
+    # plane in front of its half for the carried sum), 3 / 4 = both h parities per workgroup (convT_c1_stream2_kernel, the default
+    # from 192 samples on) with one / two walks: the same sums in the same order, bit for bit, at any batch size
     if DEV == "cuda":
-        import os
         for N, C, R in ((9, 64, 16), (5, 24, 6), (3, 7, 4), (50, 64, 8)):
             torch.manual_seed(N + R)
             x, w, b = dev(torch.randn(N, C, R, R, R)), dev(torch.randn(C, 1, 4, 4, 4) / (C * 8) ** 0.5), dev(torch.randn(1))
             scale, shift = dev(torch.randn(C)), dev(torch.randn(C) * 0.3)
-            one = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
-            os.environ["SG_CONVT_SPLIT"] = "2"
-            try:
-                two = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
-            finally:
-                del os.environ["SG_CONVT_SPLIT"]
-            assert torch.equal(one, two), "two-walk form differs at N=%d C=%d R=%d" % (N, C, R)
-            # convT_c1_stream2_kernel (both h parities per workgroup; the default from 192 samples on) at any batch size, with one
-            # and with two plane walks: the same sums in the same order
-            for split in ("1", "2"):
-                os.environ["SG_CONVT_BOTH"], os.environ["SG_CONVT_SPLIT"] = "1", split
-                try:
-                    both = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0)
-                finally:
-                    del os.environ["SG_CONVT_BOTH"], os.environ["SG_CONVT_SPLIT"]
-                assert torch.equal(one, both), "both-parity form (split %s) differs at N=%d C=%d R=%d" % (split, N, C, R)
-        x = dev(torch.randn(200, 64, 16, 16, 16))                       # 200 samples: the default path takes it
-        w, b = dev(torch.randn(64, 1, 4, 4, 4) / 23.0), dev(torch.randn(1))
+            one = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0, form=1)
+            assert torch.equal(one, ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0))
+            for form in (2, 3, 4):
+                other = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0, form=form)
+                assert torch.equal(one, other), "form %d differs from form 1 at N=%d C=%d R=%d" % (form, N, C, R)
+        # 200 samples: the dispatch rule takes the both-parity form; directly against ATen and against form 1
+        xc = torch.randn(200, 64, 16, 16, 16)
+        wc, bc = torch.randn(64, 1, 4, 4, 4) / 23.0, torch.randn(1)
+        x, w, b = dev(xc), dev(wc), dev(bc)
         got = ops.conv_transpose3d_k4s2p1(x, w, b, ACT_TANH, 0.0)
-        os.environ["SG_CONVT_BOTH"] = "0"
-        try:
-            ref1 = ops.conv_transpose3d_k4s2p1(x, w, b, ACT_TANH, 0.0)
-        finally:
-            del os.environ["SG_CONVT_BOTH"]
-        assert torch.equal(got, ref1)
+        close(got, torch.tanh(F.conv_transpose3d(xc, wc, bc, stride=2, padding=1)), what="convT 64->1 at 200 samples (default: both-parity form) vs ATen")
+        ident_s, ident_h = dev(torch.ones(64)), dev(torch.zeros(64))
+        ref1 = ops.conv_transpose3d_to1_pre_raw(x, ident_s, ident_h, ACT_NONE, 1.0, w, b, ACT_TANH, 0.0, form=1)
+        ref3 = ops.conv_transpose3d_to1_pre_raw(x, ident_s, ident_h, ACT_NONE, 1.0, w, b, ACT_TANH, 0.0, form=3)
+        assert torch.equal(ref1, ref3)
+        close(ref3, got, what="both-parity form through the input-transform entry vs the plain entry")
 
 
 def test_pack_group_rebuilds_every_stale_image_in_one_launch_and_only_then(monkeypatch):
