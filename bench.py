@@ -157,6 +157,16 @@ def conv_kernel_table():
         lambda: (mk_y(), mk_y(), mk_x()), lambda s: ops.conv_wgrad_act_raw(s[0], s[1], s[2], 1, 0.2), in_step="largest")
     hbm("ConvT 64->1 forward / Conv3d 1->64 input-gradient, 16^3 -> 32^3, 64 samples", "convT_c1_stream_kernel<true,false,true,0>",
         4.0 * (ny // 2 + BATCH * 32768 + w1.numel()), f1 / 2, lambda: mk_y(BATCH), lambda y: ops.conv_dgrad_raw(y, w1, None, 1), in_step="smallest")
+    # the launch the 5+1 step actually runs for its four grouped inference generator passes: 256 samples, the last BatchNorm +
+    # LeakyReLU folded into the loads, tanh (the largest one-channel launch of the step was not in the table)
+    g4 = 4 * BATCH
+    wt = torch.randn(64, 1, 4, 4, 4, device="cuda") / 23.0
+    bt = torch.randn(1, device="cuda")
+    sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1
+    hbm("ConvT 64->1 forward with the input transform (BatchNorm + LeakyReLU in the loads) + tanh, 16^3 -> 32^3, 256 samples (the "
+        "grouped generator pass of WGANTrainer.step)", "convT_c1_all_kernel<true,true,true,3>",
+        4.0 * (g4 * 64 * 4096 + g4 * 32768 + wt.numel()), 2.0 * 64 * 64 * 4096 * g4, lambda: mk_y(g4),
+        lambda y: ops.conv_transpose3d_to1_pre_raw(y, sc, sh, 1, 0.2, wt, bt, 3, 0.0), in_step="largest")
     return rows
 
 

@@ -1,14 +1,4 @@
-out=gpurun_out/full2; mkdir -p $out
-timeout 2400 python -m pytest tests -q -m gpu -x > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $out/pytest.log
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-python - $out <<'PY'
-import json,sys
-d=json.load(open(sys.argv[1]+'/bench.json'))
-print(d['value'], d['ms_per_step'])
-for k in d['kernels']: print(k['kernel'], k['us'], k['frac'])
-s=d['sdfnet']
-print('fwd', s['fwd_mpoints_per_s'], s['fwd_frac_of_f32_mfma_peak_executed'])
-for k in ('train_ref_20k_L128','train_ref_20k_L128_eager','train_cfg_200k_L256'): print(k, s[k]['ms_per_step'], s[k]['frac_of_f32_mfma_peak_executed'])
-for k,v in d['other_configs'].items(): print(k, v['value'], v['ms_per_step'])
-print(d['dropin_loop'])
-PY
+timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_modules.py tests/test_gpu_fullsize.py -x -q -m gpu -k "convT or conv_transpose or wgan or generator or gan" 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
+mkdir -p gpurun_out/r06; python scripts/edge_cold.py convT_forms > gpurun_out/r06/r06_convT_forms.json
+bash scripts/convt_pmc.sh > gpurun_out/r06/r06_convT_c1_counters.txt 2>&1

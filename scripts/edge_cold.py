@@ -56,4 +56,14 @@ if what == "convT":
     for nb in (256, 64, 32, 16):
         mk_y = lambda: torch.randn(nb, 64, 16, 16, 16, device="cuda")
         out["convT_%d" % nb] = both(4.0 * (nb * 32768 + nb * 64 * 4096), mk_y, lambda y: ops.conv_dgrad_raw(y, w1, None, 1))
+if what == "convT_forms":
+    # every kernel form of sg_convT3d_k4s2p1_to1_pre_impl (identity input transform + tanh), cold and warm
+    wt = torch.randn(64, 1, 4, 4, 4, device="cuda") / 23.0
+    bt = torch.randn(1, device="cuda")
+    sc, sh = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    for nb in (256, 128, 64, 48):
+        mk_y = lambda: torch.randn(nb, 64, 16, 16, 16, device="cuda")
+        for form in (1, 3, 5, 6, 7, 8):
+            out["convT_%d_form%d" % (nb, form)] = both(4.0 * (nb * 32768 + nb * 64 * 4096), mk_y,
+                                                       lambda y: ops.conv_transpose3d_to1_pre_raw(y, sc, sh, 1, 0.2, wt, bt, 3, 0.0, form=form))
 print(json.dumps(out))

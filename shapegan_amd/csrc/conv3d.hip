@@ -963,7 +963,7 @@ int sg_convT3d_k4s2p1_to1_pre_eligible(int batch, int C, int ID, int IH, int IW)
 static int convT_to1_pre(const float* x, const float* w, const float* bias, float* y, const float* in_scale,
                          const float* in_shift, int in_act, float in_slope, int batch, int C, int ID, int IH, int IW,
                          int act, float slope, int samples_per_group, long y_group_stride, int form, hipStream_t stream) {
-    SG_CHECK_ARG(x && w && y && in_scale && in_shift && samples_per_group > 0 && batch % samples_per_group == 0 && form >= 0 && form <= 4);
+    SG_CHECK_ARG(x && w && y && in_scale && in_shift && samples_per_group > 0 && batch % samples_per_group == 0 && form >= 0 && form <= 8);
     SG_CHECK_ARG(y_group_stride >= (long)samples_per_group * 8 * ID * IH * IW);
     if (!sg_convT3d_k4s2p1_to1_pre_eligible(batch, C, ID, IH, IW))
         SG_FAIL(SG_ERR_ARG, "sg_convT3d_k4s2p1_to1_pre: shape not served (C <= 64, IH * IW <= 256)");

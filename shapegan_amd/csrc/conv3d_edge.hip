@@ -1489,6 +1489,249 @@ __global__ void __launch_bounds__(512, 1) convT_c1_stream2_kernel(ConvTStreamArg
     }
 }
 
+// convT_c1_all_kernel (round 6): the plane walk with ALL 64 TAPS in one workgroup — what the ablations of the two kernels above
+// asked for (profiles/r05_convT_c1_ablation.json).  A workgroup owns (sample, a range of input planes): every A
+// fragment it loads feeds four B-fragment sets, set = 2 pd + ph (the 16 taps of each output parity pair), 64 tap rows in LDS, and a
+// thread gathers the four outputs (pd, ph) of its (position, column parity) per plane: a QUARTER of the load instructions and of
+// the L2 traffic per output of convT_c1_stream_kernel, one barrier per plane for four times the outputs.  The plane range is what
+// fills the chip: `splits` workgroups per sample walk OD / splits planes each, every one but the first starting one plane early
+// for the carried sums (nothing is stored for that plane) — 1.25 x the loads and MFMAs at 4 splits, 1.0 x at one.
+// The sums are those of the other forms, in the same order (same k order per tap, same gather expression): bit-identical outputs.
+// LDS: tap row (g2, khi, kw) of a set sits at row 8 g2 + 4 khi + {kw 1: 0, kw 3: 1, kw 2: 2, kw 0: 3}: the two column parities of a
+// gather instruction then read rows two apart (8 banks at a row pitch of 260 floats), i.e. the 32 lanes of a half-wave — 16
+// positions x 2 column parities — hit 32 different banks (the kw-major order of the kernels above: rows one apart, 33 % conflicts).
+#ifndef SG_CONVT_ALL_ILV
+#define SG_CONVT_ALL_ILV 6      // other instructions asked for in front of each MFMA of a k-step (tuning)
+#endif
+template <bool ALLCH, bool PRE, bool FULL, int EPI>
+__global__ void __launch_bounds__(512, 1) convT_c1_all_kernel(ConvTStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [2 buffers][4 sets][16 taps][stride]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int part = j % a.splits, n = (j / a.splits) * 8 + xcd;
+    if (n >= a.batch) return;     // (the whole workgroup)
+    const int P2 = a.P2, OW = a.OW, OH = a.OH, OD = a.OD;
+    const int pp = OD / a.splits;
+    const int qs = part ? part * pp - 1 : 0, qe = (part + 1) * pp;   // planes [qs, qe); plane qs of a later part only feeds the carries
+    const int nblocks = (P2 + 31) >> 5;                // <= 8
+    const int stride = nblocks * 32 + 4;               // floats per tap row
+    lds_float* const Sl = (lds_float*)S;
+    const int nks = ALLCH ? 16 : (a.Cout + 3) >> 2;    // k-steps of 4 channels
+
+    const __amdgpu_buffer_rsrc_t dres = make_rsrc_bytes(a.dy + (long)n * a.Cy * OD * P2, (long)a.Cy * OD * P2 * 4);
+    const unsigned chan = (unsigned)(OD * P2) * 4u;     // bytes between channels of a sample
+    const bool block_on = wave < nblocks;
+    const int p0 = wave * 32 + 2 * i16;
+    const unsigned voff = (block_on && p0 < P2) ? (unsigned)p0 * 4u + (unsigned)kq * chan : kBufOutside;
+    auto load_step = [&](int qd, int s, float (&dst)[2][16]) __attribute__((always_inline)) {
+        const unsigned pshift = qd < qe ? (unsigned)(qd * P2) * 4u : kBufOutside;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v;
+        if (ALLCH) {
+            v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dres, (int)voff, (int)((unsigned)(4 * s) * chan + pshift), 0));
+        } else {   // channels beyond Cout: the lane reads channel Cout-1 instead, its weight is zero
+            const int co = min(4 * s + kq, a.Cout - 1);
+            const unsigned off = voff == kBufOutside ? kBufOutside : voff - (unsigned)kq * chan + (unsigned)co * chan;
+            v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dres, (int)(s < nks ? off : kBufOutside), (int)pshift, 0));
+        }
+        dst[0][s] = v.x;
+        dst[1][s] = v.y;
+    };
+    float A0[2][16], A1[2][16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) load_step(qs, s, A0);
+    // B fragments: column i16 = tap row 8 g2 + 4 khi + kwpos of each of the four sets, k row kq = channel 4 s + kq
+    const int g2 = i16 >> 3, khi = (i16 >> 2) & 1, kwpos = i16 & 3;
+    const int kw = kwpos == 0 ? 1 : (kwpos == 1 ? 3 : (kwpos == 2 ? 2 : 0));
+    float wfr[4][16], psc[PRE ? 16 : 1], psh[PRE ? 16 : 1];
+    {
+        const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.w);
+        const long grow = (long)(n / a.spg) * a.Cout;     // this sample's group row of the input transform
+        const __amdgpu_buffer_rsrc_t sres = make_rsrc(PRE ? a.in_scale + grow : a.w), hres = make_rsrc(PRE ? a.in_shift + grow : a.w);
+        unsigned wtap[4];
+#pragma unroll
+        for (int set = 0; set < 4; ++set) {
+            const int pd = set >> 1, ph = set & 1;
+            const int kd = g2 == 0 ? (pd == 0 ? 1 : 2) : (pd == 0 ? 3 : 0);
+            const int kh = khi == 0 ? (ph == 0 ? 1 : 2) : (ph == 0 ? 3 : 0);
+            wtap[set] = (unsigned)(kd * 16 + kh * 4 + kw) * 4u;
+        }
+        const unsigned wrow = (unsigned)a.Cin_total * 256u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int co = 4 * s + kq;
+            const bool have = s < nks && co < a.Cout;
+#pragma unroll
+            for (int set = 0; set < 4; ++set) wfr[set][s] = buf_load(wres, have ? (unsigned)co * wrow + wtap[set] : kBufOutside, 0);
+            if (PRE) {
+                psc[s] = buf_load(sres, have ? (unsigned)co * 4u : kBufOutside, 0);
+                psh[s] = buf_load(hres, have ? (unsigned)co * 4u : kBufOutside, 0);
+            }
+        }
+    }
+    // gather role of this thread: outputs (pd, ph) at (qh, qw, pw)
+    const int q = tid >> 1, pw = tid & 1;
+    const int qh = q / OW, qw = q - qh * OW;
+    const bool gather_on = q < P2;
+    const int dw = pw == 0 ? -1 : 1;
+    const int kp_same = pw == 0 ? 0 : 2, kp_nb = pw == 0 ? 1 : 3;     // row positions of kw 1 / 2 (same column) and kw 3 / 0 (neighbour)
+    const bool col_nb = (unsigned)(qw + dw) < (unsigned)OW;
+    const int qc = gather_on ? q : 0;
+    const int qcol = col_nb ? dw : 0;
+    auto slot = [](int pos) { return (pos & ~31) + (pos & 1) * 16 + ((pos & 31) >> 1); };   // position -> index in a tap row
+    int goff[2][4];
+    float gmul[2][4];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const int dh = ph == 0 ? -1 : 1;
+        const bool row_nb = (unsigned)(qh + dh) < (unsigned)OH;
+        const int qrow = row_nb ? dh * OW : 0;
+        const int base = ph * 16 * stride;                 // (set = 2 pd + ph: + pd * 32 * stride at the use)
+        goff[ph][0] = base + (0 + kp_same) * stride + slot(qc);
+        goff[ph][1] = base + (0 + kp_nb) * stride + slot(qc + qcol);
+        goff[ph][2] = base + (4 + kp_same) * stride + slot(qc + qrow);
+        goff[ph][3] = base + (4 + kp_nb) * stride + slot(qc + qrow + qcol);
+        gmul[ph][0] = 1.f;
+        gmul[ph][1] = col_nb ? 1.f : 0.f;
+        gmul[ph][2] = row_nb ? 1.f : 0.f;
+        gmul[ph][3] = (row_nb && col_nb) ? 1.f : 0.f;
+    }
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+    const int IH = 2 * OH, IW = 2 * OW;
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)(n / a.spg) * a.out_group_stride + (long)(n % a.spg) * a.dx_sample);
+    const unsigned ovoff = gather_on ? (unsigned)((2 * qh) * IW + 2 * qw + pw) * 4u : kBufOutside;      // row of ph = 0; ph = 1: + IW
+    const unsigned oplane = (unsigned)(IH * IW) * 4u;
+    float carry[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // Epilogue of plane p for d parity pd (the plane's 64 tap rows are in LDS buffer p & 1, behind plane p's barrier) — the
+    // expressions of convT_c1_stream_kernel: pd 0 completes output plane 2 p = carried far taps (kd 3 of plane p - 1) + cur taps
+    // (kd 1); pd 1 completes output plane 2 p - 1 = carried cur taps (kd 2 of plane p - 1) + far taps (kd 0).  Five slices inside
+    // plane p + 1's MFMA loop: reads pd 0 | sums pd 0 | stores pd 0 + reads pd 1 | sums pd 1 | stores pd 1.
+    float etc[2][4], etf[2][4], eval[2] = {0.f, 0.f};
+    auto epi_read = [&](int p, int pd) __attribute__((always_inline)) {
+        const lds_float* pb = Sl + ((p & 1) * 64 + pd * 32) * stride;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                etc[ph][g] = pb[goff[ph][g]];
+                etf[ph][g] = pb[goff[ph][g] + 8 * stride];
+            }
+    };
+    auto epi_sum = [&](int pd) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const float sc = (etc[ph][0] + etc[ph][1] * gmul[ph][1]) + (etc[ph][2] * gmul[ph][2] + etc[ph][3] * gmul[ph][3]);
+            const float sf = (etf[ph][0] + etf[ph][1] * gmul[ph][1]) + (etf[ph][2] * gmul[ph][2] + etf[ph][3] * gmul[ph][3]);
+            const float fin = pd == 0 ? sc : sf, keep = pd == 0 ? sf : sc;
+            float v = carry[pd][ph] + fin + b0;
+            carry[pd][ph] = keep;
+            if (EPI == SG_ACT_TANH) {
+                const float ax = fabsf(v), x2 = v * v;
+                const float e = __expf(2.f * ax);
+                const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);                       // |err| ~ 1e-7
+                const float small = ax * (1.f + x2 * (-0.33333334f + x2 * 0.13333334f));          // |v| < 0.06: rel. err < 1e-8
+                v = copysignf(ax < 0.06f ? small : big, v);
+            } else if (EPI != SG_ACT_NONE) {
+                v = sg_apply_act(v, a.act, a.slope);
+            }
+            eval[ph] = v;
+        }
+    };
+    auto epi_store = [&](int p, int pd) __attribute__((always_inline)) {
+        const bool skip = p == qs && (pd == 1 || qs > 0);    // nothing complete yet at the first plane of a walk
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, eval[ph]), ores, (int)(skip ? kBufOutside : ovoff),
+                                                  (int)((unsigned)(2 * p - pd) * oplane + (unsigned)(ph * IW) * 4u), 0);
+    };
+
+    auto plane = [&](int qd, auto with_epi, float (&cur)[2][16], float (&nxt)[2][16]) __attribute__((always_inline)) {
+        lds_float* const buf = Sl + (qd & 1) * 64 * stride;
+        f32x4v c4[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int set = 0; set < 4; ++set) c4[t][set] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            // One scheduling region per k-step: the next plane's A load, a slice of the previous plane's epilogue, the input
+            // transform and the eight MFMAs.  The workgroup's two waves per SIMD move in lock-step (one barrier per plane, one
+            // workgroup per CU), so nothing but this wave's own instruction order can put the epilogue's LDS reads / VALU / stores
+            // UNDER the MFMAs: the sched_group_barrier sequence below asks for "a few other instructions, one MFMA" eight times
+            // (with the slices in front of the MFMAs as a block the matrix pipe idled through every one of them: 92 us at 256
+            // samples for 62 us of MFMAs).
+            if (decltype(with_epi)::value && s == 1) {
+                // (the barrier that publishes plane qd - 1's tap rows sits one k-step into plane qd: see convT_c1_stream_kernel)
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_step(qd + 1, s, nxt);
+            if (decltype(with_epi)::value) {
+                if (s == 1) epi_read(qd - 1, 0);
+                if (s == 3) epi_sum(0);
+                if (s == 5) {
+                    epi_store(qd - 1, 0);
+                    epi_read(qd - 1, 1);
+                }
+                if (s == 7) epi_sum(1);
+                if (s == 9) epi_store(qd - 1, 1);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v = cur[t][s];
+                if (PRE) {
+                    v = fmaf(v, psc[s], psh[s]);
+                    v = fmaxf(v, v * a.in_slope);     // LeakyReLU with 0 <= slope <= 1 (ReLU: 0, none: 1) as max(t, slope t)
+                }
+#pragma unroll
+                for (int set = 0; set < 4; ++set) c4[t][set] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wfr[set][s], c4[t][set], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // the A load first
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x096, SG_CONVT_ALL_ILV, 0);   // VALU | SALU | VMEM | DS: a piece of everything else
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // column i16 = tap row, fragment rows r = 4 kq + (0..3) of tile j = positions 2 r + j of the block: slots j * 16 + r
+        if (FULL || block_on) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int set = 0; set < 4; ++set)
+                    *(__attribute__((address_space(3))) f32x4v*)(buf + (set * 16 + i16) * stride + wave * 32 + t * 16 + 4 * kq) = c4[t][set];
+        }
+    };
+    plane(qs, IntTag<0>(), A0, A1);
+    int qd = qs + 1;
+    // (buffer parity = plane parity; the register sets alternate from the walk's first plane)
+    for (; qd + 1 < qe; qd += 2) {
+        plane(qd, IntTag<1>(), A1, A0);
+        plane(qd + 1, IntTag<1>(), A0, A1);
+    }
+    if (qd < qe) plane(qd, IntTag<1>(), A1, A0);
+    // the last plane's epilogue, and for d-parity 1 the output plane 2 OD - 1 (cur taps of the last plane alone)
+    __syncthreads();
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd) {
+        epi_read(qe - 1, pd);
+        epi_sum(pd);
+        epi_store(qe - 1, pd);
+    }
+    if (qe == OD) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float v = carry[1][ph] + b0;
+            v = EPI == SG_ACT_NONE ? v : sg_apply_act(v, a.act, a.slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff,
+                                                  (int)((unsigned)(2 * OD - 1) * oplane + (unsigned)(ph * IW) * 4u), 0);
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 size_t edge_fwd_workspace_bytes(int, int, int, int) { return 0; }   // the forward reads the grid in place
 size_t edge_wgrad_workspace_bytes(int, int, int, int) { return (size_t)512 * kEdgePartial * sizeof(float); }   // partial tiles
@@ -1667,7 +1910,53 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
     // fills the chip with twice the workgroups there and is as fast warm): taken from 192 samples on — the grouped generator pass of
     // WGANTrainer.step runs at 256.
     // `form` (sg_convT3d_k4s2p1_to1_pre_impl; 0 = this dispatch rule): 1 / 2 = one h parity per workgroup with one / two plane walks,
-    // 3 / 4 = both h parities with one / two walks.  Tests and tuning select a form through the ABI, not through the environment.
+    // 3 / 4 = both h parities with one / two walks, 5 = all 64 taps per workgroup with the plane range chosen here, 6 / 7 / 8 = the
+    // same with 1 / 2 / 4 plane ranges per sample.  Tests and tuning select a form through the ABI, not through the environment.
+    {
+        // all taps per workgroup (convT_c1_all_kernel, round 6): enough plane ranges per sample for one workgroup per CU
+        const long padded = (long)(batch + 7) / 8 * 8;
+        int splits = form == 6 ? 1 : (form == 7 ? 2 : (form == 8 ? 4 : (padded >= 192 ? 1 : (padded >= 96 ? 2 : 4))));
+        while (splits > 1 && (g.OD % splits != 0 || g.OD / splits < 2)) splits >>= 1;
+        // Measured (cold, input transform + tanh; scripts/edge_cold.py convT_forms, profiles/r06_convT_forms.json): 256 samples
+        // 128 (one parity) / 100 (both h parities) / 87 us (all taps, one plane range); 128 samples 62 / 52 / 52 (two ranges);
+        // 64 samples 33 / 50 / 32 (four ranges).  TCC requests 1.16 x the algorithmic bytes (3.9 x / 2.1 x), no LDS bank
+        // conflicts (33 %), MFMA busy 0.61 (0.44 / 0.53) — profiles/r06_convT_c1_counters.txt.  It wins where one plane range
+        // per sample fills the chip; below that the one-parity kernel's 4 workgroups per sample are as fast: taken from 192 on.
+        const bool all_default = SG_CONVT_ALL && padded >= 192;
+        if (form >= 5 || (form == 0 && all_default)) {
+            f.splits = splits;
+            const size_t lds4 = (size_t)2 * 64 * (nblocks * 32 + 4) * sizeof(float);
+            const unsigned wgs4 = (unsigned)(padded * splits);
+            static SgPerDeviceOnce once4;
+            if (once4.begin()) {      // 133 KB of dynamic LDS: the attribute, once per device, for every instantiation that may be launched
+#define SG_ATTR4(ALL_, PRE_, FULL_, EPI_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convT_c1_all_kernel<ALL_, PRE_, FULL_, EPI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 260 * 4)
+#define SG_ATTR4E(ALL_, PRE_, FULL_) do { SG_ATTR4(ALL_, PRE_, FULL_, SG_ACT_TANH); SG_ATTR4(ALL_, PRE_, FULL_, SG_ACT_NONE); SG_ATTR4(ALL_, PRE_, FULL_, -1); } while (0)
+                SG_ATTR4E(true, true, true);
+                SG_ATTR4E(true, false, true);
+                SG_ATTR4E(false, true, false);
+                SG_ATTR4E(false, false, false);
+#undef SG_ATTR4E
+#undef SG_ATTR4
+                once4.end();
+            }
+#define SG_CONVT_ALLK(ALL_, PRE_, FULL_, EPI_) \
+    hipLaunchKernelGGL((convT_c1_all_kernel<ALL_, PRE_, FULL_, EPI_>), dim3(wgs4), dim3(512), lds4, stream, f)
+#define SG_CONVT_ALLK_EPI(ALL_, PRE_, FULL_)                          \
+    do {                                                              \
+        if (act == SG_ACT_TANH) SG_CONVT_ALLK(ALL_, PRE_, FULL_, SG_ACT_TANH); \
+        else if (act == SG_ACT_NONE) SG_CONVT_ALLK(ALL_, PRE_, FULL_, SG_ACT_NONE); \
+        else SG_CONVT_ALLK(ALL_, PRE_, FULL_, -1);                     \
+    } while (0)
+            if (Cout == 64 && f.P2 == 256) {
+                if (pre) SG_CONVT_ALLK_EPI(true, true, true); else SG_CONVT_ALLK_EPI(true, false, true);
+            } else {
+                if (pre) SG_CONVT_ALLK_EPI(false, true, false); else SG_CONVT_ALLK_EPI(false, false, false);
+            }
+#undef SG_CONVT_ALLK_EPI
+#undef SG_CONVT_ALLK
+            return 1;
+        }
+    }
     const long base_wgs = (long)((batch + 7) / 8 * 8) * 2;
     const bool both = form ? form >= 3 : base_wgs >= 384;
     const bool can_split = g.OD >= 4 && g.OD % 2 == 0;

@@ -126,6 +126,9 @@ int edge_dgrad_stream_try(const float* dy, const float* w, const float* bias, fl
 #ifndef SG_FWD_C1_LDS
 #define SG_FWD_C1_LDS 1         // the LDS-staged Conv3d(1 -> C) forward at 32- / 64-wide grids (0: the gather form)
 #endif
+#ifndef SG_CONVT_ALL
+#define SG_CONVT_ALL 1          // convT_c1_all_kernel (all 64 taps per workgroup) from 192 samples on (0: the both-parity kernel, A/B)
+#endif
 #ifndef SG_CONVT_MIN_BATCH
 #define SG_CONVT_MIN_BATCH 48   // the plane-streaming ConvT(C -> 1) from this many samples on
 #endif

@@ -344,7 +344,8 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
     # the kernel forms of sg_convT3d_k4s2p1_to1_pre_impl (selected through the ABI; the library reads no environment variable):
     # 1 = one h parity per workgroup, 2 = the same with two plane walks per (sample, pd, ph) (the second workgroup recomputes the
     # plane in front of its half for the carried sum), 3 / 4 = both h parities per workgroup (convT_c1_stream2_kernel, the default
-    # from 192 samples on) with one / two walks: the same sums in the same order, bit for bit, at any batch size
+    # from 192 samples on) with one / two walks, 5 - 8 = all four (pd, ph) pairs per workgroup (convT_c1_all_kernel): the same sums
+    # in the same order, bit for bit, at any batch size
     if DEV == "cuda":
         for N, C, R in ((9, 64, 16), (5, 24, 6), (3, 7, 4), (50, 64, 8)):
             torch.manual_seed(N + R)
@@ -352,7 +353,7 @@ def test_conv_transpose3d_to_one_channel_streaming_kernel_random_shapes():
             scale, shift = dev(torch.randn(C)), dev(torch.randn(C) * 0.3)
             one = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0, form=1)
             assert torch.equal(one, ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0))
-            for form in (2, 3, 4):
+            for form in (2, 3, 4, 5, 6, 7, 8):     # (5 - 8: all 64 taps per workgroup, plane ranges chosen / 1 / 2 / 4 per sample)
                 other = ops.conv_transpose3d_to1_pre_raw(x, scale, shift, ACT_LEAKY, 0.2, w, b, ACT_TANH, 0.0, form=form)
                 assert torch.equal(one, other), "form %d differs from form 1 at N=%d C=%d R=%d" % (form, N, C, R)
         # 200 samples: the dispatch rule takes the both-parity form; directly against ATen and against form 1
