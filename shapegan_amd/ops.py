@@ -933,13 +933,48 @@ class _PackCache(object):
 
 _PART_ROW = 14 * _H + 32      # SG_SDFNET_PARTIAL_ROW: floats per tile of the backward's partial sums
 
+_side_streams = {}
+
+
+class _SideStream(object):
+    """`with _SideStream(dev) as side:` — a second HIP stream of `dev` that has waited for everything enqueued on the current one;
+    leaving the block makes the current stream wait for it.  Small reductions of a backward (the finishing launch of the tile
+    partials, the backward of the latent fold: 30 - 75 us) run there UNDER the weight-gradient GEMM batch instead of in front of /
+    behind it; their outputs are distinct elements of the gradient tensors.  Capturable (the side stream joins and leaves the
+    capture inside the block).  CPU tensors: no-op (`side` is None)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.side = None
+
+    def __enter__(self):
+        if self.dev.type != "cuda":
+            return self
+        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=self.dev)
+        self.side, self.main = side, torch.cuda.current_stream(self.dev)
+        side.wait_stream(self.main)
+        return self
+
+    def run(self):
+        """Context in which launches go to the side stream (a plain no-op context for CPU tensors)."""
+        import contextlib
+        return torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        return False
+
 
 def _sdf_partials(N, extended, dev):
     """[tiles][_PART_ROW] partial sums of one fused backward (include/shapegan_hip.h: bias_partials), tile-major."""
     return torch.empty((_lib().sg_sdfnet_bwd_blocks(N), _PART_ROW), dtype=torch.float32, device=dev)
 
 
-def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None, extended=False, seg=None):
+def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_total, bsum=None, extended=False, seg=None, side=None):
     """Weight/bias gradients from the saved dZ_l / H_l images.  x_parts: list of (tensor [N,w], col_offset, w)
     blocks of the per-point input X that are materialised row-major (points, and latents in per-point mode).
     seg: (seg_off, S, t1, t5) — the per-segment sums of dZ1 / dZ5 come out of the same finishing launch."""
@@ -969,13 +1004,15 @@ def _sdf_param_grads(ctx_params, needs, dz, dz8, acts, ldn, N, x_parts, kin_tota
     w8 = _param_grad_out(ctx_params[14], (1, _H), dev)
     b8 = _param_grad_out(ctx_params[15], (1,), dev)
     if bsum is not None:
-        arr = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
-        ws = workspace("sdf_finish", lib.sg_sdfnet_bwd_finish_workspace_bytes(N), dev)
-        seg_off, S, t1, t5 = seg if seg is not None else (None, 0, None, None)
-        check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), ldn, N, 1 if extended else 0, arr, ptr(w8), ptr(b8), ptr(w1),
-                                       kin_total, ptr(w5) + 4 * _H if extended else None, _H + kin_total, ptr(seg_off), S,
-                                       ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
-              "sdfnet_bwd_finish")
+        import contextlib
+        with (side.run() if side is not None else contextlib.nullcontext()):      # (under the GEMM batch below when a side stream is given)
+            arr = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
+            ws = workspace("sdf_finish", lib.sg_sdfnet_bwd_finish_workspace_bytes(N), dev)
+            seg_off, S, t1, t5 = seg if seg is not None else (None, 0, None, None)
+            check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), ldn, N, 1 if extended else 0, arr, ptr(w8), ptr(b8), ptr(w1),
+                                           kin_total, ptr(w5) + 4 * _H if extended else None, _H + kin_total, ptr(seg_off), S,
+                                           ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
+                  "sdfnet_bwd_finish")
     else:
         for layer_dz, out in enumerate(bouts):
             check(lib.sg_rowsum(ptr(dz) + 4 * layer_dz * _H * ldn, ptr(out), _H, N, ldn, stream()), "rowsum")
@@ -1148,18 +1185,33 @@ class SDFNetShapes(Function):
                 check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), N, N, 0, None, None, None, None, 0, None, 0, ptr(ctx.seg_off), S,
                                                ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
                       "sdfnet_bwd_finish")
-        if need_p:
-            grads = _sdf_param_grads(params, ctx.needs_input_grad[7:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
-                                     bsum, extended=True, seg=seg)
-        if (need_p or need_z) and S <= _FOLD_MAX_SHAPES:
-            # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
-            # latent gradient gz = T1^T W1[:, 3:] + T5^T W5[:, 259:]
-            w1, w5 = f32c(params[0]), f32c(params[8])
-            if need_z:
-                gz = _param_grad_out(z, (S, Lz), dev)
-            check(lib.sg_sdfnet_shape_bias_bwd(ptr(t1), ptr(t5), S, ptr(z), Lz, ptr(w1), ptr(w5),
-                                               ptr(grads[0]) if need_p else None, ptr(grads[8]) if need_p else None,
-                                               ptr(gz) if need_z else None, stream()), "sdfnet_shape_bias_bwd")
+        fold = (need_p or need_z) and S <= _FOLD_MAX_SHAPES
+        if fold and need_z:
+            gz = _param_grad_out(z, (S, Lz), dev)       # (allocated on the main stream)
+        # The finishing launch of the partials and the backward of the latent fold (both short, few workgroups) run on a side
+        # stream UNDER the weight-gradient GEMM batch: they write the bias gradients, w8, the point and latent columns of dW1 / dW5
+        # and gz, the GEMMs the hidden blocks — distinct elements.  Joined before this backward returns.
+        overlap = _SideStream(dev) if (need_p and seg is not None and fold) else None
+        if overlap is not None:
+            overlap.__enter__()
+        try:
+            if need_p:
+                grads = _sdf_param_grads(params, ctx.needs_input_grad[7:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
+                                         bsum, extended=True, seg=seg, side=overlap)
+            if fold:
+                # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
+                # latent gradient gz = T1^T W1[:, 3:] + T5^T W5[:, 259:]
+                w1, w5 = f32c(params[0]), f32c(params[8])
+                import contextlib
+                with (overlap.run() if overlap is not None else contextlib.nullcontext()):
+                    check(lib.sg_sdfnet_shape_bias_bwd(ptr(t1), ptr(t5), S, ptr(z), Lz, ptr(w1), ptr(w5),
+                                                       ptr(grads[0]) if need_p else None, ptr(grads[8]) if need_p else None,
+                                                       ptr(gz) if need_z else None, stream()), "sdfnet_shape_bias_bwd")
+        finally:
+            if overlap is not None:
+                overlap.__exit__(None, None, None)
+        if fold:
+            pass
         else:
             if need_p:
                 gemm_raw(t1, False, z, False, out=grads[0], M=_H, N=Lz, K=S, lda=S, ldb=Lz, ldc=kin_total, c_off=3)
