@@ -74,7 +74,7 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")     # newest committed profile pass first (scripts/profile_round.sh + collect_profiles.py)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")     # newest committed profile pass first (scripts/profile_round.sh + collect_profiles.py)
 COLD_BYTES = 640 << 20     # > 2 x the 256 MB Infinity Cache: what a rotation of operand sets must cover to be cold
 
 

@@ -1,5 +1,5 @@
 """sg_gemm at the PointNet GAN's Linear shapes (196 608 points x 256 x 256): forward x W^T, input gradient g W, weight gradient
-g^T x — fraction of the fp32 MFMA peak.  SG_GEMM128=0 python scripts/gemm_shapes_ab.py times the generic skeleton instead."""
+g^T x — fraction of the fp32 MFMA peak.  A library built with -DSG_GEMM128=0 (scripts/ab_build.sh x gemm.hip -DSG_GEMM128=0; SHAPEGAN_HIP_LIB=scripts/_abl/x.so) times the generic skeleton instead."""
 import json
 import os
 import sys
@@ -25,7 +25,7 @@ def t_us(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
-out = {"gemm128": os.environ.get("SG_GEMM128", "1")}
+out = {"lib": os.path.basename(os.environ.get("SHAPEGAN_HIP_LIB", "default"))}
 for P in (196608, 32768):
     x = torch.randn(P, 256, device="cuda")
     g = torch.randn(P, 256, device="cuda")

@@ -14,4 +14,4 @@ if [ -f .refscratch/train_wgan.py ]; then
   tail -2 $out/${tag}_dropin_gpu.log
 fi
 bash scripts/profile_round.sh $tag
-bash scripts/r05_extras.sh $tag
+bash scripts/round_extras.sh $tag
