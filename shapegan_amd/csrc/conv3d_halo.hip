@@ -1032,13 +1032,21 @@ __global__ void __launch_bounds__(256) pack_wgrad_dy_kernel(const float* __restr
     }
 }
 
+// NCH = input channels per workgroup.  2: the form of rounds 1 - 5 — waves (wm, wn), 128 output rows x (2 channels x 64 taps).
+// 4 (round 6, layers with Cout <= 64: the 32 -> 64 stage of the progressive discriminator, where half of the 128 rows were
+// padding and the gather GEMM — 0.42 of the matrix peak — was the faster choice): every wave owns ONE of four channels and the
+// SAME two row tiles, i.e. 64 output rows x (4 channels x 64 taps): the same 4 x 4 MFMA tiles per k-group and wave, no empty row
+// tile.  The four channels' boxes share their per-thread copy offsets (the channel is a scalar offset of the load); Cin % 4 == 0.
+template <int NCH>
 __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wbox[];  // [2 buffers][2 channels][kHD][kWROWD]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
-    const int ci0 = blockIdx.x * 2;          // the two input channels (128 output columns) of this workgroup
-    const int mt0 = blockIdx.y * 4;          // 128 output rows = 4 row tiles of 32
+    const int wm = NCH == 2 ? wave >> 1 : 0, wn = NCH == 2 ? wave & 1 : wave, r = lane & 31, kpar = lane >> 5;
+    const int ci0 = blockIdx.x * NCH;                  // the input channels (64 output columns each) of this workgroup
+    const int mt0 = blockIdx.y * (NCH == 2 ? 4 : 2);   // 128 (64) output rows = 4 (2) row tiles of 32
+    constexpr int NF = NCH == 2 ? kWNF : 2 * kWNF;     // copy elements per thread per stage
+    constexpr int NV = NCH == 2 ? kWNF : kWNF / 2;     // distinct per-thread copy offsets (NCH 4: shared by the channels)
     const int split = blockIdx.z;
     const int s_beg = split * a.per_split, s_end = min(a.nslice, s_beg + a.per_split);
 
@@ -1074,7 +1082,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
     const int pad = (prow / kHH) * kWROWD + (prow % kHH) * kROWH + (tid & 1) * kHWH + (kHWH - 1);
     lds_float* const wl = (lds_float*)wbox;
     lds_float* sdst[kWNF / 2];   // LDS destination of the row inside (buffer 0, channel 0); identical for both channels
-    unsigned voff[kWNF], cls[kWNF];
+    unsigned voff[NV], cls[NV];
 #pragma unroll
     for (int f = 0; f < kWNF / 2; ++f) {
         const int row = 8 * f + frow;
@@ -1083,7 +1091,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
         sdst[f] = wl + (inbox ? hd * kWROWD + hh * kROWH + lds_w : pad);
         pin_vgpr(sdst[f]);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < (NCH == 2 ? 2 : 1); ++c) {
             const bool ok = inbox && (ci0 + c) < a.Cin;
             voff[c * (kWNF / 2) + f] = ok ? (unsigned)(c * I3 + (hd * a.g.IH + hh) * a.g.IW + fl_w) * 4u : kBufOutside;
             cls[c * (kWNF / 2) + f] = (hd == 0 ? 1u << 26 : 0u) | (hd == kHD - 1 ? 1u << 27 : 0u) | (hh == 0 ? 1u << 28 : 0u) |
@@ -1093,9 +1101,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
             pin_vgpr(cls[c * (kWNF / 2) + f]);
         }
     }
-    float fv[kWNF];
-    unsigned eoff[kWNF];   // per stage: (cls & flags) | voff
+    float fv[NF];
+    unsigned eoff[NV];   // per stage: (cls & flags) | voff
     __amdgpu_buffer_rsrc_t xres;
+    auto xres_of = [&]() __attribute__((always_inline)) { return xres; };
+    // element f of a stage's copy: channel f / (kWNF / 2), row pattern f % (kWNF / 2); NCH 4: the channel rides in the scalar offset
+    const unsigned chan_bytes = (unsigned)I3 * 4u;
+    auto copy_load = [&](int f) __attribute__((always_inline)) {
+        if constexpr (NCH == 2) {
+            return buf_load(xres_of(), eoff[f], 0);
+        } else {
+            return buf_load(xres_of(), eoff[f % (kWNF / 2)], (unsigned)(f / (kWNF / 2)) * chan_bytes);
+        }
+    };
     const int ntw_ = (int)a.g.OW / 8, nth_ = (int)a.g.OH / 8;
     auto copy_prepare = [&](int sl) {  // slice sl -> resource base at the box origin + the padding offsets (scalar work + 18 VALU)
         uint32_t twi, thi, od, n, q1, q2;
@@ -1109,7 +1127,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                                ((int)thi == nth_ - 1 ? 1u << 29 : 0u) | (twi == 0 ? 1u << 30 : 0u) |
                                ((int)twi == ntw_ - 1 ? 1u << 31 : 0u);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) eoff[f] = (cls[f] & flags) | voff[f];
+        for (int f = 0; f < NV; ++f) eoff[f] = (cls[f] & flags) | voff[f];
     };
 
     const int nst = s_end - s_beg;
@@ -1128,20 +1146,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    bb[b][tn][h] = wl + b * (2 * kWHS) + lanebase[tn] + h * (8 * kROWH);
+                    bb[b][tn][h] = wl + b * (NCH * kWHS) + lanebase[tn] + h * (8 * kROWH);
                     pin_vgpr(bb[b][tn][h]);
                 }
 
         copy_prepare(s_beg);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) fv[f] = buf_load(xres, eoff[f], 0);
+        for (int f = 0; f < NF; ++f) fv[f] = copy_load(f);
         float4 aring[kRing][2];
 #pragma unroll
         for (int u = 0; u < kRing; ++u)
 #pragma unroll
             for (int t = 0; t < 2; ++t) aring[u][t] = buf_load4(ares[t], avoff, (unsigned)(u < G ? u : G - 1) * 1024u);
 #pragma unroll
-        for (int f = 0; f < kWNF; ++f) sdst[f % (kWNF / 2)][(f / (kWNF / 2)) * kWHS] = fv[f];
+        for (int f = 0; f < NF; ++f) sdst[f % (kWNF / 2)][(f / (kWNF / 2)) * kWHS] = fv[f];
         __syncthreads();
 
         auto stage = [&](auto tag, int st) {
@@ -1184,9 +1202,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_halo_kernel(HaloWgradArgs a) {
                 }
                 // copy of the next box: loads spread over groups 0..3, LDS stores 4 groups later
 #pragma unroll
-                for (int f = 0; f < kWNF; ++f) {
-                    if (f * 4 / kWNF == gq) fv[f] = buf_load(xres, eoff[f], 0);
-                    if (f * 4 / kWNF + 4 == gq) sdst[f % (kWNF / 2)][NXT * (2 * kWHS) + (f / (kWNF / 2)) * kWHS] = fv[f];
+                for (int f = 0; f < NF; ++f) {
+                    if (f * 4 / NF == gq) fv[f] = copy_load(f);
+                    if (f * 4 / NF + 4 == gq) sdst[f % (kWNF / 2)][NXT * (NCH * kWHS) + (f / (kWNF / 2)) * kWHS] = fv[f];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1433,10 +1451,16 @@ __global__ void __launch_bounds__(256) wgrad_halo_finalize_kernel(const float* _
 
 static bool wgrad_mode4(const ConvGeom& g) { return g.OD == 4 && g.OH == 4 && g.OW == 4; }
 
+// rows64: the 64-row form (conv_wgrad_halo_kernel<4>: four input channels per workgroup) — layers with at most 64 output channels
+// on 8-divisible grids; mtiles then counts 64-row tiles (mt_total = 2 mtiles row tiles of 32), else 128-row tiles (4 mtiles).
+static bool wgrad_rows64(const ConvGeom& g, int Cin, int Cout) {
+    return !wgrad_mode4(g) && Cout <= 64 && Cin >= 4 && Cin % 4 == 0;
+}
 static void wgrad_halo_plan(int batch, const ConvGeom& g, int Cin, int Cout, int& nslice, int& nsplit, int& mtiles) {
     nslice = wgrad_mode4(g) ? batch : batch * g.OD * (g.OH / 8) * (g.OW / 8);   // 4^3 outputs: a slice is a sample
-    mtiles = (Cout + 127) / 128;
-    const int ntiles = ((Cin + 1) / 2) * mtiles;
+    const bool rows64 = wgrad_rows64(g, Cin, Cout);
+    mtiles = rows64 ? (Cout + 63) / 64 : (Cout + 127) / 128;
+    const int ntiles = (rows64 ? Cin / 4 : (Cin + 1) / 2) * mtiles;
     nsplit = (512 + ntiles - 1) / ntiles;
     if (nsplit > nslice / 4) nsplit = nslice / 4 > 0 ? nslice / 4 : 1;   // >= 4 stages per workgroup
     if (nsplit < 1) nsplit = 1;
@@ -1449,8 +1473,11 @@ size_t halo_wgrad_workspace_bytes(int batch, int Cin, int Cout, int OD, int OH, 
     g.OH = OH;
     g.OW = OW;
     int nslice, nsplit, mtiles;
+    g.ID = 2 * OD;       // (wgrad_mode4 / wgrad_rows64 look at the output grid only)
+    g.IH = 2 * OH;
+    g.IW = 2 * OW;
     wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
-    const size_t pack = (size_t)mtiles * 4 * nslice * 8 * 64 * sizeof(float4);
+    const size_t pack = (size_t)mtiles * 4 * nslice * 8 * 64 * sizeof(float4);      // (rows64: 2 mtiles row tiles are used)
     const size_t part = (size_t)nsplit * Cout * Cin * 64 * sizeof(float);
     return pack + part + 256;
 }
@@ -1518,9 +1545,11 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     if ((long)2 * g.ID * g.IH * g.IW * 4 >= (1L << 26)) return 0;   // box offset | edge-class word needs offsets below 2^26
     int nslice, nsplit, mtiles;
     wgrad_halo_plan(batch, g, Cin, Cout, nslice, nsplit, mtiles);
-    const int ntiles = ((Cin + 1) / 2) * mtiles;
-    // auto-dispatch where it wins (round-1 A/B): full 128-row tiles and enough workgroups
-    if (!force && (Cout <= 64 || (long)ntiles * nsplit < 384)) return 0;
+    const bool rows64 = wgrad_rows64(g, Cin, Cout) && (long)4 * g.ID * g.IH * g.IW * 4 < (1L << 26);
+    if (wgrad_rows64(g, Cin, Cout) && !rows64) return 0;
+    const int ntiles = (rows64 ? Cin / 4 : (Cin + 1) / 2) * mtiles;
+    // auto-dispatch where it wins (round-1 A/B): no half-empty row tiles (Cout <= 64: the 64-row form, round 6) and enough workgroups
+    if (!force && ((Cout <= 64 && !rows64) || (long)ntiles * nsplit < 384)) return 0;
     const size_t need = halo_wgrad_workspace_bytes(batch, Cin, Cout, g.OD, g.OH, g.OW);
     if (!workspace || workspace_bytes < need) return 0;
     const int per_split = (nslice + nsplit - 1) / nsplit;
@@ -1536,8 +1565,8 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
         if (mode4)
             hipLaunchKernelGGL(pack_wgrad_dy4_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, Cout, mtiles * 4, nslice);
         else
-            hipLaunchKernelGGL(pack_wgrad_dy_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, g, Cout, mtiles * 4, nslice,
-                               dntw, dnth, dOD);
+            hipLaunchKernelGGL(pack_wgrad_dy_kernel, dim3(blocks), dim3(256), 0, stream, dy, ap, g, Cout, rows64 ? mtiles * 2 : mtiles * 4,
+                               nslice, dntw, dnth, dOD);
     }
     HaloWgradArgs a;
     a.ap = ap;
@@ -1547,7 +1576,7 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
     a.Cout = Cout;
     a.nslice = nslice;
     a.per_split = per_split;
-    a.mt_total = mtiles * 4;
+    a.mt_total = rows64 ? mtiles * 2 : mtiles * 4;
     a.dntw = dntw;
     a.dnth = dnth;
     a.dOD = dOD;
@@ -1558,8 +1587,13 @@ int halo_wgrad_try(const float* dy, const float* x, float* dw, int batch, int Ci
         hipLaunchKernelGGL(conv_wgrad_halo4_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256),
                            (size_t)2 * 2 * k4CH * sizeof(float), stream, a);
     } else {
-        const size_t lds = (size_t)2 * 2 * kWHS * sizeof(float);
-        hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256), lds, stream, a);
+        if (rows64) {
+            const size_t lds = (size_t)2 * 4 * kWHS * sizeof(float);
+            hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(Cin / 4, mtiles, nsplit), dim3(256), lds, stream, a);
+        } else {
+            const size_t lds = (size_t)2 * 2 * kWHS * sizeof(float);
+            hipLaunchKernelGGL(conv_wgrad_halo_kernel<2>, dim3((Cin + 1) / 2, mtiles, nsplit), dim3(256), lds, stream, a);
+        }
     }
     if (!direct) {
         const long total = (long)Cout * Cin * 64;
