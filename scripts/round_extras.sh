@@ -12,7 +12,7 @@ repo=$(pwd); out=$repo/gpurun_out/prof_$tag; mkdir -p $out
 python scripts/edge_cold.py all > $out/${tag}_edge_kernels_cold.json 2> $out/edge_cold.err
 python scripts/edge_cold.py convT_forms > $out/${tag}_convT_forms.json 2> $out/convT_forms.err
 for v in "nosum -DSG_ABL_NOSUM" "nostore -DSG_ABL_NOSTORE" "none -DSG_ABL_NOSUM -DSG_ABL_NOSTORE" "imgaux0 -DSG_IMG_AUX=0"; do
-  set -- $v; n=$1; shift; [ -f scripts/_abl/$n.so ] || bash scripts/ab_build.sh $n sdfnet.hip "$@" > /dev/null 2>&1
+  set -- $v; n=$1; shift; bash scripts/ab_build.sh $n sdfnet.hip "$@" > /dev/null 2>&1
 done
 { echo "# sdfnet kernels inside the 200 000-point / latent-256 auto-decoder step (rocprofv3 --kernel-trace of scripts/sdf_step_prof.py via"
   echo "# scripts/ab_run.sh; A/B builds of csrc/sdfnet.hip): base = shipped; nosum = no row-sum pieces; nostore = no dZ image stores;"
@@ -32,5 +32,5 @@ for r in sorted(rows, key=lambda r: -int(r['Calls']))[:40]:
 PY
 )
 grep "ms per unit" $out/dropin_prof.log >> $out/${tag}_dropin_loop_kernel_stats.txt
-SG_DIST_BACKEND=gloo python bench.py --gpus 2 --scaling strong --steps 5 --warmup 2 --no-extras > $out/${tag}_bench_line_2ranks_strong_gloo_one_gpu.json 2> $out/bench_2ranks_strong.err
+SG_DIST_BACKEND=gloo python bench.py --gpus 2 --scaling strong --steps 5 --warmup 2 --no-extras 2> $out/bench_2ranks_strong.err | grep "^{" > $out/${tag}_bench_line_2ranks_strong_gloo_one_gpu.json
 ls -la $out | grep -E "edge_kernels_cold|convT_forms|sdfnet_bwd_ablation|sdfnet_counters|dropin_loop|strong"
