@@ -260,8 +260,12 @@ int sg_sdfnet_shape_bias(const float* z, long nshapes, int latent, const float* 
  * (the latent columns of layers1.0 / layers2.0, model/sdf_net.py:27,41, enter sg_sdfnet_fwd as bias rows) from the per-shape sums
  * t1 / t5 [256][nshapes] of dZ1 / dZ5, in one launch: the latent columns of dW1 [256][3+L] / dW5 [256][259+L] written in place
  * (NULL, NULL to skip) and the latent gradient gz [nshapes][L] (NULL to skip); nshapes <= 6144. */
+/* (reg_scale != 0: gz additionally receives reg_weight[s] * reg_scale * z[s][k] (reg_weight NULL: 1) — the gradient of the DeepSDF
+ * latent regulariser SIGMA * mean(z_batch^2) through shape counts (train_sdf_autodecoder.py:88), so that the latent table gets ONE
+ * gradient contribution, written where its flat-buffer slice lives, instead of two tensors that autograd adds and the optimizer copies) */
 int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
-                             const float* W5, float* dW1, float* dW5, float* gz, hipStream_t stream);
+                             const float* W5, float* dW1, float* dW5, float* gz, const float* reg_weight, float reg_scale,
+                             hipStream_t stream);
 /* Everything that is derived from the bias_partials of ONE sg_sdfnet_bwd call, in one launch (replaces five: the segment sums,
  * two multi-row sums and the two-stage sum of dz8 of train_sdf_autodecoder.py:80-91's backward):
  *   bias_grads[0..6] (256 floats each; NULL: skip all column sums), b8_grad[1], and with `extended` (sg_sdfnet_bwd was given
@@ -311,8 +315,10 @@ int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float l
                     float grad_scale, float clip, hipStream_t stream);
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                  float eps, long step, float grad_scale, hipStream_t stream);
-/* Adam with the step counter (int64) and the two bias corrections (float[2]) in device memory: identical arithmetic, but
- * the call has no host-side state that changes between steps, so a captured hipGraph of a training step replays it. */
+/* Adam with the step counter (int64) in device memory: identical arithmetic, but the call has no host-side state that changes
+ * between steps, so a captured hipGraph of a training step replays it.  corr_dev: FOUR 32-bit words, zero before the first call —
+ * [0..1] the two bias corrections of the last applied step (for the host to read), [2] the arrival ticket of the one launch
+ * (ABI 7: the workgroup that finishes last advances the counter; it was a one-thread launch in front of the update), [3] unused. */
 int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                      float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream);
 /* The two Adam entries with a guard word (device memory, may be NULL = unguarded): when *skip_if_nonzero != 0 at the time the

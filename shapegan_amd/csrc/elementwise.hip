@@ -131,22 +131,36 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
-// Graph-capturable Adam: the step counter lives on the device.  One thread advances it and derives the two bias
-// corrections in double (as torch does on the host); the update kernel reads them from memory instead of its arguments.
-__global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restrict__ corr, float b1, float b2,
-                                    const int* __restrict__ skip) {
-    if (skip && *skip) return;           // a skipped step does not age the optimizer either
-    const long long t = *step + 1;
-    *step = t;
-    corr[0] = (float)(1.0 - pow((double)b1, (double)t));
-    corr[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
-}
+// Graph-capturable Adam: the step counter lives on the device.  ONE launch (round 6; it was a one-thread "prepare" launch + the
+// update): every workgroup reads the counter, thread 0 derives the two bias corrections of step t = counter + 1 in double (as torch
+// does on the host) and shares them through LDS; the workgroup that FINISHES last (arrival ticket in corr[2]) advances the counter —
+// every other workgroup has read it by then — publishes the corrections in corr[0..1] (readable by the host) and clears the ticket.
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                                                       float b1, float b2, float eps, const float* __restrict__ corr,
-                                                       float gscale, const int* __restrict__ skip) {
-    if (skip && *skip) return;
-    const float step = lr / corr[0], bc2_sqrt = corr[1];
+                                                       float b1, float b2, float eps, long long* __restrict__ step_dev,
+                                                       float* __restrict__ corr, float gscale, const int* __restrict__ skip) {
+    if (skip && *skip) return;           // a skipped step neither moves nor ages anything
+    __shared__ float sc[2];
+    __shared__ long long st;
+    if (threadIdx.x == 0) {
+        const long long t = *step_dev + 1;
+        st = t;
+        // beta^t for the integer t by repeated squaring in double (a few ulp of double, i.e. the same float after rounding except
+        // at ties; the library pow() is a routine of several microseconds — per workgroup, in front of its whole update)
+        double p1 = 1.0, p2 = 1.0, q1 = (double)b1, q2 = (double)b2;
+        for (long long e = t; e > 0; e >>= 1) {
+            if (e & 1) {
+                p1 *= q1;
+                p2 *= q2;
+            }
+            q1 *= q1;
+            q2 *= q2;
+        }
+        sc[0] = (float)(1.0 - p1);
+        sc[1] = (float)sqrt(1.0 - p2);
+    }
+    __syncthreads();
+    const float step = lr / sc[0], bc2_sqrt = sc[1];
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float gg = g[e] * gscale;
         const float mm = b1 * m[e] + (1.f - b1) * gg;
@@ -154,6 +168,16 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, co
         m[e] = mm;
         v[e] = vv;
         p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(corr + 2);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *step_dev = st;
+            corr[0] = sc[0];
+            corr[1] = sc[1];
+            *ticket = 0u;
+        }
     }
 }
 
@@ -309,9 +333,8 @@ int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* ex
                              float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
                              const int* skip_if_nonzero, hipStream_t stream) {
     SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_dev && corr_dev);
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, stream, step_dev, corr_dev, beta1, beta2, skip_if_nonzero);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, (const float*)corr_dev, grad_scale, skip_if_nonzero);
+                       beta2, eps, step_dev, corr_dev, grad_scale, skip_if_nonzero);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -1090,7 +1090,8 @@ __global__ void __launch_bounds__(256) shape_fold_kernel(const float* __restrict
 __global__ void __launch_bounds__(1024) shape_bias_bwd_kernel(const float* __restrict__ t1, const float* __restrict__ t5, int S,
                                                               const float* __restrict__ z, int L, const float* __restrict__ W1,
                                                               const float* __restrict__ W5, float* __restrict__ dW1,
-                                                              float* __restrict__ dW5, float* __restrict__ gz) {
+                                                              float* __restrict__ dW5, float* __restrict__ gz,
+                                                              const float* __restrict__ reg_weight, float reg_scale) {
     extern __shared__ float sh[];   // rows: 2 x S, columns: 2 x 256
     __shared__ double red[2][4][kH];
     const int tid = threadIdx.x, part = tid >> 8, kk = tid & 255;
@@ -1165,7 +1166,13 @@ __global__ void __launch_bounds__(1024) shape_bias_bwd_kernel(const float* __res
             }
             red[0][part][kk] = a + b;
             __syncthreads();
-            if (part == 0 && k < L) gz[(long)s * L + k] = (float)(((red[0][0][kk] + red[0][1][kk]) + red[0][2][kk]) + red[0][3][kk]);
+            if (part == 0 && k < L) {
+                float v = (float)(((red[0][0][kk] + red[0][1][kk]) + red[0][2][kk]) + red[0][3][kk]);
+                // + the gradient of a quadratic latent regulariser sum_s w_s |z_s|^2 * reg_scale / 2 (train_sdf_autodecoder.py:88):
+                // the expression of deepsdf_bwd_kernel, added in fp32 like the autograd accumulation it replaces (bit-identical)
+                if (reg_scale != 0.f) v += ((reg_weight ? reg_weight[s] : 1.f) * reg_scale) * z[(long)s * L + k];
+                gz[(long)s * L + k] = v;
+            }
             __syncthreads();
         }
     }
@@ -1348,12 +1355,13 @@ int sg_sdfnet_shape_bias(const float* z, long nshapes, int latent, const float* 
 // t1 / t5 [256][S] of dZ1 / dZ5 (sg_sdfnet_segsum or sg_rowsum): the latent columns of dW1 / dW5 (written in place, row strides of
 // the full matrices; pass NULL to skip) and the latent gradient gz [S][L] (NULL to skip).
 int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
-                             const float* W5, float* dW1, float* dW5, float* gz, hipStream_t stream) {
+                             const float* W5, float* dW1, float* dW5, float* gz, const float* reg_weight, float reg_scale,
+                             hipStream_t stream) {
     SG_CHECK_ARG(t1 && t5 && z && W1 && W5 && nshapes > 0 && latent > 0 && (dW1 == nullptr) == (dW5 == nullptr));
     SG_CHECK_ARG(nshapes <= 6144);   // a t row of every shape in 48 KB of LDS
     const size_t lds = (size_t)2 * (nshapes > kH ? nshapes : kH) * sizeof(float);
     hipLaunchKernelGGL(shape_bias_bwd_kernel, dim3((unsigned)(kH + nshapes)), dim3(1024), lds, stream, t1, t5, (int)nshapes, z,
-                       latent, W1, W5, dW1, dW5, gz);
+                       latent, W1, W5, dW1, dW5, gz, reg_weight, reg_scale);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -749,7 +749,7 @@ int sg_sdfnet_shape_bias_cpu(const float* z, long nshapes, int latent, const flo
 }
 // backward of the per-shape latent fold (header: sg_sdfnet_shape_bias_bwd)
 int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
-                                 const float* W5, float* dW1, float* dW5, float* gz, void*) {
+                                 const float* W5, float* dW1, float* dW5, float* gz, const float* reg_weight, float reg_scale, void*) {
     CPU_CHECK(t1 && t5 && z && W1 && W5 && nshapes > 0 && latent > 0 && (dW1 == nullptr) == (dW5 == nullptr));
     const long ld1 = 3 + latent, ld5 = 259 + latent;
     if (dW1) {
@@ -772,7 +772,9 @@ int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes,
                 double a = 0;
                 for (int o = 0; o < 256; ++o)
                     a += (double)t1[o * nshapes + s] * W1[o * ld1 + 3 + k] + (double)t5[o * nshapes + s] * W5[o * ld5 + 259 + k];
-                gz[s * latent + k] = (float)a;
+                float v = (float)a;
+                if (reg_scale != 0.f) v += ((reg_weight ? reg_weight[s] : 1.f) * reg_scale) * z[s * latent + k];
+                gz[s * latent + k] = v;
             }
     }
     return SG_OK;

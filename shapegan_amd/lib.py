@@ -70,7 +70,7 @@ SIGNATURES = {
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
     "sg_sdfnet_shape_bias": (c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
     "sg_sdfnet_bwd_finish_workspace_bytes": (_Z, [_L]),
     "sg_sdfnet_bwd_finish": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _Z, _P, _P]),
     "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
@@ -368,6 +368,13 @@ def tickets(name, device, count=16):
     else:
         key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _tickets.get(key)
+    if (buf is None or buf.numel() < count) and device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # a graph under capture runs on a stream of its own: take the words an eager call of the same kernel family made on this
+        # device (a trainer's warm-up steps) instead of zeroing new ones inside the graph — that was a fill launch per replay.
+        # Replays are ordered with the eager work of the stream they are launched on; the kernels leave the words at zero.
+        for (dev_index, _, nm), cand in list(_tickets.items()):
+            if dev_index == key[0] and nm == name and cand.numel() >= count:
+                return cand
     if buf is None or buf.numel() < count:
         buf = torch.zeros(count, dtype=torch.int32, device=device)
         _tickets[key] = buf

@@ -66,15 +66,22 @@ class SDFNet(SavableModule):
     def forward_shapes(self, points, latent_codes, points_per_shape):
         """points [S*pps,3], latent_codes [S,L] -> sdf [S*pps]: row s*pps+q uses latent s.  Same function as
         forward(points, latent.repeat_interleave(pps)) without materialising the tiled latents."""
-        return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_codes, int(points_per_shape), None, None,
+        return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_codes, int(points_per_shape), None, None, None,
                                       torch.is_grad_enabled(), *self._params())
 
-    def forward_segments(self, points, latent_table, shape_index, segment_offsets):
+    def prepare_latents(self, latent_table):
+        """Weight pack (if stale) and per-shape latent fold for the forward_shapes / forward_segments call that follows with the same
+        table — lets a trainer run them next to its batch assembly (ops._PackCache.prepare_fold)."""
+        self._pack_shapes.prepare_fold(self._params(), latent_table)
+
+    def forward_segments(self, points, latent_table, shape_index, segment_offsets, latent_reg=None):
         """points [N,3] grouped by shape, latent_table [S,L], shape_index [N] (int32), segment_offsets [S+1] (int64):
         sdf[i] = SDFNet(points[i], latent_table[shape_index[i]]).  The auto-decoder's latent_codes[model_indices]
         gather (train_sdf_autodecoder.py:80) without the [N,L] tensor: latent columns fold into per-shape biases and
-        the latent-table gradient comes out dense, [S,L], from per-shape sums."""
-        return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_table, 0, shape_index, segment_offsets,
+        the latent-table gradient comes out dense, [S,L], from per-shape sums.
+        latent_reg: None or (row_weight [S] | None, scale): the backward adds row_weight[s] * scale * latent_table[s] to the latent
+        gradient (see ops.SDFNetShapes)."""
+        return ops.SDFNetShapes.apply(self._pack_shapes, points, latent_table, 0, shape_index, segment_offsets, latent_reg,
                                       torch.is_grad_enabled(), *self._params())
 
     # ---- inference helpers (reference signatures) ----

@@ -930,10 +930,34 @@ class _PackCache(object):
             self.entries[dev] = entry
         return entry[1]
 
+    def prepare_fold(self, params, z):
+        """Pack (if stale) and the per-shape latent fold of `z` NOW, on the current stream, for the forward_segments / forward_shapes
+        call that follows with the same latents: a trainer runs this on a side stream next to its batch sort (both are short
+        launches that depend on nothing of each other).  The forward takes the result when latents and weights are still the ones
+        it was made from, and computes its own otherwise."""
+        z = f32c(z)
+        S, Lz = z.shape
+        packed = self.get(params, Lz, 3)
+        w1, b1, w5, b5 = f32c(params[0]), f32c(params[1]), f32c(params[8]), f32c(params[9])
+        zb1 = torch.empty((S, _H), dtype=torch.float32, device=z.device)
+        zb5 = torch.empty((S, _H), dtype=torch.float32, device=z.device)
+        check(_lib().sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(w1), ptr(b1), ptr(w5), ptr(b5), ptr(zb1), ptr(zb5), stream()),
+              "sdfnet_shape_bias")
+        # (the latents may live in a flat optimizer buffer whose kernels write through raw pointers: its parameter epoch is part of the key)
+        self.fold = (z.device, z.data_ptr(), z._version, tuple(z.shape), packed.data_ptr(), L.param_epoch_of_ptrs([z.data_ptr()]), zb1, zb5)
+
+    def take_fold(self, z, packed):
+        fold, self.fold = getattr(self, "fold", None), None
+        if fold is not None and fold[:6] == (z.device, z.data_ptr(), z._version, tuple(z.shape), packed.data_ptr(),
+                                             L.param_epoch_of_ptrs([z.data_ptr()])):
+            return fold[6], fold[7]
+        return None
+
 
 _PART_ROW = 14 * _H + 32      # SG_SDFNET_PARTIAL_ROW: floats per tile of the backward's partial sums
 
 _side_streams = {}
+_OVERLAP_MIN_POINTS = 65536      # side-stream overlap of short launches only in GPU-bound steps
 
 
 class _SideStream(object):
@@ -1114,9 +1138,12 @@ class SDFNetShapes(Function):
     train_hybrid_progressive_gan.py:90-96,138-139."""
 
     @staticmethod
-    def forward(ctx, cache, points, z, pps, sid, seg_off, grad_mode, *params):
+    def forward(ctx, cache, points, z, pps, sid, seg_off, reg, grad_mode, *params):
         """(grad_mode: the caller's torch.is_grad_enabled(), see SDFNetPoints.forward.)  Uniform segments: sid is None, row s*pps+q uses z[s].  Ragged segments: sid[N] (int32) names each point's
-        latent row and seg_off[S+1] (int64) bounds the contiguous run of every shape (points sorted by shape)."""
+        latent row and seg_off[S+1] (int64) bounds the contiguous run of every shape (points sorted by shape).
+        reg: None, or (row_weight [S] or None, scale): the backward adds row_weight[s] * scale * z[s] to the latent gradient — the
+        gradient of a quadratic latent regulariser evaluated elsewhere on a detached z (SDFAutoDecoderTrainer: one gradient
+        contribution for the latent table, written in place, instead of two that autograd adds)."""
         points, z = f32c(points), f32c(z)
         S, Lz = z.shape
         N = points.shape[0] if sid is not None else S * pps
@@ -1128,10 +1155,14 @@ class SDFNetShapes(Function):
         w1, b1, w5, b5 = f32c(params[0]), params[1], f32c(params[8]), params[9]
         # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]: both folds in one launch,
         # accumulated in double (round 6: the two sg_gemm calls were 2 - 4 launches and 24 us of the 20 000-point step)
-        zb1 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
-        zb5 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
-        check(lib.sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(w1), ptr(f32c(b1)), ptr(w5), ptr(f32c(b5)), ptr(zb1), ptr(zb5), stream()),
-              "sdfnet_shape_bias")
+        ready = cache.take_fold(z, packed)          # (made ahead by _PackCache.prepare_fold for exactly these latents and weights?)
+        if ready is not None:
+            zb1, zb5 = ready
+        else:
+            zb1 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
+            zb5 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
+            check(lib.sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(w1), ptr(f32c(b1)), ptr(w5), ptr(f32c(b5)), ptr(zb1), ptr(zb5), stream()),
+                  "sdfnet_shape_bias")
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks
@@ -1139,6 +1170,7 @@ class SDFNetShapes(Function):
                                 ptr(out), ptr(acts), N, N, stream()), "sdfnet_fwd")
         ctx.pps = pps
         ctx.seg_off = seg_off
+        ctx.reg = None if reg is None else (None if reg[0] is None else f32c(reg[0]), float(reg[1]))
         ctx.save_for_backward(points, z, out, acts, packed, *params)
         return out
 
@@ -1159,7 +1191,7 @@ class SDFNetShapes(Function):
         dz = torch.empty(7 * _H * N + 32, dtype=torch.float32, device=dev)[:7 * _H * N].view(7, _H, N)   # (+128 B: vector loads of the last row's tail)
         dz8 = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty((N, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        need_p = any(ctx.needs_input_grad[7:])
+        need_p = any(ctx.needs_input_grad[8:])
         need_z = ctx.needs_input_grad[2]
         # (the tile partials are also what the per-shape sums of a shape-sorted batch are assembled from)
         want_partials = need_p or (need_z and ctx.seg_off is not None)
@@ -1191,12 +1223,14 @@ class SDFNetShapes(Function):
         # The finishing launch of the partials and the backward of the latent fold (both short, few workgroups) run on a side
         # stream UNDER the weight-gradient GEMM batch: they write the bias gradients, w8, the point and latent columns of dW1 / dW5
         # and gz, the GEMMs the hidden blocks — distinct elements.  Joined before this backward returns.
-        overlap = _SideStream(dev) if (need_p and seg is not None and fold) else None
+        # (worth it where the step is GPU-bound: at the reference's 20 000-point batch the launches are host-paced — the stream
+        # switches cost the host more than the overlap saves — and inside a captured graph every fork / join edge is 6 - 12 us)
+        overlap = _SideStream(dev) if (need_p and seg is not None and fold and N >= _OVERLAP_MIN_POINTS) else None
         if overlap is not None:
             overlap.__enter__()
         try:
             if need_p:
-                grads = _sdf_param_grads(params, ctx.needs_input_grad[7:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
+                grads = _sdf_param_grads(params, ctx.needs_input_grad[8:], dz, dz8, acts, N, N, [(points, 0, 3)], kin_total,
                                          bsum, extended=True, seg=seg, side=overlap)
             if fold:
                 # backward of the latent fold in one launch: latent columns dW1[:, 3:] = T1 @ z, dW5[:, 259:] = T5 @ z and the
@@ -1204,9 +1238,10 @@ class SDFNetShapes(Function):
                 w1, w5 = f32c(params[0]), f32c(params[8])
                 import contextlib
                 with (overlap.run() if overlap is not None else contextlib.nullcontext()):
+                    rw, rs = ctx.reg if (ctx.reg is not None and need_z) else (None, 0.0)
                     check(lib.sg_sdfnet_shape_bias_bwd(ptr(t1), ptr(t5), S, ptr(z), Lz, ptr(w1), ptr(w5),
                                                        ptr(grads[0]) if need_p else None, ptr(grads[8]) if need_p else None,
-                                                       ptr(gz) if need_z else None, stream()), "sdfnet_shape_bias_bwd")
+                                                       ptr(gz) if need_z else None, ptr(rw), rs, stream()), "sdfnet_shape_bias_bwd")
         finally:
             if overlap is not None:
                 overlap.__exit__(None, None, None)
@@ -1223,7 +1258,10 @@ class SDFNetShapes(Function):
                 g5 = gemm_raw(t5, True, w5, False, b_off=_H + 3, M=S, N=Lz, K=_H, lda=S, ldb=_H + kin_total)
                 gz = _param_grad_out(z, g1.shape, dev)
                 check(lib.sg_axpby(ptr(g1), ptr(g5), ptr(gz), g1.numel(), 1.0, 1.0, stream()), "axpby")
-        return (None, dx, gz, None, None, None, None) + tuple(grads)
+                if ctx.reg is not None:      # (more shapes than the one-launch fold takes: the regulariser's gradient as a torch op)
+                    rw, rs = ctx.reg
+                    gz += (z * rs) if rw is None else (z * (rw * rs).unsqueeze(1))
+        return (None, dx, gz, None, None, None, None, None) + tuple(grads)
 
 
 # --------------------------------------------------------------------------------------------------------------

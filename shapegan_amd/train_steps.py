@@ -287,8 +287,16 @@ class SDFAutoDecoderTrainer(object):
         """The shape-sorted data flow described in `step`: the batch is grouped by one native counting sort
         (ops.sdf_batch_sort: keys, gathers of points / sdf, run bounds and counts; no host round trip)."""
         shapes = self.latent_codes.shape[0]
-        batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
-            indices, self.pointcloud_size, shapes, self.points, self.sdf, words=self._words)
+        if indices.numel() >= ops._OVERLAP_MIN_POINTS:
+            # GPU-bound steps: the weight pack + latent fold (they depend on the parameters only) on a side stream next to the sort
+            with ops._SideStream(self.latent_codes.device) as side:
+                with side.run():
+                    self.net.prepare_latents(self.latent_codes)
+                batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
+                    indices, self.pointcloud_size, shapes, self.points, self.sdf, words=self._words)
+        else:
+            batch_points, batch_sdf, model_indices, seg_off, counts = ops.sdf_batch_sort(
+                indices, self.pointcloud_size, shapes, self.points, self.sdf, words=self._words)
         self._sorted_calls += 1
         if self._sorted_calls == 1:
             self._poll_indices(synchronise=True)    # first call: synchronous (a systematically wrong index source fails at once)
@@ -297,12 +305,15 @@ class SDFAutoDecoderTrainer(object):
                                                     # behind a guarded (skipped) update
         self.net_opt.zero_grad()
         self.lat_opt.zero_grad()
-        output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off)
         n, width = indices.shape[0], self.latent_codes.shape[1]
+        # the regulariser's gradient w.r.t. the latent table, 2 sigma count_s z_s / (n L), is added by the backward of the latent
+        # fold (one gradient contribution for the table, written where its flat slice lives; the loss sees a detached table)
+        reg = (counts, float(2.0 / (n * width / self.sigma))) if self.sigma != 0 else None
+        output = self.net.forward_segments(batch_points, self.latent_codes, model_indices, seg_off, latent_reg=reg)
         if self.sigma != 0:
             # data term + sigma * mean(z_batch^2) through shape counts in one op; sigma rides in the denominator (sigma 0: the
             # term is 0, as in the reference's formula)
-            loss = ops.deepsdf_loss(output, batch_sdf, self.latent_codes, counts, n * width / self.sigma)
+            loss = ops.deepsdf_loss(output, batch_sdf, self.latent_codes.detach(), counts, n * width / self.sigma)
         else:
             loss = ops.weighted_l1(output, batch_sdf)
         lib.backward(loss)
