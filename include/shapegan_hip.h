@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 7
+#define SG_ABI_VERSION 8
 
 typedef struct ihipStream_t* hipStream_t; /* the opaque handle hip_runtime_api.h declares (identical re-typedef) */
 
@@ -164,6 +164,11 @@ size_t sg_gemm_nt_batched_workspace_bytes(int batch, int M, int N, long K);
 int sg_gemm_nt_batched(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
                        const long* c_off, const long* ldc, int batch, int M, int N, long K, void* workspace,
                        size_t workspace_bytes, hipStream_t stream);
+/* The same with B_b holding LayerNorm-normalised rows: C_b = A_b * relu(gamma_b (.) B_b + beta_b)^T with gamma_b = gamma + g_off[b],
+ * beta_b = beta + g_off[b] ([N] each): the hidden weight gradients of the LayerNorm MLP (K7b) straight from the xhat images. */
+int sg_gemm_nt_batched_lnrelu(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb,
+                              const float* gamma, const float* beta, const long* g_off, float* C, const long* c_off, const long* ldc,
+                              int batch, int M, int N, long K, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int sg_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t stream); /* bias grads */
 int sg_rowsum(const float* x, float* out, long rows, long len, long ld, hipStream_t stream);
 /* rows [d*rows_per_dst, (d+1)*rows_per_dst) go to outs[d] (ndst <= 8 host-side pointers to device buffers): one launch for
@@ -248,6 +253,7 @@ long sg_sdfnet_bwd_tile_start(long N, long t);
  * kernel has the operands on chip for, instead of three more passes over the [256][N] images.  sg_sdfnet_bwd_finish reduces
  * them. */
 #define SG_SDFNET_PARTIAL_ROW 3616 /* 14 * 256 + 32 */
+#define SG_SDFGEN_PARTIAL_ROW 7200 /* SG_SDFNET_PARTIAL_ROW + 14 * 256: the LayerNorm form (sg_sdfgen_bwd) */
 int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float* dz, float* dz8, float* bias_partials,
                   const float* points, long points_period, float* dx, long dx_ld, const float* packed, int kin_used, long ldn,
                   long N, hipStream_t stream);
@@ -278,6 +284,35 @@ int sg_sdfnet_shape_bias_bwd(const float* t1, const float* t5, long nshapes, con
 size_t sg_sdfnet_bwd_finish_workspace_bytes(long N);
 int sg_sdfnet_bwd_finish(const float* dz, const float* bias_partials, long ldn, long N, int extended, float* const* bias_grads,
                          float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
+                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
+                         unsigned* tickets, hipStream_t stream);
+
+/* ---- K7b: the LayerNorm form of the fused MLP — SDFGenerator (model/point_sdf_net.py:49-119) with hidden_channels 256 and
+ * num_layers 8: x = relu(LayerNorm(lin_i(x) [+ z_lin(z)])) for i = 0..6 (:104-116), cat([x, pos]) in front of lins.4 (:100), a
+ * plain Linear(256, 1) at the end (ABI 8).  The eight Linear layers have the shapes of an SDFNet without latent columns, so the
+ * kernels are those of K7 with the LayerNorm statistics combined across the waves of a tile through LDS; the latent enters as
+ * the per-shape rows zb1 = z_lin1(z) + lins.0.bias, zb5 = z_lin2(z) + lins.4.bias ([S,256], built by the caller: two small
+ * Linear layers).  `params`: lins.{0..7}.{weight,bias} (16 pointers); `norm_params`: norms.{0..6}.{weight,bias} (14 pointers);
+ * `packed`: sg_sdfnet_packed_floats(3) floats.
+ * Training: `acts` (sg_sdfgen_acts_floats(ldn) floats) receives the images xhat_l = (x - mean) * rstd [7][256][ldn] (the
+ * LayerNorm backward needs them where the ReLU is off too), the sign masks of the ReLU inputs (layout of sg_sdfnet_acts_floats)
+ * and rstd [7][ldn].  sg_sdfgen_bwd (32-point tiles, sg_sdfgen_bwd_blocks(N) of them) writes dz8 = dout, the images dZ_l (gradient
+ * of the LayerNorm INPUT) and per-tile partial sums [blocks][SG_SDFGEN_PARTIAL_ROW]: the SDFNet row (b = 0..13 and float 14*256,
+ * see sg_sdfnet_bwd) followed at float SG_SDFNET_PARTIAL_ROW by 7 blocks sum_p dY_l xhat_l (LayerNorm weight gradients) and 7
+ * blocks sum_p dY_l (LayerNorm bias gradients).  sg_sdfgen_bwd_finish reduces them (norm_grads[0..6]: weight, [7..13]: bias
+ * gradients; tickets: 32 unsigned, zero); the six 256 x 256 weight gradients are sg_gemm_nt_batched_lnrelu products of the dZ and
+ * xhat images. */
+size_t sg_sdfgen_acts_floats(long ldn);
+long sg_sdfgen_packed_norm_offset(int which); /* float offset of the packed LayerNorm weight (0) / bias (1) vectors [7][256] */
+int sg_sdfgen_pack(const float* const* params, const float* const* norm_params, float* packed, hipStream_t stream);
+int sg_sdfgen_fwd(const float* points, const float* packed, const float* zb1, const float* zb5, long points_per_shape,
+                  const int* shape_index, float eps, float* out, float* acts, long ldn, long N, hipStream_t stream);
+long sg_sdfgen_bwd_blocks(long N);
+int sg_sdfgen_bwd(const float* dout, const float* acts, float* dz, float* dz8, float* partials, const float* points,
+                  const float* packed, long ldn, long N, hipStream_t stream);
+size_t sg_sdfgen_bwd_finish_workspace_bytes(long N);
+int sg_sdfgen_bwd_finish(const float* dz, const float* partials, long ldn, long N, float* const* bias_grads, float* w8_grad,
+                         float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld, float* const* norm_grads,
                          const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
                          unsigned* tickets, hipStream_t stream);
 

@@ -169,8 +169,15 @@ struct GemmNtArgs {
     int nsplit;      // groups = batch * nsplit
     int ngroups;
     long a_off[kNtMaxBatch], b_off[kNtMaxBatch];   // element offsets of the batch members' operands
+    // LNRELU: B holds LayerNorm-normalised rows xhat and the product is taken with relu(gamma[row] * xhat + beta[row]) — the
+    // weight gradients of the LayerNorm MLP (model/point_sdf_net.py:104-116) read the activation images the fused backward needs
+    // (xhat) and rebuild the layer outputs on the way into LDS, two VALU operations per element
+    const float* gamma;
+    const float* beta;
+    long g_off[kNtMaxBatch];                       // element offset of the member's gamma / beta vectors
 };
 
+template <bool LNRELU>
 __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A | B][8][kNtChunk]
     lds_float* const sl = (lds_float*)smem;
@@ -226,6 +233,15 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
     pin_vgpr(afrag);
     pin_vgpr(bfrag);
 
+    float gr[4], br[4];   // LNRELU: gamma / beta of this thread's four B rows
+    if constexpr (LNRELU) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = j0 + p * 32 + rowl;
+            gr[p] = row < a.N ? a.gamma[a.g_off[bz] + row] : 0.f;
+            br[p] = row < a.N ? a.beta[a.g_off[bz] + row] : 0.f;
+        }
+    }
     f32x4 ra[4], rb[4];   // pieces in flight (two stages ahead)
     auto issue = [&](int s) __attribute__((always_inline)) {   // loads of stage s (clamped: a stage past the end re-reads the last)
         const int sc = s < nstage ? s : nstage - 1;
@@ -234,6 +250,14 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
         for (int p = 0; p < 4; ++p) {
             ra[p] = buf_load4v(ares, avoff[p], so + (unsigned)p * pass_a);
             rb[p] = buf_load4v(bres, bvoff[p], so + (unsigned)p * pass_b);
+        }
+    };
+    auto lnrelu = [&]() __attribute__((always_inline)) {   // the B pieces in registers: xhat -> relu(gamma xhat + beta)
+        if constexpr (LNRELU) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rb[p][j] = fmaxf(fmaf(gr[p], rb[p][j], br[p]), 0.f);
         }
     };
     auto mask_tail = [&](int s) __attribute__((always_inline)) {   // zero the k >= kend part of the last stage
@@ -257,12 +281,14 @@ __global__ void __launch_bounds__(256) gemm_nt_bigk_kernel(GemmNtArgs a) {
 
     if (nstage > 0) {
         issue(0);
+        lnrelu();
         if (nstage == 1) mask_tail(0);
         commit(0);
         issue(1);
         __syncthreads();
         auto stage = [&](auto tag, int s) __attribute__((always_inline)) {
             constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
+            lnrelu();
             if (s + 1 == nstage - 1) mask_tail(s + 1);   // the pieces in registers belong to stage s + 1
             commit(NXT);
             issue(s + 2);
@@ -955,7 +981,8 @@ int sg_segsum(const float* x, float* out, long rows, long ld, const int64_t* seg
 
 static int gemm_nt_launch(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb, float* C,
                           const long* c_off, const long* ldc, int batch, int M, int N, long K, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream, const char* who) {
+                          size_t workspace_bytes, hipStream_t stream, const char* who, const float* gamma = nullptr,
+                          const float* beta = nullptr, const long* g_off = nullptr) {
     int nsplit;
     long kchunk;
     gemm_nt_plan(M, N, K, nsplit, kchunk, batch);
@@ -975,19 +1002,27 @@ static int gemm_nt_launch(const float* A, const long* a_off, long lda, const flo
     for (int b = 0; b < kNtMaxBatch; ++b) {
         a.a_off[b] = b < batch ? a_off[b] : 0;
         a.b_off[b] = b < batch ? b_off[b] : 0;
+        a.g_off[b] = (b < batch && g_off) ? g_off[b] : 0;
     }
+    a.gamma = gamma;
+    a.beta = beta;
     a.out = direct ? C + c_off[0] : (float*)workspace;
     a.ldc = direct ? ldc[0] : N;
     const size_t lds = (size_t)2 * 2 * kNtOp * sizeof(float);
     static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
     if (attr_once.begin()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bigk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_once.end();
     }
     a.ngroups = batch * nsplit;
     const unsigned wgs = (unsigned)((a.ngroups + 7) / 8 * 8 * sg_cdiv(N, 128) * sg_cdiv(M, 128));
-    hipLaunchKernelGGL(gemm_nt_bigk_kernel, dim3(wgs), dim3(256), lds, stream, a);
+    if (gamma)
+        hipLaunchKernelGGL(gemm_nt_bigk_kernel<true>, dim3(wgs), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL(gemm_nt_bigk_kernel<false>, dim3(wgs), dim3(256), lds, stream, a);
     if (!direct) {
         GemmNtOut o;
         for (int b = 0; b < kNtMaxBatch; ++b) {
@@ -1035,6 +1070,21 @@ int sg_gemm_nt_batched(const float* A, const long* a_off, long lda, const float*
     for (int b = 0; b < batch; ++b) SG_CHECK_ARG(ldc[b] >= N);
     return gemm_nt_launch(A, a_off, lda, B, b_off, ldb, C, c_off, ldc, batch, M, N, K, workspace, workspace_bytes, stream,
                           "sg_gemm_nt_batched");
+}
+
+
+// The same with B = LayerNorm-normalised rows: C_b = A_b * relu(gamma_b (.) B_b + beta_b)^T, gamma_b / beta_b = gamma / beta + g_off[b]
+// ([N] each, one value per row of B_b).  The weight gradients of the fused LayerNorm MLP (sg_sdfgen_bwd).
+int sg_gemm_nt_batched_lnrelu(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb,
+                              const float* gamma, const float* beta, const long* g_off, float* C, const long* c_off, const long* ldc,
+                              int batch, int M, int N, long K, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(A && B && C && a_off && b_off && c_off && ldc && gamma && beta && g_off && batch > 0 && batch <= kNtMaxBatch);
+    SG_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K);
+    SG_CHECK_ARG(31L * lda * 4 + 64 < (long)kBufRange && 31L * ldb * 4 + 64 < (long)kBufRange);
+    SG_CHECK_ARG(96L * lda * 4 + K * 4 < (1L << 32) && 96L * ldb * 4 + K * 4 < (1L << 32));
+    for (int b = 0; b < batch; ++b) SG_CHECK_ARG(ldc[b] >= N);
+    return gemm_nt_launch(A, a_off, lda, B, b_off, ldb, C, c_off, ldc, batch, M, N, K, workspace, workspace_bytes, stream,
+                          "sg_gemm_nt_batched_lnrelu", gamma, beta, g_off);
 }
 
 }  // extern "C"

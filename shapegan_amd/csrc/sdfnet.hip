@@ -54,6 +54,9 @@ struct PackVectors {     // the seven bias vectors, b8 and w8 (blockIdx.y == des
     const float* b[8];
     const float* w8;
     long dst_b, dst_w8;  // offsets into the packed buffer
+    const float* g[7];   // LayerNorm weight / bias of the seven hidden layers (SDFGenerator, model/point_sdf_net.py:71); g[0] NULL: none
+    const float* be[7];
+    long dst_g, dst_be;
 };
 struct PackDescs {
     PackDesc d[16];
@@ -71,6 +74,13 @@ __global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float
         for (int l = 0; l < 7; ++l) dst[descs.v.dst_b + l * kH + t] = descs.v.b[l][t];
         dst[descs.v.dst_b + 7 * kH + t] = (t == 0) ? descs.v.b[7][0] : 0.f;
         dst[descs.v.dst_w8 + t] = descs.v.w8[t];
+        if (descs.v.g[0]) {
+#pragma unroll
+            for (int l = 0; l < 7; ++l) {
+                dst[descs.v.dst_g + l * kH + t] = descs.v.g[l][t];
+                dst[descs.v.dst_be + l * kH + t] = descs.v.be[l][t];
+            }
+        }
         return;
     }
     const PackDesc d = descs.d[blockIdx.y];
@@ -92,6 +102,7 @@ struct SdfPackLayout {
     long F1, F2, F3, F4, F5x, F5i, F6, F7;  // forward packs: A(i=out, k=in)
     long T1, T2, T3, T4, T5x, T5i, T6, T7;  // transposed packs: A(i=in, k=out)
     long W8, B;                              // w8[256], b[8][256]
+    long G, Be;                              // LayerNorm weight / bias [7][256] each (the SDFGenerator form)
     long total;
 };
 static SdfPackLayout make_layout(int KU) {
@@ -123,6 +134,8 @@ static SdfPackLayout make_layout(int KU) {
     L.T7 = take(kH * kH);
     L.W8 = take(kH);
     L.B = take(8 * kH);
+    L.G = take(7 * kH);
+    L.Be = take(7 * kH);
     L.total = o;
     return L;
 }
@@ -270,9 +283,21 @@ struct SdfFwdArgs {
     long ldn;
     long N;
     long nbig;         // workgroups [0, nbig): full tiles; the rest: kSmallTile points each
+    float eps;         // NORM: LayerNorm epsilon
 };
 
-template <int P, bool SHAPE_BIAS, bool TRAIN>   // TRAIN: `acts` is given (H images + sign masks are written)
+// The LayerNorm form (NORM; SDFGenerator, model/point_sdf_net.py:49-119 with hidden_channels 256, num_layers 8): the same eight
+// layers with x = relu(LayerNorm(lin(x) [+ z_lin(z)])) (:104-116) instead of relu(lin(x)), no tanh at the end, and
+// cat([x, pos]) (:100) where SDFNet has cat(x, input).  A point's 256 features are spread over the eight waves (32 rows each), so
+// a layer's statistics are combined through LDS: every wave reduces its 32 rows of a point to (mean, sum of squared deviations)
+// in registers (16 in-lane terms + one cross-half exchange), parks the pair in `red` in front of the barrier the write-back
+// has anyway, and combines the eight pairs behind it (Chan's formula for equal counts) — no extra barrier, no E[x^2] - E[x]^2
+// cancellation.  In training the images hold xhat = (x - mean) * rstd (the LayerNorm backward needs it where the ReLU is off
+// too; the weight-gradient GEMM applies relu(gamma xhat + beta) when it loads them), the sign masks are those of the ReLU
+// input, and rstd [7][ldn] follows the masks.
+__host__ __device__ __forceinline__ const float* sdf_rstd_base(const float* acts, long ldn) { return acts + 7L * kH * ldn + 56L * ldn; }
+
+template <int P, bool SHAPE_BIAS, bool TRAIN, bool NORM = false>   // TRAIN: `acts` is given (H images + sign masks are written)
 __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long p0) {
     constexpr int NT = P / 32;
     constexpr int LDX = P + 1;
@@ -281,6 +306,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
     float* Xs = Hs + kH * P;         // [KUp][LDX]
     float* red = Xs + a.lay.KUp * LDX;  // [16][P]
     float* Bl = red + 16 * P;           // [7][256]: the bias vectors (see init_acc_lds)
+    float* GBs = Bl + 7 * kH;           // NORM: [8 waves][gamma 32 | beta 32] of the layer in flight
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -377,22 +403,86 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
         mstore[t] = p0 + t * 32 + r < a.N ? (unsigned)(((long)kh * a.ldn + t * 32 + r) * 2) : kBufOutside;
     // (`save` stays a run-time condition even in the TRAIN instantiation: as a compile-time constant the stores lose their place
     // in the schedule, the write-back's live ranges grow and the kernel no longer fits the 128 VGPRs of two workgroups per CU)
-    auto writeback = [&](int layer) {  // H <- relu(acc); optionally save
+    // NORM: this lane's LayerNorm weight (lanes 0..31) / bias (32..63) element of a layer, row wrow + r: requested in front of the
+    // layer's GEMM, parked in LDS behind it (in front of the next weight ring: its wait covers only loads that were consumed)
+    float gbv = 0.f;
+    auto gb_load = [&](int layer) __attribute__((always_inline)) {
+        if constexpr (NORM) gbv = (a.packed + (kh ? a.lay.Be : a.lay.G))[layer * kH + wave * 32 + r];
+    };
+    auto gb_commit = [&]() __attribute__((always_inline)) {
+        if constexpr (NORM) GBs[wave * 64 + lane] = gbv;
+    };
+    auto writeback = [&](int layer) {  // H <- relu(acc) (NORM: relu(LayerNorm(acc))); optionally save
+        float mean[NT], rstd[NT];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += acc[t][q];
+                s += __shfl_xor(s, 32, 64);
+                const float mw = s * (1.f / 32.f);
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float e = acc[t][q] - mw;
+                    d = fmaf(e, e, d);
+                }
+                d += __shfl_xor(d, 32, 64);
+                if (kh == 0) {
+                    red[(2 * wave) * P + t * 32 + r] = mw;
+                    red[(2 * wave + 1) * P + t * 32 + r] = d;
+                }
+            }
+        }
         __syncthreads();
-        const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.acts + ((long)layer * kH + wrow) * a.ldn + p0);
         const bool save = a.acts != nullptr;
+        if constexpr (NORM) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const lds_float* rp = (const lds_float*)red + t * 32 + r;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum += rp[(2 * w) * P];
+                const float m = sum * 0.125f;
+                float M2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const float e = rp[(2 * w) * P] - m;
+                    M2 += rp[(2 * w + 1) * P];
+                    M2 = fmaf(32.f * e, e, M2);
+                }
+                mean[t] = m;
+                rstd[t] = 1.f / sqrtf(M2 * (1.f / 256.f) + a.eps);
+                if (TRAIN && save && wave == 0 && kh == 0 && p0 + t * 32 + r < a.N)
+                    const_cast<float*>(sdf_rstd_base(a.acts, a.ldn))[(long)layer * a.ldn + p0 + t * 32 + r] = rstd[t];
+            }
+        }
+        const __amdgpu_buffer_rsrc_t ares = make_rsrc(a.acts + ((long)layer * kH + wrow) * a.ldn + p0);
         unsigned mk[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) mk[t] = 0u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wave * 32 + frag_row(q, kh);
+            float gq = 1.f, bq = 0.f;
+            if constexpr (NORM) {
+                gq = GBs[wave * 64 + frag_row(q, kh)];
+                bq = GBs[wave * 64 + 32 + frag_row(q, kh)];
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float v = fmaxf(acc[t][q], 0.f);
+                float v, img;
+                if constexpr (NORM) {
+                    img = (acc[t][q] - mean[t]) * rstd[t];
+                    acc[t][q] = fmaf(gq, img, bq);      // (the sign mask below is that of the ReLU input)
+                    v = fmaxf(acc[t][q], 0.f);
+                } else {
+                    v = img = fmaxf(acc[t][q], 0.f);
+                }
                 Hs[row * P + t * 32 + r] = v;
                 if (save)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ares, (int)astore[t],
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, img), ares, (int)astore[t],
                                                           (int)(((q & 3) + 8 * (q >> 2)) * a.ldn * 4), SG_IMG_AUX);
             }
         }
@@ -422,7 +512,9 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
         init_acc_sid(a.zb1);
     else
         SHAPE_BIAS ? init_acc(a.zb1 + shape * kH) : init_acc_lds(0);
+    gb_load(0);
     mlp_gemm<NT>(acc, wtile(a.lay.F1, KUp / 8), KUp / 8, Xs, LDX, lane);
+    gb_commit();
     // the weight ring of the next 256-wide layer is started before each write-back (its stores would otherwise sit in front of
     // the first weight loads in the in-order return queue, see WRing)
     WRing<4> wr;
@@ -438,7 +530,9 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         init_acc_lds(l + 1);
+        gb_load(l + 1);
         mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+        gb_commit();
         next_ring(Fnext[l]);
         writeback(l + 1);
     }
@@ -447,17 +541,23 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
         init_acc_sid(a.zb5);
     else
         SHAPE_BIAS ? init_acc(a.zb5 + shape * kH) : init_acc_lds(4);
+    gb_load(4);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
     mlp_gemm<NT>(acc, wtile(a.lay.F5i, KUp / 8), KUp / 8, Xs, LDX, lane);
+    gb_commit();
     next_ring(a.lay.F6);
     writeback(4);
     // layers 6, 7
     init_acc_lds(5);
+    gb_load(5);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+    gb_commit();
     next_ring(a.lay.F7);
     writeback(5);
     init_acc_lds(6);
+    gb_load(6);
     mlp_gemm_ring<NT, 4, kH / 8>(acc, wr, Hs, P, lane, noop);
+    gb_commit();
     writeback(6);
     // layer 8: 256 -> 1, tanh.  The dot product is cut into sixteen 16-row groups summed in a fixed order, whatever the tile
     // size (a thread takes P / 32 groups of its point), so that a point's output does not depend on the tile it falls into.
@@ -480,7 +580,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
 #pragma unroll
             for (int q = 0; q < 16; ++q) v += red[q * P + tid];
             const long gp = p0 + tid;
-            if (gp < a.N) a.out[gp] = tanhf(v);
+            if (gp < a.N) a.out[gp] = NORM ? v : tanhf(v);   // (SDFGenerator ends in a plain Linear, point_sdf_net.py:106-111)
         }
     }
 }
@@ -495,13 +595,13 @@ constexpr long kCUs = 256;
 
 // (512 threads, 4 waves per SIMD = two workgroups per CU: the register budget is 128 VGPRs, stated explicitly — the kernel sat
 // just below it by luck before, and one more live value silently halves the occupancy)
-template <int P, bool SHAPE_BIAS, bool TRAIN>
+template <int P, bool SHAPE_BIAS, bool TRAIN, bool NORM = false>
 __global__ void __launch_bounds__(512, 4) sdfnet_fwd_kernel(SdfFwdArgs a) {
     const long b = blockIdx.x;
     if (b < a.nbig)
-        sdfnet_fwd_tile<P, SHAPE_BIAS, TRAIN>(a, b * P);
+        sdfnet_fwd_tile<P, SHAPE_BIAS, TRAIN, NORM>(a, b * P);
     else
-        sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS, TRAIN>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+        sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS, TRAIN, NORM>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
 }
 
 struct SdfBwdArgs {
@@ -551,6 +651,9 @@ struct SdfBwdArgs {
 constexpr int kLdg = 36;
 constexpr int kPartRow = SG_SDFNET_PARTIAL_ROW;   // 14 * 256 row sums + the tile's sum of dz8 (+ padding)
 static_assert(kPartRow >= 14 * kH + 1, "partial row");
+// the LayerNorm form appends 14 blocks: the LayerNorm weight gradients of images 0..6 (sum_p dY xhat), then the bias gradients (sum_p dY)
+constexpr int kPartRowNorm = SG_SDFGEN_PARTIAL_ROW;
+static_assert(kPartRowNorm == kPartRow + 14 * kH, "partial row of the LayerNorm form");
 
 template <int RING, int NSQ, bool HAS_NEXT, class Slice>
 __device__ __forceinline__ void chain_gemm(f32x16& acc, WRing<RING>& w, const __amdgpu_buffer_rsrc_t next,
@@ -593,8 +696,17 @@ __device__ __forceinline__ void chain_gemm(f32x16& acc, WRing<RING>& w, const __
 #else
 #define SG_PHASE_BARRIER() __syncthreads()
 #endif
-template <bool DUAL>
+// NORM (single-chain tiles only): the LayerNorm form, see sdfnet_fwd_tile.  With Y = gamma xhat + beta, H = relu(Y):
+//   dY = dH * (Y > 0),  dYh = dY * gamma,  dZ = rstd * (dYh - mean_f(dYh) - xhat * mean_f(dYh * xhat))   (means over the 256 features)
+// The two per-point means are combined across the eight waves through LDS like the forward's statistics: each wave reduces its
+// 32 rows in registers right behind its GEMM and parks the pair in front of the phase barrier that is there anyway; the second
+// half of the epilogue (behind the barrier) turns the accumulators into dZ.  The LayerNorm parameter gradients sum_p dY xhat and
+// sum_p dY are sums over the POINTS of a fragment row, i.e. over the 32 lanes of a half-wave: five DPP steps per row and
+// quantity, the lane that ends up with the total stores it into the tile's partial row (blocks 14 + image / 21 + image).
+template <bool DUAL, bool NORM = false>
 __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long p0) {
+    static_assert(!(DUAL && NORM), "the LayerNorm form runs single-chain tiles");
+    constexpr int prow = NORM ? kPartRowNorm : kPartRow;
     constexpr int NH = DUAL ? 2 : 1;
     constexpr int P = NH * 32;
     constexpr int RING = SG_BWD_RING;
@@ -603,6 +715,8 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
     float* const G1 = smem + kH * kLdg;      // chain B: points p0+32 .. p0+63
     float* const dz8s = smem + 2 * kH * kLdg;   // [64]
     float* const xs = dz8s + 64;                 // [3][64] xyz of the tile (only with a.points)
+    float* const Ss = xs + 3 * 64;               // NORM: [8 waves][2][32] per-point partial means
+    float* const GBs = Ss + 8 * 64;              // NORM: [8 waves][gamma 32 | beta 32] of the image in flight
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
@@ -614,8 +728,12 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         const long gp = p0 + tid;
         float v = 0.f;
         if (gp < a.N) {
-            const float o = a.out[gp];
-            v = a.dout[gp] * (1.f - o * o);
+            if constexpr (NORM) {
+                v = a.dout[gp];      // (no tanh behind the last Linear)
+            } else {
+                const float o = a.out[gp];
+                v = a.dout[gp] * (1.f - o * o);
+            }
             a.dz8[gp] = v;
         }
         dz8s[tid] = v;
@@ -631,7 +749,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
     __syncthreads();
     if (a.bsum && tid < 64) {       // the tile's share of the layers2.6 bias gradient: sum of dz8 (element 14 * 256 of its partial row)
         const float t8 = sg_wave_sum(tid < P ? dz8s[tid] : 0.f);
-        if (tid == 0) a.bsum[(long)blockIdx.x * kPartRow + 14 * kH] = t8;
+        if (tid == 0) a.bsum[(long)blockIdx.x * prow + 14 * kH] = t8;
     }
 
     f32x16 acc[NH];
@@ -683,7 +801,87 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wq), hi = __builtin_amdgcn_readfirstlane((unsigned)(wq >> 32));
         return make_rsrc((const void*)(((unsigned long long)hi << 32) | lo));
     };
-    {
+    // ---- NORM: operands of an image's epilogue (requested in front of its GEMM) and the two halves of the epilogue ----
+    float xh[16], gbv = 0.f, rsi = 0.f;
+    unsigned mk[NH];
+    auto norm_loads = [&](int i) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xres = layer_rsrc(a.acts, i);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xh[q] = buf_load(xres, hload[0], (unsigned)(rowoff(q) * a.ldn * 4));
+        gbv = (a.packed + (kh ? a.lay.Be : a.lay.G))[i * kH + wave * 32 + r];
+        rsi = pok[0] ? sdf_rstd_base(a.acts, a.ldn)[(long)i * a.ldn + p0 + r] : 0.f;
+    };
+    const bool nsums = a.bsum != nullptr;
+    auto norm_part1 = [&](int i) __attribute__((always_inline)) {
+        GBs[wave * 64 + lane] = gbv;     // (read back by this wave only: LDS operations of a wave execute in order)
+        const unsigned bsoff = r == 31 ? (unsigned)(4 * kh * 4) : kBufOutside;
+        const __amdgpu_buffer_rsrc_t gres = make_rsrc(a.bsum + (long)blockIdx.x * prow + kPartRow + i * kH + wrow);
+        const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.bsum + (long)blockIdx.x * prow + kPartRow + (7 + i) * kH + wrow);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float gq = GBs[wave * 64 + frag_row(q, kh)];
+            const float dy = ((mk[0] >> q) & 1u) ? acc[0][q] : 0.f;
+            if (nsums) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(dy * xh[q])), gres, (int)bsoff,
+                                                      (int)(rowoff(q) * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(dy)), bres, (int)bsoff,
+                                                      (int)(rowoff(q) * 4), 0);
+            }
+            const float dyh = dy * gq;
+            acc[0][q] = dyh;
+            s1 += dyh;
+            s2 = fmaf(dyh, xh[q], s2);
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (kh == 0) {
+            Ss[(2 * wave) * 32 + r] = s1;
+            Ss[(2 * wave + 1) * 32 + r] = s2;
+        }
+    };
+    auto norm_part2 = [&](const __amdgpu_buffer_rsrc_t zres) __attribute__((always_inline)) {
+        const lds_float* sp = (const lds_float*)Ss + r;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            m1 += sp[(2 * w) * 32];
+            m2 += sp[(2 * w + 1) * 32];
+        }
+        m1 *= (1.f / kH);
+        m2 *= (1.f / kH);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float g = rsi * ((acc[0][q] - m1) - xh[q] * m2);
+            gw[0][rowoff(q) * kLdg] = g;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), zres, (int)zstore[0], (int)(rowoff(q) * a.ldn * 4), SG_IMG_AUX);
+        }
+    };
+    if constexpr (NORM) {
+        // image 6: dH7 = w8 (x) dz8, the w8 gradient partial sum_p H7 dz8 with H7 = relu(gamma xhat + beta)
+        norm_loads(6);
+        mk[0] = load_mask(6, 0);
+        wring_start(wr, pk + (a.lay.T7 >> 2) + (long)wave * (kH / 8) * 64, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* w8 = a.packed + a.lay.W8;
+        const unsigned bsoff = r == 31 ? (unsigned)(4 * kh * 4) : kBufOutside;
+        const __amdgpu_buffer_rsrc_t w8res = make_rsrc(a.bsum + (long)blockIdx.x * prow + (ext ? 7 : 0) * kH + wrow);
+        GBs[wave * 64 + lane] = gbv;
+        const float d8 = dz8s[r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = frag_row(q, kh);
+            const float gq = GBs[wave * 64 + row], bq = GBs[wave * 64 + 32 + row];
+            const float h = pok[0] ? fmaxf(fmaf(gq, xh[q], bq), 0.f) : 0.f;
+            if (ext)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, half_sum(h * d8)), w8res, (int)bsoff,
+                                                      (int)(rowoff(q) * 4), 0);
+            acc[0][q] = pok[0] ? w8[wave * 32 + row] * d8 : 0.f;
+        }
+        norm_part1(6);
+        __syncthreads();
+        norm_part2(layer_rsrc(a.dz, 6));
+    } else {
         float hf[16][NH];
         const __amdgpu_buffer_rsrc_t hres = layer_rsrc(a.acts, 6);
 #pragma unroll
@@ -695,7 +893,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         __builtin_amdgcn_sched_barrier(0);
         const float* w8 = a.packed + a.lay.W8;
         const unsigned bsoff = r == 31 ? (unsigned)(4 * kh * 4) : kBufOutside;
-        const __amdgpu_buffer_rsrc_t w8res = make_rsrc(a.bsum + (long)blockIdx.x * kPartRow + (ext ? 7 : 0) * kH + wrow);
+        const __amdgpu_buffer_rsrc_t w8res = make_rsrc(a.bsum + (long)blockIdx.x * prow + (ext ? 7 : 0) * kH + wrow);
         const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, 6);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -770,13 +968,12 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         for (int i = 0; i < 4; ++i) {
             if (i < n) {
                 const float t = dpp_add(rs[i], IntTag<0xB1>(), IntTag<0xf>());
-                if (ssub == 0) a.bsum[(long)blockIdx.x * kPartRow + (i == 0 ? blk : xblk + i - 1) * kH + srow] = t;
+                if (ssub == 0) a.bsum[(long)blockIdx.x * prow + (i == 0 ? blk : xblk + i - 1) * kH + srow] = t;
             }
         }
     };
 
     // ---- epilogue of chain h for image `layer`, element q: dZ = acc * ReLU'(H) -> LDS tile, dz image ----
-    unsigned mk[NH];
     auto epi_q = [&](int h, int q, const __amdgpu_buffer_rsrc_t zres) __attribute__((always_inline)) {
         const float g = ((mk[h] >> q) & 1u) ? acc[h][q] : 0.f;
         gw[h][rowoff(q) * kLdg] = g;
@@ -803,6 +1000,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
         // ---- phase 1: GEMM_A(i) || epilogue_B(i + 1) ----
         if (sums) rowsum_clear();
         const unsigned mka = load_mask(i, 0);
+        if constexpr (NORM) norm_loads(i);
         zero(0);
         if (DUAL) {
             const __amdgpu_buffer_rsrc_t zprev = layer_rsrc(a.dz, i + 1);
@@ -817,6 +1015,7 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
                                               });
         }
         mk[0] = mka;
+        if constexpr (NORM) norm_part1(i);
         SG_PHASE_BARRIER();
         const __amdgpu_buffer_rsrc_t zres = layer_rsrc(a.dz, i);
         if (DUAL) {
@@ -834,8 +1033,12 @@ __device__ __forceinline__ void sdfnet_bwd_tile2(const SdfBwdArgs& a, const long
             mk[NH - 1] = mkb;
         } else {
             if (sums) rowsum_store(i + 1, xc ? XPREV : -1);
+            if constexpr (NORM) {
+                norm_part2(zres);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) epi_q(0, q, zres);
+                for (int q = 0; q < 16; ++q) epi_q(0, q, zres);
+            }
         }
         __syncthreads();
     };
@@ -914,6 +1117,10 @@ __global__ void __launch_bounds__(512, 4) sdfnet_bwd_kernel(SdfBwdArgs a) {
         sdfnet_bwd_tile2<false>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
 }
 
+__global__ void __launch_bounds__(512, 4) sdfgen_bwd_kernel(SdfBwdArgs a) {
+    sdfnet_bwd_tile2<false, true>(a, (long)blockIdx.x * kSmallTile);
+}
+
 // ---- everything that is derived from the tile partials of one backward, in ONE launch (round 6; it replaces sdfnet_segsum +
 // two rowsum_multi + the two-stage sum of dz8 = five launches of the auto-decoder step) ------------------------------------------
 //   column sums over the tiles:  group g = 0..6 -> bias gradient of dZ_{g+1}; 7 -> w8 gradient; 8..10 / 11..13 -> point columns
@@ -927,17 +1134,19 @@ __global__ void __launch_bounds__(512, 4) sdfnet_bwd_kernel(SdfBwdArgs a) {
 // splits IN SPLIT ORDER and writes the destination — the arrival order decides who does the addition, never its order.  The
 // tickets are left at zero for the next launch.
 struct SdfFinishArgs {
-    const float* part;     // [nblk][kPartRow]
+    const float* part;     // [nblk][part_row]
+    int part_row;          // kPartRow, or kPartRowNorm (the LayerNorm form: 14 more groups, 15..21 LayerNorm weight, 22..28 bias gradients)
+    int nws;               // groups per split in the workspace: 15 or 29
     const float* dz;       // [7][256][ldn]
     long ldn, nblk, nbig;
-    int ngroups;           // 15, or 7 + 1 (bias groups and the dz8 group) without the extended blocks
+    int ngroups;           // 15 (29: LayerNorm form), or 7 + 1 (bias groups and the dz8 group) without the extended blocks
     int extended;
     int nsplit;
     long tiles_per_split;
-    float* dst[15];
-    long dst_stride[15];
-    double* ws;            // [nsplit][15 * 256]
-    unsigned* tickets;     // [16], zero
+    float* dst[29];
+    long dst_stride[29];
+    double* ws;            // [nsplit][nws * 256]
+    unsigned* tickets;     // [16] ([32]: LayerNorm form), zero
     const int64_t* seg_off;
     long S;
     float* t1;
@@ -954,22 +1163,23 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
         const int g = (a.extended || gi < 7) ? gi : 14;     // (without the extended blocks: groups 0..6 and 14)
         const long t0 = sp * a.tiles_per_split;
         const long t1 = t0 + a.tiles_per_split < a.nblk ? t0 + a.tiles_per_split : a.nblk;
-        const bool on = g < 14 || col == 0;
-        const float* src = a.part + (g < 14 ? g * kH + col : 14 * kH);
+        const bool on = g != 14 || col == 0;
+        const float* src = a.part + (g < 14 ? g * kH + col : g == 14 ? 14 * kH : kPartRow + (g - 15) * kH + col);
+        const long kPR = a.part_row;
         double acc = 0;
         if (on) {
             long t = t0 + phase;
             for (; t + 28 < t1; t += 32) {       // eight loads in flight per thread
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(t + 4 * u) * kPartRow];
+                for (int u = 0; u < 8; ++u) v[u] = src[(t + 4 * u) * kPR];
                 acc += (((double)v[0] + v[1]) + ((double)v[2] + v[3])) + (((double)v[4] + v[5]) + ((double)v[6] + v[7]));
             }
-            for (; t < t1; t += 4) acc += src[t * kPartRow];
+            for (; t < t1; t += 4) acc += src[t * kPR];
         }
         red[phase][col] = acc;
         __syncthreads();
-        if (phase == 0) a.ws[((long)sp * 15 + g) * kH + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);   // (a double)
+        if (phase == 0) a.ws[((long)sp * a.nws + g) * kH + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);   // (a double)
         __syncthreads();      // (every wave's stores have been acknowledged by this XCD's L2: s_waitcnt vmcnt(0) in front of the barrier)
         if (tid == 0) {
             // ONE release per block: a device-scope fence writes this XCD's L2 back (the eight L2s are not coherent with each
@@ -986,14 +1196,14 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
             if (on) {
                 int q = phase;
                 for (; q + 12 < a.nsplit; q += 16) {
-                    const double v0 = __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double v1 = __hip_atomic_load(&a.ws[((long)(q + 4) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double v2 = __hip_atomic_load(&a.ws[((long)(q + 8) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double v3 = __hip_atomic_load(&a.ws[((long)(q + 12) * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v0 = __hip_atomic_load(&a.ws[((long)q * a.nws + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v1 = __hip_atomic_load(&a.ws[((long)(q + 4) * a.nws + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v2 = __hip_atomic_load(&a.ws[((long)(q + 8) * a.nws + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v3 = __hip_atomic_load(&a.ws[((long)(q + 12) * a.nws + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s += (v0 + v1) + (v2 + v3);
                 }
                 for (; q < a.nsplit; q += 4)
-                    s += __hip_atomic_load(&a.ws[((long)q * 15 + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s += __hip_atomic_load(&a.ws[((long)q * a.nws + g) * kH + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();      // (red[] of the first level has been read by phase 0 above: behind the barriers in between)
             red[phase][col] = s;
@@ -1020,12 +1230,13 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
     double acc = 0;
     if (interior) {
         const float* src = a.part + layer * kH + col;
+        const long kPR = a.part_row;
         long t = ta + phase;
         for (; t + 12 < tb; t += 16) {
-            const float v0 = src[t * kPartRow], v1 = src[(t + 4) * kPartRow], v2 = src[(t + 8) * kPartRow], v3 = src[(t + 12) * kPartRow];
+            const float v0 = src[t * kPR], v1 = src[(t + 4) * kPR], v2 = src[(t + 8) * kPR], v3 = src[(t + 12) * kPR];
             acc += ((double)v0 + v1) + ((double)v2 + v3);
         }
-        for (; t < tb; t += 4) acc += src[t * kPartRow];
+        for (; t < tb; t += 4) acc += src[t * kPR];
     }
     red[phase][col] = acc;
     // the cut tiles from the image: wave w takes rows 16 w .. 16 w + 15, lanes walk the points ([beg, head) and [tail, end) are
@@ -1204,8 +1415,11 @@ constexpr int kFinishMaxSplit = 32;
 constexpr long kFwdSlots = kCUs;       // one workgroup per CU (LDS)
 constexpr long kBwdSlots = 2 * kCUs;   // two per CU
 
-static size_t fwd_lds_bytes(int P, int KUp) { return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P + 7 * kH) * sizeof(float); }
+static size_t fwd_lds_bytes(int P, int KUp, bool norm = false) {
+    return ((size_t)kH * P + (size_t)KUp * (P + 1) + 16 * P + 7 * kH + (norm ? 8 * 64 : 0)) * sizeof(float);
+}
 static size_t bwd_lds_bytes(int P, int KUr, bool dx) { return ((size_t)2 * kH * kLdg + 4 * 64) * sizeof(float); }   // two chains [256][kLdg] + dz8 + xyz
+static size_t bwd_lds_bytes_norm() { return ((size_t)2 * kH * kLdg + 4 * 64 + 16 * 64) * sizeof(float); }   // + per-point means + gamma / beta
 
 template <class K>
 static int set_lds(K kern, size_t bytes) {
@@ -1231,8 +1445,8 @@ size_t sg_sdfnet_acts_floats(long ldn) { return (size_t)7 * kH * ldn + (size_t)5
 
 // params: host array of 16 device pointers in state_dict order
 //   layers1.{0,2,4,6}.{weight,bias}, layers2.{0,2,4,6}.{weight,bias}   (model/sdf_net.py:26-53)
-int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream) {
-    SG_CHECK_ARG(params && packed && latent >= 0 && (kin_used == 3 || kin_used == 3 + latent));
+static int sdf_pack(const float* const* params, const float* const* norm_params, int latent, int kin_used, float* packed,
+                    hipStream_t stream) {
     const SdfPackLayout L = make_layout(kin_used);
     const int KIN = 3 + latent;
     const float *W1 = params[0], *W2 = params[2], *W3 = params[4], *W4 = params[6];
@@ -1264,7 +1478,80 @@ int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* 
     D.v.w8 = W8;
     D.v.dst_b = L.B;
     D.v.dst_w8 = L.W8;
+    for (int l = 0; l < 7; ++l) {
+        D.v.g[l] = norm_params ? norm_params[2 * l] : nullptr;
+        D.v.be[l] = norm_params ? norm_params[2 * l + 1] : nullptr;
+    }
+    D.v.dst_g = L.G;
+    D.v.dst_be = L.Be;
     hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n + 1), dim3(256), 0, stream, D, packed);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream) {
+    SG_CHECK_ARG(params && packed && latent >= 0 && (kin_used == 3 || kin_used == 3 + latent));
+    return sdf_pack(params, nullptr, latent, kin_used, packed, stream);
+}
+
+// The SDFGenerator form (model/point_sdf_net.py:49-119, hidden_channels 256, num_layers 8).  params: the 16 tensors
+// lins.{0..7}.{weight,bias} ([256,3], [256,256] x 3, [256,259], [256,256] x 2, [1,256]: the shapes of an SDFNet without latent
+// columns); norm_params: norms.{0..6}.{weight,bias}.  Same packed size as sg_sdfnet_packed_floats(3).
+int sg_sdfgen_pack(const float* const* params, const float* const* norm_params, float* packed, hipStream_t stream) {
+    SG_CHECK_ARG(params && norm_params && packed);
+    for (int i = 0; i < 16; ++i) SG_CHECK_ARG(params[i] != nullptr);
+    for (int i = 0; i < 14; ++i) SG_CHECK_ARG(norm_params[i] != nullptr);
+    return sdf_pack(params, norm_params, 0, 3, packed, stream);
+}
+
+// float offsets of the LayerNorm weight (which = 0) / bias (1) vectors [7][256] inside a sg_sdfgen_pack image (operands of
+// sg_gemm_nt_batched_lnrelu)
+long sg_sdfgen_packed_norm_offset(int which) {
+    const SdfPackLayout L = make_layout(3);
+    return which ? L.Be : L.G;
+}
+
+// floats of the activation buffer of a training call of the LayerNorm form: the xhat images, the sign masks and rstd [7][ldn]
+size_t sg_sdfgen_acts_floats(long ldn) { return (size_t)7 * kH * ldn + (size_t)56 * ldn + (size_t)7 * ldn; }
+
+// Forward of the LayerNorm form: out[p] = SDFGenerator(pos[p], z[shape of p]) with the latent entering as the per-shape rows
+// zb1 = z_lin1(z) + lins.0.bias, zb5 = z_lin2(z) + lins.4.bias ([S,256] each; point_sdf_net.py:104-111).  Shapes are runs of
+// points_per_shape points (a multiple of 128, or >= N) or named per point by shape_index[N].  acts (optional, training):
+// sg_sdfgen_acts_floats(ldn) floats.
+int sg_sdfgen_fwd(const float* points, const float* packed, const float* zb1, const float* zb5, long points_per_shape,
+                  const int* shape_index, float eps, float* out, float* acts, long ldn, long N, hipStream_t stream) {
+    SG_CHECK_ARG(points && packed && zb1 && zb5 && out && N > 0 && eps > 0.f);
+    SG_CHECK_ARG(shape_index || (points_per_shape > 0 && (points_per_shape % 128 == 0 || points_per_shape >= N)));
+    SdfFwdArgs a;
+    a.points = points;
+    a.points_period = 0;
+    a.latent = nullptr;
+    a.latent_idx = nullptr;
+    a.L = 0;
+    a.packed = packed;
+    a.lay = make_layout(3);
+    a.zb1 = zb1;
+    a.zb5 = zb5;
+    a.pps = points_per_shape;
+    a.sid = shape_index;
+    a.out = out;
+    a.acts = acts;
+    a.ldn = ldn;
+    a.N = N;
+    a.eps = eps;
+    if (acts) SG_CHECK_ARG(ldn >= N);
+    if (acts && ldn > (1L << 24)) SG_FAIL(SG_ERR_ARG, "sg_sdfgen_fwd: at most 16 777 216 points per training call (ldn = %ld)", ldn);
+    const size_t lds = fwd_lds_bytes(64, a.lay.KUp, true);
+    const TilePlan tp = tile_plan(N, 64, 2 * kFwdSlots);
+    a.nbig = tp.nbig;
+    const dim3 grid((unsigned)(tp.nbig + tp.nsmall));
+    if (acts) {
+        if (set_lds(sdfnet_fwd_kernel<64, true, true, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfgen_fwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true, true, true>), grid, dim3(512), lds, stream, a);
+    } else {
+        if (set_lds(sdfnet_fwd_kernel<64, true, false, true>, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfgen_fwd: cannot reserve %zu B LDS", lds);
+        hipLaunchKernelGGL((sdfnet_fwd_kernel<64, true, false, true>), grid, dim3(512), lds, stream, a);
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -1293,6 +1580,7 @@ int sg_sdfnet_fwd(const float* points, long points_period, const float* latent, 
     a.acts = acts;
     a.ldn = ldn;
     a.N = N;
+    a.eps = 0.f;
     if (acts) SG_CHECK_ARG(ldn >= N);
     if (acts && ldn > (1L << 24)) SG_FAIL(SG_ERR_ARG, "sg_sdfnet_fwd: at most 16 777 216 points per training call (ldn = %ld)", ldn);
     const bool shape_bias = zb1 != nullptr;
@@ -1419,24 +1707,23 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
 // gradient w8_grad[256] and the three point columns of dW1 / dW5 (w1_cols / w5_cols: element (row, c) at [row * ld + c]);
 // b8_grad[1] = sum of dz8; optionally (seg_off != NULL) the per-segment sums t1 / t5 [256][nseg] of dZ1 / dZ5.
 size_t sg_sdfnet_bwd_finish_workspace_bytes(long N) { return (size_t)kFinishMaxSplit * 15 * kH * sizeof(double); }
+size_t sg_sdfgen_bwd_finish_workspace_bytes(long N) { return (size_t)kFinishMaxSplit * 29 * kH * sizeof(double); }
 
-int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long N, int extended, float* const* bias_grads,
-                         float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
-                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
-                         unsigned* tickets, hipStream_t stream) {
-    SG_CHECK_ARG(dz && partials && N > 0 && ldn >= N && workspace && tickets && nseg >= 0);
-    SG_CHECK_ARG(!bias_grads || b8_grad);
-    SG_CHECK_ARG(!extended || !bias_grads || (w8_grad && w1_cols && w5_cols));
-    SG_CHECK_ARG(nseg == 0 || (seg_off && t1 && t5));
-    const TilePlan tp = tile_plan(N, SG_BWD_TILE, kBwdSlots);
+static int sdf_finish(const char* who, bool norm, const float* dz, const float* partials, long ldn, long N, int extended,
+                      float* const* bias_grads, float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols,
+                      long w5_ld, float* const* norm_grads, const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace,
+                      size_t workspace_bytes, unsigned* tickets, hipStream_t stream) {
+    const TilePlan tp = norm ? TilePlan{0, (N + kSmallTile - 1) / kSmallTile} : tile_plan(N, SG_BWD_TILE, kBwdSlots);
     SdfFinishArgs a;
     a.part = partials;
+    a.part_row = norm ? kPartRowNorm : kPartRow;
+    a.nws = norm ? 29 : 15;
     a.dz = dz;
     a.ldn = ldn;
     a.nblk = tp.nbig + tp.nsmall;
     a.nbig = tp.nbig;
     a.extended = extended ? 1 : 0;
-    a.ngroups = bias_grads ? (extended ? 15 : 8) : 0;
+    a.ngroups = bias_grads ? (norm ? 29 : extended ? 15 : 8) : 0;
     // a split adds about 64 tiles (16 per thread, eight loads in flight), at most kFinishMaxSplit splits: every block ends in
     // a device-scope release (an L2 write-back), so few, longer blocks
     long nsplit = (a.nblk + 63) / 64;
@@ -1444,14 +1731,14 @@ int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long 
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;
     a.tiles_per_split = (a.nblk + nsplit - 1) / nsplit;
-    if (workspace_bytes < (size_t)nsplit * 15 * kH * sizeof(double)) SG_FAIL(SG_ERR_WORKSPACE, "sg_sdfnet_bwd_finish: workspace too small");
-    for (int g = 0; g < 15; ++g) {
+    if (workspace_bytes < (size_t)nsplit * a.nws * kH * sizeof(double)) SG_FAIL(SG_ERR_WORKSPACE, "%s: workspace too small", who);
+    for (int g = 0; g < 29; ++g) {
         a.dst[g] = nullptr;
         a.dst_stride[g] = 1;
     }
     if (bias_grads) {
         for (int g = 0; g < 7; ++g) {
-            SG_CHECK_ARG(bias_grads[g] != nullptr);
+            if (!bias_grads[g]) SG_FAIL(SG_ERR_ARG, "%s: bias_grads[%d] is NULL", who, g);
             a.dst[g] = bias_grads[g];
         }
         a.dst[14] = b8_grad;
@@ -1464,6 +1751,11 @@ int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long 
                 a.dst_stride[11 + c] = w5_ld;
             }
         }
+        if (norm)
+            for (int g = 0; g < 14; ++g) {
+                if (!norm_grads[g]) SG_FAIL(SG_ERR_ARG, "%s: norm_grads[%d] is NULL", who, g);
+                a.dst[15 + g] = norm_grads[g];
+            }
     }
     a.ws = static_cast<double*>(workspace);
     a.tickets = tickets;
@@ -1477,6 +1769,66 @@ int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long 
     hipLaunchKernelGGL(sdfnet_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
     SG_CHECK_LAUNCH();
     return SG_OK;
+}
+
+int sg_sdfnet_bwd_finish(const float* dz, const float* partials, long ldn, long N, int extended, float* const* bias_grads,
+                         float* w8_grad, float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld,
+                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
+                         unsigned* tickets, hipStream_t stream) {
+    SG_CHECK_ARG(dz && partials && N > 0 && ldn >= N && workspace && tickets && nseg >= 0);
+    SG_CHECK_ARG(!bias_grads || b8_grad);
+    SG_CHECK_ARG(!extended || !bias_grads || (w8_grad && w1_cols && w5_cols));
+    SG_CHECK_ARG(nseg == 0 || (seg_off && t1 && t5));
+    return sdf_finish("sg_sdfnet_bwd_finish", false, dz, partials, ldn, N, extended, bias_grads, w8_grad, b8_grad, w1_cols, w1_ld,
+                      w5_cols, w5_ld, nullptr, seg_off, nseg, t1, t5, workspace, workspace_bytes, tickets, stream);
+}
+
+// ---- the LayerNorm form (SDFGenerator, model/point_sdf_net.py:49-119) --------------------------------------------------------
+// Backward-data: dz8 = dout (no tanh), dZ_l through LayerNorm + ReLU; 32-point tiles, partials [sg_sdfgen_bwd_blocks(N)]
+// [SG_SDFGEN_PARTIAL_ROW] (the SDFNet row with `points`, then the 7 + 7 LayerNorm weight / bias gradient blocks).
+long sg_sdfgen_bwd_blocks(long N) { return (N + kSmallTile - 1) / kSmallTile; }
+
+int sg_sdfgen_bwd(const float* dout, const float* acts, float* dz, float* dz8, float* partials, const float* points,
+                  const float* packed, long ldn, long N, hipStream_t stream) {
+    SG_CHECK_ARG(dout && acts && dz && dz8 && partials && points && packed && N > 0 && ldn >= N);
+    if (ldn > (1L << 24)) SG_FAIL(SG_ERR_ARG, "sg_sdfgen_bwd: at most 16 777 216 points per call (ldn = %ld)", ldn);
+    SdfBwdArgs a;
+    a.points = points;
+    a.points_period = 0;
+    a.dout = dout;
+    a.out = nullptr;
+    a.acts = acts;
+    a.dz = dz;
+    a.dz8 = dz8;
+    a.bsum = partials;
+    a.dx = nullptr;
+    a.dx_ld = 0;
+    a.packed = packed;
+    a.lay = make_layout(3);
+    a.ldn = ldn;
+    a.N = N;
+    a.nbig = 0;
+    a.nblk = sg_sdfgen_bwd_blocks(N);
+    const size_t lds = bwd_lds_bytes_norm();
+    if (set_lds(sdfgen_bwd_kernel, lds)) SG_FAIL(SG_ERR_HIP, "sg_sdfgen_bwd: cannot reserve %zu B LDS", lds);
+    hipLaunchKernelGGL(sdfgen_bwd_kernel, dim3((unsigned)a.nblk), dim3(512), lds, stream, a);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// The sums derived from one sg_sdfgen_bwd call's partials (one launch): bias_grads[0..6] = row sums of dZ1..dZ7, w8 / b8
+// gradients, the point columns of dW1 / dW5 (element (row, c) at [row * ld + c]), norm_grads[0..6] = LayerNorm weight gradients
+// of norms.0..6, norm_grads[7..13] = their bias gradients; optionally the per-segment sums t1 / t5 [256][nseg] of dZ1 / dZ5 (the
+// gradients of the per-shape rows zb1 / zb5, transposed).  tickets: 32 words, zero.
+int sg_sdfgen_bwd_finish(const float* dz, const float* partials, long ldn, long N, float* const* bias_grads, float* w8_grad,
+                         float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld, float* const* norm_grads,
+                         const int64_t* seg_off, long nseg, float* t1, float* t5, void* workspace, size_t workspace_bytes,
+                         unsigned* tickets, hipStream_t stream) {
+    SG_CHECK_ARG(dz && partials && N > 0 && ldn >= N && workspace && tickets && nseg >= 0);
+    SG_CHECK_ARG(bias_grads && norm_grads && w8_grad && b8_grad && w1_cols && w5_cols);
+    SG_CHECK_ARG(nseg == 0 || (seg_off && t1 && t5));
+    return sdf_finish("sg_sdfgen_bwd_finish", true, dz, partials, ldn, N, 1, bias_grads, w8_grad, b8_grad, w1_cols, w1_ld, w5_cols,
+                      w5_ld, norm_grads, seg_off, nseg, t1, t5, workspace, workspace_bytes, tickets, stream);
 }
 
 }  // extern "C"

@@ -71,6 +71,14 @@ SIGNATURES = {
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
     "sg_sdfnet_shape_bias": (c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "sg_sdfgen_acts_floats": (_Z, [_L]),
+    "sg_sdfgen_packed_norm_offset": (_L, [_I]),
+    "sg_sdfgen_pack": (c_int, [_P, _P, _P, _P]),
+    "sg_sdfgen_fwd": (c_int, [_P, _P, _P, _P, _L, _P, _F, _P, _P, _L, _L, _P]),
+    "sg_sdfgen_bwd_blocks": (_L, [_L]),
+    "sg_sdfgen_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
+    "sg_sdfgen_bwd_finish_workspace_bytes": (_Z, [_L]),
+    "sg_sdfgen_bwd_finish": (c_int, [_P, _P, _L, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _Z, _P, _P]),
     "sg_sdfnet_bwd_finish_workspace_bytes": (_Z, [_L]),
     "sg_sdfnet_bwd_finish": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _Z, _P, _P]),
     "sg_sdfnet_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _L, _L, _P]),
@@ -94,6 +102,7 @@ SIGNATURES = {
     "sg_gemm_nt": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _L, _P, _Z, _P]),
     "sg_gemm_nt_batched_workspace_bytes": (_Z, [_I, _I, _I, _L]),
     "sg_gemm_nt_batched": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _L, _P, _Z, _P]),
+    "sg_gemm_nt_batched_lnrelu": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _P, _Z, _P]),
     "sg_layernorm_fwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _F, _I, _P]),
     "sg_layernorm_bwd_workspace_bytes": (_Z, [_L, _I]),
     "sg_layernorm_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P, _Z, _P]),
@@ -210,6 +219,7 @@ def check_comm(rc, what=""):
 # Entry points WITHOUT a twin: size queries and layout helpers are host code of libshapegan_hip.so (callable without a GPU; the
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
+    "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks",
     "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
     "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
     "sg_conv3d_k4s2p1_image_layout"}
@@ -232,7 +242,7 @@ def _load_hip():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.sg_abi_version() != 7:
+        if lib.sg_abi_version() != 8:
             raise RuntimeError("libshapegan_hip.so ABI version mismatch")
         _hip = lib
     return _hip

@@ -8,6 +8,9 @@ objects are parameter containers; every forward below runs through shapegan_amd.
     added on load — the [B,P,256] broadcast sum never exists; the skip concat `cat([x, pos])` (:100) is written by the
     same pass as the tail of a 259-float row;
   * `x.max(dim=-2)[0]` (:40): `sg_segmax_fwd` (+ scatter / gather adjoints for backward and double backward).
+The training configuration of train_point_gan.py:21 (hidden_channels 256, num_layers 8, norm) has the layer shapes of an SDFNet
+without latent columns: on the GPU its whole forward is ONE launch of the fused MLP kernel in its LayerNorm form (`ops.sdfgen_fused`,
+csrc/sdfnet.hip), its backward the fused backward-data kernel + one finishing launch + one weight-gradient GEMM batch.
 """
 import torch
 import torch.nn as nn
@@ -86,6 +89,12 @@ class SDFGenerator(nn.Module):
                 fan_out = 1
         self.z_lin1 = nn.Linear(latent_channels, hidden_channels)
         self.z_lin2 = nn.Linear(latent_channels, hidden_channels)
+        self._pack = ops._GenPackCache()
+
+    def _fused(self, pos):
+        """The one-launch form covers the script's configuration on the GPU; every other one runs layer by layer."""
+        return (pos.is_cuda and self.hidden_channels == 256 and self.num_layers == 8
+                and all(n.elementwise_affine and n.eps == self.norms[0].eps for n in self.norms))
 
     def forward(self, pos, z):
         pos = pos.unsqueeze(0) if pos.dim() == 2 else pos
@@ -98,6 +107,14 @@ class SDFGenerator(nn.Module):
         B, P = pos.shape[0], pos.shape[1]
         half = self.num_layers // 2
         pos2 = pos.reshape(B * P, 3)
+        if self._fused(pos):
+            # the latent enters layers 0 and num_layers/2 as one bias row per shape (:104-111)
+            zb1 = ops.linear(z, self.z_lin1.weight, self.z_lin1.bias + self.lins[0].bias)
+            zb5 = ops.linear(z, self.z_lin2.weight, self.z_lin2.bias + self.lins[half].bias)
+            params = [t for lin in self.lins for t in (lin.weight, lin.bias)] + \
+                     [t for norm in self.norms[:7] for t in (norm.weight, norm.bias)]
+            out = ops.sdfgen_fused(self._pack, pos2, zb1, zb5, P, self.norms[0].eps, params)
+            return out.reshape(B, P, 1)
         x = pos2
         for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             last = i == self.num_layers - 1

@@ -1264,6 +1264,129 @@ class SDFNetShapes(Function):
         return (None, dx, gz, None, None, None, None, None) + tuple(grads)
 
 
+class _GenPackCache(object):
+    """MFMA-fragment image of an SDFGenerator's 30 tensors (lins.{0..7}.{weight,bias}, norms.{0..6}.{weight,bias}), rebuilt when a
+    parameter changed; one entry per device (see _PackCache)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, params):
+        dev = params[0].device
+        ptrs = [p.data_ptr() for p in params]
+        key = (L.param_epoch_of_ptrs(ptrs),) + tuple(ptrs) + tuple(p._version for p in params)
+        entry = self.entries.get(dev)
+        if entry is None or entry[0] != key or not L.writers_known(*params):
+            lib = _lib()
+            packed = torch.empty(lib.sg_sdfnet_packed_floats(3), dtype=torch.float32, device=dev)
+            lins = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params[:16]])
+            norms = (ctypes.c_void_p * 14)(*[ptr(f32c(p.detach())) for p in params[16:]])
+            check(lib.sg_sdfgen_pack(lins, norms, ptr(packed), stream()), "sdfgen_pack")
+            entry = (key, packed)
+            self.entries[dev] = entry
+        return entry[1]
+
+
+_GEN_PART_ROW = _PART_ROW + 14 * _H      # SG_SDFGEN_PARTIAL_ROW
+
+
+class SDFGenFused(Function):
+    """SDFGenerator.forward (model/point_sdf_net.py:89-119) for hidden_channels 256 / num_layers 8 as ONE launch, and its backward
+    as the fused backward-data kernel + one finishing launch + one weight-gradient GEMM batch: out[s * pps + q] for pos [S * pps, 3]
+    and the per-shape rows zb1 = z_lin1(z) + lins.0.bias, zb5 = z_lin2(z) + lins.4.bias ([S, 256]; their two small Linear layers stay
+    with the caller and autograd).  params: lins.{0..7}.{weight,bias}, norms.{0..6}.{weight,bias}; the gradients of lins.0.bias /
+    lins.4.bias arrive through zb1 / zb5."""
+
+    @staticmethod
+    def forward(ctx, cache, pos, zb1, zb5, pps, eps, grad_mode, *params):
+        pos, zb1, zb5 = f32c(pos), f32c(zb1), f32c(zb5)
+        S = zb1.shape[0]
+        N = pos.shape[0]
+        if N != S * pps or zb1.shape != (S, _H) or zb5.shape != (S, _H):
+            raise RuntimeError("SDFGenFused: need pos for all %d x %d samples and [S, 256] rows" % (S, pps))
+        lib = _lib()
+        dev = pos.device
+        packed = cache.get(params)
+        sid = None
+        if not (pps % 128 == 0 or pps >= N):      # (tiles may straddle shapes: every point names its row)
+            sid = torch.arange(S, dtype=torch.int32, device=dev).repeat_interleave(pps)
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad[2:4] + ctx.needs_input_grad[7:])
+        out = torch.empty(N, dtype=torch.float32, device=dev)
+        acts = torch.empty(lib.sg_sdfgen_acts_floats(N), dtype=torch.float32, device=dev) if need_grad else None
+        check(lib.sg_sdfgen_fwd(ptr(pos), ptr(packed), ptr(zb1), ptr(zb5), pps, ptr(sid), float(eps), ptr(out), ptr(acts), N, N,
+                                stream()), "sdfgen_fwd")
+        ctx.pps, ctx.S = pps, S
+        ctx.save_for_backward(pos, acts, packed, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        pos, acts, packed = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        if acts is None:
+            raise RuntimeError("SDFGenerator: backward through a forward that ran without grad mode")
+        lib = _lib()
+        dev = pos.device
+        N, S, pps = pos.shape[0], ctx.S, ctx.pps
+        gout = f32c(gout).reshape(-1)
+        dz = torch.empty(7 * _H * N + 32, dtype=torch.float32, device=dev)[:7 * _H * N].view(7, _H, N)
+        dz8 = torch.empty(N, dtype=torch.float32, device=dev)
+        bsum = torch.empty((lib.sg_sdfgen_bwd_blocks(N), _GEN_PART_ROW), dtype=torch.float32, device=dev)
+        check(lib.sg_sdfgen_bwd(ptr(gout), ptr(acts), ptr(dz), ptr(dz8), ptr(bsum), ptr(pos), ptr(packed), N, N, stream()), "sdfgen_bwd")
+        grads = [None] * 30
+        w1 = _param_grad_out(params[0], (_H, 3), dev)
+        w5 = _param_grad_out(params[8], (_H, _H + 3), dev)
+        scratch = torch.empty((2, _H), dtype=torch.float32, device=dev)     # row sums of dZ1 / dZ5: the zb rows carry those gradients
+        bouts = [scratch[0] if pi == 1 else scratch[1] if pi == 9 else _param_grad_out(params[pi], (_H,), dev)
+                 for pi in (1, 3, 5, 7, 9, 11, 13)]
+        w8 = _param_grad_out(params[14], (1, _H), dev)
+        b8 = _param_grad_out(params[15], (1,), dev)
+        ngr = [_param_grad_out(params[16 + 2 * l], (_H,), dev) for l in range(7)] + \
+              [_param_grad_out(params[17 + 2 * l], (_H,), dev) for l in range(7)]
+        seg_off = torch.arange(S + 1, dtype=torch.int64, device=dev) * pps
+        t1 = torch.empty((_H, S), dtype=torch.float32, device=dev)
+        t5 = torch.empty((_H, S), dtype=torch.float32, device=dev)
+        barr = (ctypes.c_void_p * 7)(*[ptr(t) for t in bouts])
+        narr = (ctypes.c_void_p * 14)(*[ptr(t) for t in ngr])
+        ws = workspace("sdfgen_finish", lib.sg_sdfgen_bwd_finish_workspace_bytes(N), dev)
+        check(lib.sg_sdfgen_bwd_finish(ptr(dz), ptr(bsum), N, N, barr, ptr(w8), ptr(b8), ptr(w1), 3, ptr(w5) + 4 * _H, _H + 3, narr,
+                                       ptr(seg_off), S, ptr(t1), ptr(t5), ptr(ws), ws.numel(),
+                                       ptr(L.tickets("sdfgen_finish", dev, 32)), stream()), "sdfgen_bwd_finish")
+        # the six 256 x 256 x N products dZ_l relu(gamma xhat_{l-1} + beta)^T in one launch (+ one finalize)
+        hidden = [_param_grad_out(params[pi], (_H, _H), dev) for pi in (2, 4, 6, 10, 12)]
+        pairs = ((4, 3), (1, 0), (2, 1), (3, 2), (5, 4), (6, 5))
+        outs = [(w5, _H + 3)] + [(hidden[i], _H) for i in range(5)]
+        arr = ctypes.c_long * 6
+        a_off = arr(*[ldz * _H * N for ldz, _ in pairs])
+        b_off = arr(*[ai * _H * N for _, ai in pairs])
+        g_off = arr(*[ai * _H for _, ai in pairs])
+        c_off = arr(*[(o.data_ptr() - w5.data_ptr()) // 4 for o, _ in outs])
+        ldcs = arr(*[ld for _, ld in outs])
+        gws = workspace("gemm_nt", lib.sg_gemm_nt_batched_workspace_bytes(6, _H, _H, N), dev)
+        check(lib.sg_gemm_nt_batched_lnrelu(ptr(dz), a_off, N, ptr(acts), b_off, N,
+                                            ptr(packed) + 4 * lib.sg_sdfgen_packed_norm_offset(0),
+                                            ptr(packed) + 4 * lib.sg_sdfgen_packed_norm_offset(1), g_off, ptr(w5), c_off, ldcs, 6,
+                                            _H, _H, N, ptr(gws), gws.numel(), stream()), "gemm_nt_batched_lnrelu")
+        grads[0], grads[8] = w1, w5
+        for i, pi in enumerate((2, 4, 6, 10, 12)):
+            grads[pi] = hidden[i]
+        for i, pi in enumerate((1, 3, 5, 7, 9, 11, 13)):
+            grads[pi] = None if pi in (1, 9) else bouts[i]
+        grads[14], grads[15] = w8, b8
+        for l in range(7):
+            grads[16 + 2 * l], grads[17 + 2 * l] = ngr[l], ngr[7 + l]
+        needs = ctx.needs_input_grad[7:]
+        grads = [g if needs[i] else None for i, g in enumerate(grads)]
+        gzb1 = t1.t() if ctx.needs_input_grad[2] else None
+        gzb5 = t5.t() if ctx.needs_input_grad[3] else None
+        return (None, None, gzb1, gzb5, None, None, None) + tuple(grads)
+
+
+def sdfgen_fused(cache, pos, zb1, zb5, pps, eps, params):
+    return SDFGenFused.apply(cache, pos, zb1, zb5, pps, eps, torch.is_grad_enabled(), *params)
+
+
 # --------------------------------------------------------------------------------------------------------------
 # reductions and latent-table rows (K9 / K10)
 # --------------------------------------------------------------------------------------------------------------
