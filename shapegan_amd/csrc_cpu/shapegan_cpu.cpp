@@ -22,6 +22,7 @@
 typedef void* hipStream_t_;
 #define SG_OK 0
 #define SG_SDFNET_PARTIAL_ROW (14 * 256 + 32)   // include/shapegan_hip.h (the twin does not include the HIP header)
+#define SG_SDFGEN_PARTIAL_ROW (SG_SDFNET_PARTIAL_ROW + 14 * 256)
 #define SG_ERR_ARG (-1)
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
 
@@ -291,6 +292,27 @@ int sg_gemm_nt_batched_cpu(const float* A, const long* a_off, long lda, const fl
     for (int b = 0; b < batch; ++b) {
         const int rc = sg_gemm_nt_cpu(A + a_off[b], lda, B + b_off[b], ldb, C + c_off[b], ldc[b], M, N, K, ws, wb, st);
         if (rc) return rc;
+    }
+    return SG_OK;
+}
+int sg_gemm_nt_batched_lnrelu_cpu(const float* A, const long* a_off, long lda, const float* B, const long* b_off, long ldb,
+                                  const float* gamma, const float* beta, const long* g_off, float* C, const long* c_off, const long* ldc,
+                                  int batch, int M, int N, long K, void*, size_t, void*) {
+    CPU_CHECK(A && B && C && a_off && b_off && c_off && ldc && gamma && beta && g_off && batch > 0 && batch <= 8 && M > 0 && N > 0 && K > 0);
+    for (int m = 0; m < batch; ++m) {
+        const float *Am = A + a_off[m], *Bm = B + b_off[m], *gm = gamma + g_off[m], *bt = beta + g_off[m];
+        float* Cm = C + c_off[m];
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < N; ++j) {
+                const float *a = Am + i * lda, *b = Bm + j * ldb;
+                double s = 0;
+                for (long k = 0; k < K; ++k) {
+                    const float h = gm[j] * b[k] + bt[j];
+                    s += (double)a[k] * (double)(h > 0.f ? h : 0.f);
+                }
+                Cm[i * ldc[m] + j] = (float)s;
+            }
     }
     return SG_OK;
 }
@@ -808,6 +830,182 @@ int sg_sdfnet_bwd_finish_cpu(const float* dz, const float* bias_partials, long l
         for (long t = 0; t < nblk; ++t) s8 += bias_partials[t * SG_SDFNET_PARTIAL_ROW + 14 * 256];
         b8_grad[0] = (float)s8;
     }
+#pragma omp parallel for schedule(static)
+    for (long pair = 0; pair < 256 * nseg; ++pair) {
+        const long row = pair / nseg, sgm = pair % nseg;
+        double a = 0, b = 0;
+        for (long e = seg_off[sgm]; e < seg_off[sgm + 1]; ++e) {
+            a += dz[row * ldn + e];
+            b += dz[(4L * 256 + row) * ldn + e];
+        }
+        t1[pair] = (float)a;
+        t5[pair] = (float)b;
+    }
+    return SG_OK;
+}
+
+// ---- K7b: the LayerNorm form (SDFGenerator, model/point_sdf_net.py:49-119; header: sg_sdfgen_*) ------------------------------------
+// The LayerNorm vectors sit where sg_sdfgen_packed_norm_offset (host code of the HIP library, shared) says: float offsets of the
+// HIP image's layout for kin_used = 3, far behind this twin's own 462 337 floats.
+static const long kGenG = 809216, kGenBe = 811008;
+int sg_sdfgen_pack_cpu(const float* const* params, const float* const* norm_params, float* packed, void* st) {
+    CPU_CHECK(params && norm_params && packed);
+    const int rc = sg_sdfnet_pack_cpu(params, 0, 3, packed, st);
+    if (rc) return rc;
+    for (int l = 0; l < 7; ++l) {
+        memcpy(packed + kGenG + l * 256, norm_params[2 * l], sizeof(float) * 256);
+        memcpy(packed + kGenBe + l * 256, norm_params[2 * l + 1], sizeof(float) * 256);
+    }
+    return SG_OK;
+}
+// x (256 pre-LayerNorm values) -> xhat, rstd; h = relu(gamma xhat + beta)
+static inline float ln_relu(const float* x, const float* g, const float* b, float eps, float* xhat, float* h) {
+    double m = 0;
+    for (int o = 0; o < 256; ++o) m += x[o];
+    m /= 256;
+    double v = 0;
+    for (int o = 0; o < 256; ++o) v += ((double)x[o] - m) * ((double)x[o] - m);
+    const float rstd = (float)(1.0 / sqrt(v / 256 + (double)eps));
+    for (int o = 0; o < 256; ++o) {
+        xhat[o] = (float)((double)x[o] - m) * rstd;
+        const float y = g[o] * xhat[o] + b[o];
+        h[o] = y > 0.f ? y : 0.f;
+    }
+    return rstd;
+}
+int sg_sdfgen_fwd_cpu(const float* points, const float* packed, const float* zb1, const float* zb5, long points_per_shape,
+                      const int* shape_index, float eps, float* out, float* acts, long ldn, long N, void*) {
+    CPU_CHECK(points && packed && zb1 && zb5 && out && N > 0 && eps > 0.f && (shape_index || points_per_shape > 0));
+    CPU_CHECK(!acts || ldn >= N);
+    const CpuSdf v = sdf_view(packed, 3);
+    const float *G = packed + kGenG, *Be = packed + kGenBe;
+    float* rstd_img = acts ? acts + 7L * 256 * ldn + 56L * ldn : nullptr;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < N; ++p) {
+        float x[256], xh[256], h[256];
+        const float* xin = points + p * 3;
+        const long shape = shape_index ? shape_index[p] : p / points_per_shape;
+        auto norm = [&](int layer) {
+            const float r = ln_relu(x, G + layer * 256, Be + layer * 256, eps, xh, h);
+            if (acts) {
+                for (int o = 0; o < 256; ++o) acts[((long)layer * 256 + o) * ldn + p] = xh[o];
+                rstd_img[(long)layer * ldn + p] = r;
+            }
+        };
+        dense(v.W1k, 3, xin, zb1 + shape * 256, x, false, false);
+        norm(0);
+        dense(v.W2, 256, h, v.b + 256, x, false, false);
+        norm(1);
+        dense(v.W3, 256, h, v.b + 512, x, false, false);
+        norm(2);
+        dense(v.W4, 256, h, v.b + 768, x, false, false);
+        norm(3);
+        dense(v.W5x, 256, h, zb5 + shape * 256, x, false, false);
+        dense(v.W5i, 3, xin, nullptr, x, false, true);
+        norm(4);
+        dense(v.W6, 256, h, v.b + 1280, x, false, false);
+        norm(5);
+        dense(v.W7, 256, h, v.b + 1536, x, false, false);
+        norm(6);
+        float s = v.b8[0];
+        for (int k = 0; k < 256; ++k) s += v.w8[k] * h[k];
+        out[p] = s;
+    }
+    return SG_OK;
+}
+int sg_sdfgen_bwd_cpu(const float* dout, const float* acts, float* dz, float* dz8, float* partials, const float* points,
+                      const float* packed, long ldn, long N, void*) {
+    CPU_CHECK(dout && acts && dz && dz8 && partials && points && packed && N > 0 && ldn >= N);
+    const CpuSdf v = sdf_view(packed, 3);
+    const float *G = packed + kGenG, *Be = packed + kGenBe;
+    const float* Wt[7] = {nullptr, v.W2, v.W3, v.W4, v.W5x, v.W6, v.W7};
+    const float* rstd_img = acts + 7L * 256 * ldn + 56L * ldn;
+    const long nblk = (N + 31) / 32;
+#pragma omp parallel for schedule(static)
+    for (long t = 0; t < nblk; ++t) {
+        std::vector<double> acc(28 * 256, 0.0);      // the tile's partial row (blocks 0..13, then the 14 LayerNorm blocks)
+        double s8 = 0;
+        const long p0 = t * 32, p1 = p0 + 32 < N ? p0 + 32 : N;
+        for (long p = p0; p < p1; ++p) {
+            float g[256], gn[256];
+            const float d8 = dout[p];
+            dz8[p] = d8;
+            s8 += d8;
+            // dH of image `layer` in g -> dZ (through ReLU and LayerNorm), stored; the LayerNorm parameter sums
+            auto through_norm = [&](int layer) {
+                const float *gm = G + layer * 256, *bt = Be + layer * 256;
+                const float rs = rstd_img[(long)layer * ldn + p];
+                double m1 = 0, m2 = 0;
+                float dyh[256];
+                for (int r = 0; r < 256; ++r) {
+                    const float xh = acts[((long)layer * 256 + r) * ldn + p];
+                    const float dy = gm[r] * xh + bt[r] > 0.f ? g[r] : 0.f;
+                    acc[(14 + layer) * 256 + r] += (double)dy * xh;
+                    acc[(21 + layer) * 256 + r] += dy;
+                    dyh[r] = dy * gm[r];
+                    m1 += dyh[r];
+                    m2 += (double)dyh[r] * xh;
+                }
+                m1 /= 256;
+                m2 /= 256;
+                for (int r = 0; r < 256; ++r) {
+                    const float xh = acts[((long)layer * 256 + r) * ldn + p];
+                    g[r] = (float)(rs * ((double)dyh[r] - m1 - (double)xh * m2));
+                    dz[((long)layer * 256 + r) * ldn + p] = g[r];
+                    acc[layer * 256 + r] += g[r];
+                }
+            };
+            for (int r = 0; r < 256; ++r) {
+                const float xh = acts[(6L * 256 + r) * ldn + p];
+                const float y = G[6 * 256 + r] * xh + Be[6 * 256 + r];
+                acc[7 * 256 + r] += (double)d8 * (y > 0.f ? y : 0.f);      // w8 gradient: sum_p dz8 H7
+                g[r] = v.w8[r] * d8;
+            }
+            through_norm(6);
+            for (int layer = 5; layer >= 0; --layer) {
+                dense_t(Wt[layer + 1], 256, g, gn, false);
+                if (layer == 3)
+                    for (int c = 0; c < 3; ++c)
+                        for (int r = 0; r < 256; ++r) acc[(11 + c) * 256 + r] += (double)g[r] * points[p * 3 + c];   // g = dZ5
+                memcpy(g, gn, sizeof(g));
+                through_norm(layer);
+            }
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 256; ++r) acc[(8 + c) * 256 + r] += (double)g[r] * points[p * 3 + c];           // g = dZ1
+        }
+        float* prow = partials + t * SG_SDFGEN_PARTIAL_ROW;
+        for (int e = 0; e < 14 * 256; ++e) prow[e] = (float)acc[e];
+        prow[14 * 256] = (float)s8;
+        for (int e = 0; e < 14 * 256; ++e) prow[SG_SDFNET_PARTIAL_ROW + e] = (float)acc[14 * 256 + e];
+    }
+    return SG_OK;
+}
+int sg_sdfgen_bwd_finish_cpu(const float* dz, const float* partials, long ldn, long N, float* const* bias_grads, float* w8_grad,
+                             float* b8_grad, float* w1_cols, long w1_ld, float* w5_cols, long w5_ld, float* const* norm_grads,
+                             const int64_t* seg_off, long nseg, float* t1, float* t5, void*, size_t, unsigned*, void*) {
+    CPU_CHECK(dz && partials && N > 0 && ldn >= N && nseg >= 0 && bias_grads && norm_grads && w8_grad && b8_grad && w1_cols && w5_cols);
+    CPU_CHECK(nseg == 0 || (seg_off && t1 && t5));
+    const long nblk = (N + 31) / 32;
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < 28L * 256; ++e) {
+        const long g = e / 256, row = e % 256;
+        const long src = g < 14 ? e : SG_SDFNET_PARTIAL_ROW + (e - 14 * 256);
+        double s = 0;
+        for (long t = 0; t < nblk; ++t) s += partials[t * SG_SDFGEN_PARTIAL_ROW + src];
+        if (g < 7)
+            bias_grads[g][row] = (float)s;
+        else if (g == 7)
+            w8_grad[row] = (float)s;
+        else if (g < 11)
+            w1_cols[row * w1_ld + (g - 8)] = (float)s;
+        else if (g < 14)
+            w5_cols[row * w5_ld + (g - 11)] = (float)s;
+        else
+            norm_grads[g - 14][row] = (float)s;
+    }
+    double s8 = 0;
+    for (long t = 0; t < nblk; ++t) s8 += partials[t * SG_SDFGEN_PARTIAL_ROW + 14 * 256];
+    b8_grad[0] = (float)s8;
 #pragma omp parallel for schedule(static)
     for (long pair = 0; pair < 256 * nseg; ++pair) {
         const long row = pair / nseg, sgm = pair % nseg;

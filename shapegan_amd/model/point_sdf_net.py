@@ -41,12 +41,43 @@ def _run_mlp(seq, x):
 
 class PointNet(nn.Module):
     """point_sdf_net.py:11-47: per-point MLP 4 -> 64 -> 128 -> 256 -> 512, max over the points of a shape, MLP
-    512 -> 256 -> 128 -> out_channels."""
+    512 -> 256 -> 128 -> out_channels.
+
+    The adjoint of the max is sparse: of a shape's P points only the (at most 512) that hold a channel's maximum pass a
+    gradient — to the parameters of nn1, to the input (the gradient penalty of train_point_gan.py:61-70 differentiates with
+    respect to the distance channel) and in the double backward.  For large clouds the forward therefore runs nn1 twice: once
+    over all points WITHOUT recording anything (only the argmax indices are kept: no activation is saved, no dense backward
+    ever runs), and once, recorded, over the 512 selected points of every shape, whose c-th row's c-th output IS the maximum of
+    channel c.  Same function, same (sub)gradient as `x.max(dim=-2)[0]` (autograd routes the gradient to the argmax row
+    as well), closed under double backward because it is made of the same Linear / ReLU operators on a gathered batch; the cost
+    of everything behind the plain forward drops by P / 512."""
+
+    SPARSE_MIN_POINTS = 1024       # below: the selected rows would be more than half of the cloud
 
     def __init__(self, out_channels):
         super(PointNet, self).__init__()
         self.nn1 = _mlp([4, 64, 128, 256, 512])
         self.nn2 = _mlp([512, 256, 128, out_channels])
+
+    def selected_points(self, x):
+        """x [B,P,4] -> [B,512] int64: for every channel of nn1 the point of the shape that holds its maximum (nothing recorded)."""
+        B, P = x.shape[0], x.shape[1]
+        with torch.no_grad():
+            h = _run_mlp(self.nn1, x.reshape(-1, 4))
+            return ops.SegMax.apply(h.reshape(B, P, h.shape[-1]))[1].long()
+
+    def forward_selected(self, xs):
+        """xs [B,512,4], row c = the point that holds the maximum of channel c: nn2(max over the cloud of nn1), recorded."""
+        B, C = xs.shape[0], xs.shape[1]
+        hs = _run_mlp(self.nn1, xs.reshape(-1, 4))
+        return _run_mlp(self.nn2, hs.reshape(B, C, C).diagonal(dim1=1, dim2=2))
+
+    @staticmethod
+    def gather_points(x, idx):
+        """Rows idx [B,C] of x [B,P,K] -> [B,C,K] (differentiable: the backward is the sparse scatter-add)."""
+        B, P = x.shape[0], x.shape[1]
+        rows = (idx + torch.arange(B, device=x.device).unsqueeze(1) * P).reshape(-1)
+        return x.reshape(B * P, -1).index_select(0, rows).reshape(B, idx.shape[1], -1)
 
     def forward(self, pos, dist, batch=None):
         dist = dist.unsqueeze(-1) if dist.size(-1) != 1 else dist
@@ -57,6 +88,11 @@ class PointNet(nn.Module):
             h = ops.scatter_max(h, batch.reshape(-1))           # [B,512], torch_scatter.scatter_max(...)[0]  (:42)
             return _run_mlp(self.nn2, h)
         lead, P = x.shape[:-2], x.shape[-2]
+        if P >= self.SPARSE_MIN_POINTS and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.nn1.parameters())):
+            x3 = x.reshape(-1, P, 4)
+            out = self.forward_selected(self.gather_points(x3, self.selected_points(x3)))
+            return out.reshape(tuple(lead) + (out.shape[-1],))
         h = _run_mlp(self.nn1, x.reshape(-1, 4))
         h = ops.segmax(h.reshape(-1, P, h.shape[-1]))           # [B,512]
         out = _run_mlp(self.nn2, h)
@@ -92,8 +128,8 @@ class SDFGenerator(nn.Module):
         self._pack = ops._GenPackCache()
 
     def _fused(self, pos):
-        """The one-launch form covers the script's configuration on the GPU; every other one runs layer by layer."""
-        return (pos.is_cuda and self.hidden_channels == 256 and self.num_layers == 8
+        """The one-launch form covers the script's configuration; every other one runs layer by layer."""
+        return (self.hidden_channels == 256 and self.num_layers == 8
                 and all(n.elementwise_affine and n.eps == self.norms[0].eps for n in self.norms))
 
     def forward(self, pos, z):

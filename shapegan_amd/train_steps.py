@@ -580,12 +580,26 @@ class PointGANTrainer(object):
         return d_loss.detach(), gp.detach()
 
     def generator_step(self, uniform, z):
-        """:76-83."""
+        """:76-83.  For large clouds the update is evaluated on the points that matter: the critic sees the generated cloud
+        through a max over its points, so only the (at most 512) points of a shape that hold a channel's maximum pass a gradient
+        back — and both networks treat points independently.  One plain evaluation of generator and per-point critic over all
+        points (nothing recorded) finds those points; the recorded evaluation, its backward and the parameter gradients then run
+        on 512 points per shape instead of P.  Loss and gradients are those of the dense evaluation (the points left out
+        contribute exact zeros)."""
         pos = uniform[..., :3]
         self.g_opt.zero_grad()
-        fake = self.generator(pos, z)
-        with frozen(self.critic):
-            out = self.critic(pos, fake)
+        if pos.shape[-2] >= self.critic.SPARSE_MIN_POINTS:
+            with torch.no_grad():
+                fake = self.generator(pos, z)
+                idx = self.critic.selected_points(torch.cat([pos, fake], dim=-1))
+            pos_s = self.critic.gather_points(pos, idx)                           # [B,512,3]
+            fake_s = self.generator(pos_s, z)
+            with frozen(self.critic):
+                out = self.critic.forward_selected(torch.cat([pos_s, fake_s], dim=-1))
+        else:
+            fake = self.generator(pos, z)
+            with frozen(self.critic):
+                out = self.critic(pos, fake)
         loss = ops.neg_mean(out)
         self.g_bucket.arm()
         lib.backward(loss)

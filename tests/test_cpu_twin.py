@@ -44,6 +44,7 @@ def test_twin_exports_every_entry_point():
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
             "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
+            "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks",
             "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
             "sg_conv3d_k4s2p1_image_layout")
 
@@ -200,6 +201,18 @@ def test_training_trajectories(on_cpu, golden_steps, monkeypatch):
     M.test_autoencoder_trajectory(golden_steps)
     M.test_sdf_autodecoder_trajectory(golden_steps)
     M.test_hybrid_wgan_trajectory(golden_steps)
+
+
+def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
+    """SURVEY.md 8f rank 4 on the twin: SDFGenerator(128, 256, 8) runs the LayerNorm form of the fused MLP entry points
+    (sg_sdfgen_pack / _fwd / _bwd / _bwd_finish, sg_gemm_nt_batched_lnrelu) — against the reference-made fixtures, the oracles and
+    the module's own layer-by-layer path."""
+    assert L.load().sg_sdfgen_packed_norm_offset(0) == 809216 and L.load().sg_sdfgen_packed_norm_offset(1) == 811008   # (the twin's copy)
+    M.test_point_gan_modules(golden_steps_f4)
+    M.test_point_gan_trajectory(golden_steps_f4)
+    M.test_sdf_generator_fused_vs_layerwise_and_oracle()
+    M.test_gemm_nt_lnrelu_matches_torch()
+    M.test_point_gan_sparse_max_adjoint_matches_dense_and_oracle()
 
 
 def test_two_threads_drive_two_modules_concurrently(on_cpu):

@@ -664,6 +664,64 @@ def test_point_gan_modules(golden_steps_f4):
         assert_summary_close(p.grad, grads[k], 1e-3, 1e-7, "PointNet grad vs fixture " + k)
 
 
+def test_sdf_generator_fused_vs_layerwise_and_oracle():
+    """SDFGenerator(128, 256, 8): the one-launch LayerNorm form of the fused MLP kernels (ops.sdfgen_fused: 64- and 32-point forward
+    tiles, 32-point backward tiles, uniform shapes of 1 152 points = 9 x 128) against the layer-by-layer path of the same module
+    (GEMM + LayerNorm kernels) and the fp32 / fp64 oracles of point_sdf_net.py:89-119 — output and every parameter gradient,
+    including non-trivial LayerNorm weights / biases."""
+    from shapegan_amd.model.point_sdf_net import SDFGenerator
+    torch.manual_seed(91)
+    G = SDFGenerator(128, 256, 8, True, dropout=0.0)
+    with torch.no_grad():
+        for n in G.norms:
+            n.weight.uniform_(0.5, 1.5)
+            n.bias.uniform_(-0.3, 0.3)
+    g0 = _cpu_state(G)
+    G = G.to(DEV)
+    B, P = 3, 1152
+    pos, z, w = torch.rand(B, P, 3) * 2 - 1, torch.randn(B, 128), torch.randn(B, P, 1)
+    out = G(pos.to(DEV), z.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    fused = {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None}
+    G.zero_grad()
+    G._fused = lambda pos: False                      # the same module, layer by layer
+    out_l = G(pos.to(DEV), z.to(DEV))
+    (out_l * w.to(DEV)).sum().backward()
+    close(out, out_l, rtol=1e-4, atol=1e-5, what="fused SDFGenerator vs layer-by-layer")
+    P64 = O.clone_state({k: v.double() for k, v in g0.items()})
+    o64 = O.sdf_generator_forward(P64, pos.double(), z.double())
+    (o64 * w.double()).sum().backward()
+    P32 = O.clone_state(g0)
+    (O.sdf_generator_forward(P32, pos, z) * w).sum().backward()
+    close(out, o64.float(), rtol=1e-4, atol=1e-5, what="fused SDFGenerator vs fp64 oracle")
+    for k, p in G.named_parameters():
+        if k.startswith("norms.7"):                    # LayerNorm(1) behind the last layer: never used (point_sdf_net.py:71,113)
+            assert k not in fused and p.grad is None
+            continue
+        check_against_oracles(fused[k], P32[k].grad, P64[k].grad, "fused SDFGenerator grad " + k, rtol=2e-4, noise_factor=8.0)
+        check_against_oracles(p.grad, P32[k].grad, P64[k].grad, "layerwise SDFGenerator grad " + k, rtol=2e-4, noise_factor=8.0)
+
+
+def test_gemm_nt_lnrelu_matches_torch():
+    """sg_gemm_nt_batched_lnrelu: C_b = A_b relu(gamma_b (.) B_b + beta_b)^T over a long K with a ragged tail, two batch members."""
+    from shapegan_amd import ops
+    from shapegan_amd.lib import ptr, check, stream, workspace
+    import ctypes
+    torch.manual_seed(92)
+    K, H = 4133, 256
+    a = torch.randn(2, H, K, device=DEV)
+    b = torch.randn(2, H, K, device=DEV)
+    gam, bet = torch.rand(2, H, device=DEV) + 0.5, torch.randn(2, H, device=DEV) * 0.3
+    out = torch.empty(2, H, H, device=DEV)
+    lib = ops._lib()
+    arr = ctypes.c_long * 2
+    ws = workspace("gemm_nt", lib.sg_gemm_nt_batched_workspace_bytes(2, H, H, K), a.device)
+    check(lib.sg_gemm_nt_batched_lnrelu(ptr(a), arr(0, H * K), K, ptr(b), arr(0, H * K), K, ptr(gam), ptr(bet), arr(0, H), ptr(out),
+                                        arr(0, H * H), arr(H, H), 2, H, H, K, ptr(ws), ws.numel(), stream()), "gemm_nt_batched_lnrelu")
+    want = torch.einsum("bik,bjk->bij", a.double().cpu(), torch.relu(gam[:, :, None] * b + bet[:, :, None]).double().cpu())
+    close(out, want.float(), rtol=1e-4, atol=1e-3, what="gemm_nt_batched_lnrelu")
+
+
 def test_point_gan_trajectory(golden_steps_f4):
     """train_point_gan.py:52-83: critic update with the gradient penalty on the distance channel (double backward through
     the max over points), then a generator update."""
@@ -686,6 +744,50 @@ def test_point_gan_trajectory(golden_steps_f4):
     np.testing.assert_allclose([dl.item(), gp.item(), gl.item()], gd["step/losses"], rtol=2e-4, atol=1e-6)
     _check_updates(d, d0, o32.D, o64.D, "point gan critic", gd, "step/d_final")
     _check_updates(g, g0, o32.G, o64.G, "point gan generator", gd, "step/g_final")
+
+
+def test_point_gan_sparse_max_adjoint_matches_dense_and_oracle():
+    """Clouds of >= PointNet.SPARSE_MIN_POINTS points: the critic update (with the gradient penalty's double backward) and the
+    generator update evaluated on the points that hold a channel's maximum (model/point_sdf_net.py PointNet, PointGANTrainer.
+    generator_step) against the same trainers forced onto the dense path and against the fp32 / fp64 oracles of
+    train_point_gan.py:52-83 — losses and every parameter gradient."""
+    import copy
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    torch.manual_seed(93)
+    g, d = SDFGenerator(128, 256, 8, True, dropout=0.0), PointNet(out_channels=1)
+    g0, d0 = _cpu_state(g), _cpu_state(d)
+    B, P = 2, 1280
+    assert P >= PointNet.SPARSE_MIN_POINTS
+    uniform = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1)
+    z1, z2, alpha = torch.randn(B, 128), torch.randn(B, 128), torch.rand(B, 1, 1)
+    runs = {}
+    for name in ("sparse", "dense"):
+        gg, dd = copy.deepcopy(g).to(DEV), copy.deepcopy(d).to(DEV)
+        if name == "dense":
+            dd.SPARSE_MIN_POINTS = 10 ** 9
+        tr = PointGANTrainer(gg, dd)
+        dl, gp = tr.critic_step(uniform.to(DEV), z1.to(DEV), alpha.to(DEV))
+        dgr = {k: p.grad.detach().clone() for k, p in dd.named_parameters()}
+        gl = tr.generator_step(uniform.to(DEV), z2.to(DEV))
+        ggr = {k: p.grad.detach().clone() for k, p in gg.named_parameters() if p.grad is not None}
+        runs[name] = ([dl.item(), gp.item(), gl.item()], dgr, ggr)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        o = O.PointGANOracle({k: v.to(dt) for k, v in g0.items()}, {k: v.to(dt) for k, v in d0.items()})
+        dl, gp = o.critic_step(uniform.to(dt), z1.to(dt), alpha.to(dt))
+        dgr = {k: v.grad.detach().clone() for k, v in o.D.items()}
+        gl = o.generator_step(uniform.to(dt), z2.to(dt))
+        ggr = {k: v.grad.detach().clone() for k, v in o.G.items() if v.grad is not None}
+        ref[dt] = ([dl.item(), gp.item(), gl.item()], dgr, ggr)
+    for name in ("sparse", "dense"):
+        np.testing.assert_allclose(runs[name][0], ref[torch.float64][0], rtol=2e-4, atol=1e-6, err_msg=name)
+        for which, what in ((1, "critic"), (2, "generator")):
+            for k, got in runs[name][which].items():
+                if k.startswith("norms.7"):
+                    continue
+                check_against_oracles(got, ref[torch.float32][which][k], ref[torch.float64][which][k],
+                                      "%s path, %s grad %s" % (name, what, k), rtol=2e-4, noise_factor=8.0)
 
 
 def test_dp_shards_sum_to_full_batch_gradient():

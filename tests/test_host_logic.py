@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         home = comm if name in L.COMM_SIGNATURES else lib       # the RCCL exchange lives in libshapegan_comm.so
         assert hasattr(home, name), "missing export: " + name
     assert declared == set(L.SIGNATURES) | set(L.COMM_SIGNATURES), (declared ^ (set(L.SIGNATURES) | set(L.COMM_SIGNATURES)))
-    assert L.load().sg_abi_version() == 7
+    assert L.load().sg_abi_version() == 8
     assert L.load_comm().sg_allreduce_unique_id_bytes() == 128
 
 
