@@ -484,6 +484,16 @@ int sg_layernorm_bwd(const float* x, long ldx, const float* rowbias, long rows_p
 size_t sg_colsum_tall_workspace_bytes(long batch, long rows, int cols);
 int sg_colsum_tall(const float* x, float* out, long batch, long batch_stride, long rows, int cols, long ld, void* workspace,
                    size_t workspace_bytes, hipStream_t stream);
+/* PointNet.nn1 (Linear 4 -> 64 -> 128 -> 256 -> 512, ReLU between; model/point_sdf_net.py:14-23) over whole clouds followed by the
+ * max over each cloud's points (:40) as ONE fused launch that never writes the per-point layers (ABI 8): out [B][512] = the maxima,
+ * idx [B][512] = the point of the cloud that holds each (int32; lowest point on a tie; NaN is ignored by the maximum).  x [B][P][4],
+ * P a multiple of 32; `packed`: sg_pointnet_packed_floats() floats from sg_pointnet_pack(nn1.{0,2,4,6}.weight); biases:
+ * nn1.{0,2,4,6}.bias.  The plain pass of the sparse-adjoint critic: the recorded evaluation runs on the selected points only. */
+size_t sg_pointnet_packed_floats(void);
+int sg_pointnet_pack(const float* const* weights, float* packed, hipStream_t stream);
+size_t sg_pointnet_select_workspace_bytes(long B, long P);
+int sg_pointnet_select(const float* x, const float* packed, const float* const* biases, long B, long P, float* out, int* idx,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t sg_segmax_workspace_bytes(long B, long P, int C);   /* scratch of sg_segmax_fwd (0 when it needs none) */
 int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, void* workspace, size_t workspace_bytes,
                   hipStream_t stream);

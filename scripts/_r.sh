@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python -m pytest tests/test_gpu_modules.py -x -q -k "point_gan or sdf_generator or lnrelu" 2>&1 | tail -15
+python -m pytest tests/test_gpu_modules.py -x -q -k "point or sdf_generator or lnrelu" 2>&1 | tail -15
 python scripts/point_gan_bench.py
 for w in critic generator; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/f4prof_$w -o f4 -- python scripts/point_gan_prof.py $w > gpurun_out/f4prof_$w.log 2>&1

@@ -457,20 +457,50 @@ __global__ void __launch_bounds__(256) segmax_part_kernel(const float* __restric
         *reinterpret_cast<int4*>(pi + o) = make_int4(bp[0], bp[1], bp[2], bp[3]);
     }
 }
+// (block = 64 channels x 4 chunk phases, four partials of a phase in flight: a cloud of 16 384 points arrives as 512 partials per
+//  channel — one thread walking them one dependent load at a time took 260 us for 36 x 512 channels.  (value, point) pairs are
+//  totally ordered by seg_beats, so the order in which partials are combined does not change the result.)
 __global__ void __launch_bounds__(256) segmax_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
                                                            float* __restrict__ out, int* __restrict__ idx, int nchunk, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sv[4][64];
+    __shared__ int sp[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const long b = blockIdx.y;
-    if (c >= C) return;
     float v = -INFINITY;
     int p = kSegNone;
-    for (int k = 0; k < nchunk; ++k) {
-        const float u = pv[(b * nchunk + k) * C + c];
-        const int q = pi[(b * nchunk + k) * C + c];
-        if (seg_beats(u, q, v, p)) v = u, p = q;
+    if (c < C) {
+        const float* v0 = pv + b * nchunk * C + c;
+        const int* p0 = pi + b * nchunk * C + c;
+        int k = ph;
+        for (; k + 12 < nchunk; k += 16) {
+            float u[4];
+            int q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[j] = v0[(long)(k + 4 * j) * C];
+                q[j] = p0[(long)(k + 4 * j) * C];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (seg_beats(u[j], q[j], v, p)) v = u[j], p = q[j];
+        }
+        for (; k < nchunk; k += 4) {
+            const float u = v0[(long)k * C];
+            const int q = p0[(long)k * C];
+            if (seg_beats(u, q, v, p)) v = u, p = q;
+        }
     }
-    out[b * C + c] = v;
-    idx[b * C + c] = p;
+    sv[ph][cl] = v;
+    sp[ph][cl] = p;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (seg_beats(sv[w][cl], sp[w][cl], v, p)) v = sv[w][cl], p = sp[w][cl];
+        out[b * C + c] = v;
+        idx[b * C + c] = p;
+    }
 }
 
 // dx[b][p][c] = (p == idx[b][c]) ? dy[b][c] : 0   (adjoint of the max; every element written)
@@ -619,9 +649,18 @@ int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, v
         int* pi = (int*)(pv + (size_t)B * nchunk * C);
         hipLaunchKernelGGL(segmax_part_kernel, dim3(sg_cdiv(C, 256), nchunk, (unsigned)B), dim3(256), 0, stream, x, pv, pi, P, C,
                            nchunk);
-        hipLaunchKernelGGL(segmax_merge_kernel, dim3(sg_cdiv(C, 256), (unsigned)B), dim3(256), 0, stream, pv, pi, out, idx, nchunk,
+        hipLaunchKernelGGL(segmax_merge_kernel, dim3(sg_cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, pv, pi, out, idx, nchunk,
                            C);
     }
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// the second level of sg_segmax_fwd on its own: out / idx [B][C] from nchunk partial (value, point) pairs per cloud and channel,
+// pv / pi [(b * nchunk + k) * C + c] (internal: the tiles of sg_pointnet_select)
+int sg_segmax_merge_partials(const float* pv, const int* pi, float* out, int* idx, long B, int nchunk, int C, hipStream_t stream) {
+    SG_CHECK_ARG(pv && pi && out && idx && B > 0 && nchunk > 0 && C > 0);
+    hipLaunchKernelGGL(segmax_merge_kernel, dim3(sg_cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, pv, pi, out, idx, nchunk, C);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -436,7 +436,7 @@ __device__ __forceinline__ void sdfnet_fwd_tile(const SdfFwdArgs& a, const long 
             }
         }
         __syncthreads();
-        const bool save = a.acts != nullptr;
+        const bool save = (NORM ? TRAIN : true) && a.acts != nullptr;
         if constexpr (NORM) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -602,6 +602,114 @@ __global__ void __launch_bounds__(512, 4) sdfnet_fwd_kernel(SdfFwdArgs a) {
         sdfnet_fwd_tile<P, SHAPE_BIAS, TRAIN, NORM>(a, b * P);
     else
         sdfnet_fwd_tile<kSmallTile, SHAPE_BIAS, TRAIN, NORM>(a, a.nbig * P + (b - a.nbig) * kSmallTile);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// PointNet.nn1 over a whole cloud, reduced to WHICH point holds each channel's maximum (model/point_sdf_net.py:14-23,40: Linear
+// 4 -> 64 -> 128 -> 256 -> 512 with ReLU between, `x.max(dim=-2)`): the plain pass of the sparse-adjoint critic
+// (shapegan_amd/model/point_sdf_net.py PointNet.selected_points).  One workgroup walks a tile of 32 points through the four layers
+// on the fused-MLP machinery above — activations in LDS (H1 / H3 share a buffer, H2 has its own), weights streamed from their
+// MFMA-packed L2-resident image — and never writes the 512-wide layer: a wave reduces its 32 x 32 fragment of it over the tile's
+// points (five DPP max steps per row, the point found by a ballot on equality with the maximum: lowest point wins a tie) and the
+// tile stores one (value, point) pair per channel.  Per point: 16 B in, 128 B / 32 of partials out instead of the 2 KB row of
+// the last layer plus the 1.9 KB of the three hidden ones.  sg_pointnet_select merges the tiles of a cloud (segmax_merge_kernel).
+// NaN: ignored by the maximum (a cloud whose channel is NaN everywhere selects its first point).
+struct PnSelArgs {
+    const float* x;        // [N][4]
+    const float* packed;   // W1 | W2 | W3 | W4 images
+    const float* b[4];
+    float* pv;             // [tiles][512]
+    int* pi;
+    long N, pps;           // pps: points per cloud (a multiple of 32)
+};
+constexpr long kPnW1 = 0, kPnW2 = kPnW1 + 64 * 8, kPnW3 = kPnW2 + 128 * 64, kPnW4 = kPnW3 + 256 * 128, kPnTotal = kPnW4 + 512 * 256;
+
+__global__ void __launch_bounds__(512, 4) pointnet_select_kernel(PnSelArgs a) {
+    constexpr int P = 32, LDX = P + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const A = smem;                 // [256][P]: H1 (64 rows), later H3
+    float* const Bm = A + 256 * P;         // [128][P]: H2
+    float* const Xs = Bm + 128 * P;        // [8][LDX]
+    float* const Bl = Xs + 8 * LDX;        // biases: 64 | 128 | 256 | 512
+    float* const PV = Bl + 960;            // [512]
+    int* const PI = reinterpret_cast<int*>(PV + 512);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, r = lane & 31;
+    const long p0 = (long)blockIdx.x * P;
+    if (tid < 4 * P) {
+        const int pp = tid >> 2, c = tid & 3;
+        Xs[c * LDX + pp] = p0 + pp < a.N ? a.x[(p0 + pp) * 4 + c] : 0.f;
+    } else if (tid < 8 * P) {
+        const int e = tid - 4 * P;
+        Xs[(4 + (e >> 5)) * LDX + (e & 31)] = 0.f;
+    }
+    for (int e = tid; e < 960; e += 512) Bl[e] = e < 64 ? a.b[0][e] : e < 192 ? a.b[1][e - 64] : e < 448 ? a.b[2][e - 192] : a.b[3][e - 448];
+    __syncthreads();
+    const float4* pk = reinterpret_cast<const float4*>(a.packed);
+    f32x16 acc[1];
+    auto init = [&](int boff, int row0) __attribute__((always_inline)) {
+        const lds_float* b = (const lds_float*)Bl + boff + row0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] = b[frag_row(q, kh)];
+    };
+    auto relu_to = [&](float* H, int row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) H[(row0 + frag_row(q, kh)) * P + r] = fmaxf(acc[0][q], 0.f);
+    };
+    if (wave < 2) {       // 4 -> 64
+        init(0, wave * 32);
+        mlp_gemm<1>(acc, pk + (kPnW1 >> 2) + (long)wave * 1 * 64, 1, Xs, LDX, lane);
+        relu_to(A, wave * 32);
+    }
+    __syncthreads();
+    if (wave < 4) {       // 64 -> 128
+        init(64, wave * 32);
+        mlp_gemm<1>(acc, pk + (kPnW2 >> 2) + (long)wave * 8 * 64, 8, A, P, lane);
+        relu_to(Bm, wave * 32);
+    }
+    __syncthreads();
+    init(192, wave * 32);   // 128 -> 256
+    mlp_gemm<1>(acc, pk + (kPnW3 >> 2) + (long)wave * 16 * 64, 16, Bm, P, lane);
+    relu_to(A, wave * 32);
+    __syncthreads();
+    auto dpp_max = [&](float v, auto ctrl, auto rowmask) __attribute__((always_inline)) {
+        return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000u, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                             decltype(rowmask)::value, 0xf, false)));
+    };
+    const bool pok = p0 + r < a.N;
+    const int plocal = (int)(p0 % a.pps);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {    // 256 -> 512, no activation behind it (point_sdf_net.py:22)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] = 0.f;
+        const int t = pass * 8 + wave;
+        mlp_gemm<1>(acc, pk + (kPnW4 >> 2) + (long)t * 32 * 64, 32, A, P, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float v = pok ? acc[0][q] : -INFINITY;
+            float m = dpp_max(v, IntTag<0xB1>(), IntTag<0xf>());
+            m = dpp_max(m, IntTag<0x4E>(), IntTag<0xf>());
+            m = dpp_max(m, IntTag<0x141>(), IntTag<0xf>());
+            m = dpp_max(m, IntTag<0x140>(), IntTag<0xf>());
+            m = dpp_max(m, IntTag<0x142>(), IntTag<0xa>());
+            const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31));
+            const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
+            const unsigned long long eq = __ballot(v == (kh ? m1 : m0));
+            const unsigned lo = (unsigned)eq, hi = (unsigned)(eq >> 32);
+            if (lane == 0) {
+                const int c0 = t * 32 + frag_row(q, 0), c1 = t * 32 + frag_row(q, 1);
+                // (the bias is the same for every point of a channel: added behind the maximum — rounding is monotonic, the value
+                //  equals max(x + b) and the selected point is unchanged)
+                PV[c0] = m0 + Bl[448 + c0];
+                PI[c0] = plocal + (lo ? __builtin_ctz(lo) : 0);
+                PV[c1] = m1 + Bl[448 + c1];
+                PI[c1] = plocal + (hi ? __builtin_ctz(hi) : 0);
+            }
+        }
+    }
+    __syncthreads();
+    a.pv[(long)blockIdx.x * 512 + tid] = PV[tid];
+    a.pi[(long)blockIdx.x * 512 + tid] = PI[tid];
 }
 
 struct SdfBwdArgs {
@@ -1435,6 +1543,8 @@ static int set_lds(K kern, size_t bytes) {
 
 using namespace sg;
 
+extern "C" int sg_segmax_merge_partials(const float* pv, const int* pi, float* out, int* idx, long B, int nchunk, int C, hipStream_t stream);
+
 extern "C" {
 
 size_t sg_sdfnet_packed_floats(int kin_used) { return (size_t)make_layout(kin_used).total; }
@@ -1829,6 +1939,51 @@ int sg_sdfgen_bwd_finish(const float* dz, const float* partials, long ldn, long 
     SG_CHECK_ARG(nseg == 0 || (seg_off && t1 && t5));
     return sdf_finish("sg_sdfgen_bwd_finish", true, dz, partials, ldn, N, 1, bias_grads, w8_grad, b8_grad, w1_cols, w1_ld, w5_cols,
                       w5_ld, norm_grads, seg_off, nseg, t1, t5, workspace, workspace_bytes, tickets, stream);
+}
+
+
+// ---- PointNet.nn1 + max as one selection pass (see pointnet_select_kernel) -----------------------------------------------------
+size_t sg_pointnet_packed_floats(void) { return (size_t)kPnTotal; }
+
+// params: nn1.{0,2,4,6}.weight ([64,4], [128,64], [256,128], [512,256])
+int sg_pointnet_pack(const float* const* weights, float* packed, hipStream_t stream) {
+    SG_CHECK_ARG(weights && packed && weights[0] && weights[1] && weights[2] && weights[3]);
+    PackDescs D;
+    D.d[0] = PackDesc{weights[0], 4, 1, 64, 4, 2, 1, kPnW1};
+    D.d[1] = PackDesc{weights[1], 64, 1, 128, 64, 4, 8, kPnW2};
+    D.d[2] = PackDesc{weights[2], 128, 1, 256, 128, 8, 16, kPnW3};
+    D.d[3] = PackDesc{weights[3], 256, 1, 512, 256, 16, 32, kPnW4};
+    D.n = 4;
+    D.v.g[0] = nullptr;
+    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, 4), dim3(256), 0, stream, D, packed);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+size_t sg_pointnet_select_workspace_bytes(long B, long P) { return (size_t)B * ((P + 31) / 32) * 512 * 8; }
+
+// x [B][P][4] (P a multiple of 32) -> out [B][512] = max over the cloud of nn1(x), idx [B][512] = the point that holds it
+// (int32, lowest point on a tie); biases: nn1.{0,2,4,6}.bias.
+int sg_pointnet_select(const float* x, const float* packed, const float* const* biases, long B, long P, float* out, int* idx,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SG_CHECK_ARG(x && packed && biases && out && idx && B > 0 && P > 0 && P % 32 == 0 && B * P < (1L << 31));
+    for (int i = 0; i < 4; ++i) SG_CHECK_ARG(biases[i] != nullptr);
+    if (!workspace || workspace_bytes < sg_pointnet_select_workspace_bytes(B, P) || ((uintptr_t)workspace & 15) != 0)
+        SG_FAIL(SG_ERR_WORKSPACE, "sg_pointnet_select: workspace too small or not 16-byte aligned");
+    const long tiles = B * (P / 32);
+    PnSelArgs a;
+    a.x = x;
+    a.packed = packed;
+    for (int i = 0; i < 4; ++i) a.b[i] = biases[i];
+    a.pv = static_cast<float*>(workspace);
+    a.pi = reinterpret_cast<int*>(a.pv + tiles * 512);
+    a.N = B * P;
+    a.pps = P;
+    const size_t lds = ((size_t)256 * 32 + 128 * 32 + 8 * 33 + 960 + 1024) * sizeof(float);
+    if (set_lds(pointnet_select_kernel, lds)) SG_FAIL(SG_ERR_HIP, "sg_pointnet_select: cannot reserve %zu B LDS", lds);
+    hipLaunchKernelGGL(pointnet_select_kernel, dim3((unsigned)tiles), dim3(512), lds, stream, a);
+    SG_CHECK_LAUNCH();
+    return sg_segmax_merge_partials(a.pv, a.pi, out, idx, B, (int)(P / 32), 512, stream);
 }
 
 }  // extern "C"

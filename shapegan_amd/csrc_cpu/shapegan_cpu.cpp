@@ -1020,6 +1020,52 @@ int sg_sdfgen_bwd_finish_cpu(const float* dz, const float* partials, long ldn, l
     return SG_OK;
 }
 
+// ---- PointNet.nn1 + max as a selection pass (header: sg_pointnet_pack / sg_pointnet_select) -----------------------------------------
+// packed buffer of this twin: the four weight matrices row-major, one after the other
+int sg_pointnet_pack_cpu(const float* const* weights, float* packed, void*) {
+    CPU_CHECK(weights && packed && weights[0] && weights[1] && weights[2] && weights[3]);
+    const long n[4] = {64 * 4, 128 * 64, 256 * 128, 512 * 256};
+    float* p = packed;
+    for (int i = 0; i < 4; ++i, p += n[i - 1]) memcpy(p, weights[i], sizeof(float) * n[i]);
+    return SG_OK;
+}
+int sg_pointnet_select_cpu(const float* x, const float* packed, const float* const* biases, long B, long P, float* out, int* idx,
+                           void*, size_t, void*) {
+    CPU_CHECK(x && packed && biases && out && idx && B > 0 && P > 0 && P % 32 == 0);
+    const float *W1 = packed, *W2 = W1 + 256, *W3 = W2 + 8192, *W4 = W3 + 32768;
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < B; ++b) {
+        std::vector<float> best(512, -INFINITY);
+        std::vector<int> bp(512, 0);
+        for (long p = 0; p < P; ++p) {
+            const float* in = x + (b * P + p) * 4;
+            float h1[64], h2[128], h3[256];
+            for (int o = 0; o < 64; ++o) {
+                float s = biases[0][o];
+                for (int k = 0; k < 4; ++k) s += W1[o * 4 + k] * in[k];
+                h1[o] = s > 0.f ? s : 0.f;
+            }
+            for (int o = 0; o < 128; ++o) {
+                float s = biases[1][o];
+                for (int k = 0; k < 64; ++k) s += W2[o * 64 + k] * h1[k];
+                h2[o] = s > 0.f ? s : 0.f;
+            }
+            for (int o = 0; o < 256; ++o) {
+                float s = biases[2][o];
+                for (int k = 0; k < 128; ++k) s += W3[o * 128 + k] * h2[k];
+                h3[o] = s > 0.f ? s : 0.f;
+            }
+            for (int o = 0; o < 512; ++o) {
+                float s = biases[3][o];
+                for (int k = 0; k < 256; ++k) s += W4[o * 256 + k] * h3[k];
+                if (s > best[o]) best[o] = s, bp[o] = (int)p;
+            }
+        }
+        for (int o = 0; o < 512; ++o) out[b * 512 + o] = best[o], idx[b * 512 + o] = bp[o];
+    }
+    return SG_OK;
+}
+
 // ---- K8 - K11: elementwise, reductions, table rows, optimizers ---------------------------------------------------------------
 int sg_axpby_cpu(const float* x, const float* y, float* out, long n, float a, float b, void*) {
     CPU_CHECK(x && out && n > 0);

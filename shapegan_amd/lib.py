@@ -108,6 +108,10 @@ SIGNATURES = {
     "sg_layernorm_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P, _Z, _P]),
     "sg_colsum_tall_workspace_bytes": (_Z, [_L, _L, _I]),
     "sg_colsum_tall": (c_int, [_P, _P, _L, _L, _L, _I, _L, _P, _Z, _P]),
+    "sg_pointnet_packed_floats": (_Z, []),
+    "sg_pointnet_pack": (c_int, [_P, _P, _P]),
+    "sg_pointnet_select_workspace_bytes": (_Z, [_L, _L]),
+    "sg_pointnet_select": (c_int, [_P, _P, _P, _L, _L, _P, _P, _P, _Z, _P]),
     "sg_segmax_workspace_bytes": (_Z, [_L, _L, _I]),
     "sg_segmax_fwd": (c_int, [_P, _P, _P, _L, _L, _I, _P, _Z, _P]),
     "sg_segmax_scatter": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
@@ -219,7 +223,7 @@ def check_comm(rc, what=""):
 # Entry points WITHOUT a twin: size queries and layout helpers are host code of libshapegan_hip.so (callable without a GPU; the
 # twin keeps its opaque buffers within those sizes), the *_impl variants force a particular HIP kernel (tests / tuning).
 NO_TWIN = {n for n in SIGNATURES if n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n.endswith("_impl")} | {
-    "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks",
+    "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks", "sg_pointnet_packed_floats",
     "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
     "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
     "sg_conv3d_k4s2p1_image_layout"}

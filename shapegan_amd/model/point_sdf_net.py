@@ -58,10 +58,15 @@ class PointNet(nn.Module):
         super(PointNet, self).__init__()
         self.nn1 = _mlp([4, 64, 128, 256, 512])
         self.nn2 = _mlp([512, 256, 128, out_channels])
+        self._pack = ops._PointPackCache()
 
     def selected_points(self, x):
-        """x [B,P,4] -> [B,512] int64: for every channel of nn1 the point of the shape that holds its maximum (nothing recorded)."""
+        """x [B,P,4] -> [B,512] int64: for every channel of nn1 the point of the shape that holds its maximum (nothing recorded).
+        Clouds of a multiple of 32 points: one fused launch that never writes the per-point layers (ops.pointnet_select)."""
         B, P = x.shape[0], x.shape[1]
+        if P % 32 == 0:
+            lins = [m for m in self.nn1 if isinstance(m, nn.Linear)]
+            return ops.pointnet_select(self._pack, x, [l.weight for l in lins], [l.bias for l in lins])[1].long()
         with torch.no_grad():
             h = _run_mlp(self.nn1, x.reshape(-1, 4))
             return ops.SegMax.apply(h.reshape(B, P, h.shape[-1]))[1].long()

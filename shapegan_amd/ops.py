@@ -1383,6 +1383,42 @@ class SDFGenFused(Function):
         return (None, None, gzb1, gzb5, None, None, None) + tuple(grads)
 
 
+class _PointPackCache(object):
+    """MFMA-fragment image of PointNet.nn1's four weight matrices, rebuilt when one of them changed (see _PackCache)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, weights):
+        dev = weights[0].device
+        ptrs = [p.data_ptr() for p in weights]
+        key = (L.param_epoch_of_ptrs(ptrs),) + tuple(ptrs) + tuple(p._version for p in weights)
+        entry = self.entries.get(dev)
+        if entry is None or entry[0] != key or not L.writers_known(*weights):
+            lib = _lib()
+            packed = torch.empty(lib.sg_pointnet_packed_floats(), dtype=torch.float32, device=dev)
+            arr = (ctypes.c_void_p * 4)(*[ptr(f32c(p.detach())) for p in weights])
+            check(lib.sg_pointnet_pack(arr, ptr(packed), stream()), "pointnet_pack")
+            entry = (key, packed)
+            self.entries[dev] = entry
+        return entry[1]
+
+
+def pointnet_select(cache, x, weights, biases):
+    """x [B,P,4] (P a multiple of 32) -> (max over the cloud of nn1(x) [B,512], the point that holds it [B,512] int32): one fused
+    launch + the merge of its tiles; nothing is recorded (model/point_sdf_net.py:14-23,40)."""
+    x = f32c(x.detach())
+    B, P = x.shape[0], x.shape[1]
+    lib = _lib()
+    packed = cache.get(weights)
+    out = torch.empty((B, 512), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, 512), dtype=torch.int32, device=x.device)
+    ws = workspace("pointnet_select", lib.sg_pointnet_select_workspace_bytes(B, P), x.device)
+    barr = (ctypes.c_void_p * 4)(*[ptr(f32c(b.detach())) for b in biases])
+    check(lib.sg_pointnet_select(ptr(x), ptr(packed), barr, B, P, ptr(out), ptr(idx), ptr(ws), ws.numel(), stream()), "pointnet_select")
+    return out, idx
+
+
 def sdfgen_fused(cache, pos, zb1, zb5, pps, eps, params):
     return SDFGenFused.apply(cache, pos, zb1, zb5, pps, eps, torch.is_grad_enabled(), *params)
 

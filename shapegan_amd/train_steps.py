@@ -563,15 +563,31 @@ class PointGANTrainer(object):
 
     def critic_step(self, uniform, z, alpha):
         """:52-74.  The reference keeps the generator graph here and discards its gradients (G_optimizer.zero_grad at
-        :77 precedes the only G_optimizer.step); they are not computed."""
+        :77 precedes the only G_optimizer.step); they are not computed.  Large clouds: the three critic evaluations (real,
+        generated, interpolated) are ONE plain pass of the per-point network over 3 B clouds that finds the points holding the
+        maxima, and one recorded pass over those 512 points per cloud (PointNet.forward_selected) — the outputs, the penalty's
+        gradient with respect to the interpolated distances and its double backward are those of three separate calls."""
         pos, dist = uniform[..., :3], uniform[..., 3:]
         self.d_opt.zero_grad()
         with torch.no_grad():
             fake = self.generator(pos, z)
-        out_real = self.critic(pos, dist)
-        out_fake = self.critic(pos, fake)
-        d_loss = ops.mean(out_fake) - ops.mean(out_real)
-        gp = self.gradient_penalty(pos, dist, fake, alpha)
+        if pos.dim() == 3 and pos.shape[-2] >= self.critic.SPARSE_MIN_POINTS:
+            B = pos.shape[0]
+            interpolated = ops.lerp_rows(dist, fake, alpha)
+            interpolated.requires_grad_(True)
+            x = torch.cat([torch.cat([pos, d], dim=-1) for d in (dist, fake, interpolated)], dim=0)      # [3B,P,4]
+            xs = self.critic.gather_points(x, self.critic.selected_points(x.detach()))
+            out = self.critic.forward_selected(xs)
+            out_real, out_fake, out_i = out[:B], out[B:2 * B], out[2 * B:]
+            d_loss = ops.mean(out_fake) - ops.mean(out_real)
+            grad = torch.autograd.grad(out_i, interpolated, grad_outputs=torch.ones_like(out_i), create_graph=True,
+                                       retain_graph=True, only_inputs=True)[0]
+            gp = ops.gradient_penalty(grad, self.gp_weight)
+        else:
+            out_real = self.critic(pos, dist)
+            out_fake = self.critic(pos, fake)
+            d_loss = ops.mean(out_fake) - ops.mean(out_real)
+            gp = self.gradient_penalty(pos, dist, fake, alpha)
         loss = d_loss + gp
         self.d_bucket.arm()
         lib.backward(loss)

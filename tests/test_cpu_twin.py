@@ -44,7 +44,7 @@ def test_twin_exports_every_entry_point():
     for n in L.NO_TWIN:
         assert n.endswith("_impl") or n.endswith("_workspace_bytes") or n.endswith("_workspace_bytes_for") or n in (
             "sg_abi_version", "sg_last_error", "sg_sdfnet_packed_floats", "sg_sdfnet_acts_floats", "sg_sdfnet_bwd_blocks", "sg_sdfnet_bwd_tile_start", "sg_sdf_batch_sort_max_shapes",
-            "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks",
+            "sg_sdfgen_acts_floats", "sg_sdfgen_packed_norm_offset", "sg_sdfgen_bwd_blocks", "sg_pointnet_packed_floats",
             "sg_conv3d_k4s2p1_wgrad_act_eligible", "sg_convT3d_k4s2p1_to1_pre_eligible", "sg_conv3d_k4s2p1_wgrad_dy_image",
             "sg_conv3d_k4s2p1_image_layout")
 
@@ -213,6 +213,7 @@ def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
     M.test_sdf_generator_fused_vs_layerwise_and_oracle()
     M.test_gemm_nt_lnrelu_matches_torch()
     M.test_point_gan_sparse_max_adjoint_matches_dense_and_oracle()
+    M.test_pointnet_select_matches_layerwise()
 
 
 def test_two_threads_drive_two_modules_concurrently(on_cpu):

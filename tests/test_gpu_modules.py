@@ -746,6 +746,28 @@ def test_point_gan_trajectory(golden_steps_f4):
     _check_updates(g, g0, o32.G, o64.G, "point gan generator", gd, "step/g_final")
 
 
+def test_pointnet_select_matches_layerwise():
+    """ops.pointnet_select (nn1 + max over the cloud in one fused launch, per-point layers never written) against the module's
+    GEMM path + torch.max: maxima, and the selected points (equal, or holding a value that ties the maximum to rounding)."""
+    from shapegan_amd import ops
+    from shapegan_amd.model.point_sdf_net import PointNet, _run_mlp
+    torch.manual_seed(94)
+    D = PointNet(out_channels=1).to(DEV)
+    B, P = 3, 1056
+    x = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).to(DEV)
+    lins = [m for m in D.nn1 if isinstance(m, torch.nn.Linear)]
+    out, idx = ops.pointnet_select(D._pack, x, [l.weight for l in lins], [l.bias for l in lins])
+    with torch.no_grad():
+        h = _run_mlp(D.nn1, x.reshape(-1, 4)).reshape(B, P, 512)
+    ref, ridx = h.max(dim=1)
+    close(out, ref, rtol=1e-5, atol=1e-6, what="pointnet_select maxima")
+    assert int(idx.min()) >= 0 and int(idx.max()) < P
+    sel = h.gather(1, idx.long().unsqueeze(1)).squeeze(1)
+    close(sel, ref, rtol=1e-5, atol=1e-6, what="value at the selected point")
+    assert float((idx.long() == ridx).float().mean()) > 0.99
+    assert torch.equal(D.selected_points(x), idx.long())
+
+
 def test_point_gan_sparse_max_adjoint_matches_dense_and_oracle():
     """Clouds of >= PointNet.SPARSE_MIN_POINTS points: the critic update (with the gradient penalty's double backward) and the
     generator update evaluated on the points that hold a channel's maximum (model/point_sdf_net.py PointNet, PointGANTrainer.
