@@ -29,7 +29,8 @@ Rank 0 prints ONE JSON line (schema in the task contract).  At N=1 with the defa
                   step (MFMA-bound ones against the fp32 MFMA peak, Cin=1 / Cout=1 edge layers against HBM),
   `sdfnet`        the SDFNet half of the metric (fused forward, both auto-decoder training configs) with algorithmic AND
                   executed FLOP rates,
-  `other_configs` BASELINE configs[2] / [3] / [4] on the same GPU (a few timed steps each: value, ms per step, the SDFNet share),
+  `other_configs` BASELINE configs[2] / [3] / [4] on the same GPU (a few timed steps each: value, ms per step, the SDFNet share)
+  and `point_gan` (critic / generator update times of train_point_gan.py at 12 x 16 384 points),
   `cpu_baseline`  the same step on the host cores — the reference's own modules where the checkout exists (`kind: "reference"`),
                   else the CPU restatement (`kind: "port"`, `reference_present: false`) — and the GPU-vs-oracle loss agreement;
                   `value` = ALL host cores, filled with concurrent 32-thread replicas of the step (one process stops scaling at
@@ -693,6 +694,37 @@ def other_configs(steps=4, warmup=3):
                      "sdfnet_executed_flop_over_step_time_frac_of_f32_mfma_peak": round(flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
         del step
     torch.cuda.empty_cache()
+    out["point_gan"] = point_gan_updates()
+    torch.cuda.empty_cache()
+    return out
+
+
+def point_gan_updates(P=16384, B=12, steps=5, warmup=3):
+    """SURVEY.md 8f rank 4 (train_point_gan.py:52-83 at its (num_points, batch) = (16 384, 12) stage): one critic update with the
+    gradient penalty and one generator update of the PointNet GAN, in time and points per second.  FLOP rates in two arithmetics:
+    the reference's dense autograd (4.58 / 3.40 MFLOP per point) and the one executed here (the max over a cloud has a sparse adjoint:
+    everything behind the plain passes runs on 512 points per cloud, shapegan_amd/model/point_sdf_net.py)."""
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    torch.manual_seed(0)
+    tr = PointGANTrainer(SDFGenerator(128, 256, 8, True).cuda(), PointNet(1).cuda())
+    u = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).cuda()
+    z, a = torch.randn(B, 128, device="cuda"), torch.rand(B, 1, 1, device="cuda")
+    out = {"workload": "train_point_gan.py WGAN-GP, SDFGenerator(128, 256, 8) vs PointNet critic, %d clouds x %d points, fp32" % (B, P)}
+    g, d, sp = 0.790e6, 0.345e6, 512.0 / P
+    for name, fn, ref, exe in (("critic_update", lambda: tr.critic_step(u, z, a), g + 11 * d, g + 3 * d + sp * 11 * d),
+                               ("generator_update", lambda: tr.generator_step(u, z), 3 * (g + d), g + d + sp * 3 * (g + d))):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name] = {"ms": round(ms, 3), "mpoints_per_s": round(B * P / ms / 1e3, 2),
+                     "reference_arithmetic_frac_of_f32_mfma_peak": round(ref * B * P / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                     "executed_arithmetic_frac_of_f32_mfma_peak": round(exe * B * P / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     return out
 
 
