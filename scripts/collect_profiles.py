@@ -12,7 +12,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
-for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wgan", "point_gan"):
+for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wgan", "point_gan", "point_gan_critic", "point_gan_generator"):
     f = os.path.join(src, "%s_%s_kernel_stats.csv" % (tag, name))
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))

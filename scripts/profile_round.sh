@@ -22,6 +22,8 @@ run_stats sdf_train python $repo/scripts/sdf_train_bench.py
 run_stats hybrid_progressive python $repo/bench.py --config hybrid_progressive --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 run_stats hybrid_wgan python $repo/bench.py --config hybrid_wgan --steps 4 --warmup 1 --no-cpu-baseline --no-extras
 run_stats point_gan python $repo/scripts/point_gan_bench.py
+run_stats point_gan_critic python $repo/scripts/point_gan_prof.py critic
+run_stats point_gan_generator python $repo/scripts/point_gan_prof.py generator
 run_pmc mfma_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python $repo/scripts/prof_targets.py mfma
 run_pmc hbm_fetch "FETCH_SIZE" python $repo/scripts/prof_targets.py hbm
 run_pmc hbm_write "WRITE_SIZE" python $repo/scripts/prof_targets.py hbm
