@@ -499,6 +499,13 @@ int sg_segmax_fwd(const float* x, float* out, int* idx, long B, long P, int C, v
                   hipStream_t stream);
 int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P, int C, hipStream_t stream);
 int sg_segmax_gather(const float* x, const int* idx, float* out, long B, long P, int C, hipStream_t stream);
+/* The diagonal last layer of the critic's selected-points pass (ABI 8): row r = b C + c of the gathered batch h [B*C][K] is the point
+ * that holds the maximum of channel c, so nn1's last Linear (model/point_sdf_net.py:22) reduces to out[r] = bias[c] + h[r] . w[c]
+ * (sg_rowdot); its adjoints out[r][k] = g[r] w[c][k] (sg_rowscale) and out[c][k] = sum_b g[b C + c] h[b C + c][k] (sg_rowouter)
+ * make the three closed under differentiation (the gradient penalty of train_point_gan.py:61-70 differentiates twice). */
+int sg_rowdot(const float* h, const float* w, const float* bias, float* out, long B, int C, int K, hipStream_t stream);
+int sg_rowscale(const float* g, const float* w, float* out, long B, int C, int K, hipStream_t stream);
+int sg_rowouter(const float* g, const float* h, float* out, long B, int C, int K, hipStream_t stream);
 /* torch_scatter.scatter_max over a ragged `batch` vector (model/point_sdf_net.py:42-43, train_point_gan_ref.py:109-110):
  * out[b][c] = max over rows i with batch[i] == b of x[i][c] (0 for a segment without members, as torch_scatter), arg = the
  * first row attaining it (-1 when empty); scatter = backward (zero-filled), gather = backward of the backward. */

@@ -503,6 +503,43 @@ __global__ void __launch_bounds__(256) segmax_merge_kernel(const float* __restri
     }
 }
 
+// ---- the selected points' last layer: only the DIAGONAL of nn1's 512-wide output is used (row c of a cloud's gathered batch is
+// the point that holds the maximum of channel c, model/point_sdf_net.py PointNet.forward_selected), so the 256 -> 512 Linear of
+// the recorded pass is a row-wise dot product with the row's own weight row instead of a [B*512, 512] GEMM of which 511/512 is
+// thrown away — and so are its backward and double backward.  Three bilinear kernels, closed under differentiation:
+//   rowdot:   out[r]    = bias[c] + sum_k h[r][k] w[c][k]            r = b C + c
+//   rowscale: out[r][k] = g[r] w[c][k]
+//   rowouter: out[c][k] = sum_b g[b C + c] h[b C + c][k]
+__global__ void __launch_bounds__(256) rowdot_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, long R, int C, int K) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63, c = (int)(r % C);
+    const float *hr = h + r * K, *wr = w + (long)c * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(hr[k], wr[k], s);
+    s = sg_wave_sum(s);
+    if (lane == 0) out[r] = s + (bias ? bias[c] : 0.f);
+}
+__global__ void __launch_bounds__(256) rowscale_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out,
+                                                       long R, int C, int K) {
+    const long total = R * K;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / K;
+        const int k = (int)(e - r * K);
+        out[e] = g[r] * w[(long)(r % C) * K + k];
+    }
+}
+__global__ void __launch_bounds__(256) rowouter_kernel(const float* __restrict__ g, const float* __restrict__ h, float* __restrict__ out,
+                                                       long B, int C, int K) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)C * K) return;
+    const int c = (int)(e / K), k = (int)(e - (long)c * K);
+    float s = 0.f;
+    for (long b = 0; b < B; ++b) s = fmaf(g[b * C + c], h[(b * C + c) * K + k], s);
+    out[e] = s;
+}
+
 // dx[b][p][c] = (p == idx[b][c]) ? dy[b][c] : 0   (adjoint of the max; every element written)
 __global__ void __launch_bounds__(256) segmax_scatter_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
                                                              float* __restrict__ dx, long B, long P, int C) {
@@ -670,6 +707,28 @@ int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P
     long blocks = (B * P * C + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(segmax_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, idx, dx, B, P, C);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// The diagonal last layer of the selected-points pass (see rowdot_kernel): h [B*C][K], w [C][K], bias [C] or NULL, g / out [B*C].
+int sg_rowdot(const float* h, const float* w, const float* bias, float* out, long B, int C, int K, hipStream_t stream) {
+    SG_CHECK_ARG(h && w && out && B > 0 && C > 0 && K > 0);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((B * C + 3) / 4)), dim3(256), 0, stream, h, w, bias, out, B * C, C, K);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_rowscale(const float* g, const float* w, float* out, long B, int C, int K, hipStream_t stream) {
+    SG_CHECK_ARG(g && w && out && B > 0 && C > 0 && K > 0);
+    long blocks = (B * C * K + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, w, out, B * C, C, K);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+int sg_rowouter(const float* g, const float* h, float* out, long B, int C, int K, hipStream_t stream) {
+    SG_CHECK_ARG(g && h && out && B > 0 && C > 0 && K > 0);
+    hipLaunchKernelGGL(rowouter_kernel, dim3((unsigned)(((long)C * K + 255) / 256)), dim3(256), 0, stream, g, h, out, B, C, K);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -1547,6 +1547,35 @@ int sg_segmax_scatter_cpu(const float* dy, const int* idx, float* dx, long B, lo
         for (int c = 0; c < C; ++c) dx[(b * P + idx[b * C + c]) * C + c] = dy[b * C + c];
     return SG_OK;
 }
+int sg_rowdot_cpu(const float* h, const float* w, const float* bias, float* out, long B, int C, int K, void*) {
+    CPU_CHECK(h && w && out && B > 0 && C > 0 && K > 0);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < B * C; ++r) {
+        const int c = (int)(r % C);
+        double s = bias ? bias[c] : 0.0;
+        for (int k = 0; k < K; ++k) s += (double)h[r * K + k] * w[(long)c * K + k];
+        out[r] = (float)s;
+    }
+    return SG_OK;
+}
+int sg_rowscale_cpu(const float* g, const float* w, float* out, long B, int C, int K, void*) {
+    CPU_CHECK(g && w && out && B > 0 && C > 0 && K > 0);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < B * C; ++r)
+        for (int k = 0; k < K; ++k) out[r * K + k] = g[r] * w[(long)(r % C) * K + k];
+    return SG_OK;
+}
+int sg_rowouter_cpu(const float* g, const float* h, float* out, long B, int C, int K, void*) {
+    CPU_CHECK(g && h && out && B > 0 && C > 0 && K > 0);
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < (long)C * K; ++e) {
+        const long c = e / K, k = e % K;
+        double s = 0;
+        for (long b = 0; b < B; ++b) s += (double)g[b * C + c] * h[(b * C + c) * K + k];
+        out[e] = (float)s;
+    }
+    return SG_OK;
+}
 int sg_segmax_gather_cpu(const float* x, const int* idx, float* out, long B, long P, int C, void*) {
     CPU_CHECK(x && idx && out && B > 0 && P > 0 && C > 0);
     for (long b = 0; b < B; ++b)

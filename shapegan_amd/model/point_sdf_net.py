@@ -74,8 +74,12 @@ class PointNet(nn.Module):
     def forward_selected(self, xs):
         """xs [B,512,4], row c = the point that holds the maximum of channel c: nn2(max over the cloud of nn1), recorded."""
         B, C = xs.shape[0], xs.shape[1]
-        hs = _run_mlp(self.nn1, xs.reshape(-1, 4))
-        return _run_mlp(self.nn2, hs.reshape(B, C, C).diagonal(dim1=1, dim2=2))
+        mods = list(self.nn1)
+        h3 = _run_mlp(mods[:-1], xs.reshape(-1, 4))              # [B*512, 256], through the ReLU in front of the last Linear
+        # the last Linear's output c of row c only: a row-wise dot product with the row's own weight row (ops.RowDot) instead of
+        # the [B*512, 512] product whose diagonal it is
+        m = ops.rowdot(h3.reshape(B, C, h3.shape[-1]), mods[-1].weight, mods[-1].bias)
+        return _run_mlp(self.nn2, m)
 
     @staticmethod
     def gather_points(x, idx):

@@ -1383,6 +1383,78 @@ class SDFGenFused(Function):
         return (None, None, gzb1, gzb5, None, None, None) + tuple(grads)
 
 
+class RowDot(Function):
+    """out[b, c] = bias[c] + h[b, c, :] . w[c, :] — the diagonal of `h @ w.T + bias` for h [B, C, K], w [C, K]: the last layer of
+    PointNet's selected-points pass (only output c of row c is used).  RowDot / RowScale / RowOuter are each other's adjoints, so
+    the gradient penalty's double backward stays on these three kernels."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias):
+        h, w = f32c(h), f32c(w)
+        B, C, K = h.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=h.device)
+        check(_lib().sg_rowdot(ptr(h), ptr(w), ptr(f32c(bias)) if bias is not None else None, ptr(out), B, C, K, stream()), "rowdot")
+        ctx.save_for_backward(h, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        gh = RowScale.apply(g, w) if ctx.needs_input_grad[0] else None
+        gw = RowOuter.apply(g, h) if ctx.needs_input_grad[1] else None
+        gb = _colsum_any(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gh, gw, gb
+
+
+class RowScale(Function):
+    """out[b, c, k] = g[b, c] w[c, k]."""
+
+    @staticmethod
+    def forward(ctx, g, w):
+        g, w = f32c(g), f32c(w)
+        B, C = g.shape
+        K = w.shape[1]
+        out = torch.empty((B, C, K), dtype=torch.float32, device=g.device)
+        check(_lib().sg_rowscale(ptr(g), ptr(w), ptr(out), B, C, K, stream()), "rowscale")
+        ctx.save_for_backward(g, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        g, w = ctx.saved_tensors
+        return (RowDot.apply(G, w, None) if ctx.needs_input_grad[0] else None,
+                RowOuter.apply(g, G) if ctx.needs_input_grad[1] else None)
+
+
+class RowOuter(Function):
+    """out[c, k] = sum_b g[b, c] h[b, c, k]."""
+
+    @staticmethod
+    def forward(ctx, g, h):
+        g, h = f32c(g), f32c(h)
+        B, C, K = h.shape
+        out = torch.empty((C, K), dtype=torch.float32, device=g.device)
+        check(_lib().sg_rowouter(ptr(g), ptr(h), ptr(out), B, C, K, stream()), "rowouter")
+        ctx.save_for_backward(g, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        g, h = ctx.saved_tensors
+        return (RowDot.apply(h, G, None) if ctx.needs_input_grad[0] else None,
+                RowScale.apply(g, G) if ctx.needs_input_grad[1] else None)
+
+
+def _colsum_any(g):
+    """Column sums of a [B, C] gradient as a differentiable op (ColSum is linear: its own adjoint is a broadcast)."""
+    return ColSum.apply(g)
+
+
+def rowdot(h, w, bias=None):
+    return RowDot.apply(h, w, bias)
+
+
 class _PointPackCache(object):
     """MFMA-fragment image of PointNet.nn1's four weight matrices, rebuilt when one of them changed (see _PackCache)."""
 

@@ -214,6 +214,7 @@ def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
     M.test_gemm_nt_lnrelu_matches_torch()
     M.test_point_gan_sparse_max_adjoint_matches_dense_and_oracle()
     M.test_pointnet_select_matches_layerwise()
+    M.test_rowdot_family_matches_torch_to_second_order()
 
 
 def test_two_threads_drive_two_modules_concurrently(on_cpu):

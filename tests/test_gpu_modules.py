@@ -746,6 +746,30 @@ def test_point_gan_trajectory(golden_steps_f4):
     _check_updates(g, g0, o32.G, o64.G, "point gan generator", gd, "step/g_final")
 
 
+def test_rowdot_family_matches_torch_to_second_order():
+    """ops.rowdot (the diagonal last layer of PointNet's selected-points pass) and its adjoints RowScale / RowOuter against
+    torch.einsum: value, first derivatives and the derivatives of a functional of the first derivatives (the gradient penalty's
+    double backward goes through exactly these)."""
+    from shapegan_amd import ops
+    torch.manual_seed(95)
+    B, C, K = 3, 6, 10
+    base = [torch.randn(B, C, K), torch.randn(C, K), torch.randn(C), torch.randn(B, C), torch.randn(B, C, K), torch.randn(C, K)]
+
+    def run(fn, dev):
+        h, w, b, v = (t.clone().to(dev).requires_grad_(True) for t in base[:4])
+        r1, r2 = base[4].to(dev), base[5].to(dev)
+        out = fn(h, w, b)
+        gh, gw = torch.autograd.grad(out, (h, w), grad_outputs=v, create_graph=True)
+        second = (gh * r1).sum() + (gw * r2).sum() + out.pow(2).sum()
+        second.backward()
+        return [out.detach().cpu(), gh.detach().cpu(), gw.detach().cpu()] + [t.grad.cpu() for t in (h, w, b, v)]
+
+    got = run(lambda h, w, b: ops.rowdot(h, w, b), DEV)
+    want = run(lambda h, w, b: torch.einsum("bck,ck->bc", h, w) + b, "cpu")
+    for i, (g, r) in enumerate(zip(got, want)):
+        close(g, r, rtol=1e-5, atol=1e-5, what="rowdot family, quantity %d" % i)
+
+
 def test_pointnet_select_matches_layerwise():
     """ops.pointnet_select (nn1 + max over the cloud in one fused launch, per-point layers never written) against the module's
     GEMM path + torch.max: maxima, and the selected points (equal, or holding a value that ties the maximum to rounding)."""
