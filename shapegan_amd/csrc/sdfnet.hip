@@ -624,15 +624,15 @@ struct PnSelArgs {
 };
 constexpr long kPnW1 = 0, kPnW2 = kPnW1 + 64 * 8, kPnW3 = kPnW2 + 128 * 64, kPnW4 = kPnW3 + 256 * 128, kPnTotal = kPnW4 + 512 * 256;
 
-__global__ void __launch_bounds__(512, 4) pointnet_select_kernel(PnSelArgs a) {
+__global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
     constexpr int P = 32, LDX = P + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const A = smem;                 // [256][P]: H1 (64 rows), later H3
     float* const Bm = A + 256 * P;         // [128][P]: H2
     float* const Xs = Bm + 128 * P;        // [8][LDX]
     float* const Bl = Xs + 8 * LDX;        // biases: 64 | 128 | 256 | 512
-    float* const PV = Bl + 960;            // [512]
-    int* const PI = reinterpret_cast<int*>(PV + 512);
+    float* const PV = Bm;                  // [512] + [512] ints: over H2, which is dead once the third layer has been read (54 KB
+    int* const PI = reinterpret_cast<int*>(PV + 512);   //  in all: three workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
     const long p0 = (long)blockIdx.x * P;
@@ -1979,7 +1979,7 @@ int sg_pointnet_select(const float* x, const float* packed, const float* const* 
     a.pi = reinterpret_cast<int*>(a.pv + tiles * 512);
     a.N = B * P;
     a.pps = P;
-    const size_t lds = ((size_t)256 * 32 + 128 * 32 + 8 * 33 + 960 + 1024) * sizeof(float);
+    const size_t lds = ((size_t)256 * 32 + 128 * 32 + 8 * 33 + 960) * sizeof(float);
     if (set_lds(pointnet_select_kernel, lds)) SG_FAIL(SG_ERR_HIP, "sg_pointnet_select: cannot reserve %zu B LDS", lds);
     hipLaunchKernelGGL(pointnet_select_kernel, dim3((unsigned)tiles), dim3(512), lds, stream, a);
     SG_CHECK_LAUNCH();
