@@ -97,6 +97,65 @@ def test_sdf_autodecoder_sorted_step_world2_cpu(tmp_path):
     DP.check_sdf(tmp_path)
 
 
+def _point_gan_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from shapegan_amd import lib as L
+    from shapegan_amd import parallel
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    L.load_cpu()
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(11)                     # identical replicas by seed
+    G, D = SDFGenerator(128, 256, 8, True, dropout=0.0), PointNet(out_channels=1)
+    if rank == 0:
+        torch.save({"g": G.state_dict(), "d": D.state_dict()}, os.path.join(out_dir, "init.pt"))
+    tr = PointGANTrainer(G, D)
+    gen = torch.Generator().manual_seed(5)
+    B, P = 4, 1024                            # P >= PointNet.SPARSE_MIN_POINTS: the selected-points path on every rank
+    uniform = torch.cat([torch.rand(B, P, 3, generator=gen) * 2 - 1, torch.rand(B, P, 1, generator=gen) * 0.2 - 0.1], -1)
+    z1, z2, alpha = torch.randn(B, 128, generator=gen), torch.randn(B, 128, generator=gen), torch.rand(B, 1, 1, generator=gen)
+    sl = slice(rank * (B // world), (rank + 1) * (B // world))
+    out = {}
+    tr.critic_step(uniform[sl], z1[sl], alpha[sl])
+    out["d"] = {k: (p.grad * tr.d_opt.grad_scale).clone() for k, p in D.named_parameters()}
+    tr.generator_step(uniform[sl], z2[sl])
+    out["g"] = {k: (p.grad * tr.g_opt.grad_scale).clone() for k, p in G.named_parameters() if p.grad is not None}
+    out["final"] = {"g": G.state_dict(), "d": D.state_dict()}
+    out["data"] = (uniform, z1, z2, alpha)
+    torch.save(out, os.path.join(out_dir, "pg%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_point_gan_updates_world2_cpu(tmp_path):
+    """SURVEY.md 8f rank 4 under process-per-GPU DP: PointGANTrainer's critic (+ gradient penalty) and generator updates on two
+    half batches (the selected-points path of the critic, the generator update on the selected points) leave both ranks with the
+    same averaged gradients — those of the full batch in the fp64 oracle — and bit-identical replicas."""
+    from oracle import torch_oracle as O
+    mp.spawn(_point_gan_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "pg%d.pt" % r)) for r in (0, 1))
+    for net in ("d", "g"):
+        for k in r0[net]:
+            assert torch.equal(r0[net][k], r1[net][k]), (net, k)
+        for k, v in r0["final"][net].items():
+            assert torch.equal(v, r1["final"][net][k]), (net, k)
+    init = torch.load(os.path.join(str(tmp_path), "init.pt"))
+    uniform, z1, z2, alpha = (t.double() for t in r0["data"])
+    o = O.PointGANOracle({k: v.double() for k, v in init["g"].items()}, {k: v.double() for k, v in init["d"].items()})
+    o.critic_step(uniform, z1, alpha)
+    dref = {k: v.grad.clone() for k, v in o.D.items()}
+    o.generator_step(uniform, z2)
+    gref = {k: v.grad.clone() for k, v in o.G.items() if v.grad is not None}
+    for got, ref, what in ((r0["d"], dref, "critic"), (r0["g"], gref, "generator")):
+        for k, v in got.items():
+            if k.startswith("norms.7"):
+                continue
+            scale = float(ref[k].abs().max()) + 1e-12
+            err = float((v.double() - ref[k]).abs().max())
+            assert err <= 5e-4 * scale + 1e-9, (what, k, err, scale)
+
+
 def _pattern_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
