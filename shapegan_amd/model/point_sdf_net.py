@@ -102,8 +102,14 @@ class PointNet(nn.Module):
             x3 = x.reshape(-1, P, 4)
             out = self.forward_selected(self.gather_points(x3, self.selected_points(x3)))
             return out.reshape(tuple(lead) + (out.shape[-1],))
-        h = _run_mlp(self.nn1, x.reshape(-1, 4))
-        h = ops.segmax(h.reshape(-1, P, h.shape[-1]))           # [B,512]
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.nn1.parameters()))
+        if not needs_graph and P % 32 == 0 and P >= 32:
+            # nothing to record: nn1 and the max in one fused launch (the per-point layers are never written)
+            lins = [m for m in self.nn1 if isinstance(m, nn.Linear)]
+            h = ops.pointnet_select(self._pack, x.reshape(-1, P, 4), [l.weight for l in lins], [l.bias for l in lins])[0]
+        else:
+            h = _run_mlp(self.nn1, x.reshape(-1, 4))
+            h = ops.segmax(h.reshape(-1, P, h.shape[-1]))       # [B,512]
         out = _run_mlp(self.nn2, h)
         return out.reshape(tuple(lead) + (out.shape[-1],))
 

@@ -790,6 +790,10 @@ def test_pointnet_select_matches_layerwise():
     close(sel, ref, rtol=1e-5, atol=1e-6, what="value at the selected point")
     assert float((idx.long() == ridx).float().mean()) > 0.99
     assert torch.equal(D.selected_points(x), idx.long())
+    with torch.no_grad():                       # nothing to record: the module's forward is the fused launch + nn2
+        got = D(x[..., :3], x[..., 3:])
+        want = _run_mlp(D.nn2, ref)
+    close(got, want, rtol=1e-5, atol=1e-6, what="PointNet forward without grad (fused selection pass)")
 
 
 def test_point_gan_sparse_max_adjoint_matches_dense_and_oracle():
