@@ -30,7 +30,11 @@ def test_library_exports_every_declared_symbol():
         home = comm if name in L.COMM_SIGNATURES else lib       # the RCCL exchange lives in libshapegan_comm.so
         assert hasattr(home, name), "missing export: " + name
     assert declared == set(L.SIGNATURES) | set(L.COMM_SIGNATURES), (declared ^ (set(L.SIGNATURES) | set(L.COMM_SIGNATURES)))
-    assert L.load().sg_abi_version() == 8
+    abi = int(re.search(r"#define SG_ABI_VERSION (\d+)", header).group(1))
+    assert L.load().sg_abi_version() == abi == 8
+    # every place that pins the ABI number agrees with the header (the driver's build check runs __graft_entry__.build())
+    assert "sg_abi_version() == %d" % abi in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "sg_abi_version() != %d" % abi in open(os.path.join(ROOT, "shapegan_amd", "lib.py")).read()
     assert L.load_comm().sg_allreduce_unique_id_bytes() == 128
 
 
