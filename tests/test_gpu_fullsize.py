@@ -426,3 +426,45 @@ def test_sdfnet_sorted_batches_at_random_sizes_equal_their_pieces():
         close(full[1], a[1] + b[1], rtol=1e-3, what=what + " d latent table")
         for (name, _), g, ga, gb in zip(net.named_parameters(), full[2], a[2], b[2]):
             close(g, ga + gb, rtol=1e-3, what=what + " grad " + name)
+
+
+def test_point_gan_updates_at_12x16384_points_sparse_vs_dense():
+    """SURVEY.md 8f rank 4 at the (num_points, batch) = (16 384, 12) stage of train_point_gan.py:29-34: the trainer's updates —
+    fused selection pass, recorded passes on the 512 selected points per cloud, generator update on the selected points — against
+    the same trainer forced onto the dense path (every point recorded, fused LayerNorm-MLP backward over all 196 608 points):
+    losses and every parameter gradient.  Size-independent property on top: moving points that hold NO maximum (without letting them
+    take one over) changes neither the critic's output nor any gradient."""
+    import copy
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    torch.manual_seed(21)
+    g, d = SDFGenerator(128, 256, 8, True, dropout=0.0).cuda(), PointNet(out_channels=1).cuda()
+    B, P = 12, 16384
+    uniform = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).cuda()
+    z1, z2, alpha = torch.randn(B, 128).cuda(), torch.randn(B, 128).cuda(), torch.rand(B, 1, 1).cuda()
+    runs = {}
+    for name in ("sparse", "dense"):
+        gg, dd = copy.deepcopy(g), copy.deepcopy(d)
+        if name == "dense":
+            dd.SPARSE_MIN_POINTS = 10 ** 9
+        tr = PointGANTrainer(gg, dd)
+        dl, gp = tr.critic_step(uniform, z1, alpha)
+        dgr = {k: p.grad.detach().clone() for k, p in dd.named_parameters()}
+        gl = tr.generator_step(uniform, z2)
+        ggr = {k: p.grad.detach().clone() for k, p in gg.named_parameters() if p.grad is not None}
+        runs[name] = ([dl.item(), gp.item(), gl.item()], dgr, ggr)
+    np.testing.assert_allclose(runs["sparse"][0], runs["dense"][0], rtol=2e-4, atol=1e-6)
+    for which, what in ((1, "critic"), (2, "generator")):
+        for k, ref in runs["dense"][which].items():
+            close_mostly(runs["sparse"][which][k], ref, rtol=2e-4, max_bad_frac=2e-3, what="%s grad %s, sparse vs dense" % (what, k))
+    # the critic sees a cloud through the selected points only
+    x = uniform[:2].clone()
+    idx = d.selected_points(x)
+    keep = torch.zeros(2, P, dtype=torch.bool, device="cuda")
+    keep.scatter_(1, idx, True)
+    moved = x.clone()
+    for b in range(2):                         # every other point becomes a copy of a selected one of ITS cloud: it can tie a maximum, not beat it
+        moved[b][~keep[b]] = x[b, idx[b, 0]]
+    with torch.no_grad():
+        a, b = d(x[..., :3], x[..., 3:]), d(moved[..., :3], moved[..., 3:])
+    close(a, b, rtol=1e-5, what="critic output after moving unselected points")
