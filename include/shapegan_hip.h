@@ -351,9 +351,11 @@ int sg_rmsprop_step(float* p, const float* g, float* square_avg, long n, float l
 int sg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                  float eps, long step, float grad_scale, hipStream_t stream);
 /* Adam with the step counter (int64) in device memory: identical arithmetic, but the call has no host-side state that changes
- * between steps, so a captured hipGraph of a training step replays it.  corr_dev: FOUR 32-bit words, zero before the first call —
- * [0..1] the two bias corrections of the last applied step (for the host to read), [2] the arrival ticket of the one launch
- * (ABI 7: the workgroup that finishes last advances the counter; it was a one-thread launch in front of the update), [3] unused. */
+ * between steps, so a captured hipGraph of a training step replays it.  corr_dev: SG_ADAM_DEV_WORDS 32-bit words, zero before the
+ * first call — [0..1] the two bias corrections of the last applied step (for the host to read), [2] and [32 + 32 i], i < 16: the
+ * arrival tickets of the one launch (the workgroup that is last to have read the counter advances it; two levels, 128 bytes apart:
+ * atomics on one word are served one after the other), left at zero by every call. */
+#define SG_ADAM_DEV_WORDS 544
 int sg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                      float eps, long long* step_dev, float* corr_dev, float grad_scale, hipStream_t stream);
 /* The two Adam entries with a guard word (device memory, may be NULL = unguarded): when *skip_if_nonzero != 0 at the time the

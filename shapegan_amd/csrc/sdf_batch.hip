@@ -17,13 +17,17 @@
 
 namespace sg {
 
-constexpr int kSortChunk = 512;
-constexpr int kSortRounds = kSortChunk / 64;
+// Chunk = ROUNDS x 64 entries.  Eight rounds keep the per-chunk tables (hist / base: [chunks][S] ints) small for large batches and
+// many shapes; the reference's own batch (20 000 entries of 64 shapes) takes ONE round per wave — 313 independent waves instead of
+// 40 chains of eight dependent rounds (the scatter was 26 us of that step's 37 us sort) — when the tables then stay below 4 MB.
 constexpr int kSortMaxShapes = 16384;   // one int of LDS per shape
+constexpr long kSortSmallTableInts = 1L << 20;
 
+template <int kSortRounds>
 __global__ void __launch_bounds__(64) sdf_sort_hist_kernel(const int64_t* __restrict__ idx, long n, long pc, int S,
                                                            int* __restrict__ keys, int* __restrict__ hist,
                                                            int* __restrict__ flag, int* __restrict__ flag_dev, int flag_value) {
+    constexpr int kSortChunk = kSortRounds * 64;
     extern __shared__ int cnt[];
     const int lane = threadIdx.x;
     const long chunk = blockIdx.x;
@@ -63,9 +67,19 @@ __global__ void __launch_bounds__(1024) sdf_sort_prefix_kernel(const int* __rest
     const int s = blockIdx.x * 64 + lane;
     const long per = (nchunk + 15) / 16;
     const long c0 = wave * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
+    // (eight loads in flight per thread: a wave's range is a chain of dependent additions, not of dependent loads)
     int run = 0;
-    if (s < S)
-        for (long c = c0; c < c1; ++c) run += hist[c * S + s];
+    if (s < S) {
+        long c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            int h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = hist[(c + u) * S + s];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) run += h[u];
+        }
+        for (; c < c1; ++c) run += hist[c * S + s];
+    }
     part[wave][lane] = run;
     __syncthreads();
     int pre = 0, all = 0;
@@ -77,7 +91,18 @@ __global__ void __launch_bounds__(1024) sdf_sort_prefix_kernel(const int* __rest
     }
     if (s < S) {
         run = pre;
-        for (long c = c0; c < c1; ++c) {
+        long c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            int h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = hist[(c + u) * S + s];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                base[(c + u) * S + s] = run;
+                run += h[u];
+            }
+        }
+        for (; c < c1; ++c) {
             base[c * S + s] = run;
             run += hist[c * S + s];
         }
@@ -85,12 +110,14 @@ __global__ void __launch_bounds__(1024) sdf_sort_prefix_kernel(const int* __rest
     }
 }
 
+template <int kSortRounds>
 __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __restrict__ idx, const int* __restrict__ keys,
                                                               const int* __restrict__ base, const int* __restrict__ total,
                                                               long n, int S, long table_rows, const float* __restrict__ points,
                                                               const float* __restrict__ sdf, float* __restrict__ out_points,
                                                               float* __restrict__ out_sdf, int* __restrict__ out_shape,
                                                               int64_t* __restrict__ seg_off, float* __restrict__ counts) {
+    constexpr int kSortChunk = kSortRounds * 64;
     extern __shared__ int pos[];     // [S] next free position of every shape for this chunk
     __shared__ int lsum[64];
     const int lane = threadIdx.x;
@@ -172,7 +199,11 @@ __global__ void __launch_bounds__(64) sdf_sort_scatter_kernel(const int64_t* __r
     }
 }
 
-static long sort_chunks(long n) { return (n + kSortChunk - 1) / kSortChunk; }
+static int sort_rounds(long n, long S) { return ((n + 63) / 64) * S <= kSortSmallTableInts ? 1 : 8; }
+static long sort_chunks(long n, long S) {
+    const long c = 64L * sort_rounds(n, S);
+    return (n + c - 1) / c;
+}
 
 }  // namespace sg
 
@@ -184,7 +215,7 @@ int sg_sdf_batch_sort_max_shapes(void) { return kSortMaxShapes; }
 
 // workspace: keys[n] | hist[nchunk][S] | base[nchunk][S] | total[S] | flag   (ints)
 size_t sg_sdf_batch_sort_workspace_bytes(long n, long nshapes) {
-    return (size_t)(n + 2 * sort_chunks(n) * nshapes + nshapes + 4) * sizeof(int);
+    return (size_t)(n + 2 * sort_chunks(n, nshapes) * nshapes + nshapes + 4) * sizeof(int);
 }
 
 int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long nshapes, const float* points,
@@ -196,25 +227,38 @@ int sg_sdf_batch_sort(const int64_t* indices, long n, long pointcloud_size, long
     SG_CHECK_ARG(n > 0 && n < (1L << 31) && pointcloud_size > 0 && nshapes > 0 && nshapes <= kSortMaxShapes);
     if (!workspace || workspace_bytes < sg_sdf_batch_sort_workspace_bytes(n, nshapes))
         SG_FAIL(SG_ERR_WORKSPACE, "sg_sdf_batch_sort: workspace too small");
-    const long nc = sort_chunks(n);
+    const long nc = sort_chunks(n, nshapes);
+    const bool one = sort_rounds(n, nshapes) == 1;
     const int S = (int)nshapes;
     int* keys = (int*)workspace;
     int* hist = keys + n;
     int* base = hist + nc * S;
     int* total = base + nc * S;
     const size_t lds = (size_t)S * sizeof(int);
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (lds > 48 * 1024) {     // (only with thousands of shapes: the eight-round form)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_hist_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_scatter_kernel),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_scatter_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_sort_scatter_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             SG_FAIL(SG_ERR_HIP, "sg_sdf_batch_sort: cannot reserve %zu B LDS", lds);
     }
-    hipLaunchKernelGGL(sdf_sort_hist_kernel, dim3((unsigned)nc), dim3(64), lds, stream, indices, n, pointcloud_size, S, keys,
-                       hist, bad_index_flag, bad_index_device, bad_index_value);
+    if (one)
+        hipLaunchKernelGGL(sdf_sort_hist_kernel<1>, dim3((unsigned)nc), dim3(64), lds, stream, indices, n, pointcloud_size, S, keys,
+                           hist, bad_index_flag, bad_index_device, bad_index_value);
+    else
+        hipLaunchKernelGGL(sdf_sort_hist_kernel<8>, dim3((unsigned)nc), dim3(64), lds, stream, indices, n, pointcloud_size, S, keys,
+                           hist, bad_index_flag, bad_index_device, bad_index_value);
     hipLaunchKernelGGL(sdf_sort_prefix_kernel, dim3((unsigned)((S + 63) / 64)), dim3(1024), 0, stream, hist, base, total, nc, S);
-    hipLaunchKernelGGL(sdf_sort_scatter_kernel, dim3((unsigned)nc), dim3(64), lds, stream, indices, keys, base, total, n, S,
-                       nshapes * pointcloud_size, points, sdf, out_points, out_sdf, out_shape, seg_off, counts);
+    if (one)
+        hipLaunchKernelGGL(sdf_sort_scatter_kernel<1>, dim3((unsigned)nc), dim3(64), lds, stream, indices, keys, base, total, n, S,
+                           nshapes * pointcloud_size, points, sdf, out_points, out_sdf, out_shape, seg_off, counts);
+    else
+        hipLaunchKernelGGL(sdf_sort_scatter_kernel<8>, dim3((unsigned)nc), dim3(64), lds, stream, indices, keys, base, total, n, S,
+                           nshapes * pointcloud_size, points, sdf, out_points, out_sdf, out_shape, seg_off, counts);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -179,7 +179,7 @@ class Adam(_Base):
         self.capturable = capturable
         if capturable:
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.f.flat.device)
-            self.corr_dev = torch.zeros(4, dtype=torch.float32, device=self.f.flat.device)     # corrections [2] + arrival ticket + pad
+            self.corr_dev = torch.zeros(544, dtype=torch.float32, device=self.f.flat.device)   # SG_ADAM_DEV_WORDS: corrections [2] + arrival tickets
         self.exp_avg = torch.zeros_like(self.f.flat)
         self.exp_avg_sq = torch.zeros_like(self.f.flat)
         # torch keeps one step counter per parameter; a parameter that never had a grad never advances
