@@ -19,9 +19,10 @@ namespace sg {
 
 // Chunk = ROUNDS x 64 entries.  Eight rounds keep the per-chunk tables (hist / base: [chunks][S] ints) small for large batches and
 // many shapes; the reference's own batch (20 000 entries of 64 shapes) takes ONE round per wave — 313 independent waves instead of
-// 40 chains of eight dependent rounds (the scatter was 26 us of that step's 37 us sort) — when the tables then stay below 4 MB.
+// 40 chains of eight dependent rounds (the scatter was 26 us of that step's 37 us sort) — when the tables then stay below 128 KB:
+// the chunk prefix is one workgroup per 64 shapes walking the chunks (3 125 one-round chunks of a 200 000-entry batch took it 82 us).
 constexpr int kSortMaxShapes = 16384;   // one int of LDS per shape
-constexpr long kSortSmallTableInts = 1L << 20;
+constexpr long kSortSmallTableInts = 1L << 15;
 
 template <int kSortRounds>
 __global__ void __launch_bounds__(64) sdf_sort_hist_kernel(const int64_t* __restrict__ idx, long n, long pc, int S,
