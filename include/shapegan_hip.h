@@ -262,6 +262,10 @@ int sg_sdfnet_bwd(const float* dout, const float* out, const float* acts, float*
  * model/sdf_net.py:27,41,57-59), both [nshapes][256] outputs in one launch, accumulated in double and rounded once. */
 int sg_sdfnet_shape_bias(const float* z, long nshapes, int latent, const float* W1, const float* b1, const float* W5, const float* b5,
                          float* zb1, float* zb5, hipStream_t stream);
+/* sg_sdfnet_pack(params, latent, 3, packed) and sg_sdfnet_shape_bias(z, ..., zb1, zb5) of the same parameters in ONE launch (ABI 8):
+ * every step of the shape-sorted auto-decoder needs both behind its optimizer step (train_sdf_autodecoder.py:80-91). */
+int sg_sdfnet_pack_shape_bias(const float* const* params, int latent, float* packed, const float* z, long nshapes, float* zb1,
+                              float* zb5, hipStream_t stream);
 /* Per-shape mode: backward of the latent fold zb1[s][o] = b1[o] + sum_k z[s][k] W1[o][3+k], zb5[s][o] = b5[o] + sum_k z[s][k] W5[o][259+k]
  * (the latent columns of layers1.0 / layers2.0, model/sdf_net.py:27,41, enter sg_sdfnet_fwd as bias rows) from the per-shape sums
  * t1 / t5 [256][nshapes] of dZ1 / dZ5, in one launch: the latent columns of dW1 [256][3+L] / dW5 [256][259+L] written in place
@@ -365,6 +369,13 @@ int sg_adam_step_guarded(float* p, const float* g, float* exp_avg, float* exp_av
 int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                              float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
                              const int* skip_if_nonzero, hipStream_t stream);
+/* sg_adam_step_dev_guarded for up to four flat buffers in ONE launch (ABI 8): the optimizers of one training step
+ * (train_sdf_autodecoder.py:44-45,90-91 steps the network's and the latent table's one after the other).  Every argument is an array
+ * of nsets entries; one guard word (may be NULL) covers all. */
+int sg_adam_step_dev_multi(int nsets, float* const* p, const float* const* g, float* const* exp_avg, float* const* exp_avg_sq,
+                           const long* n, const float* lr, const float* beta1, const float* beta2, const float* eps,
+                           long long* const* step_dev, float* const* corr_dev, const float* grad_scale, const int* skip_if_nonzero,
+                           hipStream_t stream);
 int sg_clamp(float* p, long n, float lo, float hi, hipStream_t stream);
 /* clamp of `ntensors` tensors (host arrays of device pointers and element counts) in one launch per 16 tensors:
  * Discriminator.clip_weights (model/gan.py:67-69) over the module-level surface, eight parameter tensors per critic update */

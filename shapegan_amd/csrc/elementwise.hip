@@ -120,36 +120,52 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     // `skip` (optional): a device word an earlier kernel of the stream sets when this step's batch must not be applied
     // (sg_sdf_batch_sort's bad-index word): the update is then a no-op — parameters and both moments keep their values
     if (skip && *skip) return;
-    const float step = lr / bc1;
+    // (every rounding spelled out, the same in the three Adam kernels: left to the compiler, `b2 v + (1 - b2) g g` was contracted
+    //  into different fma forms in different kernels — one ulp apart, which a trajectory test over several steps sees)
+    const float step = lr / bc1, c1 = 1.f - b1, c2 = 1.f - b2;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-        const float gg = g[e] * gscale;
-        const float mm = b1 * m[e] + (1.f - b1) * gg;
-        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+        const float gg = __fmul_rn(g[e], gscale);
+        const float mm = __fmaf_rn(b1, m[e], __fmul_rn(c1, gg));
+        const float vv = __fmaf_rn(b2, v[e], __fmul_rn(__fmul_rn(c2, gg), gg));
         m[e] = mm;
         v[e] = vv;
-        p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2_sqrt), eps);
+        p[e] = __fsub_rn(p[e], __fmul_rn(step, __fdiv_rn(mm, denom)));
     }
 }
 
 // Graph-capturable Adam: the step counter lives on the device.  ONE launch (round 6; it was a one-thread "prepare" launch + the
-// update).  Every thread reads the counter (a scalar load next to its element loads) and derives the two bias corrections of step
-// t = counter + 1 itself, in double as torch does on the host — nothing is shared, no barrier stands between a workgroup's loads and
-// its update.  The counter is advanced by the workgroup that is the LAST TO HAVE READ it: thread 0 takes an arrival ticket as soon
+// update).  Thread 0 of a workgroup reads the counter and shares it; every thread derives the two bias corrections of step
+// t = counter + 1 itself, in double as torch does on the host.  The counter is advanced by the workgroup that is the LAST TO HAVE
+// READ it: thread 0 takes an arrival ticket as soon
 // as its own read has returned — the increment is made to depend on the loaded value — and the one that draws the last ticket
 // stores t, publishes the corrections in corr[0..1] (readable by the host) and clears the tickets, all under the other
 // workgroups' element traffic.  Tickets on two levels: atomics on ONE word are served one after the other (~10 ns each) — the 900
 // workgroups of a 460 k-parameter update on a single ticket word were 9 of that launch's 14.7 us (the host-counter kernel: 5.6).
 // Workgroup b arrives at word b % 16 (128 bytes apart); the last arrival of a word arrives at the master word, the last of those
 // advances the counter.
-__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                       float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                                                       float b1, float b2, float eps, long long* __restrict__ step_dev,
-                                                       float* __restrict__ corr, float gscale, const int* __restrict__ skip) {
-    if (skip && *skip) return;           // a skipped step neither moves nor ages anything
-    const long long t = *step_dev + 1;
+struct AdamDevSet {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+    float lr, b1, b2, eps, gscale;
+    long long* step_dev;
+    float* corr;
+    unsigned nblocks;
+};
+__device__ __forceinline__ void adam_dev_body(const AdamDevSet& a, const unsigned bx, const unsigned nb) {
+    // ONE read of the counter per workgroup, shared through LDS: the ticket below says "this workgroup has read the counter" — with a
+    // read per wave, a wave that reads late could see the value the last-ticket workgroup has already stored (found by the bit-equality
+    // test of the fused launch: a few elements a step ahead in their bias correction)
+    __shared__ long long t_shared;
+    if (threadIdx.x == 0) t_shared = *a.step_dev + 1;
+    __syncthreads();
+    const long long t = t_shared;
     // beta^t for the integer t by repeated squaring in double (a few ulp of double, i.e. the same float after rounding except at
     // ties; the library pow() is a routine of several microseconds)
-    double p1 = 1.0, p2 = 1.0, q1 = (double)b1, q2 = (double)b2;
+    double p1 = 1.0, p2 = 1.0, q1 = (double)a.b1, q2 = (double)a.b2;
     for (long long e = t; e > 0; e >>= 1) {
         if (e & 1) {
             p1 *= q1;
@@ -162,28 +178,49 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, co
     if (threadIdx.x == 0) {
         unsigned one = 1u;
         asm volatile("" : "+v"(one) : "v"((unsigned)t));      // the tickets are taken after the counter's value has arrived
-        unsigned* master = reinterpret_cast<unsigned*>(corr + 2);
-        const unsigned w = blockIdx.x & 15u, nw = gridDim.x < 16u ? gridDim.x : 16u;
-        unsigned* mine = reinterpret_cast<unsigned*>(corr + 32 + 32 * w);
-        if (atomicAdd(mine, one) == (gridDim.x - w + 15u) / 16u - 1u) {
+        unsigned* master = reinterpret_cast<unsigned*>(a.corr + 2);
+        const unsigned w = bx & 15u, nw = nb < 16u ? nb : 16u;
+        unsigned* mine = reinterpret_cast<unsigned*>(a.corr + 32 + 32 * w);
+        if (atomicAdd(mine, one) == (nb - w + 15u) / 16u - 1u) {
             *mine = 0u;
             if (atomicAdd(master, one) == nw - 1u) {
-                *step_dev = t;
-                corr[0] = bc1;
-                corr[1] = bc2_sqrt;
+                *a.step_dev = t;
+                a.corr[0] = bc1;
+                a.corr[1] = bc2_sqrt;
                 *master = 0u;
             }
         }
     }
-    const float step = lr / bc1;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-        const float gg = g[e] * gscale;
-        const float mm = b1 * m[e] + (1.f - b1) * gg;
-        const float vv = b2 * v[e] + (1.f - b2) * gg * gg;
+    const float step = a.lr / bc1, b1 = a.b1, b2 = a.b2;
+    float* __restrict__ p = a.p;
+    float* __restrict__ m = a.m;
+    float* __restrict__ v = a.v;
+    const float* __restrict__ g = a.g;
+    // (roundings spelled out as in adam_kernel)
+    const float c1 = 1.f - b1, c2 = 1.f - b2;
+    for (long e = (long)bx * 256 + threadIdx.x; e < a.n; e += (long)nb * 256) {
+        const float gg = __fmul_rn(g[e], a.gscale);
+        const float mm = __fmaf_rn(b1, m[e], __fmul_rn(c1, gg));
+        const float vv = __fmaf_rn(b2, v[e], __fmul_rn(__fmul_rn(c2, gg), gg));
         m[e] = mm;
         v[e] = vv;
-        p[e] = p[e] - step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2_sqrt), a.eps);
+        p[e] = __fsub_rn(p[e], __fmul_rn(step, __fdiv_rn(mm, denom)));
     }
+}
+__global__ void __launch_bounds__(256) adam_dev_kernel(AdamDevSet a, const int* __restrict__ skip) {
+    if (skip && *skip) return;           // a skipped step neither moves nor ages anything
+    adam_dev_body(a, blockIdx.x, gridDim.x);
+}
+// up to four flat buffers (the optimizers of one training step: train_sdf_autodecoder.py:44-45 has two) in ONE launch: grid y = buffer
+struct AdamDevMulti {
+    AdamDevSet s[4];
+};
+__global__ void __launch_bounds__(256) adam_dev_multi_kernel(AdamDevMulti a, const int* __restrict__ skip) {
+    if (skip && *skip) return;
+    const AdamDevSet& s = a.s[blockIdx.y];
+    if (blockIdx.x >= s.nblocks) return;
+    adam_dev_body(s, blockIdx.x, s.nblocks);
 }
 
 __global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, long n, float lo, float hi) {
@@ -338,8 +375,28 @@ int sg_adam_step_dev_guarded(float* p, const float* g, float* exp_avg, float* ex
                              float beta2, float eps, long long* step_dev, float* corr_dev, float grad_scale,
                              const int* skip_if_nonzero, hipStream_t stream) {
     SG_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_dev && corr_dev);
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, step_dev, corr_dev, grad_scale, skip_if_nonzero);
+    AdamDevSet a{p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, corr_dev, (unsigned)ew_grid(n, 2)};
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(a.nblocks), dim3(256), 0, stream, a, skip_if_nonzero);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+// The same for up to four flat buffers in one launch (every argument an array of nsets entries; one guard word for all).
+int sg_adam_step_dev_multi(int nsets, float* const* p, const float* const* g, float* const* exp_avg, float* const* exp_avg_sq,
+                           const long* n, const float* lr, const float* beta1, const float* beta2, const float* eps,
+                           long long* const* step_dev, float* const* corr_dev, const float* grad_scale, const int* skip_if_nonzero,
+                           hipStream_t stream) {
+    SG_CHECK_ARG(nsets > 0 && nsets <= 4 && p && g && exp_avg && exp_avg_sq && n && lr && beta1 && beta2 && eps && step_dev && corr_dev &&
+                 grad_scale);
+    AdamDevMulti a;
+    unsigned most = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int k = i < nsets ? i : 0;
+        SG_CHECK_ARG(p[k] && g[k] && exp_avg[k] && exp_avg_sq[k] && n[k] > 0 && step_dev[k] && corr_dev[k]);
+        a.s[i] = AdamDevSet{p[k], g[k], exp_avg[k], exp_avg_sq[k], n[k], lr[k], beta1[k], beta2[k], eps[k], grad_scale[k], step_dev[k],
+                            corr_dev[k], (unsigned)ew_grid(n[k], 2)};
+        if (i < nsets && a.s[i].nblocks > most) most = a.s[i].nblocks;
+    }
+    hipLaunchKernelGGL(adam_dev_multi_kernel, dim3(most, nsets), dim3(256), 0, stream, a, skip_if_nonzero);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

@@ -66,9 +66,10 @@ struct PackDescs {
 
 // dst[((t*nsq + sq)*64 + lane)*4 + j] = M(t*32 + (lane&31), (sq*4 + j)*2 + (lane>>5))
 // (row blockIdx.y == descs.n: the bias vectors and w8 — one launch instead of two, round 6)
-__global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float* __restrict__ dst) {
-    if ((int)blockIdx.y == descs.n) {
-        if (blockIdx.x != 0) return;
+__device__ __forceinline__ void pack_mfma_a_body(const PackDescs& descs, float* __restrict__ dst, const unsigned bx, const unsigned by,
+                                                 const unsigned gx) {
+    if ((int)by == descs.n) {
+        if (bx != 0) return;
         const int t = threadIdx.x;
 #pragma unroll
         for (int l = 0; l < 7; ++l) dst[descs.v.dst_b + l * kH + t] = descs.v.b[l][t];
@@ -83,9 +84,9 @@ __global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float
         }
         return;
     }
-    const PackDesc d = descs.d[blockIdx.y];
+    const PackDesc d = descs.d[by];
     const long total = (long)d.ntiles * d.nsq * 256;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    for (long e = (long)bx * 256 + threadIdx.x; e < total; e += (long)gx * 256) {
         const int j = (int)(e & 3);
         const int lane = (int)((e >> 2) & 63);
         const long q = e >> 8;
@@ -95,6 +96,9 @@ __global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float
         const int c = (sq * 4 + j) * 2 + (lane >> 5);
         dst[d.dst_off + e] = (r < d.R && c < d.C) ? d.src[(long)r * d.rs + (long)c * d.cs] : 0.f;
     }
+}
+__global__ void __launch_bounds__(256) pack_mfma_a_kernel(PackDescs descs, float* __restrict__ dst) {
+    pack_mfma_a_body(descs, dst, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 struct SdfPackLayout {
@@ -1374,16 +1378,15 @@ __global__ void __launch_bounds__(1024) sdfnet_finish_kernel(SdfFinishArgs a) {
 // A [S, L] x [L, 256] product of a few MFLOP: workgroup = 16 shapes x 16 outputs of one matrix, K in chunks of 64 through LDS,
 // accumulated in DOUBLE and rounded once — the value does not depend on a tile or split-K plan, and it is the correctly rounded
 // sum up to the last bit.
-__global__ void __launch_bounds__(256) shape_fold_kernel(const float* __restrict__ z, int S, int L, const float* __restrict__ W1,
-                                                         const float* __restrict__ W5, const float* __restrict__ b1,
-                                                         const float* __restrict__ b5, float* __restrict__ zb1,
-                                                         float* __restrict__ zb5) {
+__device__ __forceinline__ void shape_fold_body(const float* __restrict__ z, int S, int L, const float* __restrict__ W1,
+                                                const float* __restrict__ W5, const float* __restrict__ b1,
+                                                const float* __restrict__ b5, float* __restrict__ zb1, float* __restrict__ zb5,
+                                                const int fx, const int fy, const int which) {
     __shared__ float zs[16][65];
     __shared__ float ws[16][65];
-    const int which = blockIdx.z;
     const float* W = which ? W5 + kH + 3 : W1 + 3;
     const long ldw = which ? kH + 3 + L : 3 + L;
-    const int s0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+    const int s0 = fx * 16, o0 = fy * 16;
     const int tid = threadIdx.x, sl = tid >> 4, ol = tid & 15;
     double acc = 0;
     for (int k0 = 0; k0 < L; k0 += 64) {
@@ -1399,6 +1402,27 @@ __global__ void __launch_bounds__(256) shape_fold_kernel(const float* __restrict
         for (int k = 0; k < 64; ++k) acc = fma((double)zs[sl][k], (double)ws[ol][k], acc);
     }
     if (s0 + sl < S) ((which ? zb5 : zb1) + (long)(s0 + sl) * kH)[o0 + ol] = (float)(acc + (double)(which ? b5 : b1)[o0 + ol]);
+}
+__global__ void __launch_bounds__(256) shape_fold_kernel(const float* __restrict__ z, int S, int L, const float* __restrict__ W1,
+                                                         const float* __restrict__ W5, const float* __restrict__ b1,
+                                                         const float* __restrict__ b5, float* __restrict__ zb1,
+                                                         float* __restrict__ zb5) {
+    shape_fold_body(z, S, L, W1, W5, b1, b5, zb1, zb5, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// the weight pack (kin_used = 3) and the latent fold of the same parameters in ONE launch — both read only the parameter tensors and
+// the latents, and every step of the shape-sorted auto-decoder needs both behind its optimizer step (train_sdf_autodecoder.py:80-91):
+// workgroups [0, 64 (n + 1)) pack, the rest fold
+__global__ void __launch_bounds__(256) pack_fold_kernel(PackDescs descs, float* __restrict__ dst, const float* __restrict__ z, int S, int L,
+                                                        const float* __restrict__ W1, const float* __restrict__ W5,
+                                                        const float* __restrict__ b1, const float* __restrict__ b5,
+                                                        float* __restrict__ zb1, float* __restrict__ zb5) {
+    const unsigned npack = 64u * (unsigned)(descs.n + 1);
+    if (blockIdx.x < npack) {
+        pack_mfma_a_body(descs, dst, blockIdx.x & 63u, blockIdx.x >> 6, 64u);
+    } else {
+        const unsigned f = blockIdx.x - npack, sx = (unsigned)((S + 15) / 16);
+        shape_fold_body(z, S, L, W1, W5, b1, b5, zb1, zb5, (int)(f % sx), (int)((f / sx) & 15u), (int)(f / (sx * 16u)));
+    }
 }
 
 // ---- backward of the per-shape latent fold (the latent columns of layers1.0 / layers2.0 enter the forward as per-shape bias rows) ----
@@ -1555,8 +1579,13 @@ size_t sg_sdfnet_acts_floats(long ldn) { return (size_t)7 * kH * ldn + (size_t)5
 
 // params: host array of 16 device pointers in state_dict order
 //   layers1.{0,2,4,6}.{weight,bias}, layers2.{0,2,4,6}.{weight,bias}   (model/sdf_net.py:26-53)
+struct FoldJob {       // sdf_pack with the latent fold in the same launch (NULL z: pack only)
+    const float* z;
+    long nshapes;
+    float *zb1, *zb5;
+};
 static int sdf_pack(const float* const* params, const float* const* norm_params, int latent, int kin_used, float* packed,
-                    hipStream_t stream) {
+                    hipStream_t stream, const FoldJob* fold = nullptr) {
     const SdfPackLayout L = make_layout(kin_used);
     const int KIN = 3 + latent;
     const float *W1 = params[0], *W2 = params[2], *W3 = params[4], *W4 = params[6];
@@ -1594,7 +1623,13 @@ static int sdf_pack(const float* const* params, const float* const* norm_params,
     }
     D.v.dst_g = L.G;
     D.v.dst_be = L.Be;
-    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n + 1), dim3(256), 0, stream, D, packed);
+    if (fold) {
+        const unsigned blocks = 64u * (unsigned)(n + 1) + (unsigned)((fold->nshapes + 15) / 16) * 16u * 2u;
+        hipLaunchKernelGGL(pack_fold_kernel, dim3(blocks), dim3(256), 0, stream, D, packed, fold->z, (int)fold->nshapes, latent, W1, W5,
+                           params[1], params[9], fold->zb1, fold->zb5);
+    } else {
+        hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(64, n + 1), dim3(256), 0, stream, D, packed);
+    }
     SG_CHECK_LAUNCH();
     return SG_OK;
 }
@@ -1602,6 +1637,15 @@ static int sdf_pack(const float* const* params, const float* const* norm_params,
 int sg_sdfnet_pack(const float* const* params, int latent, int kin_used, float* packed, hipStream_t stream) {
     SG_CHECK_ARG(params && packed && latent >= 0 && (kin_used == 3 || kin_used == 3 + latent));
     return sdf_pack(params, nullptr, latent, kin_used, packed, stream);
+}
+
+// sg_sdfnet_pack(params, latent, 3, packed) and sg_sdfnet_shape_bias(z, nshapes, latent, W1, b1, W5, b5, zb1, zb5) in ONE launch
+// (per-shape mode: both are needed behind every optimizer step of the shape-sorted auto-decoder, train_sdf_autodecoder.py:80-91).
+int sg_sdfnet_pack_shape_bias(const float* const* params, int latent, float* packed, const float* z, long nshapes, float* zb1,
+                              float* zb5, hipStream_t stream) {
+    SG_CHECK_ARG(params && packed && latent > 0 && z && zb1 && zb5 && nshapes > 0);
+    const FoldJob job{z, nshapes, zb1, zb5};
+    return sdf_pack(params, nullptr, latent, 3, packed, stream, &job);
 }
 
 // The SDFGenerator form (model/point_sdf_net.py:49-119, hidden_channels 256, num_layers 8).  params: the 16 tensors

@@ -770,6 +770,12 @@ int sg_sdfnet_shape_bias_cpu(const float* z, long nshapes, int latent, const flo
     return SG_OK;
 }
 // backward of the per-shape latent fold (header: sg_sdfnet_shape_bias_bwd)
+int sg_sdfnet_pack_shape_bias_cpu(const float* const* params, int latent, float* packed, const float* z, long nshapes, float* zb1,
+                                  float* zb5, void* st) {
+    CPU_CHECK(params && packed && latent > 0 && z && zb1 && zb5 && nshapes > 0);
+    const int rc = sg_sdfnet_pack_cpu(params, latent, 3, packed, st);
+    return rc ? rc : sg_sdfnet_shape_bias_cpu(z, nshapes, latent, params[0], params[1], params[8], params[9], zb1, zb5, st);
+}
 int sg_sdfnet_shape_bias_bwd_cpu(const float* t1, const float* t5, long nshapes, const float* z, int latent, const float* W1,
                                  const float* W5, float* dW1, float* dW5, float* gz, const float* reg_weight, float reg_scale, void*) {
     CPU_CHECK(t1 && t5 && z && W1 && W5 && nshapes > 0 && latent > 0 && (dW1 == nullptr) == (dW5 == nullptr));
@@ -1162,6 +1168,9 @@ int sg_adam_step_cpu(float* p, const float* g, float* m, float* v, long n, float
                      float gscale, void* stream) {
     return sg_adam_step_guarded_cpu(p, g, m, v, n, lr, b1, b2, eps, step, gscale, nullptr, stream);
 }
+int sg_adam_step_dev_multi_cpu(int nsets, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n,
+                               const float* lr, const float* b1, const float* b2, const float* eps, long long* const* step_dev,
+                               float* const* corr_dev, const float* gscale, const int* skip, void* stream);
 int sg_adam_step_dev_guarded_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                                  long long* step_dev, float* corr_dev, float gscale, const int* skip, void*) {
     CPU_CHECK(p && g && m && v && n > 0 && step_dev && corr_dev);
@@ -1170,6 +1179,17 @@ int sg_adam_step_dev_guarded_cpu(float* p, const float* g, float* m, float* v, l
     corr_dev[0] = (float)(1.0 - pow((double)b1, (double)t));
     corr_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
     adam_update(p, g, m, v, n, lr, b1, b2, eps, corr_dev[0], corr_dev[1], gscale);
+    return SG_OK;
+}
+int sg_adam_step_dev_multi_cpu(int nsets, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n,
+                               const float* lr, const float* b1, const float* b2, const float* eps, long long* const* step_dev,
+                               float* const* corr_dev, const float* gscale, const int* skip, void* stream) {
+    CPU_CHECK(nsets > 0 && nsets <= 4 && p && g && m && v && n && lr && b1 && b2 && eps && step_dev && corr_dev && gscale);
+    for (int i = 0; i < nsets; ++i) {
+        const int rc = sg_adam_step_dev_guarded_cpu(p[i], g[i], m[i], v[i], n[i], lr[i], b1[i], b2[i], eps[i], step_dev[i], corr_dev[i],
+                                                    gscale[i], skip, stream);
+        if (rc) return rc;
+    }
     return SG_OK;
 }
 int sg_adam_step_dev_cpu(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

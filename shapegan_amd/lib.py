@@ -70,6 +70,7 @@ SIGNATURES = {
     "sg_sdfnet_bwd_blocks": (c_long, [_L]),
     "sg_sdfnet_bwd_tile_start": (c_long, [_L, _L]),
     "sg_sdfnet_shape_bias": (c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sg_sdfnet_pack_shape_bias": (c_int, [_P, _I, _P, _P, _L, _P, _P, _P]),
     "sg_sdfnet_shape_bias_bwd": (c_int, [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
     "sg_sdfgen_acts_floats": (_Z, [_L]),
     "sg_sdfgen_packed_norm_offset": (_L, [_I]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "sg_adam_step_dev": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P]),
     "sg_adam_step_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _P, _P]),
     "sg_adam_step_dev_guarded": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _F, _P, _P]),
+    "sg_adam_step_dev_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sg_clamp": (c_int, [_P, _L, _F, _F, _P]),
     "sg_clamp_multi": (c_int, [_P, _P, _I, _F, _F, _P]),
     "sg_voxel_prepare": (c_int, [_P, _P, _L, _F, _F, _P]),

@@ -914,21 +914,52 @@ class _PackCache(object):
     def __init__(self):
         self.entries = {}
 
-    def get(self, params, latent, kin_used):
-        dev = params[0].device
+    def _lookup(self, params, latent, kin_used):
+        """(key, the device's image if it is still the image of these parameters, else None)."""
         ptrs = [p.data_ptr() for p in params]
         key = (kin_used, latent, L.param_epoch_of_ptrs(ptrs)) + tuple(ptrs) + tuple(p._version for p in params)
-        entry = self.entries.get(dev)
+        entry = self.entries.get(params[0].device)
         # (parameters outside a flat optimizer buffer can be written through `.data` without a trace: never reuse their image)
         if entry is None or entry[0] != key or not L.writers_known(*params):
+            return key, None
+        return key, entry[1]
+
+    def get(self, params, latent, kin_used):
+        key, packed = self._lookup(params, latent, kin_used)
+        if packed is None:
             lib = _lib()
-            n = lib.sg_sdfnet_packed_floats(kin_used)
-            packed = torch.empty(n, dtype=torch.float32, device=dev)
+            dev = params[0].device
+            packed = torch.empty(lib.sg_sdfnet_packed_floats(kin_used), dtype=torch.float32, device=dev)
             arr = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params])
             check(lib.sg_sdfnet_pack(arr, latent, kin_used, ptr(packed), stream()), "sdfnet_pack")
-            entry = (key, packed)
-            self.entries[dev] = entry
-        return entry[1]
+            self.entries[dev] = (key, packed)
+        return packed
+
+    def get_with_fold(self, params, z):
+        """Per-shape mode: (image, zb1, zb5) for latents z [S, L] — the image rebuilt when stale, the fold zb = b + z W[:, latent
+        columns]^T of layers1.0 / layers2.0 always; ONE launch when the image is stale (sg_sdfnet_pack_shape_bias: behind every
+        optimizer step both are due), the fold alone otherwise, nothing when a fold made ahead (prepare_fold) is still current."""
+        z = f32c(z)
+        S, Lz = z.shape
+        dev = z.device
+        lib = _lib()
+        key, packed = self._lookup(params, Lz, 3)
+        if packed is not None:
+            ready = self.take_fold(z, packed)
+            if ready is not None:
+                return (packed,) + ready
+        zb1 = torch.empty((S, _H), dtype=torch.float32, device=dev)
+        zb5 = torch.empty((S, _H), dtype=torch.float32, device=dev)
+        if packed is None:
+            packed = torch.empty(lib.sg_sdfnet_packed_floats(3), dtype=torch.float32, device=dev)
+            arr = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params])
+            check(lib.sg_sdfnet_pack_shape_bias(arr, Lz, ptr(packed), ptr(z), S, ptr(zb1), ptr(zb5), stream()), "sdfnet_pack_shape_bias")
+            self.entries[dev] = (key, packed)
+            self.fold = None
+        else:
+            check(lib.sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(f32c(params[0])), ptr(f32c(params[1])), ptr(f32c(params[8])),
+                                           ptr(f32c(params[9])), ptr(zb1), ptr(zb5), stream()), "sdfnet_shape_bias")
+        return packed, zb1, zb5
 
     def prepare_fold(self, params, z):
         """Pack (if stale) and the per-shape latent fold of `z` NOW, on the current stream, for the forward_segments / forward_shapes
@@ -1151,18 +1182,10 @@ class SDFNetShapes(Function):
             raise RuntimeError("SDFNetShapes: need points for all %d x %d samples" % (S, pps))
         kin_total = 3 + Lz
         lib = _lib()
-        packed = cache.get(params, Lz, 3)
-        w1, b1, w5, b5 = f32c(params[0]), params[1], f32c(params[8]), params[9]
         # zb1[s,o] = b1[o] + sum_k z[s,k] W1[o,3+k];  zb5[s,o] = b5[o] + sum_k z[s,k] W5[o,259+k]: both folds in one launch,
-        # accumulated in double (round 6: the two sg_gemm calls were 2 - 4 launches and 24 us of the 20 000-point step)
-        ready = cache.take_fold(z, packed)          # (made ahead by _PackCache.prepare_fold for exactly these latents and weights?)
-        if ready is not None:
-            zb1, zb5 = ready
-        else:
-            zb1 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
-            zb5 = torch.empty((S, _H), dtype=torch.float32, device=points.device)
-            check(lib.sg_sdfnet_shape_bias(ptr(z), S, Lz, ptr(w1), ptr(f32c(b1)), ptr(w5), ptr(f32c(b5)), ptr(zb1), ptr(zb5), stream()),
-                  "sdfnet_shape_bias")
+        # accumulated in double — the same launch as the weight pack when that is stale (behind every optimizer step), none at all
+        # when _PackCache.prepare_fold made them ahead for exactly these latents and weights
+        packed, zb1, zb5 = cache.get_with_fold(params, z)
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad[1:])
         out = torch.empty(N, dtype=torch.float32, device=points.device)
         acts = torch.empty(lib.sg_sdfnet_acts_floats(N), dtype=torch.float32, device=points.device) if need_grad else None   # H1..H7 + sign masks

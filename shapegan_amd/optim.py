@@ -197,6 +197,14 @@ class Adam(_Base):
             for i in self._advanced.pop():
                 self.steps[i] -= 1
 
+    def _prepare_capturable(self):
+        f = self.f
+        if not f.coherent():
+            if any(p.grad is None for p in f.params):
+                raise RuntimeError("Adam(capturable=True) updates the whole flat buffer in one fixed launch: every "
+                                   "parameter needs a gradient on every step (torch.optim would skip the missing ones)")
+            f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
+
     def step(self):
         lib = L.load()
         f = self.f
@@ -205,11 +213,7 @@ class Adam(_Base):
         uniform = f.coherent() and len(set(self.steps)) == 1
         guard = self.guard.data_ptr() if self.guard is not None else None
         if self.capturable:
-            if not f.coherent():
-                if any(p.grad is None for p in f.params):
-                    raise RuntimeError("Adam(capturable=True) updates the whole flat buffer in one fixed launch: every "
-                                       "parameter needs a gradient on every step (torch.optim would skip the missing ones)")
-                f.adopt_grads()      # gradients that arrived as ordinary tensors: copied into their slices (capturable too)
+            self._prepare_capturable()
             L.note_device(f.flat)
             check(lib.sg_adam_step_dev_guarded(base_p, f.grad.data_ptr(), base_m, base_v, f.total, self.lr, self.betas[0],
                                                self.betas[1], self.eps, self.step_dev.data_ptr(), self.corr_dev.data_ptr(),
@@ -233,3 +237,36 @@ class Adam(_Base):
                                                self.betas[1], self.eps, self.steps[first[o]], self.grad_scale, guard, stream()),
                       "adam_step")
         L.bump_param_epoch(f.range)
+
+
+def step_together(optimizers):
+    """`for o in optimizers: o.step()` — as ONE launch when they are two to four capturable Adam optimizers on one device that share
+    their guard word (sg_adam_step_dev_multi: the network's and the latent table's optimizer of train_sdf_autodecoder.py:44-45,
+    90-91 inside a captured step), one after the other otherwise."""
+    import ctypes
+    opts = list(optimizers)
+    same = (2 <= len(opts) <= 4 and all(isinstance(o, Adam) and o.capturable for o in opts)
+            and len({o.f.flat.device for o in opts}) == 1
+            and len({None if o.guard is None else o.guard.data_ptr() for o in opts}) == 1)
+    if not same:
+        for o in opts:
+            o.step()
+        return
+    lib = L.load()
+    for o in opts:
+        o.f.check_storage()
+        o._prepare_capturable()
+    n = len(opts)
+    ptrs = lambda vals: (ctypes.c_void_p * n)(*vals)
+    floats = lambda vals: (ctypes.c_float * n)(*vals)
+    L.note_device(opts[0].f.flat)
+    guard = opts[0].guard.data_ptr() if opts[0].guard is not None else None
+    check(lib.sg_adam_step_dev_multi(n, ptrs([o.f.flat.data_ptr() for o in opts]), ptrs([o.f.grad.data_ptr() for o in opts]),
+                                     ptrs([o.exp_avg.data_ptr() for o in opts]), ptrs([o.exp_avg_sq.data_ptr() for o in opts]),
+                                     (ctypes.c_long * n)(*[o.f.total for o in opts]), floats([o.lr for o in opts]),
+                                     floats([o.betas[0] for o in opts]), floats([o.betas[1] for o in opts]),
+                                     floats([o.eps for o in opts]), ptrs([o.step_dev.data_ptr() for o in opts]),
+                                     ptrs([o.corr_dev.data_ptr() for o in opts]), floats([o.grad_scale for o in opts]), guard,
+                                     stream()), "adam_step_dev_multi")
+    for o in opts:
+        L.bump_param_epoch(o.f.range)

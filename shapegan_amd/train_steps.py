@@ -319,8 +319,7 @@ class SDFAutoDecoderTrainer(object):
         lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
-        self.net_opt.step()
-        self.lat_opt.step()
+        optim.step_together((self.net_opt, self.lat_opt))      # one launch when both are capturable (the graphed step)
         self._updates.append(self._words.seq)
         return loss.detach()
 
@@ -344,8 +343,7 @@ class SDFAutoDecoderTrainer(object):
         lib.backward(loss)
         self.net_bucket.allreduce()
         self.lat_bucket.allreduce()
-        self.net_opt.step()
-        self.lat_opt.step()
+        optim.step_together((self.net_opt, self.lat_opt))      # one launch when both are capturable (the graphed step)
         self._updates.append(self._words.seq)
         return loss.detach()
 

@@ -217,6 +217,10 @@ def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
     M.test_rowdot_family_matches_torch_to_second_order()
 
 
+def test_adam_step_together(on_cpu):
+    M.test_adam_step_together_equals_separate_steps()
+
+
 def test_two_threads_drive_two_modules_concurrently(on_cpu):
     """The DataParallel shape (train_hybrid_progressive_gan.py:62-68: replicas called from one Python thread each; SURVEY.md 8b
     "safe under DataParallel-style multi-thread calls"): two threads run forward + backward of native modules at the same time,

@@ -945,6 +945,46 @@ def test_sdf_autodecoder_graphed_step_equals_eager():
     torch.testing.assert_close(runs[0][2], runs[1][2], rtol=1e-6, atol=1e-9)
 
 
+def test_adam_step_together_equals_separate_steps():
+    """optim.step_together: two capturable Adam optimizers (different sizes, learning rates, betas — one of them larger than a
+    single round of the update's workgroups, so that both levels of its arrival tickets are used) stepped in ONE launch against
+    the same optimizers stepped one after the other, five steps: parameters, both moments, device counters and corrections
+    bit-identical; optimizers that do not qualify fall back to separate steps."""
+    from shapegan_amd import optim
+    torch.manual_seed(96)
+    shapes = ([(700, 700), (33,)], [(5, 128)])
+    hyper = (dict(lr=1e-3, betas=(0.9, 0.999)), dict(lr=5e-3, betas=(0.8, 0.99)))
+
+    def make():
+        torch.manual_seed(97)
+        sets = [[torch.nn.Parameter(torch.randn(sh, device=DEV)) for sh in group] for group in shapes]
+        return sets, [optim.Adam(ps, capturable=True, **h) for ps, h in zip(sets, hyper)]
+
+    (pa, oa), (pb, ob) = make(), make()
+    gen = torch.Generator().manual_seed(98)
+    for step in range(5):
+        grads = [[torch.randn(sh, generator=gen) for sh in group] for group in shapes]
+        for sets, opts in ((pa, oa), (pb, ob)):
+            for o in opts:
+                o.zero_grad()
+            for ps, gs in zip(sets, grads):
+                for p, g in zip(ps, gs):
+                    p.grad = g.to(DEV)
+        optim.step_together(oa)
+        for o in ob:
+            o.step()
+    for x, y in zip(oa, ob):
+        assert torch.equal(x.f.flat, y.f.flat) and torch.equal(x.exp_avg, y.exp_avg) and torch.equal(x.exp_avg_sq, y.exp_avg_sq)
+        assert int(x.step_dev.item()) == int(y.step_dev.item()) == 5
+        assert torch.equal(x.corr_dev[:2], y.corr_dev[:2]) and not bool(x.corr_dev[2:].any())      # tickets left at zero
+    # a host-counter optimizer in the list: no fused launch, same result as stepping it alone
+    q = [torch.nn.Parameter(torch.ones(4, device=DEV))]
+    o = optim.Adam(q, lr=1e-2)
+    q[0].grad = torch.ones(4, device=DEV)
+    optim.step_together([o])
+    torch.testing.assert_close(q[0].detach().cpu(), torch.full((4,), 0.99), rtol=1e-6, atol=1e-7)
+
+
 def test_autoencoder_graphed_step_equals_eager():
     """AutoencoderTrainer.step_graphed (captured once, replayed) walks the same trajectory as the eager step at the script's
     small batch: BatchNorm running statistics / counters, native losses and the device-side Adam step all live in the graph."""
