@@ -17,7 +17,7 @@ for name in ("bench", "wgan_step", "sdf_train", "hybrid_progressive", "hybrid_wg
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for name in ("stream_calibration.json", "edge_kernels_by_batch.json", "point_gan_bench.txt", "wgan_step_timeline.txt", "sdf200k_step_timeline.txt",
-             "sdf20k_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json",
+             "sdf20k_step_timeline.txt", "sdf20k_graphed_step_timeline.txt", "convT_c1_counters.txt", "bench_line.json", "bench_line_2ranks_gloo_one_gpu.json",
              "pytest_gpu.log", "dropin_gpu.log", "write_pattern.jsonl", "edge_kernels_cold.json", "fwd_c1_ablation.json",
              "convT_c1_ablation.json", "dgrad_paired_stores.json", "convT_forms.json", "sdfnet_bwd_ablation.txt", "sdfnet_counters.txt",
              "dropin_loop_kernel_stats.txt", "bench_line_2ranks_strong_gloo_one_gpu.json"):

@@ -46,5 +46,5 @@ python bench.py > $out/${tag}_bench_line.json 2> $out/bench_line.err
 SG_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --no-extras > $out/${tag}_bench_line_2ranks_gloo_one_gpu.json 2> $out/bench_2ranks.err
 # ordered launch lists of one steady-state step
 bash scripts/timeline_run.sh > $out/timeline.log 2>&1
-for n in wgan sdf200k sdf20k; do cp gpurun_out/timeline/$n.txt $out/${tag}_${n}_step_timeline.txt; done
+for n in wgan sdf200k sdf20k sdf20k_graphed; do cp gpurun_out/timeline/$n.txt $out/${tag}_${n}_step_timeline.txt; done
 ls -la $out | head -60

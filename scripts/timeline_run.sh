@@ -8,5 +8,6 @@ tl() { name=$1; marker=$2; per=$3; shift; shift; shift
   [ -n "$f" ] && python $repo/scripts/step_timeline.py $f $marker $per > $out/$name.txt 2>&1; }
 tl sdf200k adam_kernel 2 python $repo/scripts/sdf_step_prof.py 200000 256
 tl sdf20k adam_kernel 2 python $repo/scripts/sdf_step_prof.py 20000 128
+tl sdf20k_graphed adam_dev_multi 1 python $repo/scripts/sdf_step_prof_graphed.py 20000 128
 tl wgan rmsprop 6 python $repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras
 ls -la $out
