@@ -119,6 +119,9 @@ def md_tables():
             L += ["| %s | %.3f ms = %.2f Mpoints/s = %.3f executed |" % (what, s_[key]["ms_per_step"], s_[key]["mpoints_per_s"],
                                                                        s_[key]["frac_of_f32_mfma_peak_executed"])]
         for key, v in d.get("other_configs", {}).items():
+            if key == "point_gan" and "error" in v:
+                L += ["| other_configs.point_gan | failed: %s |" % v["error"]]
+                continue
             if key == "point_gan":
                 for upd in ("critic_update", "generator_update"):
                     u = v[upd]
