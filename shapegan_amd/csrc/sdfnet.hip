@@ -635,8 +635,6 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
     float* const Bm = A + 256 * P;         // [128][P]: H2
     float* const Xs = Bm + 128 * P;        // [8][LDX]
     float* const Bl = Xs + 8 * LDX;        // biases: 64 | 128 | 256 | 512
-    float* const PV = Bm;                  // [512] + [512] ints: over H2, which is dead once the third layer has been read (54 KB
-    int* const PI = reinterpret_cast<int*>(PV + 512);   //  in all: three workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, r = lane & 31;
     const long p0 = (long)blockIdx.x * P;
@@ -688,6 +686,11 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
         for (int q = 0; q < 16; ++q) acc[0][q] = 0.f;
         const int t = pass * 8 + wave;
         mlp_gemm<1>(acc, pk + (kPnW4 >> 2) + (long)t * 32 * 64, 32, A, P, lane);
+        // a wave's 32 rows end up one per lane: (maximum, point) of row L in lane L, written with v_writelane from the scalars the
+        // reduction produces — two coalesced 128-byte stores per pass and wave (the first form parked every pair in LDS from inside
+        // sixteen one-lane branches, a barrier and a second store behind them: 13 % of the kernel)
+        float resm = 0.f;
+        int resi = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float v = pok ? acc[0][q] : -INFINITY;
@@ -696,24 +699,24 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
             m = dpp_max(m, IntTag<0x141>(), IntTag<0xf>());
             m = dpp_max(m, IntTag<0x140>(), IntTag<0xf>());
             m = dpp_max(m, IntTag<0x142>(), IntTag<0xa>());
-            const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31));
-            const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
-            const unsigned long long eq = __ballot(v == (kh ? m1 : m0));
+            const int m0 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31);
+            const int m1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63);
+            const unsigned long long eq = __ballot(v == __builtin_bit_cast(float, kh ? m1 : m0));
             const unsigned lo = (unsigned)eq, hi = (unsigned)(eq >> 32);
-            if (lane == 0) {
-                const int c0 = t * 32 + frag_row(q, 0), c1 = t * 32 + frag_row(q, 1);
-                // (the bias is the same for every point of a channel: added behind the maximum — rounding is monotonic, the value
-                //  equals max(x + b) and the selected point is unchanged)
-                PV[c0] = m0 + Bl[448 + c0];
-                PI[c0] = plocal + (lo ? __builtin_ctz(lo) : 0);
-                PV[c1] = m1 + Bl[448 + c1];
-                PI[c1] = plocal + (hi ? __builtin_ctz(hi) : 0);
-            }
+            const int i0 = lo ? __builtin_ctz(lo) : 0, i1 = hi ? __builtin_ctz(hi) : 0;
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resm) : "s"(m0), "n"(frag_row(q, 0)));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resm) : "s"(m1), "n"(frag_row(q, 1)));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resi) : "s"(i0), "n"(frag_row(q, 0)));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resi) : "s"(i1), "n"(frag_row(q, 1)));
+        }
+        if (lane < 32) {
+            // (the bias is the same for every point of a channel: added behind the maximum — rounding is monotonic, the value
+            //  equals max(x + b) and the selected point is unchanged)
+            const int c = t * 32 + lane;
+            a.pv[(long)blockIdx.x * 512 + c] = resm + Bl[448 + c];
+            a.pi[(long)blockIdx.x * 512 + c] = plocal + resi;
         }
     }
-    __syncthreads();
-    a.pv[(long)blockIdx.x * 512 + tid] = PV[tid];
-    a.pi[(long)blockIdx.x * 512 + tid] = PI[tid];
 }
 
 struct SdfBwdArgs {
