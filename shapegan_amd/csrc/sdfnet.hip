@@ -678,7 +678,6 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
         return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000u, __builtin_bit_cast(int, v), decltype(ctrl)::value,
                                                                              decltype(rowmask)::value, 0xf, false)));
     };
-    const bool pok = p0 + r < a.N;
     const int plocal = (int)(p0 % a.pps);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {    // 256 -> 512, no activation behind it (point_sdf_net.py:22)
@@ -693,7 +692,7 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
         int resi = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float v = pok ? acc[0][q] : -INFINITY;
+            const float v = acc[0][q];        // (clouds are multiples of 32 points: every lane of every tile is a point)
             float m = dpp_max(v, IntTag<0xB1>(), IntTag<0xf>());
             m = dpp_max(m, IntTag<0x4E>(), IntTag<0xf>());
             m = dpp_max(m, IntTag<0x141>(), IntTag<0xf>());
@@ -701,8 +700,8 @@ __global__ void __launch_bounds__(512, 6) pointnet_select_kernel(PnSelArgs a) {
             m = dpp_max(m, IntTag<0x142>(), IntTag<0xa>());
             const int m0 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31);
             const int m1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63);
-            const unsigned long long eq = __ballot(v == __builtin_bit_cast(float, kh ? m1 : m0));
-            const unsigned lo = (unsigned)eq, hi = (unsigned)(eq >> 32);
+            const unsigned lo = (unsigned)__ballot(v == __builtin_bit_cast(float, m0));          // (compares against the scalars: no
+            const unsigned hi = (unsigned)(__ballot(v == __builtin_bit_cast(float, m1)) >> 32);   //  per-lane select of the half's maximum)
             const int i0 = lo ? __builtin_ctz(lo) : 0, i1 = hi ? __builtin_ctz(hi) : 0;
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resm) : "s"(m0), "n"(frag_row(q, 0)));
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(resm) : "s"(m1), "n"(frag_row(q, 1)));
