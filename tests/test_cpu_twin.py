@@ -213,7 +213,8 @@ def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
     M.test_sdf_generator_fused_vs_layerwise_and_oracle()
     M.test_gemm_nt_lnrelu_matches_torch()
     M.test_point_gan_sparse_max_adjoint_matches_dense_and_oracle()
-    M.test_pointnet_select_matches_layerwise()
+    for b, p in ((3, 1056), (1, 32), (5, 64)):
+        M.test_pointnet_select_matches_layerwise(b, p)
     M.test_rowdot_family_matches_torch_to_second_order()
 
 

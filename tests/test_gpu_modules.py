@@ -770,14 +770,15 @@ def test_rowdot_family_matches_torch_to_second_order():
         close(g, r, rtol=1e-5, atol=1e-5, what="rowdot family, quantity %d" % i)
 
 
-def test_pointnet_select_matches_layerwise():
+@pytest.mark.parametrize("B,P", [(3, 1056), (1, 32), (5, 64)])
+def test_pointnet_select_matches_layerwise(B, P):
     """ops.pointnet_select (nn1 + max over the cloud in one fused launch, per-point layers never written) against the module's
-    GEMM path + torch.max: maxima, and the selected points (equal, or holding a value that ties the maximum to rounding)."""
+    GEMM path + torch.max: maxima, and the selected points (equal, or holding a value that ties the maximum to rounding); one-tile
+    clouds and a single cloud included."""
     from shapegan_amd import ops
     from shapegan_amd.model.point_sdf_net import PointNet, _run_mlp
     torch.manual_seed(94)
     D = PointNet(out_channels=1).to(DEV)
-    B, P = 3, 1056
     x = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).to(DEV)
     lins = [m for m in D.nn1 if isinstance(m, torch.nn.Linear)]
     out, idx = ops.pointnet_select(D._pack, x, [l.weight for l in lins], [l.bias for l in lins])
