@@ -645,8 +645,12 @@ int halo_pack_jobs_launch(const PackJobs& jobs, hipStream_t stream) {
     return jobs.n;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
+// R32 (Cin <= 32: the progressive discriminator's 32-channel stage, model/progressive_gan.py:38): only the first 32 rows of the
+// 64-row tile exist, so instead of two waves multiplying an empty row block the four waves share row block 0 and take ONE of the
+// workgroup's four column tiles each — half the MFMAs per workgroup, none of them on padding.
+template <int MODE, bool R32>
+__device__ __forceinline__ void conv_dgrad_halo_body(HaloDgradArgs a) {
+    constexpr int NTN = R32 ? 1 : 2;      // column tiles per wave
     constexpr int kDCC = 16, kDNF = 16, kDBUF = kDNF * 256;   // channels per stage = copy elements per thread; floats per LDS buffer
     using BX = DBox<MODE>;
     constexpr int kDB = BX::CH;
@@ -664,14 +668,15 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int wm = R32 ? 0 : wave >> 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
+    const int tnf = R32 ? wave >> 1 : 0;      // R32: this wave's column tile
     // lane -> position inside a 32-position column tile; address of tap (td,th): lanebase + tn*TNOFF + (1-td)*PL + (1-th)*BW
     const int lpart = MODE == 0 ? (r >> 3) * BX::BW + (r & 7) : (r >> 4) * BX::PL + ((r >> 2) & 3) * BX::BW + (r & 3);
-    const int lanebase = wn * BX::WNOFF + lpart + 1 - kpar;
+    const int lanebase = wn * BX::WNOFF + tnf * BX::TNOFF + lpart + 1 - kpar;
 
-    f32x16 acc[2];
+    f32x16 acc[NTN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTN; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
@@ -744,16 +749,16 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     const int nn = MODE == 0 ? (int)n : (int)n + wn;
     const __amdgpu_buffer_rsrc_t ores = make_rsrc(a.dx + (long)(nn < a.batch ? nn : 0) * a.g.Cx * I3);
     const __amdgpu_buffer_rsrc_t bres = make_rsrc(a.bias ? a.bias : a.dx);
-    unsigned ovoff[2];
+    unsigned ovoff[NTN];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < NTN; ++tn) {
         int qd, qh, qw;
         if (MODE == 0) {
             qd = qd0 + wn;
-            qh = qh0 + tn * 4 + (r >> 3);
+            qh = qh0 + (tnf + tn) * 4 + (r >> 3);
             qw = qw0 + (r & 7);
         } else {
-            qd = 2 * tn + (r >> 4);
+            qd = 2 * (tnf + tn) + (r >> 4);
             qh = (r >> 2) & 3;
             qw = r & 3;
         }
@@ -771,9 +776,9 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
 #else
     const bool paired = a.ppw >= 2;
 #endif
-    float keep[2][16];
+    float keep[NTN][16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTN; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) keep[t][q] = 0.f;
     auto write_parity = [&](int par) __attribute__((always_inline)) {   // dx[n'][ci][2q + p] = act(acc + bias[ci]); acc = 0
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                     const int cis = ci0 + wm * 32 + (q & 3) + 8 * (q >> 2);
                     const float bv = a.bias && cis < a.Cin ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) keep[tn][q] = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
+                    for (int tn = 0; tn < NTN; ++tn) keep[tn][q] = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
                 }
             } else if (paired) {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -796,7 +801,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                     if (cis < a.Cin) {   // Cin % 8 == 0: the whole 8-channel block is in or out
                         const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
 #pragma unroll
-                        for (int tn = 0; tn < 2; ++tn) {
+                        for (int tn = 0; tn < NTN; ++tn) {
                             u32x2 v;
                             v.x = __builtin_bit_cast(unsigned, keep[tn][q]);
                             v.y = __builtin_bit_cast(unsigned, sg_apply_act(acc[tn][q] + bv, a.act, a.slope));
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                     if (cis < a.Cin) {
                         const float bv = a.bias ? buf_load(bres, bvoff, (unsigned)cis * 4u) : 0.f;
 #pragma unroll
-                        for (int tn = 0; tn < 2; ++tn) {
+                        for (int tn = 0; tn < NTN; ++tn) {
                             const float v = sg_apply_act(acc[tn][q] + bv, a.act, a.slope);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ores, (int)ovoff[tn],
                                                                   (int)((unsigned)cis * (unsigned)I3 * 4u + oshift + 4u * pw), 0);
@@ -821,7 +826,7 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTN; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     };
@@ -848,9 +853,9 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
     // that follows.  Both are scalars computed by the caller, the body itself is branch-free.
     auto stage = [&](auto tag, unsigned dys, unsigned wnext) __attribute__((always_inline)) {
         constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
-        float bq[2][4];
+        float bq[NTN][4];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < NTN; ++tn) {
             const lds_float* hb = bb[CUR][0] + tn * BX::TNOFF;
             bq[tn][0] = hb[O00];   // j=0: td=0, th=0
             bq[tn][1] = hb[O01];   // j=1: td=0, th=1
@@ -863,14 +868,14 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
             const float4 a_cur = aring[c % kRing];
             aring[c % kRing] = c + kRing < kDCC ? buf_load4(wres, wvoff, wcur + (unsigned)(c + kRing) * 1024u)
                                                 : buf_load4(wres, wvoff, wnext + (unsigned)(c + kRing - kDCC) * 1024u);
-            float b[2][4];
+            float b[NTN][4];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[tn][j] = bq[tn][j];
             if (c + 1 < kDCC) {
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
+                for (int tn = 0; tn < NTN; ++tn) {
                     const lds_float* hb = bb[CUR][c + 1] + tn * BX::TNOFF;
                     bq[tn][0] = hb[O00];
                     bq[tn][1] = hb[O01];
@@ -886,14 +891,11 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
                 for (int f = 2 * (c - kDCC / 2); f < 2 * (c - kDCC / 2) + 2; ++f) sdst[NXT * kDBUF + 256 * f] = fv[f];
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[0][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b[1][0], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[0][1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b[1][1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[0][2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b[1][2], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[0][3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b[1][3], acc[1], 0, 0, 0);
+            const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[tn][j], acc[tn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         wcur = wnext;
@@ -915,6 +917,15 @@ __global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
         if (s < nstage) stage(IntTag<0>(), dlast, wlast);   // odd stage count: only with one parity per workgroup
         write_parity(par);
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_dgrad_halo_kernel(HaloDgradArgs a) {
+    conv_dgrad_halo_body<MODE, false>(a);
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_dgrad_halo32_kernel(HaloDgradArgs a) {
+    conv_dgrad_halo_body<MODE, true>(a);
 }
 
 size_t halo_dgrad_workspace_bytes(int Cin, int Cout) { return (size_t)8 * ((Cin + 63) / 64) * 64 * Cout * 8 * sizeof(float); }
@@ -975,8 +986,13 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
         if (cost2 <= cost3) lds = 56 * 1024;
     }
     const dim3 grid((unsigned)tiles, mtiles, 8 / ppw);
-    if (mode1)
+    const bool r32 = Cin <= 32;      // (one 64-row tile of which only the first 32 rows exist)
+    if (mode1 && r32)
+        hipLaunchKernelGGL((conv_dgrad_halo32_kernel<1>), grid, dim3(256), lds, stream, a);
+    else if (mode1)
         hipLaunchKernelGGL((conv_dgrad_halo_kernel<1>), grid, dim3(256), lds, stream, a);
+    else if (r32)
+        hipLaunchKernelGGL((conv_dgrad_halo32_kernel<0>), grid, dim3(256), lds, stream, a);
     else
         hipLaunchKernelGGL((conv_dgrad_halo_kernel<0>), grid, dim3(256), lds, stream, a);
     return 1;

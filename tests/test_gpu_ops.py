@@ -826,9 +826,10 @@ def test_conv_fwd_halo_kernel(N, Ci, Co, R):
 
 
 @pytest.mark.parametrize("N,Ci,Co,O", [(2, 64, 128, 8), (1, 32, 16, 8), (1, 64, 32, 16), (2, 128, 64, 8), (1, 40, 48, 8),
-                                       (4, 128, 256, 4), (3, 96, 32, 4), (1, 64, 16, 4)])
+                                       (4, 128, 256, 4), (3, 96, 32, 4), (1, 64, 16, 4), (2, 32, 64, 16), (3, 32, 64, 4)])
 def test_conv_dgrad_halo_kernel(N, Ci, Co, O):
-    """The LDS-halo dgrad / ConvTranspose3d forward (forced) == ATen conv_transpose3d."""
+    """The LDS-halo dgrad / ConvTranspose3d forward (forced) == ATen conv_transpose3d (Ci = 32: the 32-row form, both grid modes,
+    single and paired parity stores)."""
     from shapegan_amd import ops
     from shapegan_amd.lib import ACT_LEAKY
     torch.manual_seed(N + Ci + Co + O)
