@@ -664,7 +664,7 @@ __device__ __forceinline__ void conv_dgrad_halo_body(HaloDgradArgs a) {
         n = blockIdx.x * 2;  // first sample of the pair
     }
     const int qd0 = tdi * 2, qh0 = thi * 8, qw0 = twi * 8;
-    const int ci0 = blockIdx.y * 64;
+    const int ci0 = blockIdx.y * (R32 ? 32 : 64);      // (R32: grid y counts 32-row tiles)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -700,7 +700,7 @@ __device__ __forceinline__ void conv_dgrad_halo_body(HaloDgradArgs a) {
     const int G = a.Cout;  // one k-group per output channel
     const int par0 = blockIdx.z * a.ppw, par_end = par0 + a.ppw;
     const unsigned par_bytes = (unsigned)(a.mtiles * 2) * (unsigned)G * 1024u;   // weight image: [parity][row tile][G][64] float4
-    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + ((long)(blockIdx.y * 2 + wm) * G) * 64);
+    const __amdgpu_buffer_rsrc_t wres = make_rsrc(a.wp + ((long)(R32 ? blockIdx.y : blockIdx.y * 2 + wm) * G) * 64);
     const unsigned wvoff = lane * 16;
 
     // ---- copy bookkeeping: element f of a stage is box index e = tid + 256 f, dense (ci, [sample,] hd, hh, hw); a buffer
@@ -985,8 +985,10 @@ int halo_dgrad_try(const float* dy, const float* w, const float* bias, float* dx
         const long cost2 = ((wgs + 511) / 512) * 2, cost3 = ((wgs + 767) / 768) * 3;
         if (cost2 <= cost3) lds = 56 * 1024;
     }
-    const dim3 grid((unsigned)tiles, mtiles, 8 / ppw);
-    const bool r32 = Cin <= 32;      // (one 64-row tile of which only the first 32 rows exist)
+    // 32-row workgroups (four waves, one column tile each): when only 32 rows of the tile exist (Cin <= 32), and when 64-row workgroups
+    // would leave CUs without one (small batches: 128 workgroups at 16 samples of a 4^3 grid) — twice as many, half as long
+    const bool r32 = Cin <= 32 || tiles * mtiles * (8 / ppw) < 256;
+    const dim3 grid((unsigned)tiles, r32 ? (unsigned)((Cin + 31) / 32) : (unsigned)mtiles, 8 / ppw);
     if (mode1 && r32)
         hipLaunchKernelGGL((conv_dgrad_halo32_kernel<1>), grid, dim3(256), lds, stream, a);
     else if (mode1)
