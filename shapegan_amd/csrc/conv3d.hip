@@ -544,7 +544,8 @@ size_t sg_conv3d_k4s2p1_fwd_workspace_bytes(int batch, int Cin, int Cout, int OD
     const size_t splitk = tiles >= 512 ? 0 : per * 8 * sizeof(float);
     const size_t pack = halo_fwd_workspace_bytes(Cin, Cout);
     const size_t edge = (Cin == 1 && Cout <= 64) ? edge_fwd_workspace_bytes(batch, OD, OH, OW) : 0;
-    const size_t sp = splitk > pack ? splitk : pack;
+    // (4^3 outputs at small batches: the halo kernel's image AND its channel-split partials — at most 8 — side by side)
+    const size_t sp = (OD == 4 && OH == 4 && OW == 4) ? pack + splitk : (splitk > pack ? splitk : pack);
     return sp > edge ? sp : edge;
 }
 
@@ -576,6 +577,16 @@ static int fwd_call(const float* x, const float* w, const float* bias, float* y,
                                     stream, 0, 0, packed_already);
         if (rc < 0) return rc;
         if (rc == 1) {
+            SG_CHECK_LAUNCH();
+            return SG_OK;
+        }
+        if (rc > 16) {      // the 4^3 halo kernel with its input channels split over rc - 16 workgroups: partial sums behind the image
+            const int csplit = rc - 16;
+            FwdEpi epi{y, bias, g.O3(), Cout, FastDiv((uint32_t)g.O3()), act, slope};
+            const float* partial = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + halo_fwd_workspace_bytes(Cin, Cout));
+            const long fb = (long)Cout * ((npos + 1023) >> 10);
+            hipLaunchKernelGGL((splitk_finalize_kernel<FwdEpi>), dim3((unsigned)fb), dim3(256), 0, stream, partial, epi, Cout, (int)npos,
+                               csplit);
             SG_CHECK_LAUNCH();
             return SG_OK;
         }

@@ -45,6 +45,11 @@ struct HaloFwdArgs {
     FastDiv dntw, dnth, dOD;
     int act;
     float slope;
+    // conv_fwd_halo4_kernel with the input channels split over `csplit` workgroups (grid z): raw partial sums
+    // partial[(z * Cout + co) * npos + n * 64 + p], finished (sum, bias, activation) by the gather kernel's split-K finalize
+    int csplit;
+    float* partial;
+    long npos;
 };
 
 // Wp[(mt*G + g)*64 + lane] = float4{ W[mt*32 + (lane&31)][8g + 2j + (lane>>5)] , j = 0..3 }   (G = Cin*8 groups)
@@ -274,7 +279,9 @@ __global__ void __launch_bounds__(NW * 64) conv_fwd_halo_kernel(HaloFwdArgs a) {
 // fragment read (2 od x 4 oh x 4 ow, strides 208 / 20 / 1) conflict-free.
 // 8 waves: (K half) x (row tile pair) x (position half): waves 0-3 take channels 0-3 of every 8-channel stage, waves 4-7
 // channels 4-7 — a sample has only 64 output positions, so the second wave group comes from splitting K; the two
-// partial accumulators meet in LDS at the end.  Grid = batch x Cout/64.
+// partial accumulators meet in LDS at the end.  Grid = batch x Cout/64 (x csplit: small batches — 16 samples are 64 workgroups, and
+// one workgroup's walk over 128 channels is 130 us however few there are — split the input channels over 2 - 8 workgroups
+// that write raw partial sums; round 6, it was the gather GEMM at 0.44 of the matrix peak below 160 workgroups).
 constexpr int k4HALF = 5, k4ROW = 10, k4PLANE = 104, k4CH = 10 * k4PLANE;   // 1040 floats per channel
 constexpr int k4CC = 8;                                                      // channels per stage
 constexpr int k4BUF = k4CC * k4CH;                                           // 8320 floats = 33 KB per buffer
@@ -284,6 +291,7 @@ __global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float halo[];  // [2][k4CC][k4CH]
     lds_float* const hl = (lds_float*)halo;
     const int n = blockIdx.x, co0 = blockIdx.y * 64;
+    const int cpw = a.Cin / a.csplit, cb = blockIdx.z * cpw;      // this workgroup's input channels [cb, cb + cpw)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, r = lane & 31, kpar = lane >> 5;
@@ -313,7 +321,7 @@ __global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
 
     // copy: a channel is 512 contiguous floats; thread t moves element t of each of the stage's 8 channels
     const int I3 = 512;
-    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x + (long)n * a.g.Cx * I3);
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x + ((long)n * a.g.Cx + cb) * I3);
     unsigned xvoff = tid * 4;
     lds_float* sdst = hl + ((tid >> 6) + 1) * k4PLANE + (((tid >> 3) & 7) + 1) * k4ROW + (((tid & 7) + 1) & 1) * k4HALF +
                       (((tid & 7) + 1) >> 1);
@@ -324,10 +332,10 @@ __global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
 #pragma unroll
     for (int c = 0; c < k4CC; ++c) fv[c] = buf_load(xres, xvoff, c * (I3 * 4));
     // weight groups of this wave in order: stage s, own channel c, j -> group (s*8 + kh*4 + c)*8 + j = s*64 + kh*32 + (c*8+j)
-    const int nstage = a.Cin / k4CC, nq = nstage * 32;
+    const int nstage = cpw / k4CC, nq = nstage * 32, s0 = cb / k4CC;
     auto group_of = [&](int q) {
         q = q < nq ? q : nq - 1;
-        return (q >> 5) * 64 + kh * 32 + (q & 31);
+        return ((q >> 5) + s0) * 64 + kh * 32 + (q & 31);
     };
     float4 aring[kRing];
 #pragma unroll
@@ -340,7 +348,7 @@ __global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
     auto stage = [&](auto tag, int s) {
         constexpr int CUR = decltype(tag)::value, NXT = CUR ^ 1;
         int cnext = (s + 1) * k4CC;
-        cnext = cnext > a.Cin - k4CC ? a.Cin - k4CC : cnext;
+        cnext = cnext > cpw - k4CC ? cpw - k4CC : cnext;
         const unsigned xs = (unsigned)cnext * (I3 * 4);
         float bq[4];
         {
@@ -400,6 +408,15 @@ __global__ void __launch_bounds__(512) conv_fwd_halo4_kernel(HaloFwdArgs a) {
     }
     __syncthreads();
     if (kh == 1) return;
+    if (a.csplit > 1) {      // raw partial sums, row-major [co][sample * 64 + p] per channel split
+        float* po = a.partial + (long)blockIdx.z * a.Cout * a.npos + (long)n * 64 + p;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kpar;
+            if (co < a.Cout) po[(long)co * a.npos] = acc[q] + red[q * 64 + lane];
+        }
+        return;
+    }
     // y[n][co][p], p = od*16 + oh*4 + ow: 32 consecutive floats per (co, position half)
     float* yo = a.y + (long)n * a.Cout * 64 + p;
 #pragma unroll
@@ -425,7 +442,15 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         const int mtiles = sg_cdiv(Cout, 64);
         // (one round of workgroups costs ~130 us at 128 -> 256 channels whatever its size; the split-K gather kernel is faster
         // below ~160 of them: 113 vs 132 us at 32 samples, 195 vs 129 us at 48 — scripts/small_batch_ab2.py, round 4)
-        if (!force && (long)batch * mtiles < 160) return 0;
+        // Below that, the input channels are split over 2 - 8 workgroups per (sample, row tile) that write partial sums (finished by
+        // the caller with the gather kernel's split-K finalize: return code 16 + csplit): 256 workgroups of 4+ stages each
+        int csplit = 1;
+        if (!force && (long)batch * mtiles < 160) {
+            while (csplit < 8 && (long)batch * mtiles * csplit < 256 && (Cin / (2 * csplit)) % k4CC == 0 && Cin / (2 * csplit) >= 2 * k4CC)
+                csplit *= 2;
+            if (csplit == 1) return 0;
+            if (workspace_bytes < halo_fwd_workspace_bytes(Cin, Cout) + (size_t)csplit * Cout * batch * 64 * sizeof(float)) return 0;
+        }
         float4* wp = (float4*)workspace;
         const int ntile = mtiles * 2;
         const long total = (long)ntile * Cin * 8 * 64;
@@ -446,6 +471,9 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
         a.dntw = a.dnth = a.dOD = FastDiv(1);
         a.act = act;
         a.slope = slope;
+        a.csplit = csplit;
+        a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + halo_fwd_workspace_bytes(Cin, Cout));
+        a.npos = (long)batch * 64;
         const size_t lds4 = (size_t)2 * k4BUF * sizeof(float);   // 66.5 KB: above the default dynamic-LDS limit
         static SgPerDeviceOnce attr_once;   // > 48 KB of dynamic LDS needs the attribute once per DEVICE
         if (attr_once.begin()) {
@@ -453,8 +481,8 @@ int halo_fwd_try(const float* x, const float* w, const float* bias, float* y, in
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
             attr_once.end();
         }
-        hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles), dim3(512), lds4, stream, a);
-        return 1;
+        hipLaunchKernelGGL(conv_fwd_halo4_kernel, dim3((unsigned)batch, mtiles, csplit), dim3(512), lds4, stream, a);
+        return csplit > 1 ? 16 + csplit : 1;
     }
     // eligible: 8x8 position tiles exist, whole stages of 4 channels, enough output channels to fill 64-row MFMA tiles
     if (g.OW % 8 != 0 || g.OH % 8 != 0 || Cin % kCC != 0 || Cin < 8 || Cout < 32) return 0;

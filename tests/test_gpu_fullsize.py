@@ -30,10 +30,12 @@ def close_mostly(a, b, rtol=RTOL, max_bad_frac=1e-3, what=""):
         assert float((a - b).abs().max()) <= 0.5 * float(b.abs().max()), what + ": outlier larger than the tensor scale"
 
 
-@pytest.mark.parametrize("N,Ci,Co,R", [(128, 64, 128, 16), (128, 128, 256, 8), (64, 64, 128, 16), (16, 32, 64, 32)])
+@pytest.mark.parametrize("N,Ci,Co,R", [(128, 64, 128, 16), (128, 128, 256, 8), (64, 64, 128, 16), (16, 32, 64, 32), (16, 128, 256, 8),
+                                       (3, 128, 256, 8), (5, 64, 96, 8)])
 def test_conv3d_full_size_vs_aten(N, Ci, Co, R):
-    """gan.Discriminator layers 2 / 3 at the critic's concatenated fake+real batch (2 x 64), the generator-step batch (64)
-    and the progressive discriminator's 32 -> 64 stage at batch 16: forward (+ LeakyReLU epilogue), input gradient, weight
+    """gan.Discriminator layers 2 / 3 at the critic's concatenated fake+real batch (2 x 64), the generator-step batch (64),
+    the progressive discriminator's 32 -> 64 stage at batch 16 and the 4^3-output layer at the hybrid GANs' small batches (the halo
+    kernel with its input channels split over 4 / 8 / 2 workgroups + the split-K finalize): forward (+ LeakyReLU epilogue), input gradient, weight
     gradient and bias gradient through ops.conv3d_k4s2p1, i.e. whatever kernel the dispatcher picks at this size."""
     from shapegan_amd import ops
     from shapegan_amd.lib import ACT_LEAKY
