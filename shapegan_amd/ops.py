@@ -1228,16 +1228,22 @@ class SDFNetShapes(Function):
             # per-shape sums of dZ1 / dZ5: T[o, s] = sum_{p in shape s} dZ[o, p]   (each shape's points are contiguous)
             t1 = torch.empty((_H, S), dtype=torch.float32, device=dev)
             t5 = torch.empty((_H, S), dtype=torch.float32, device=dev)
-            if ctx.seg_off is None:
+            seg_off = ctx.seg_off
+            if seg_off is None and need_p:
+                # uniform segments (the hybrid GANs' shapes of pps grid points each): the same path as the sorted batch — the
+                # per-shape sums come out of the tile partials in the finishing launch instead of two passes over the dZ1 / dZ5
+                # images (2 x 42 us per generator update of train_hybrid_wgan.py:84-91)
+                seg_off = torch.arange(S + 1, dtype=torch.int64, device=dev) * pps
+            if seg_off is None:
                 check(lib.sg_rowsum(ptr(dz), ptr(t1), _H * S, pps, pps, stream()), "rowsum")
                 check(lib.sg_rowsum(ptr(dz) + 4 * 4 * _H * N, ptr(t5), _H * S, pps, pps, stream()), "rowsum")
             elif need_p:
                 # interior tiles of a segment come from the backward's own per-tile partials, in the launch that also finishes
                 # the bias gradients (sg_sdfnet_bwd_finish inside _sdf_param_grads): no pass over the images
-                seg = (ctx.seg_off, S, t1, t5)
+                seg = (seg_off, S, t1, t5)
             else:
                 ws = workspace("sdf_finish", lib.sg_sdfnet_bwd_finish_workspace_bytes(N), dev)
-                check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), N, N, 0, None, None, None, None, 0, None, 0, ptr(ctx.seg_off), S,
+                check(lib.sg_sdfnet_bwd_finish(ptr(dz), ptr(bsum), N, N, 0, None, None, None, None, 0, None, 0, ptr(seg_off), S,
                                                ptr(t1), ptr(t5), ptr(ws), ws.numel(), ptr(L.tickets("sdf_finish", dev)), stream()),
                       "sdfnet_bwd_finish")
         fold = (need_p or need_z) and S <= _FOLD_MAX_SHAPES
