@@ -715,9 +715,11 @@ def point_gan_updates(P=16384, B=12, steps=5, warmup=3):
     z, a = torch.randn(B, 128, device="cuda"), torch.rand(B, 1, 1, device="cuda")
     out = {"workload": "train_point_gan.py WGAN-GP, SDFGenerator(128, 256, 8) vs PointNet critic, %d clouds x %d points, fp32" % (B, P)}
     g, d, sp = 0.790e6, 0.345e6, 512.0 / P
-    for name, fn, ref, exe in (("critic_update", lambda: tr.critic_step(u, z, a), g + 11 * d, g + 3 * d + sp * 11 * d),
-                               ("generator_update", lambda: tr.generator_step(u, z), 3 * (g + d), g + d + sp * 3 * (g + d))):
-        for _ in range(warmup):
+    # (each update as one captured graph launch, like the 20 000-point auto-decoder step: ~110 launches of 5 - 60 us behind a dense
+    #  pass of 3 ms are paced by the host when launched eagerly on a slow one)
+    for name, fn, ref, exe in (("critic_update", lambda: tr.critic_step_graphed(u, z, a), g + 11 * d, g + 3 * d + sp * 11 * d),
+                               ("generator_update", lambda: tr.generator_step_graphed(u, z), 3 * (g + d), g + d + sp * 3 * (g + d))):
+        for _ in range(warmup + 1):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -725,7 +727,7 @@ def point_gan_updates(P=16384, B=12, steps=5, warmup=3):
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        out[name] = {"ms": round(ms, 3), "mpoints_per_s": round(B * P / ms / 1e3, 2),
+        out[name] = {"launch": "one captured graph per update", "ms": round(ms, 3), "mpoints_per_s": round(B * P / ms / 1e3, 2),
                      "reference_arithmetic_frac_of_f32_mfma_peak": round(ref * B * P / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                      "executed_arithmetic_frac_of_f32_mfma_peak": round(exe * B * P / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     return out

@@ -19,8 +19,9 @@ tr = PointGANTrainer(G, D)
 for P, B in ((1024, 32), (4096, 32), (16384, 12), (32768, 6)):
     u = torch.cat([torch.rand(B, P, 3) * 2 - 1, torch.rand(B, P, 1) * 0.2 - 0.1], -1).cuda()
     z, a = torch.randn(B, 128, device="cuda"), torch.rand(B, 1, 1, device="cuda")
-    tc = timeit(lambda: tr.critic_step(u, z, a))
-    tg = timeit(lambda: tr.generator_step(u, z))
+    tr = PointGANTrainer(G, D)        # (fresh graphs per stage: every update is one captured graph launch)
+    tc = timeit(lambda: tr.critic_step_graphed(u, z, a))
+    tg = timeit(lambda: tr.generator_step_graphed(u, z))
     # FLOP per point, forward: SDFGenerator 2 (3 256 + 3 256^2 + 259 256 + 2 256^2 + 256) = 0.790 M, PointNet 2 (4 64 + 64 128
     # + 128 256 + 256 512) = 0.345 M.
     # REFERENCE arithmetic (dense autograd, train_point_gan.py:52-83): critic update = G forward + D(real) + D(fake) + D(interpolated)

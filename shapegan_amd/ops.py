@@ -905,6 +905,12 @@ class BatchNormAct(Function):
 _H = 256
 
 
+def _capturing(t):
+    """A graph under capture must contain the weight pack even when the image happens to be current at capture time: the replays
+    run after optimizer steps (possibly captured in OTHER graphs) that the capture-time check cannot see."""
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 class _PackCache(object):
     """MFMA-fragment image of the 16 SDFNet tensors, rebuilt only when a parameter changed (in-place optimizer
     steps bump tensor._version).  One entry per device: nn.DataParallel replicas (train_hybrid_progressive_gan.py:62-68) are
@@ -920,7 +926,7 @@ class _PackCache(object):
         key = (kin_used, latent, L.param_epoch_of_ptrs(ptrs)) + tuple(ptrs) + tuple(p._version for p in params)
         entry = self.entries.get(params[0].device)
         # (parameters outside a flat optimizer buffer can be written through `.data` without a trace: never reuse their image)
-        if entry is None or entry[0] != key or not L.writers_known(*params):
+        if entry is None or entry[0] != key or not L.writers_known(*params) or _capturing(params[0]):
             return key, None
         return key, entry[1]
 
@@ -1305,7 +1311,7 @@ class _GenPackCache(object):
         ptrs = [p.data_ptr() for p in params]
         key = (L.param_epoch_of_ptrs(ptrs),) + tuple(ptrs) + tuple(p._version for p in params)
         entry = self.entries.get(dev)
-        if entry is None or entry[0] != key or not L.writers_known(*params):
+        if entry is None or entry[0] != key or not L.writers_known(*params) or _capturing(params[0]):
             lib = _lib()
             packed = torch.empty(lib.sg_sdfnet_packed_floats(3), dtype=torch.float32, device=dev)
             lins = (ctypes.c_void_p * 16)(*[ptr(f32c(p.detach())) for p in params[:16]])
@@ -1495,7 +1501,7 @@ class _PointPackCache(object):
         ptrs = [p.data_ptr() for p in weights]
         key = (L.param_epoch_of_ptrs(ptrs),) + tuple(ptrs) + tuple(p._version for p in weights)
         entry = self.entries.get(dev)
-        if entry is None or entry[0] != key or not L.writers_known(*weights):
+        if entry is None or entry[0] != key or not L.writers_known(*weights) or _capturing(weights[0]):
             lib = _lib()
             packed = torch.empty(lib.sg_pointnet_packed_floats(), dtype=torch.float32, device=dev)
             arr = (ctypes.c_void_p * 4)(*[ptr(f32c(p.detach())) for p in weights])

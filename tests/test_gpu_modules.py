@@ -841,6 +841,41 @@ def test_point_gan_sparse_max_adjoint_matches_dense_and_oracle():
                                       "%s path, %s grad %s" % (name, what, k), rtol=2e-4, noise_factor=8.0)
 
 
+def test_point_gan_graphed_updates_equal_eager():
+    """PointGANTrainer.critic_step_graphed / generator_step_graphed (captured once, replayed) walk the same trajectory as the eager
+    updates over an interleaved sequence — the generator changes between critic replays, so a weight image frozen at capture time
+    would show (the packs are rebuilt inside the graphs)."""
+    import copy
+    from shapegan_amd.model.point_sdf_net import PointNet, SDFGenerator
+    from shapegan_amd.train_steps import PointGANTrainer
+    torch.manual_seed(99)
+    g, d = SDFGenerator(128, 256, 8, True, dropout=0.0).to(DEV), PointNet(out_channels=1).to(DEV)
+    B, P = 2, 1024
+    gen = torch.Generator().manual_seed(5)
+    data = [(torch.cat([torch.rand(B, P, 3, generator=gen) * 2 - 1, torch.rand(B, P, 1, generator=gen) * 0.2 - 0.1], -1).to(DEV),
+             torch.randn(B, 128, generator=gen).to(DEV), torch.rand(B, 1, 1, generator=gen).to(DEV)) for _ in range(8)]
+    runs = []
+    for graphed in (False, True):
+        tr = PointGANTrainer(copy.deepcopy(g), copy.deepcopy(d))
+        cs = tr.critic_step_graphed if graphed else tr.critic_step
+        gs = tr.generator_step_graphed if graphed else tr.generator_step
+        losses = []
+        for i, (u, z, a) in enumerate(data):
+            dl, gp = cs(u, z, a)
+            losses += [float(dl), float(gp)]
+            if i % 2 == 1:
+                losses.append(float(gs(u, z)))
+        runs.append((losses, {k: v.detach().clone() for k, v in tr.generator.state_dict().items()},
+                     {k: v.detach().clone() for k, v in tr.critic.state_dict().items()}))
+    # the losses are the sensitive quantity (a stale generator image changes the critic's losses in the second digit); the weights
+    # are compared at a few optimizer steps' size: the scatter-add behind the gathered points (index_select's backward, duplicates
+    # added atomically) is not run-to-run reproducible in the last bit, and RMSprop's first steps are lr * sign(g)
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-5, atol=1e-7)
+    for which in (1, 2):
+        for k in runs[0][which]:
+            torch.testing.assert_close(runs[0][which][k], runs[1][which][k], rtol=0, atol=1e-3, msg=k)
+
+
 def test_dp_shards_sum_to_full_batch_gradient():
     """Distributed math on one GPU: averaged shard gradients == full-batch gradient for the BN-free
     critic, i.e. what one RCCL all-reduce of the flat buffers + grad_scale 1/G produces."""
