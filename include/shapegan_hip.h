@@ -516,6 +516,11 @@ int sg_segmax_gather(const float* x, const int* idx, float* out, long B, long P,
  * that holds the maximum of channel c, so nn1's last Linear (model/point_sdf_net.py:22) reduces to out[r] = bias[c] + h[r] . w[c]
  * (sg_rowdot); its adjoints out[r][k] = g[r] w[c][k] (sg_rowscale) and out[c][k] = sum_b g[b C + c] h[b C + c][k] (sg_rowouter)
  * make the three closed under differentiation (the gradient penalty of train_point_gan.py:61-70 differentiates twice). */
+/* Deterministic adjoint of gathering C rows per group out of x [N][K] (the selected points of every cloud, rows of a group may repeat:
+ * several channels can select the same point): dx[rows[b C + c]][k] += g[b C + c][k] without atomics — the first channel that names
+ * a row receives the sum of its duplicates through a fixed tree of additions.  dx zeroed by the caller; rows of different groups are
+ * distinct; C <= 1024, C K <= 8192. */
+int sg_scatter_rows_grouped(const float* g, const int64_t* rows, float* dx, long B, int C, int K, hipStream_t stream);
 int sg_rowdot(const float* h, const float* w, const float* bias, float* out, long B, int C, int K, hipStream_t stream);
 int sg_rowscale(const float* g, const float* w, float* out, long B, int C, int K, hipStream_t stream);
 int sg_rowouter(const float* g, const float* h, float* out, long B, int C, int K, hipStream_t stream);

@@ -540,6 +540,69 @@ __global__ void __launch_bounds__(256) rowouter_kernel(const float* __restrict__
     out[e] = s;
 }
 
+// ---- adjoint of gathering the selected points of every cloud (PointNet.gather_points): dx[rows[b C + c]][k] += g[b C + c][k],
+// where several channels of a cloud may have selected the SAME point.  ATen's index_add does this with atomic float adds (the
+// order of duplicates, and with it the last bit, changes from run to run); here a cloud's C rows are one workgroup: thread c is
+// the LEADER of its row if no c' < c names the same row, and a leader adds the duplicates in increasing c' and writes the sum —
+// deterministic, no atomics.  dx is zeroed by the caller (rows that no channel selected stay zero).
+__global__ void __launch_bounds__(1024) scatter_rows_grouped_kernel(const float* __restrict__ g, const int64_t* __restrict__ rows,
+                                                                    float* __restrict__ dx, int C, int K) {
+    // Duplicates are the rule, not the exception (with random weights a handful of points hold the maxima of hundreds of channels):
+    // a leader walking its duplicates one after the other took 150 us.  Here every channel finds its NEXT duplicate (smallest
+    // e > c with the same row) in one sweep, and the chains are summed by pointer jumping — acc[c] += acc[next[c]], next[c] =
+    // next[next[c]], ten synchronous steps for 1024 channels — a fixed tree of additions whatever the timing: deterministic.
+    __shared__ int srow[1024];       // row numbers relative to the group's first (a cloud's rows span less than 2^31)
+    __shared__ short nxt[2][1024];
+    __shared__ long long base;
+    extern __shared__ float sacc[];  // [2][C * K]
+    const long b = blockIdx.x;
+    const int c = threadIdx.x, CK = C * K;
+    const long long mine64 = c < C ? rows[b * C + c] : 0;
+    if (c == 0) base = mine64;
+    __syncthreads();
+    const int mine = c < C ? (int)(mine64 - base) : 0x7fffffff - c;       // (padding entries: distinct from everything real)
+    srow[c] = mine;
+    for (int e = c; e < CK; e += 1024) sacc[e] = g[b * CK + e];
+    __syncthreads();
+    bool before = c >= C;
+    int next = -1;
+    if (c < C) {
+        // (16-byte LDS reads; the row table is padded to 1024 entries with values that match nothing)
+        const int c4 = c & ~3;
+        for (int e = 0; e < c4; e += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(&srow[e]);
+            before |= (v.x == mine) | (v.y == mine) | (v.z == mine) | (v.w == mine);
+        }
+        for (int e = c4; e < c; ++e) before |= srow[e] == mine;
+        for (int e = ((C + 3) & ~3) - 4; e > c4; e -= 4) {
+            const int4 v = *reinterpret_cast<const int4*>(&srow[e]);
+            next = v.w == mine ? e + 3 : next;
+            next = v.z == mine ? e + 2 : next;
+            next = v.y == mine ? e + 1 : next;
+            next = v.x == mine ? e : next;
+        }
+        for (int e = c4 + 3; e > c; --e) next = srow[e] == mine ? e : next;
+    }
+    nxt[0][c] = (short)next;
+    __syncthreads();
+    int cur = 0;
+    for (int span = 1; span < C; span <<= 1) {       // chains are at most C long: ceil(log2 C) jumps
+        const int n = nxt[cur][c];
+        if (n >= 0) {
+            for (int k = 0; k < K; ++k) sacc[(cur ^ 1) * CK + c * K + k] = sacc[cur * CK + c * K + k] + sacc[cur * CK + n * K + k];
+            nxt[cur ^ 1][c] = nxt[cur][n];
+        } else {
+            if (c < C)
+                for (int k = 0; k < K; ++k) sacc[(cur ^ 1) * CK + c * K + k] = sacc[cur * CK + c * K + k];
+            nxt[cur ^ 1][c] = -1;       // (also the padding threads: an unwritten entry would be read as a pointer in the next step)
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (!before)
+        for (int k = 0; k < K; ++k) dx[mine64 * K + k] = sacc[cur * CK + c * K + k];
+}
+
 // dx[b][p][c] = (p == idx[b][c]) ? dy[b][c] : 0   (adjoint of the max; every element written)
 __global__ void __launch_bounds__(256) segmax_scatter_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
                                                              float* __restrict__ dx, long B, long P, int C) {
@@ -707,6 +770,15 @@ int sg_segmax_scatter(const float* dy, const int* idx, float* dx, long B, long P
     long blocks = (B * P * C + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(segmax_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, idx, dx, B, P, C);
+    SG_CHECK_LAUNCH();
+    return SG_OK;
+}
+
+// Deterministic adjoint of a grouped row gather (see scatter_rows_grouped_kernel): g [B*C][K], rows [B*C] (int64 row numbers into
+// dx [N][K]; the rows of group b may repeat, rows of different groups are distinct), dx zeroed by the caller.  C <= 1024, C K <= 8192.
+int sg_scatter_rows_grouped(const float* g, const int64_t* rows, float* dx, long B, int C, int K, hipStream_t stream) {
+    SG_CHECK_ARG(g && rows && dx && B > 0 && C > 0 && C <= 1024 && K > 0 && (long)C * K <= 8192);
+    hipLaunchKernelGGL(scatter_rows_grouped_kernel, dim3((unsigned)B), dim3(1024), (size_t)2 * C * K * sizeof(float), stream, g, rows, dx, C, K);
     SG_CHECK_LAUNCH();
     return SG_OK;
 }

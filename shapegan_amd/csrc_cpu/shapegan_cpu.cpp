@@ -1567,6 +1567,23 @@ int sg_segmax_scatter_cpu(const float* dy, const int* idx, float* dx, long B, lo
         for (int c = 0; c < C; ++c) dx[(b * P + idx[b * C + c]) * C + c] = dy[b * C + c];
     return SG_OK;
 }
+int sg_scatter_rows_grouped_cpu(const float* g, const int64_t* rows, float* dx, long B, int C, int K, void*) {
+    CPU_CHECK(g && rows && dx && B > 0 && C > 0 && C <= 1024 && K > 0);
+    for (long b = 0; b < B; ++b)
+        for (int c2 = 0; c2 < C; ++c2) {
+            const int64_t mine = rows[b * C + c2];
+            bool led = false;
+            for (int e = 0; e < c2 && !led; ++e) led = rows[b * C + e] == mine;
+            if (led) continue;
+            for (int k = 0; k < K; ++k) {
+                float s = g[(b * C + c2) * K + k];
+                for (int e = c2 + 1; e < C; ++e)
+                    if (rows[b * C + e] == mine) s += g[(b * C + e) * K + k];
+                dx[mine * K + k] = s;
+            }
+        }
+    return SG_OK;
+}
 int sg_rowdot_cpu(const float* h, const float* w, const float* bias, float* out, long B, int C, int K, void*) {
     CPU_CHECK(h && w && out && B > 0 && C > 0 && K > 0);
 #pragma omp parallel for schedule(static)

@@ -118,6 +118,7 @@ SIGNATURES = {
     "sg_segmax_fwd": (c_int, [_P, _P, _P, _L, _L, _I, _P, _Z, _P]),
     "sg_segmax_scatter": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "sg_segmax_gather": (c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "sg_scatter_rows_grouped": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "sg_rowdot": (c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "sg_rowscale": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "sg_rowouter": (c_int, [_P, _P, _P, _L, _I, _I, _P]),

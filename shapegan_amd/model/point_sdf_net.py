@@ -83,10 +83,11 @@ class PointNet(nn.Module):
 
     @staticmethod
     def gather_points(x, idx):
-        """Rows idx [B,C] of x [B,P,K] -> [B,C,K] (differentiable: the backward is the sparse scatter-add)."""
-        B, P = x.shape[0], x.shape[1]
+        """Rows idx [B,C] of x [B,P,K] -> [B,C,K] (differentiable: the backward is a deterministic scatter-add of the few selected
+        rows — several channels may have selected the same point —, closed under double backward: ops.GatherRowsGrouped)."""
+        B, P, C = x.shape[0], x.shape[1], idx.shape[1]
         rows = (idx + torch.arange(B, device=x.device).unsqueeze(1) * P).reshape(-1)
-        return x.reshape(B * P, -1).index_select(0, rows).reshape(B, idx.shape[1], -1)
+        return ops.gather_rows_grouped(x.reshape(B * P, -1), rows, C).reshape(B, C, -1)
 
     def forward(self, pos, dist, batch=None):
         dist = dist.unsqueeze(-1) if dist.size(-1) != 1 else dist

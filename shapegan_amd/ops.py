@@ -1418,6 +1418,47 @@ class SDFGenFused(Function):
         return (None, None, gzb1, gzb5, None, None, None) + tuple(grads)
 
 
+class GatherRowsGrouped(Function):
+    """x [N, K] -> x[rows] for rows [B * C] (C rows per group; the rows of a group may repeat): PointNet.gather_points.  Its adjoint
+    (ScatterRowsGrouped) adds duplicates in a fixed order without atomics, and the two are each other's adjoints — the gradient
+    penalty's double backward stays deterministic."""
+
+    @staticmethod
+    def forward(ctx, x, rows, C):
+        x = f32c(x)
+        out = torch.empty((rows.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+        check(_lib().sg_gather_rows(ptr(x), ptr(rows), ptr(out), rows.numel(), x.shape[1], stream()), "gather_rows")
+        ctx.N, ctx.C = x.shape[0], C
+        ctx.save_for_backward(rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        return ScatterRowsGrouped.apply(g, rows, ctx.C, ctx.N), None, None
+
+
+class ScatterRowsGrouped(Function):
+    @staticmethod
+    def forward(ctx, g, rows, C, N):
+        g = f32c(g)
+        K = g.shape[1]
+        dx = torch.zeros((N, K), dtype=torch.float32, device=g.device)
+        check(_lib().sg_scatter_rows_grouped(ptr(g), ptr(rows), ptr(dx), rows.numel() // C, C, K, stream()), "scatter_rows_grouped")
+        ctx.C = C
+        ctx.save_for_backward(rows)
+        return dx
+
+    @staticmethod
+    def backward(ctx, gg):
+        (rows,) = ctx.saved_tensors
+        return GatherRowsGrouped.apply(gg, rows, ctx.C), None, None, None
+
+
+def gather_rows_grouped(x, rows, C):
+    return GatherRowsGrouped.apply(x, rows, C)
+
+
 class RowDot(Function):
     """out[b, c] = bias[c] + h[b, c, :] . w[c, :] — the diagonal of `h @ w.T + bias` for h [B, C, K], w [C, K]: the last layer of
     PointNet's selected-points pass (only output c of row c is used).  RowDot / RowScale / RowOuter are each other's adjoints, so

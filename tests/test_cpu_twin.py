@@ -216,6 +216,8 @@ def test_point_gan_family_on_the_fused_generator(on_cpu, golden_steps_f4):
     for b, p in ((3, 1056), (1, 32), (5, 64)):
         M.test_pointnet_select_matches_layerwise(b, p)
     M.test_rowdot_family_matches_torch_to_second_order()
+    for args in ((6, 512, 1280, 200), (2, 100, 300, 300), (1, 1, 5, 1)):
+        M.test_gather_rows_grouped_and_its_deterministic_adjoint(*args)
 
 
 def test_adam_step_together(on_cpu):
